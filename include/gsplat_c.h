@@ -1,0 +1,189 @@
+/* gsplat_c.h -- C-ABI of libgsplat_hip.so: the MI355X (gfx950) splat render hot path.
+ *
+ * The reference (aras-p/UnityGaussianSplatting) has no FFI: its "operator boundary" is Unity's
+ * ComputeShader / CommandBuffer / GraphicsBuffer API, driven from C# in
+ *   package/Runtime/GaussianSplatRenderer.cs  (buffers :373-445, constants :487-510,597-606,624-631,
+ *                                              dispatch order :108-211, :579-639)
+ *   package/Runtime/GpuSorting.cs             (Args / SupportResources / Dispatch :32-87,142-198)
+ * This header is that binding contract restated as plain C: one entry point per thing the C# records
+ * into its CommandBuffer.  A .NET host binds it with [DllImport("gsplat_hip")] (see INTEGRATION.md and
+ * unitygaussiansplatting_amd/dotnet/GaussianSplatNative.cs); the tests bind it with ctypes.
+ *
+ * Conventions
+ *  - every function returns int32: 0 = GS_OK, < 0 = gs_error.  Nothing throws, nothing calls back.
+ *  - handles are opaque.  One gs_context = one GPU + one HIP stream.  All work of a context is enqueued
+ *    on that stream in call order (like one Unity CommandBuffer); calls on one context are NOT thread
+ *    safe (Unity records on its single render thread); different contexts are independent.
+ *  - host pointers passed in are only read during the call (data is copied); the caller keeps ownership.
+ *  - matrices are float[16], row-major m[row*4+col], column vectors (HLSL mul(M, v) with Unity's layout).
+ *  - the *_download / *_synchronize functions block; everything else is asynchronous.
+ */
+#ifndef GSPLAT_C_H
+#define GSPLAT_C_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GS_ABI_VERSION 1
+
+typedef enum gs_error {
+    GS_OK = 0,
+    GS_ERR_INVALID_ARGUMENT = -1,   /* null handle, bad size, bad enum (C#: ArgumentOutOfRangeException, GaussianSplatAsset.cs:47,66) */
+    GS_ERR_HIP = -2,                /* a HIP runtime call failed; gs_last_error_string() has the detail */
+    GS_ERR_UNSUPPORTED_FORMAT = -3, /* BC7 colour (needs a block decoder) */
+    GS_ERR_OUT_OF_MEMORY = -4,
+    GS_ERR_INVALID_ASSET = -5,      /* blob sizes do not match splat_count/formats (C#: HasValidAsset, GaussianSplatRenderer.cs:361-368) */
+    GS_ERR_PAIR_OVERFLOW = -6,      /* tile-pair buffer too small for this frame; the renderer grew it -- draw again */
+    GS_ERR_SORT_TIMEOUT = -7,       /* a bounded spin in the sort's look-back expired (never expected; reported instead of hanging) */
+    GS_ERR_NO_DEVICE = -8
+} gs_error;
+
+/* GaussianSplatAsset.cs:31-37 / :51-57 / :70-81 */
+typedef enum gs_vector_format { GS_VECTOR_FLOAT32 = 0, GS_VECTOR_NORM16 = 1, GS_VECTOR_NORM11 = 2, GS_VECTOR_NORM6 = 3 } gs_vector_format;
+typedef enum gs_color_format { GS_COLOR_FLOAT32X4 = 0, GS_COLOR_FLOAT16X4 = 1, GS_COLOR_NORM8X4 = 2, GS_COLOR_BC7 = 3 } gs_color_format;
+typedef enum gs_sh_format {
+    GS_SH_FLOAT32 = 0, GS_SH_FLOAT16 = 1, GS_SH_NORM11 = 2, GS_SH_NORM6 = 3,
+    GS_SH_CLUSTER64K = 4, GS_SH_CLUSTER32K = 5, GS_SH_CLUSTER16K = 6, GS_SH_CLUSTER8K = 7, GS_SH_CLUSTER4K = 8
+} gs_sh_format;
+
+typedef struct gs_context gs_context;
+typedef struct gs_asset gs_asset;
+typedef struct gs_renderer gs_renderer;
+typedef struct gs_target gs_target;
+typedef struct gs_sorter gs_sorter;
+
+/* The five blobs of a GaussianSplatAsset (GaussianSplatAsset.cs:205-229), as uploaded by
+ * GaussianSplatRenderer.CreateResourcesForAsset (GaussianSplatRenderer.cs:373-405). */
+typedef struct gs_asset_desc {
+    uint32_t splat_count;
+    uint32_t pos_format;      /* gs_vector_format */
+    uint32_t scale_format;    /* gs_vector_format */
+    uint32_t color_format;    /* gs_color_format  */
+    uint32_t sh_format;       /* gs_sh_format     */
+    uint32_t memory_kind;     /* 0: pointers are host memory, copied.  1: pointers are device memory on the
+                                 context's GPU, BORROWED (must outlive the asset; e.g. buffers filled by an RCCL broadcast) */
+    const void* pos_data;    uint64_t pos_size;
+    const void* other_data;  uint64_t other_size;
+    const void* color_data;  uint64_t color_size;
+    const void* sh_data;     uint64_t sh_size;
+    const void* chunk_data;  uint64_t chunk_size;   /* NULL / 0 => _SplatChunkCount = 0 (all-fp32 asset) */
+} gs_asset_desc;
+
+/* Per-frame constants of CSCalcViewData (GaussianSplatRenderer.cs:597-606; SplatUtilities.compute:40-45,86-89)
+ * plus the two Unity built-ins the shader reads (UNITY_MATRIX_VP, UNITY_MATRIX_P) and the camera clip range
+ * the fixed-function rasteriser applies to the splat quads. */
+typedef struct gs_frame_params {
+    float matrix_mv[16];             /* _MatrixMV = worldToCameraMatrix * localToWorld */
+    float matrix_object_to_world[16];/* _MatrixObjectToWorld */
+    float matrix_world_to_object[16];/* _MatrixWorldToObject */
+    float matrix_vp[16];             /* UNITY_MATRIX_VP (clip.w must be view depth: perspective camera) */
+    float proj_m00, proj_m11;        /* UNITY_MATRIX_P._m00 / ._m11 */
+    float screen_w, screen_h;        /* _VecScreenParams.xy */
+    float cam_pos_world[3];          /* _VecWorldSpaceCameraPos.xyz */
+    float splat_scale;               /* m_SplatScale   [0.1, 2]   */
+    float opacity_scale;             /* m_OpacityScale [0.05, 20] */
+    uint32_t sh_order;               /* m_SHOrder 0..3 */
+    uint32_t sh_only;                /* m_SHOnly */
+    float near_clip, far_clip;       /* camera near/far: a splat whose centre depth (clip.w) is outside is clipped */
+} gs_frame_params;
+
+typedef struct gs_frame_stats {
+    uint64_t tile_pairs;        /* P: (16x16 tile, splat) overlaps emitted by the binning kernel this frame */
+    uint64_t pair_capacity;     /* current capacity of the pair buffers */
+    uint32_t visible_splats;    /* splats that survived culling (emitted >= 1 pair) */
+    uint32_t tiles_x, tiles_y;
+    uint32_t sort_error;        /* != 0 => GS_ERR_SORT_TIMEOUT was raised */
+} gs_frame_stats;
+
+/* hipEvent-timed stage durations of the last frame, ms (the four ProfilerMarkers of
+ * GaussianSplatRenderer.cs:20-22,287 split further).  Only valid after gs_renderer_set_profiling(r,1). */
+typedef struct gs_stage_times {
+    float calc_distances_ms;   /* CSCalcDistances (+ fused digit histograms) */
+    float sort_ms;             /* 4 Onesweep passes */
+    float calc_view_ms;        /* CSCalcViewData */
+    float bin_ms;              /* tile binning: count + scan + emit */
+    float pair_sort_ms;        /* stable sort of (tile, i) pairs by tile */
+    float blend_ms;            /* per-tile front-to-back composite (RenderGaussianSplats.shader) */
+    float resolve_ms;          /* GaussianComposite.shader */
+    float total_ms;
+} gs_stage_times;
+
+int32_t gs_abi_version(void);
+const char* gs_error_string(int32_t err);
+const char* gs_last_error_string(void);          /* thread-local detail of the last failure */
+
+/* ---- context ------------------------------------------------------------------------------------ */
+/* `hip_stream` may be NULL (the context creates its own non-blocking stream) or a hipStream_t owned by
+ * the caller (e.g. torch.cuda.current_stream().cuda_stream) on `device`. */
+int32_t gs_context_create(int32_t device, void* hip_stream, gs_context** out);
+int32_t gs_context_destroy(gs_context* ctx);
+int32_t gs_context_synchronize(gs_context* ctx);
+int32_t gs_context_device_info(gs_context* ctx, char* name_out, size_t name_cap, int32_t* cu_count, uint64_t* hbm_bytes);
+
+/* ---- asset (replaces CreateResourcesForAsset's buffer uploads, GaussianSplatRenderer.cs:373-405) - */
+int32_t gs_asset_create(gs_context* ctx, const gs_asset_desc* desc, gs_asset** out);
+int32_t gs_asset_destroy(gs_asset* asset);                         /* DisposeResourcesForAsset :527-565 */
+int32_t gs_asset_splat_count(const gs_asset* asset, uint32_t* out);
+/* device addresses + sizes of pos, other, color, sh, chunk (for an RCCL broadcast by the host) */
+int32_t gs_asset_device_blobs(const gs_asset* asset, void* ptrs[5], uint64_t sizes[5]);
+
+/* ---- renderer (per GaussianSplatRenderer component) ---------------------------------------------- */
+/* allocates m_GpuView (N x 40 B), m_GpuSortDistances, m_GpuSortKeys, the sorter's SupportResources and the
+ * tile-binning buffers; runs CSSetIndices (GaussianSplatRenderer.cs:407,423-445). */
+int32_t gs_renderer_create(gs_context* ctx, gs_asset* asset, gs_renderer** out);
+int32_t gs_renderer_destroy(gs_renderer* r);
+/* CSSetIndices (SplatUtilities.compute:59-67): order[i] = i */
+int32_t gs_renderer_reset_order(gs_renderer* r);
+/* SortPoints (GaussianSplatRenderer.cs:612-639): CSCalcDistances with _MatrixMV = `matrix_sort`
+ * (= worldToCameraMatrix with m20,m21,m22 negated, times localToWorld -- the host builds it exactly as
+ * the C# does), then GpuSorting.Dispatch on (distances, order). */
+int32_t gs_renderer_sort(gs_renderer* r, const float matrix_sort[16]);
+/* CalcViewData (GaussianSplatRenderer.cs:579-610): CSCalcViewData into the N x 40 B view buffer */
+int32_t gs_renderer_calc_view(gs_renderer* r, const gs_frame_params* p);
+/* the DrawProcedural of SortAndRenderSplats (GaussianSplatRenderer.cs:156-166): blends all splats in
+ * order[] front-to-back into `rt` (RGBA16F, premultiplied; "Blend OneMinusDstAlpha One"). rt is NOT cleared. */
+int32_t gs_renderer_draw(gs_renderer* r, const gs_frame_params* p, gs_target* rt);
+/* convenience: sort (if do_sort) + calc_view + clear + draw, one call */
+int32_t gs_renderer_render(gs_renderer* r, const float matrix_sort[16], const gs_frame_params* p, gs_target* rt, int32_t do_sort);
+/* 0 (default): "exact" -- accumulate in fp16 (RTNE after every blend, like the RGBA16F ROP).
+ * 1: "fast" -- accumulate in fp32, stop a pixel when 1-A < 1/4096. */
+int32_t gs_renderer_set_blend_mode(gs_renderer* r, int32_t mode);
+int32_t gs_renderer_set_profiling(gs_renderer* r, int32_t enabled);
+int32_t gs_renderer_reserve_pairs(gs_renderer* r, uint64_t pair_capacity);
+/* blocking readbacks (parity hooks; synchronise the stream) */
+int32_t gs_renderer_download_order(gs_renderer* r, uint32_t* out, size_t count);        /* _OrderBuffer / m_GpuSortKeys */
+int32_t gs_renderer_download_distances(gs_renderer* r, uint32_t* out, size_t count);    /* m_GpuSortDistances (sorted keys after a sort) */
+int32_t gs_renderer_upload_order(gs_renderer* r, const uint32_t* in, size_t count);
+int32_t gs_renderer_download_view(gs_renderer* r, void* out, size_t bytes);             /* N x 40 B SplatViewData */
+int32_t gs_renderer_frame_stats(gs_renderer* r, gs_frame_stats* out);                   /* blocks; reports + clears overflow/timeouts */
+int32_t gs_renderer_stage_times(gs_renderer* r, gs_stage_times* out);                   /* blocks */
+
+/* ---- render target: the _GaussianSplatRT temporary (GaussianSplatRenderer.cs:194-196) ------------- */
+int32_t gs_target_create(gs_context* ctx, uint32_t width, uint32_t height, gs_target** out);
+int32_t gs_target_destroy(gs_target* t);
+int32_t gs_target_clear(gs_target* t);                                  /* ClearRenderTarget(Color, (0,0,0,0)) */
+int32_t gs_target_download(gs_target* t, void* out_rgba16f, size_t bytes);   /* W*H*8 B, row 0 = top; blocks */
+/* GaussianComposite.shader:25-39 + its "Blend SrcAlpha OneMinusSrcAlpha": out = lerp(bg, GammaToLinearSpace(C/A), A).
+ * Writes W*H*4 floats (linear RGBA, out.a = A + bg.a*(1-A)) into a device buffer owned by the target, then
+ * optionally copies it to `out_rgba32f` (may be NULL) and/or an sRGB-encoded 8-bit image `out_rgba8` (may be NULL). */
+int32_t gs_target_resolve(gs_target* t, const float background_rgba[4], float* out_rgba32f, uint8_t* out_rgba8);
+int32_t gs_target_device_ptr(gs_target* t, void** rgba16f_dev, void** resolved_rgba32f_dev);
+
+/* ---- stand-alone sorter: GpuSorting (GpuSorting.cs) ----------------------------------------------- */
+/* SupportResources.Load(count) :48-63 */
+int32_t gs_sorter_create(gs_context* ctx, uint32_t max_count, gs_sorter** out);
+int32_t gs_sorter_destroy(gs_sorter* s);
+/* Dispatch :142-198 -- stable ascending sort of (uint32 key, uint32 payload) pairs in DEVICE buffers, in place
+ * (KEY_UINT PAYLOAD_UINT SHOULD_ASCEND SORT_PAIRS).  key_bits in [1,32]: only the low key_bits take part. */
+int32_t gs_sorter_dispatch(gs_sorter* s, void* keys_dev, void* values_dev, uint32_t count, uint32_t key_bits);
+/* same on host arrays (upload, sort, download); blocks */
+int32_t gs_sorter_sort_host(gs_sorter* s, uint32_t* keys, uint32_t* values, uint32_t count, uint32_t key_bits);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GSPLAT_C_H */

@@ -1,0 +1,668 @@
+// gs_oracle.cpp -- CPU restatement of the reference's per-frame splat render path.
+//
+// *** TEST INFRASTRUCTURE ONLY. ***  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+// load this library, and only as the checker / reported CPU baseline.  The product path
+// (unitygaussiansplatting_amd + libgsplat_hip.so) never links, imports or falls back to it.
+//
+// *** PARITY UNPINNED. ***  The reference (aras-p/UnityGaussianSplatting) is HLSL + Unity C#; it cannot be
+// built or run in this environment (no dxc / Unity / dotnet) and it ships no unit tests or golden vectors for
+// this path other than full-scene PNGs of INRIA models that are not available offline.
+// This file is therefore a line-by-line restatement of the shader source, with the places where HLSL leaves
+// evaluation order / precision to the GPU compiler pinned to the canonical forms listed in DESIGN.md
+// ("canonical arithmetic").  The HIP kernels use the same canonical forms, so most outputs compare bit-exact.
+//
+// Each function cites the reference lines it restates (paths relative to /root/reference/package/).
+//
+// Build: see oracle/Makefile  (g++ -O2 -fopenmp -ffp-contract=off; no fast-math).
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <numeric>
+#include <vector>
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#include "../include/gsplat_c.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// small vector helpers; every multiply-add is an explicit fmaf (canonical arithmetic)
+// ---------------------------------------------------------------------------------------------
+struct f3 { float x, y, z; };
+struct f4 { float x, y, z, w; };
+
+inline float dot3(f3 a, f3 b) { return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)); }
+inline float dot2(float ax, float ay, float bx, float by) { return fmaf(ay, by, ax * bx); }
+inline float lerpf(float a, float b, float t) { return fmaf(t, b - a, a); }            // HLSL lerp: a + t*(b-a)
+inline float saturatef(float x) { return fminf(fmaxf(x, 0.0f), 1.0f); }
+inline float signf(float x) { return (x > 0.0f) ? 1.0f : ((x < 0.0f) ? -1.0f : 0.0f); }
+// mul(M, float4(v,1)) row r of a row-major 4x4
+inline float mul_row(const float* m, int r, f3 v) {
+    return fmaf(m[r * 4 + 2], v.z, fmaf(m[r * 4 + 1], v.y, fmaf(m[r * 4 + 0], v.x, m[r * 4 + 3])));
+}
+// mul((float3x3)M, v) row r
+inline float mul3_row(const float* m, int r, f3 v) {
+    return fmaf(m[r * 4 + 2], v.z, fmaf(m[r * 4 + 1], v.y, m[r * 4 + 0] * v.x));
+}
+
+// ---- IEEE half conversion, round-to-nearest-even (HLSL f32tof16 / f16tof32; Burst math.f32tof16) ----
+inline uint16_t f32tof16(float f) {
+    uint32_t x; std::memcpy(&x, &f, 4);
+    const uint32_t sign = (x >> 16) & 0x8000u;
+    x &= 0x7fffffffu;
+    if (x > 0x7f800000u) return (uint16_t)(sign | 0x7e00u);             // NaN
+    if (x >= 0x477ff000u) return (uint16_t)(sign | 0x7c00u);            // >= 65520 -> inf (also inf)
+    if (x < 0x38800000u) {                                              // < 2^-14: half subnormal or zero
+        if (x < 0x33000000u) return (uint16_t)sign;                     // < 2^-25 -> 0
+        const uint32_t e = x >> 23;                                     // 102..112
+        const uint32_t m = (x & 0x7fffffu) | 0x800000u;                 // 24-bit significand
+        const uint32_t shift = 126u - e;                                // 14..24: result = m >> shift (RTNE)
+        uint32_t r = m >> shift;
+        const uint32_t rem = m & ((1u << shift) - 1u);
+        const uint32_t half = 1u << (shift - 1u);
+        if (rem > half || (rem == half && (r & 1u))) r++;
+        return (uint16_t)(sign | r);
+    }
+    uint32_t r = x - 0x38000000u;                                       // rebias exponent 127 -> 15
+    const uint32_t rem = r & 0x1fffu;
+    r >>= 13;
+    if (rem > 0x1000u || (rem == 0x1000u && (r & 1u))) r++;
+    return (uint16_t)(sign | r);
+}
+inline float f16tof32(uint32_t h) {
+    h &= 0xffffu;
+    const uint32_t sign = (h & 0x8000u) << 16;
+    const uint32_t e = (h >> 10) & 0x1fu;
+    uint32_t m = h & 0x3ffu;
+    uint32_t x;
+    if (e == 0) {
+        if (m == 0) x = sign;
+        else {                                                          // subnormal: normalise
+            int s = 0;
+            while (!(m & 0x400u)) { m <<= 1; s++; }
+            m &= 0x3ffu;
+            x = sign | ((uint32_t)(113 - s) << 23) | (m << 13);
+        }
+    } else if (e == 31) x = sign | 0x7f800000u | (m << 13);
+    else x = sign | ((e + 112u) << 23) | (m << 13);
+    float f; std::memcpy(&f, &x, 4);
+    return f;
+}
+inline float round_f16(float f) { return f16tof32(f32tof16(f)); }
+
+// ---------------------------------------------------------------------------------------------
+// asset view
+// ---------------------------------------------------------------------------------------------
+struct Asset {
+    uint32_t n, posFmt, scaleFmt, colorFmt, shFmt, chunkCount;
+    const uint8_t *pos, *other, *color, *sh, *chunk;
+};
+
+Asset make_asset(const gs_asset_desc* d) {
+    Asset a;
+    a.n = d->splat_count; a.posFmt = d->pos_format; a.scaleFmt = d->scale_format;
+    a.colorFmt = d->color_format; a.shFmt = d->sh_format;
+    a.pos = (const uint8_t*)d->pos_data; a.other = (const uint8_t*)d->other_data;
+    a.color = (const uint8_t*)d->color_data; a.sh = (const uint8_t*)d->sh_data;
+    a.chunk = (const uint8_t*)d->chunk_data;
+    a.chunkCount = (d->chunk_data && d->chunk_size) ? (uint32_t)(d->chunk_size / 64) : 0;   // GaussianSplatRenderer.cs:504
+    return a;
+}
+
+inline uint32_t load_u32(const uint8_t* p, uint64_t byteAddr) { uint32_t v; std::memcpy(&v, p + byteAddr, 4); return v; }
+inline float load_f32(const uint8_t* p, uint64_t byteAddr) { float v; std::memcpy(&v, p + byteAddr, 4); return v; }
+
+// GaussianSplatting.hlsl:325-343 LoadUShort / LoadUInt (2-byte aligned addresses stitched from aligned dwords;
+// on a byte-addressable CPU this is a plain unaligned little-endian load)
+inline uint32_t LoadUShort(const uint8_t* p, uint64_t a) { uint16_t v; std::memcpy(&v, p + a, 2); return v; }
+inline uint32_t LoadUInt(const uint8_t* p, uint64_t a) { return load_u32(p, a); }
+
+// GaussianSplatting.hlsl:261-300 DecodePacked_*; division by (2^bits-1) is the canonical multiply by the
+// fp32-rounded reciprocal (DESIGN.md canonical arithmetic #2)
+constexpr float R63 = 1.0f / 63.0f, R31 = 1.0f / 31.0f, R2047 = 1.0f / 2047.0f, R1023 = 1.0f / 1023.0f,
+                R65535 = 1.0f / 65535.0f, R255 = 1.0f / 255.0f;
+inline f3 DecodePacked_6_5_5(uint32_t e) { return { (float)(e & 63) * R63, (float)((e >> 6) & 31) * R31, (float)((e >> 11) & 31) * R31 }; }
+inline f3 DecodePacked_5_6_5(uint32_t e) { return { (float)(e & 31) * R31, (float)((e >> 5) & 63) * R63, (float)((e >> 11) & 31) * R31 }; }
+inline f3 DecodePacked_11_10_11(uint32_t e) { return { (float)(e & 2047) * R2047, (float)((e >> 11) & 1023) * R1023, (float)((e >> 21) & 2047) * R2047 }; }
+inline f3 DecodePacked_16_16_16(uint32_t e0, uint32_t e1) { return { (float)(e0 & 65535) * R65535, (float)((e0 >> 16) & 65535) * R65535, (float)(e1 & 65535) * R65535 }; }
+
+inline uint32_t vec_stride(uint32_t fmt) { return fmt == 0 ? 12u : fmt == 1 ? 6u : fmt == 2 ? 4u : 2u; }
+
+// GaussianSplatting.hlsl:346-392 LoadAndDecodeVector
+inline f3 LoadAndDecodeVector(const uint8_t* buf, uint64_t addrU, uint32_t fmt) {
+    if (fmt == 0) return { load_f32(buf, addrU), load_f32(buf, addrU + 4), load_f32(buf, addrU + 8) };
+    if (fmt == 1) return DecodePacked_16_16_16(LoadUInt(buf, addrU), LoadUShort(buf, addrU + 4));
+    if (fmt == 2) return DecodePacked_11_10_11(LoadUInt(buf, addrU));
+    return DecodePacked_6_5_5(LoadUShort(buf, addrU));
+}
+
+struct Chunk {          // GaussianSplatting.hlsl:196-202 SplatChunkInfo
+    uint32_t colR, colG, colB, colA;
+    float posX[2], posY[2], posZ[2];
+    uint32_t sclX, sclY, sclZ;
+    uint32_t shR, shG, shB;
+};
+static_assert(sizeof(Chunk) == 64, "ChunkInfo is 64 B");
+inline Chunk load_chunk(const Asset& a, uint32_t ci) { Chunk c; std::memcpy(&c, a.chunk + (uint64_t)ci * 64, 64); return c; }
+
+// GaussianSplatting.hlsl:394-421 LoadSplatPosValue / LoadSplatPos
+inline f3 LoadSplatPos(const Asset& a, uint32_t idx) {
+    f3 pos = LoadAndDecodeVector(a.pos, (uint64_t)idx * vec_stride(a.posFmt), a.posFmt);
+    const uint32_t chunkIdx = idx / 256;
+    if (chunkIdx < a.chunkCount) {
+        const Chunk c = load_chunk(a, chunkIdx);
+        pos.x = lerpf(c.posX[0], c.posX[1], pos.x);
+        pos.y = lerpf(c.posY[0], c.posY[1], pos.y);
+        pos.z = lerpf(c.posZ[0], c.posZ[1], pos.z);
+    }
+    return pos;
+}
+
+// GaussianSplatting.hlsl:113-127,183-194  DecodeMorton2D_16x16 / SplatIndexToPixelIndex
+inline void SplatIndexToPixelIndex(uint32_t idx, uint32_t& x, uint32_t& y) {
+    uint32_t t = idx;
+    t = (t & 0xFF) | ((t & 0xFE) << 7);
+    t &= 0x5555;
+    t = (t ^ (t >> 1)) & 0x3333;
+    t = (t ^ (t >> 2)) & 0x0f0f;
+    const uint32_t mx = t & 0xF, my = t >> 8;
+    const uint32_t width = 2048 / 16;
+    idx >>= 8;
+    x = (idx % width) * 16 + mx;
+    y = (idx / width) * 16 + my;
+}
+
+// GaussianSplatting.hlsl:5-11
+inline float InvSquareCentered01(float x) {
+    x -= 0.5f;
+    x *= 0.5f;
+    x = sqrtf(fabsf(x)) * signf(x);
+    return x + 0.5f;
+}
+
+// GaussianSplatting.hlsl:219-229 DecodeRotation(DecodePacked_10_10_10_2(enc)).  round(pq.w*3) == the 2-bit field.
+inline f4 DecodeRotation(uint32_t enc) {
+    const float px = (float)(enc & 1023) * R1023, py = (float)((enc >> 10) & 1023) * R1023, pz = (float)((enc >> 20) & 1023) * R1023;
+    const uint32_t idx = (enc >> 30) & 3;
+    const float SQRT2 = 1.41421356237f, INV_SQRT2 = 0.70710678118f;
+    const float qx = fmaf(px, SQRT2, -INV_SQRT2), qy = fmaf(py, SQRT2, -INV_SQRT2), qz = fmaf(pz, SQRT2, -INV_SQRT2);
+    const float qw = sqrtf(1.0f - saturatef(dot3({qx, qy, qz}, {qx, qy, qz})));
+    f4 q = {qx, qy, qz, qw};
+    if (idx == 0) q = {qw, qx, qy, qz};          // q.wxyz
+    if (idx == 1) q = {qx, qw, qy, qz};          // q.xwyz
+    if (idx == 2) q = {qx, qy, qw, qz};          // q.xywz
+    return q;
+}
+
+struct SplatData {      // GaussianSplatting.hlsl:134-137,209-216
+    f3 pos; f4 rot; f3 scale; float opacity;
+    f3 col; f3 sh[15];
+};
+
+// GaussianSplatting.hlsl:428-608 LoadSplatData
+SplatData LoadSplatData(const Asset& a, uint32_t idx) {
+    SplatData s;
+    uint32_t cx, cy;
+    SplatIndexToPixelIndex(idx, cx, cy);
+    const uint32_t scaleFmt = a.scaleFmt, shFormat = a.shFmt;
+    uint32_t otherStride = 4 + vec_stride(scaleFmt);
+    if (shFormat > 3) otherStride += 2;
+    const uint64_t otherAddr = (uint64_t)idx * otherStride;
+    uint32_t shStride = 0;
+    if (shFormat == 0) shStride = 192;
+    else if (shFormat == 1 || shFormat > 3) shStride = 96;
+    else if (shFormat == 2) shStride = 60;
+    else if (shFormat == 3) shStride = 32;
+
+    s.pos = LoadAndDecodeVector(a.pos, (uint64_t)idx * vec_stride(a.posFmt), a.posFmt);
+    s.rot = DecodeRotation(LoadUInt(a.other, otherAddr));
+    s.scale = LoadAndDecodeVector(a.other, otherAddr + 4, scaleFmt);
+    // _SplatColor.Load(coord): texel fetch with the texture's own format conversion
+    f4 col;
+    const uint64_t texel = (uint64_t)cy * 2048 + cx;
+    if (a.colorFmt == 0) {
+        col = { load_f32(a.color, texel * 16), load_f32(a.color, texel * 16 + 4), load_f32(a.color, texel * 16 + 8), load_f32(a.color, texel * 16 + 12) };
+    } else if (a.colorFmt == 1) {
+        const uint32_t lo = load_u32(a.color, texel * 8), hi = load_u32(a.color, texel * 8 + 4);
+        col = { f16tof32(lo), f16tof32(lo >> 16), f16tof32(hi), f16tof32(hi >> 16) };
+    } else {
+        const uint32_t e = load_u32(a.color, texel * 4);        // R8G8B8A8_UNorm: x/255
+        col = { (float)(e & 255) * R255, (float)((e >> 8) & 255) * R255, (float)((e >> 16) & 255) * R255, (float)(e >> 24) * R255 };
+    }
+
+    uint32_t shIndex = idx;
+    if (shFormat > 3) shIndex = LoadUShort(a.other, otherAddr + otherStride - 2);
+    const uint64_t shOffset = (uint64_t)shIndex * shStride;
+    if (shFormat == 0) {
+        for (int k = 0; k < 15; ++k)
+            s.sh[k] = { load_f32(a.sh, shOffset + k * 12), load_f32(a.sh, shOffset + k * 12 + 4), load_f32(a.sh, shOffset + k * 12 + 8) };
+    } else if (shFormat == 1 || shFormat > 3) {
+        for (int k = 0; k < 15; ++k)
+            s.sh[k] = { f16tof32(LoadUShort(a.sh, shOffset + k * 6)), f16tof32(LoadUShort(a.sh, shOffset + k * 6 + 2)), f16tof32(LoadUShort(a.sh, shOffset + k * 6 + 4)) };
+    } else if (shFormat == 2) {
+        for (int k = 0; k < 15; ++k) s.sh[k] = DecodePacked_11_10_11(load_u32(a.sh, shOffset + k * 4));
+    } else {
+        for (int k = 0; k < 15; ++k) s.sh[k] = DecodePacked_5_6_5(LoadUShort(a.sh, shOffset + k * 2));
+    }
+
+    const uint32_t chunkIdx = idx / 256;
+    if (chunkIdx < a.chunkCount) {                                      // :565-603
+        const Chunk c = load_chunk(a, chunkIdx);
+        const f3 sclMin = { f16tof32(c.sclX), f16tof32(c.sclY), f16tof32(c.sclZ) };
+        const f3 sclMax = { f16tof32(c.sclX >> 16), f16tof32(c.sclY >> 16), f16tof32(c.sclZ >> 16) };
+        const f4 colMin = { f16tof32(c.colR), f16tof32(c.colG), f16tof32(c.colB), f16tof32(c.colA) };
+        const f4 colMax = { f16tof32(c.colR >> 16), f16tof32(c.colG >> 16), f16tof32(c.colB >> 16), f16tof32(c.colA >> 16) };
+        const f3 shMin = { f16tof32(c.shR), f16tof32(c.shG), f16tof32(c.shB) };
+        const f3 shMax = { f16tof32(c.shR >> 16), f16tof32(c.shG >> 16), f16tof32(c.shB >> 16) };
+        s.pos = { lerpf(c.posX[0], c.posX[1], s.pos.x), lerpf(c.posY[0], c.posY[1], s.pos.y), lerpf(c.posZ[0], c.posZ[1], s.pos.z) };
+        s.scale = { lerpf(sclMin.x, sclMax.x, s.scale.x), lerpf(sclMin.y, sclMax.y, s.scale.y), lerpf(sclMin.z, sclMax.z, s.scale.z) };
+        for (int r = 0; r < 3; ++r) { s.scale.x *= s.scale.x; s.scale.y *= s.scale.y; s.scale.z *= s.scale.z; }   // ^8
+        col = { lerpf(colMin.x, colMax.x, col.x), lerpf(colMin.y, colMax.y, col.y), lerpf(colMin.z, colMax.z, col.z), lerpf(colMin.w, colMax.w, col.w) };
+        col.w = InvSquareCentered01(col.w);
+        if (shFormat > 0 && shFormat <= 3)
+            for (int k = 0; k < 15; ++k)
+                s.sh[k] = { lerpf(shMin.x, shMax.x, s.sh[k].x), lerpf(shMin.y, shMax.y, s.sh[k].y), lerpf(shMin.z, shMax.z, s.sh[k].z) };
+    }
+    s.opacity = col.w;
+    s.col = { col.x, col.y, col.z };
+    return s;
+}
+
+// SplatUtilities.compute:52-57
+inline uint32_t FloatToSortableUint(float f) {
+    uint32_t fu; std::memcpy(&fu, &f, 4);
+    const uint32_t mask = (uint32_t)(-(int32_t)(fu >> 31)) | 0x80000000u;
+    return fu ^ mask;
+}
+
+// GaussianSplatting.hlsl:130-179 ShadeSH (half == float on desktop)
+const float SH_C1 = 0.4886025f;
+const float SH_C2[5] = { 1.0925484f, -1.0925484f, 0.3153916f, -1.0925484f, 0.5462742f };
+const float SH_C3[7] = { -0.5900436f, 2.8906114f, -0.4570458f, 0.3731763f, -0.4570458f, 1.4453057f, -0.5900436f };
+
+inline float sh_channel(float col, const float* sh /*15 coeffs of one channel, stride 3*/, float x, float y, float z, int shOrder, bool onlySH) {
+    auto S = [&](int k) { return sh[(k - 1) * 3]; };   // S(1)..S(15)
+    float res = onlySH ? 0.5f : col;
+    if (shOrder >= 1) {
+        float t = (-S(1)) * y;
+        t = fmaf(S(2), z, t);
+        t = fmaf(-S(3), x, t);
+        res = fmaf(SH_C1, t, res);
+        if (shOrder >= 2) {
+            const float xx = x * x, yy = y * y, zz = z * z;
+            const float xy = x * y, yz = y * z, xz = x * z;
+            float a = (SH_C2[0] * xy) * S(4);
+            a = fmaf(SH_C2[1] * yz, S(5), a);
+            a = fmaf(SH_C2[2] * (fmaf(2.0f, zz, -xx) - yy), S(6), a);
+            a = fmaf(SH_C2[3] * xz, S(7), a);
+            a = fmaf(SH_C2[4] * (xx - yy), S(8), a);
+            res += a;
+            if (shOrder >= 3) {
+                float b = ((SH_C3[0] * y) * fmaf(3.0f, xx, -yy)) * S(9);
+                b = fmaf((SH_C3[1] * xy) * z, S(10), b);
+                b = fmaf((SH_C3[2] * y) * (fmaf(4.0f, zz, -xx) - yy), S(11), b);
+                b = fmaf((SH_C3[3] * z) * (fmaf(2.0f, zz, -3.0f * xx) - 3.0f * yy), S(12), b);
+                b = fmaf((SH_C3[4] * x) * (fmaf(4.0f, zz, -xx) - yy), S(13), b);
+                b = fmaf((SH_C3[5] * z) * (xx - yy), S(14), b);
+                b = fmaf((SH_C3[6] * x) * fmaf(-3.0f, yy, xx), S(15), b);
+                res += b;
+            }
+        }
+    }
+    return fmaxf(res, 0.0f);
+}
+
+struct ViewData {           // GaussianSplatting.hlsl:610-615  (40 bytes)
+    float pos[4];
+    float axis1[2], axis2[2];
+    uint32_t color[2];
+};
+static_assert(sizeof(ViewData) == 40, "SplatViewData is 40 B");
+
+// SplatUtilities.compute:189-252 CSCalcViewData for one splat (cutouts / deleted bits: count 0)
+ViewData CalcViewDataOne(const Asset& a, const gs_frame_params& P, uint32_t idx) {
+    const SplatData splat = LoadSplatData(a, idx);
+    ViewData view; std::memset(&view, 0, sizeof(view));
+
+    const f3 centerWorldPos = { mul_row(P.matrix_object_to_world, 0, splat.pos), mul_row(P.matrix_object_to_world, 1, splat.pos), mul_row(P.matrix_object_to_world, 2, splat.pos) };
+    const float clip[4] = { mul_row(P.matrix_vp, 0, centerWorldPos), mul_row(P.matrix_vp, 1, centerWorldPos), mul_row(P.matrix_vp, 2, centerWorldPos), mul_row(P.matrix_vp, 3, centerWorldPos) };
+    for (int k = 0; k < 4; ++k) view.pos[k] = clip[k];
+    const bool behindCam = !(clip[3] > 0.0f);                     // centerClipPos.w <= 0 (NaN counts as behind)
+    if (behindCam) return view;
+
+    // CalcMatrixFromRotationScale (GaussianSplatting.hlsl:29-46): mul(mr, diag(scale))
+    const float x = splat.rot.x, y = splat.rot.y, z = splat.rot.z, w = splat.rot.w;
+    float mr[3][3] = {
+        { fmaf(-2.0f, fmaf(z, z, y * y), 1.0f), 2.0f * fmaf(-w, z, x * y),            2.0f * fmaf(w, y, x * z) },
+        { 2.0f * fmaf(w, z, x * y),            fmaf(-2.0f, fmaf(z, z, x * x), 1.0f), 2.0f * fmaf(-w, x, y * z) },
+        { 2.0f * fmaf(-w, y, x * z),           2.0f * fmaf(w, x, y * z),            fmaf(-2.0f, fmaf(y, y, x * x), 1.0f) } };
+    float M[3][3];
+    for (int i = 0; i < 3; ++i) { M[i][0] = mr[i][0] * splat.scale.x; M[i][1] = mr[i][1] * splat.scale.y; M[i][2] = mr[i][2] * splat.scale.z; }
+    // CalcCovariance3D (:48-53): sig = M * M^T, 6 unique
+    auto sig = [&](int i, int j) { return fmaf(M[i][2], M[j][2], fmaf(M[i][1], M[j][1], M[i][0] * M[j][0])); };
+    const float splatScale2 = P.splat_scale * P.splat_scale;
+    const float c00 = sig(0, 0) * splatScale2, c01 = sig(0, 1) * splatScale2, c02 = sig(0, 2) * splatScale2;
+    const float c11 = sig(1, 1) * splatScale2, c12 = sig(1, 2) * splatScale2, c22 = sig(2, 2) * splatScale2;
+
+    // CalcCovariance2D (:56-90)
+    f3 viewPos = { mul_row(P.matrix_mv, 0, splat.pos), mul_row(P.matrix_mv, 1, splat.pos), mul_row(P.matrix_mv, 2, splat.pos) };
+    const float aspect = P.proj_m00 / P.proj_m11;
+    const float tanFovX = 1.0f / P.proj_m00;
+    const float tanFovY = 1.0f / (P.proj_m11 * aspect);
+    const float limX = 1.3f * tanFovX, limY = 1.3f * tanFovY;
+    viewPos.x = fminf(fmaxf(viewPos.x / viewPos.z, -limX), limX) * viewPos.z;
+    viewPos.y = fminf(fmaxf(viewPos.y / viewPos.z, -limY), limY) * viewPos.z;
+    const float focal = P.screen_w * P.proj_m00 / 2.0f;
+    const float zz2 = viewPos.z * viewPos.z;
+    const float J00 = focal / viewPos.z, J02 = -(focal * viewPos.x) / zz2;
+    const float J11 = focal / viewPos.z, J12 = -(focal * viewPos.y) / zz2;
+    const float* W = P.matrix_mv;
+    // T = J * W (rows 0,1; J's zero entries dropped)
+    float T[2][3];
+    for (int j = 0; j < 3; ++j) {
+        T[0][j] = fmaf(J02, W[2 * 4 + j], J00 * W[0 * 4 + j]);
+        T[1][j] = fmaf(J12, W[2 * 4 + j], J11 * W[1 * 4 + j]);
+    }
+    const float V[3][3] = { { c00, c01, c02 }, { c01, c11, c12 }, { c02, c12, c22 } };
+    // cov = T * (V * T^T)
+    float VT[3][2];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 2; ++j) VT[i][j] = fmaf(V[i][2], T[j][2], fmaf(V[i][1], T[j][1], V[i][0] * T[j][0]));
+    auto covf = [&](int i, int j) { return fmaf(T[i][2], VT[2][j], fmaf(T[i][1], VT[1][j], T[i][0] * VT[0][j])); };
+    const float cov00 = covf(0, 0) + 0.3f, cov01 = covf(0, 1), cov11 = covf(1, 1) + 0.3f;
+
+    // DecomposeCovariance (SplatUtilities.compute:149-159, the live #else branch)
+    const float diag1 = cov00, diag2 = cov11, offDiag = cov01;
+    const float mid = 0.5f * (diag1 + diag2);
+    const float hx = (diag1 - diag2) / 2.0f;
+    const float radius = sqrtf(dot2(hx, offDiag, hx, offDiag));
+    const float lambda1 = mid + radius;
+    const float lambda2 = fmaxf(mid - radius, 0.1f);
+    float dvx = offDiag, dvy = lambda1 - diag1;
+    const float invLen = 1.0f / sqrtf(dot2(dvx, dvy, dvx, dvy));        // normalize(): 0,0 -> NaN (splat vanishes)
+    dvx *= invLen; dvy *= invLen;
+    dvy = -dvy;
+    const float maxSize = 4096.0f;
+    const float s1 = fminf(sqrtf(2.0f * lambda1), maxSize), s2 = fminf(sqrtf(2.0f * lambda2), maxSize);
+    view.axis1[0] = s1 * dvx;  view.axis1[1] = s1 * dvy;
+    view.axis2[0] = s2 * dvy;  view.axis2[1] = s2 * (-dvx);
+
+    // view direction + SH (SplatUtilities.compute:241-248)
+    const f3 worldViewDir = { P.cam_pos_world[0] - centerWorldPos.x, P.cam_pos_world[1] - centerWorldPos.y, P.cam_pos_world[2] - centerWorldPos.z };
+    f3 objViewDir = { mul3_row(P.matrix_world_to_object, 0, worldViewDir), mul3_row(P.matrix_world_to_object, 1, worldViewDir), mul3_row(P.matrix_world_to_object, 2, worldViewDir) };
+    const float invN = 1.0f / sqrtf(dot3(objViewDir, objViewDir));
+    objViewDir = { objViewDir.x * invN, objViewDir.y * invN, objViewDir.z * invN };
+    const float dx = -objViewDir.x, dy = -objViewDir.y, dz = -objViewDir.z;     // ShadeSH: dir *= -1
+    const float* shp = &splat.sh[0].x;
+    const bool onlySH = P.sh_only != 0;
+    const float r = sh_channel(splat.col.x, shp + 0, dx, dy, dz, (int)P.sh_order, onlySH);
+    const float g = sh_channel(splat.col.y, shp + 1, dx, dy, dz, (int)P.sh_order, onlySH);
+    const float b = sh_channel(splat.col.z, shp + 2, dx, dy, dz, (int)P.sh_order, onlySH);
+    const float al = fminf(splat.opacity * P.opacity_scale, 65000.0f);
+    view.color[0] = ((uint32_t)f32tof16(r) << 16) | f32tof16(g);
+    view.color[1] = ((uint32_t)f32tof16(b) << 16) | f32tof16(al);
+    return view;
+}
+
+// ---------------------------------------------------------------------------------------------
+// rasteriser restatement: RenderGaussianSplats.shader:35-108 + fixed-function state :10-12
+// ---------------------------------------------------------------------------------------------
+struct Prepared {
+    float cx, cy;           // splat centre in pixels (y down)
+    float a1x, a1y, a2x, a2y;
+    float inv1, inv2;       // 1/|axis|^2
+    float r, g, b, a;       // colour as the vertex shader unpacks it (f16 -> f32)
+    int x0, x1, y0, y1;     // pixel rect of the quad's bounding box, clamped to the screen (x0>x1 => nothing)
+    int tx0, tx1, ty0, ty1; // 16x16 tile rect of the *tight* footprint used by the shipped binning kernel
+    bool valid;
+};
+
+inline bool finitef(float v) { return std::isfinite(v); }
+
+// Shared definition of "is this splat drawn at all, and where": see DESIGN.md "compositor semantics".
+Prepared prepare(const ViewData& v, const gs_frame_params& P) {
+    Prepared p; std::memset(&p, 0, sizeof(p));
+    p.x0 = 1; p.x1 = 0; p.tx0 = 1; p.tx1 = 0;
+    const float W = P.screen_w, H = P.screen_h;
+    const float w = v.pos[3];
+    if (!(w > 0.0f)) return p;                                   // vert: behindCam -> NaN vertex -> primitive discarded
+    if (!(w >= P.near_clip && w <= P.far_clip)) return p;        // all 4 vertices share z/w: depth-clipped as a whole
+    if (!(finitef(v.axis1[0]) && finitef(v.axis1[1]) && finitef(v.axis2[0]) && finitef(v.axis2[1]))) return p;
+    p.r = f16tof32(v.color[0] >> 16); p.g = f16tof32(v.color[0]); p.b = f16tof32(v.color[1] >> 16); p.a = f16tof32(v.color[1]);
+    if (!(p.a >= 1.0f / 255.0f)) return p;                       // alpha = saturate(e*a) <= a < 1/255: every fragment discards
+    const float invw = 1.0f / w;
+    p.cx = fmaf(0.5f * (v.pos[0] * invw), W, 0.5f * W);          // (0.5 + 0.5*ndc.x) * W
+    p.cy = fmaf(-0.5f * (v.pos[1] * invw), H, 0.5f * H);         // (0.5 - 0.5*ndc.y) * H   (image rows top-down)
+    if (!(finitef(p.cx) && finitef(p.cy))) return p;
+    p.a1x = v.axis1[0]; p.a1y = v.axis1[1]; p.a2x = v.axis2[0]; p.a2y = v.axis2[1];
+    p.inv1 = 1.0f / dot2(p.a1x, p.a1y, p.a1x, p.a1y);
+    p.inv2 = 1.0f / dot2(p.a2x, p.a2y, p.a2x, p.a2y);
+    if (!(finitef(p.inv1) && finitef(p.inv2))) return p;
+    // quad = c + qx*axis1 + qy*axis2, q in [-2,2]^2  ->  bounding box half extents
+    const float exr = 2.0f * (fabsf(p.a1x) + fabsf(p.a2x));
+    const float eyr = 2.0f * (fabsf(p.a1y) + fabsf(p.a2y));
+    auto pix_range = [](float c, float e, float size, int& lo, int& hi) {
+        float flo = ceilf((c - e) - 0.5f), fhi = floorf((c + e) - 0.5f);
+        flo = fmaxf(flo, 0.0f); fhi = fminf(fhi, size - 1.0f);
+        if (!(flo <= fhi)) { lo = 1; hi = 0; return; }
+        lo = (int)flo; hi = (int)fhi;
+    };
+    const float slack = 0.01f;
+    pix_range(p.cx, exr + slack, W, p.x0, p.x1);
+    pix_range(p.cy, eyr + slack, H, p.y0, p.y1);
+    if (p.x0 > p.x1 || p.y0 > p.y1) { p.x0 = 1; p.x1 = 0; return p; }
+    // tight footprint of the shipped binning: quad  INTERSECT  {exp(-|q|^2)*a >= 1/255} = disc |q|^2 <= ln(255 a)
+    const float r2 = fmaf(logf(255.0f * p.a), 1.0001f, 1.0e-4f);
+    const float rr = sqrtf(fmaxf(r2, 0.0f));
+    const float exe = rr * sqrtf(dot2(p.a1x, p.a2x, p.a1x, p.a2x));
+    const float eye = rr * sqrtf(dot2(p.a1y, p.a2y, p.a1y, p.a2y));
+    int bx0, bx1, by0, by1;
+    pix_range(p.cx, fminf(exr, exe) + slack, W, bx0, bx1);
+    pix_range(p.cy, fminf(eyr, eye) + slack, H, by0, by1);
+    if (bx0 <= bx1 && by0 <= by1) { p.tx0 = bx0 >> 4; p.tx1 = bx1 >> 4; p.ty0 = by0 >> 4; p.ty1 = by1 >> 4; }
+    p.valid = true;
+    return p;
+}
+
+} // namespace
+
+// =================================================================================================
+// C interface (loaded with ctypes by tests / bench cpu_baseline)
+// =================================================================================================
+extern "C" {
+
+int32_t gso_num_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+void gso_set_num_threads(int32_t n) {
+#ifdef _OPENMP
+    omp_set_num_threads(n > 0 ? n : 1);
+#else
+    (void)n;
+#endif
+}
+
+// half conversion exposed for the f16 known-answer tests
+uint16_t gso_f32tof16(float f) { return f32tof16(f); }
+float gso_f16tof32(uint16_t h) { return f16tof32(h); }
+
+// SplatUtilities.compute:59-67 CSSetIndices
+void gso_set_indices(uint32_t* order, uint32_t n) { for (uint32_t i = 0; i < n; ++i) order[i] = i; }
+
+// SplatUtilities.compute:69-82 CSCalcDistances; `matrix_sort` is the _MatrixMV of GaussianSplatRenderer.cs:629
+void gso_calc_distances(const gs_asset_desc* d, const uint32_t* order, const float* matrix_sort, uint32_t* keys) {
+    const Asset a = make_asset(d);
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < (int64_t)a.n; ++i) {
+        const uint32_t origIdx = order[i];
+        const f3 pos = LoadSplatPos(a, origIdx);
+        const float z = mul_row(matrix_sort, 2, pos);
+        keys[i] = FloatToSortableUint(z);
+    }
+}
+
+// GpuSorting.Dispatch semantics (GpuSorting.cs:142-198; DeviceRadixSort.hlsl): stable ascending sort of
+// (key, payload) pairs, comparing the low `key_bits` bits.  Implemented as a plain LSD counting sort.
+void gso_sort_pairs(uint32_t* keys, uint32_t* vals, uint32_t n, uint32_t key_bits) {
+    std::vector<uint32_t> k2(n), v2(n);
+    uint32_t *ks = keys, *vs = vals, *kd = k2.data(), *vd = v2.data();
+    for (uint32_t shift = 0; shift < key_bits; shift += 8) {
+        uint64_t hist[257] = {0};
+        const uint32_t bits = std::min(8u, key_bits - shift), mask = (1u << bits) - 1u;
+        for (uint32_t i = 0; i < n; ++i) hist[((ks[i] >> shift) & mask) + 1]++;
+        for (int b = 0; b < 256; ++b) hist[b + 1] += hist[b];
+        for (uint32_t i = 0; i < n; ++i) { const uint64_t p = hist[(ks[i] >> shift) & mask]++; kd[p] = ks[i]; vd[p] = vs[i]; }
+        std::swap(ks, kd); std::swap(vs, vd);
+    }
+    if (ks != keys) { std::memcpy(keys, ks, (size_t)n * 4); std::memcpy(vals, vs, (size_t)n * 4); }
+}
+
+// independent second opinion for the sort tests: std::stable_sort on indices
+void gso_stable_sort_reference(const uint32_t* keys, uint32_t* perm_out, uint32_t n, uint32_t key_bits) {
+    std::iota(perm_out, perm_out + n, 0u);
+    const uint32_t mask = key_bits >= 32 ? 0xffffffffu : ((1u << key_bits) - 1u);
+    std::stable_sort(perm_out, perm_out + n, [&](uint32_t x, uint32_t y) { return (keys[x] & mask) < (keys[y] & mask); });
+}
+
+// LoadSplatData exposed for the codec known-answer tests: out[0..58] =
+// pos3, rot4 (xyzw), scale3, opacity, col3, sh 15x3
+void gso_decode_splat(const gs_asset_desc* d, uint32_t idx, float* out) {
+    const Asset a = make_asset(d);
+    const SplatData s = LoadSplatData(a, idx);
+    float* o = out;
+    *o++ = s.pos.x; *o++ = s.pos.y; *o++ = s.pos.z;
+    *o++ = s.rot.x; *o++ = s.rot.y; *o++ = s.rot.z; *o++ = s.rot.w;
+    *o++ = s.scale.x; *o++ = s.scale.y; *o++ = s.scale.z;
+    *o++ = s.opacity;
+    *o++ = s.col.x; *o++ = s.col.y; *o++ = s.col.z;
+    for (int k = 0; k < 15; ++k) { *o++ = s.sh[k].x; *o++ = s.sh[k].y; *o++ = s.sh[k].z; }
+}
+void gso_decode_all(const gs_asset_desc* d, float* out /* n x 59 */) {
+    const Asset a = make_asset(d);
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < (int64_t)a.n; ++i) gso_decode_splat(d, (uint32_t)i, out + i * 59);
+}
+void gso_pixel_index(uint32_t idx, uint32_t* xy) { SplatIndexToPixelIndex(idx, xy[0], xy[1]); }
+
+// SplatUtilities.compute:189-252 CSCalcViewData over all splats
+void gso_calc_view(const gs_asset_desc* d, const gs_frame_params* P, void* view_out) {
+    const Asset a = make_asset(d);
+    ViewData* out = (ViewData*)view_out;
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < (int64_t)a.n; ++i) out[i] = CalcViewDataOne(a, *P, (uint32_t)i);
+}
+
+// The DrawProcedural of GaussianSplatRenderer.cs:156-166 with RenderGaussianSplats.shader, executed splat by
+// splat in order[] (instance order), "Blend OneMinusDstAlpha One" into an RGBA16F target (rt, W*H*4 halfs,
+// row 0 = top).  mode 0: the ROP rounds to fp16 after every blend; mode 1: fp32 accumulation, a pixel stops
+// once 1-A < 1/4096 (the shipped "fast" mode), rounded to fp16 once at the end.
+// tile_pairs_out (optional) = number of (16x16 tile, splat) overlaps of the shipped binning's footprint.
+// Parallel over row bands; each band walks all splats in order, so the result is independent of thread count.
+int32_t gso_draw(const void* view_in, const uint32_t* order, uint32_t n, const gs_frame_params* P, int32_t mode,
+                 uint16_t* rt, uint64_t* tile_pairs_out, uint32_t* visible_out) {
+    const ViewData* view = (const ViewData*)view_in;
+    const int W = (int)P->screen_w, H = (int)P->screen_h;
+    std::vector<Prepared> prep(n);
+    uint64_t pairs = 0; uint32_t visible = 0;
+#pragma omp parallel for schedule(static) reduction(+ : pairs, visible)
+    for (int64_t i = 0; i < (int64_t)n; ++i) {
+        prep[i] = prepare(view[order[i]], *P);
+        if (prep[i].valid && prep[i].tx0 <= prep[i].tx1) {
+            pairs += (uint64_t)(prep[i].tx1 - prep[i].tx0 + 1) * (uint64_t)(prep[i].ty1 - prep[i].ty0 + 1);
+            visible++;
+        }
+    }
+    if (tile_pairs_out) *tile_pairs_out = pairs;
+    if (visible_out) *visible_out = visible;
+
+    int nthreads = 1;
+#ifdef _OPENMP
+    nthreads = omp_get_max_threads();
+#endif
+    const int bands = std::max(1, std::min(H, nthreads * 4));
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int band = 0; band < bands; ++band) {
+        const int yb0 = (int)((int64_t)H * band / bands), yb1 = (int)((int64_t)H * (band + 1) / bands) - 1;
+        if (yb0 > yb1) continue;
+        const int rows = yb1 - yb0 + 1;
+        std::vector<float> acc((size_t)rows * W * 4);
+        for (int y = 0; y < rows; ++y)
+            for (int x = 0; x < W; ++x)
+                for (int c = 0; c < 4; ++c) acc[((size_t)y * W + x) * 4 + c] = f16tof32(rt[((size_t)(yb0 + y) * W + x) * 4 + c]);
+        for (uint32_t i = 0; i < n; ++i) {
+            const Prepared& p = prep[i];
+            if (!p.valid || p.x0 > p.x1) continue;
+            const int y0 = std::max(p.y0, yb0), y1 = std::min(p.y1, yb1);
+            for (int py = y0; py <= y1; ++py) {
+                const float dy = ((float)py + 0.5f) - p.cy;
+                float* row = &acc[(size_t)(py - yb0) * W * 4];
+                for (int px = p.x0; px <= p.x1; ++px) {
+                    const float dx = ((float)px + 0.5f) - p.cx;
+                    // interpolated quad coordinate (i.pos of the v2f): q = [axis1 axis2]^-1 * delta, axes orthogonal
+                    const float q1 = fmaf(dy, p.a1y, dx * p.a1x) * p.inv1;
+                    const float q2 = fmaf(dy, p.a2y, dx * p.a2x) * p.inv2;
+                    if (!(fabsf(q1) <= 2.0f && fabsf(q2) <= 2.0f)) continue;     // outside the quad
+                    float* d = row + (size_t)px * 4;
+                    if (mode == 1 && (1.0f - d[3]) < (1.0f / 4096.0f)) continue; // fast mode: pixel finished
+                    const float power = -fmaf(q2, q2, q1 * q1);                 // frag: -dot(i.pos, i.pos)
+                    float alpha = expf(power);
+                    alpha = saturatef(alpha * p.a);
+                    if (alpha < 1.0f / 255.0f) continue;                        // discard
+                    const float t = 1.0f - d[3];                                 // OneMinusDstAlpha
+                    float nr = fmaf(p.r * alpha, t, d[0]);
+                    float ng = fmaf(p.g * alpha, t, d[1]);
+                    float nb = fmaf(p.b * alpha, t, d[2]);
+                    float na = fmaf(alpha, t, d[3]);
+                    if (mode == 0) { nr = round_f16(nr); ng = round_f16(ng); nb = round_f16(nb); na = round_f16(na); }
+                    d[0] = nr; d[1] = ng; d[2] = nb; d[3] = na;
+                }
+            }
+        }
+        for (int y = 0; y < rows; ++y)
+            for (int x = 0; x < W; ++x)
+                for (int c = 0; c < 4; ++c) rt[((size_t)(yb0 + y) * W + x) * 4 + c] = f32tof16(acc[((size_t)y * W + x) * 4 + c]);
+    }
+    return 0;
+}
+
+// GaussianComposite.shader:25-39 with "Blend SrcAlpha OneMinusSrcAlpha" onto a constant background.
+// UnityCG.cginc GammaToLinearSpace: c*(c*(c*0.305306011+0.682171111)+0.012522878).
+void gso_resolve(const uint16_t* rt, uint32_t W, uint32_t H, const float* bg, float* out32f, uint8_t* out8) {
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < (int64_t)W * H; ++i) {
+        const float C[3] = { f16tof32(rt[i * 4 + 0]), f16tof32(rt[i * 4 + 1]), f16tof32(rt[i * 4 + 2]) };
+        const float A = f16tof32(rt[i * 4 + 3]);
+        float o[4];
+        if (!(A > 0.0f)) { o[0] = bg[0]; o[1] = bg[1]; o[2] = bg[2]; o[3] = bg[3]; }
+        else {
+            const float invA = 1.0f / A;
+            for (int c = 0; c < 3; ++c) {
+                const float s = C[c] * invA;
+                const float lin = s * fmaf(s, fmaf(s, 0.305306011f, 0.682171111f), 0.012522878f);
+                o[c] = fmaf(A, lin - bg[c], bg[c]);
+            }
+            o[3] = fmaf(A, 1.0f - bg[3], bg[3]);
+        }
+        if (out32f) for (int c = 0; c < 4; ++c) out32f[i * 4 + c] = o[c];
+        if (out8) {
+            for (int c = 0; c < 3; ++c) {       // linear -> sRGB 8-bit (what an R8G8B8A8_SRGB target stores)
+                const float l = saturatef(o[c]);
+                const float s = (l <= 0.0031308f) ? 12.92f * l : fmaf(1.055f, powf(l, 1.0f / 2.4f), -0.055f);
+                out8[i * 4 + c] = (uint8_t)floorf(fmaf(saturatef(s), 255.0f, 0.5f));
+            }
+            out8[i * 4 + 3] = (uint8_t)floorf(fmaf(saturatef(o[3]), 255.0f, 0.5f));
+        }
+    }
+}
+
+} // extern "C"

@@ -1,0 +1,114 @@
+"""ctypes binding of oracle/libgs_oracle.so -- the CPU restatement used ONLY as the checker in tests,
+smoke() and bench.py's cpu_baseline leg (never by the product path)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from unitygaussiansplatting_amd._abi import VIEW_DTYPE, gs_asset_desc, gs_frame_params, make_asset_desc
+
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_SO = os.path.join(_ROOT, "oracle", "libgs_oracle.so")
+
+
+def build(force: bool = False) -> str:
+    src = os.path.join(_ROOT, "oracle", "gs_oracle.cpp")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", os.path.join(_ROOT, "oracle"), "-B" if force else "-s"], stdout=subprocess.DEVNULL)
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = C.CDLL(build())
+        _lib.gso_f16tof32.restype = C.c_float
+        _lib.gso_f16tof32.argtypes = [C.c_uint16]
+        _lib.gso_f32tof16.restype = C.c_uint16
+        _lib.gso_f32tof16.argtypes = [C.c_float]
+        _lib.gso_num_threads.restype = C.c_int32
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Oracle:
+    """Holds an asset description and runs the reference-semantics stages on the CPU."""
+
+    def __init__(self, asset):
+        self.asset = asset
+        self._keep = []
+        self.desc = make_asset_desc(asset, self._keep)
+        self.n = asset.splatCount
+        self.order = np.arange(self.n, dtype=np.uint32)      # CSSetIndices
+        self.keys = np.zeros(self.n, np.uint32)
+        self.view = np.zeros(self.n, VIEW_DTYPE)
+
+    def reset_order(self):
+        lib().gso_set_indices(_p(self.order), C.c_uint32(self.n))
+
+    def calc_distances(self, matrix_sort: np.ndarray):
+        m = np.ascontiguousarray(matrix_sort, np.float32).reshape(16)
+        lib().gso_calc_distances(C.byref(self.desc), _p(self.order), _p(m), _p(self.keys))
+        return self.keys
+
+    def sort(self, matrix_sort: np.ndarray):
+        """SortPoints: distances through the current order, then the stable pair sort."""
+        self.calc_distances(matrix_sort)
+        lib().gso_sort_pairs(_p(self.keys), _p(self.order), C.c_uint32(self.n), C.c_uint32(32))
+        return self.order
+
+    def calc_view(self, params: gs_frame_params):
+        lib().gso_calc_view(C.byref(self.desc), C.byref(params), _p(self.view))
+        return self.view
+
+    def draw(self, params: gs_frame_params, mode: int = 0, rt: np.ndarray | None = None):
+        W, H = int(params.screen_w), int(params.screen_h)
+        if rt is None:
+            rt = np.zeros((H, W, 4), np.uint16)
+        pairs = C.c_uint64(0)
+        vis = C.c_uint32(0)
+        lib().gso_draw(_p(self.view), _p(self.order), C.c_uint32(self.n), C.byref(params), C.c_int32(mode), _p(rt),
+                       C.byref(pairs), C.byref(vis))
+        self.tile_pairs, self.visible = pairs.value, vis.value
+        return rt
+
+    def decode_all(self) -> np.ndarray:
+        out = np.zeros((self.n, 59), np.float32)
+        lib().gso_decode_all(C.byref(self.desc), _p(out))
+        return out
+
+
+def sort_pairs(keys: np.ndarray, vals: np.ndarray, key_bits: int = 32):
+    k = np.ascontiguousarray(keys, np.uint32).copy()
+    v = np.ascontiguousarray(vals, np.uint32).copy()
+    lib().gso_sort_pairs(_p(k), _p(v), C.c_uint32(len(k)), C.c_uint32(key_bits))
+    return k, v
+
+
+def stable_sort_reference(keys: np.ndarray, key_bits: int = 32) -> np.ndarray:
+    k = np.ascontiguousarray(keys, np.uint32)
+    perm = np.zeros(len(k), np.uint32)
+    lib().gso_stable_sort_reference(_p(k), _p(perm), C.c_uint32(len(k)), C.c_uint32(key_bits))
+    return perm
+
+
+def resolve(rt: np.ndarray, bg=(0.0, 0.0, 0.0, 0.0)):
+    H, W, _ = rt.shape
+    out32 = np.zeros((H, W, 4), np.float32)
+    out8 = np.zeros((H, W, 4), np.uint8)
+    b = np.asarray(bg, np.float32)
+    lib().gso_resolve(_p(np.ascontiguousarray(rt)), C.c_uint32(W), C.c_uint32(H), _p(b), _p(out32), _p(out8))
+    return out32, out8
+
+
+def f16_to_f32(a: np.ndarray) -> np.ndarray:
+    return np.ascontiguousarray(a, np.uint16).view(np.float16).astype(np.float32)

@@ -1,0 +1,422 @@
+// gs_device_math.h -- per-splat arithmetic of the gfx950 kernels (decode, sort key, view data).
+//
+// Everything here is plain IEEE fp32 with explicit fmaf() and is compiled with -ffp-contract=off, so the
+// numbers are a function of the source only ("canonical arithmetic").  The functions are
+// __host__ __device__ so that tests/test_host_math.py can compile this header with g++ and compare it with
+// the oracle bit for bit on the CPU box; the shipped library only ever calls them from device code.
+//
+// Reference lines restated (paths relative to /root/reference/package/Shaders/):
+//   GaussianSplatting.hlsl :5-11 InvSquareCentered01, :29-53 CalcMatrixFromRotationScale/CalcCovariance3D,
+//   :56-90 CalcCovariance2D, :113-127,183-194 Morton texel address, :130-179 ShadeSH, :219-229 DecodeRotation,
+//   :261-300 DecodePacked_*, :325-421 LoadUShort/LoadUInt/LoadAndDecodeVector/LoadSplatPos, :428-608 LoadSplatData
+//   SplatUtilities.compute :52-57 FloatToSortableUint, :107-162 DecomposeCovariance, :189-252 CSCalcViewData
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#define GS_HD __host__ __device__ __forceinline__
+#else
+#include <cmath>
+#include <cstring>
+#define GS_HD inline
+#endif
+
+namespace gsm {
+
+struct AssetView {              // device (or, in the host test, host) pointers to the five blobs
+    const uint8_t* pos;
+    const uint8_t* other;
+    const uint8_t* color;
+    const uint8_t* sh;
+    const uint8_t* chunk;
+    uint32_t n, posFmt, scaleFmt, colorFmt, shFmt, chunkCount;
+};
+
+struct FrameConsts {            // gs_frame_params flattened for kernel argument passing
+    float mv[12];               // rows 0..2 of _MatrixMV
+    float o2w[12];              // rows 0..2 of _MatrixObjectToWorld
+    float w2o[12];              // rows 0..2 of _MatrixWorldToObject (3x3 part used)
+    float vp[16];               // UNITY_MATRIX_VP
+    float p00, p11, screenW, screenH;
+    float camx, camy, camz;
+    float splatScale, opacityScale;
+    uint32_t shOrder, shOnly;
+    float nearClip, farClip;
+};
+
+struct ViewData { float pos[4]; float axis1[2]; float axis2[2]; uint32_t color[2]; };   // 40 B SplatViewData
+
+// ---- bit casts / half ---------------------------------------------------------------------------
+GS_HD uint32_t f2u(float f) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __float_as_uint(f);
+#else
+    uint32_t u; memcpy(&u, &f, 4); return u;
+#endif
+}
+GS_HD float u2f(uint32_t u) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __uint_as_float(u);
+#else
+    float f; memcpy(&f, &u, 4); return f;
+#endif
+}
+GS_HD float f16tof32(uint32_t h) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __half2float(__ushort_as_half((unsigned short)(h & 0xffffu)));
+#else
+    h &= 0xffffu;
+    const uint32_t sign = (h & 0x8000u) << 16, e = (h >> 10) & 0x1fu;
+    uint32_t m = h & 0x3ffu, x;
+    if (e == 0) {
+        if (m == 0) x = sign;
+        else { int s = 0; while (!(m & 0x400u)) { m <<= 1; s++; } m &= 0x3ffu; x = sign | ((uint32_t)(113 - s) << 23) | (m << 13); }
+    } else if (e == 31) x = sign | 0x7f800000u | (m << 13);
+    else x = sign | ((e + 112u) << 23) | (m << 13);
+    return u2f(x);
+#endif
+}
+GS_HD uint32_t f32tof16(float f) {     // round to nearest even
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (uint32_t)__half_as_ushort(__float2half_rn(f));
+#else
+    uint32_t x = f2u(f);
+    const uint32_t sign = (x >> 16) & 0x8000u;
+    x &= 0x7fffffffu;
+    if (x > 0x7f800000u) return sign | 0x7e00u;
+    if (x >= 0x477ff000u) return sign | 0x7c00u;
+    if (x < 0x38800000u) {
+        if (x < 0x33000000u) return sign;
+        const uint32_t e = x >> 23, m = (x & 0x7fffffu) | 0x800000u, shift = 126u - e;
+        uint32_t r = m >> shift;
+        const uint32_t rem = m & ((1u << shift) - 1u), half = 1u << (shift - 1u);
+        if (rem > half || (rem == half && (r & 1u))) r++;
+        return sign | r;
+    }
+    uint32_t r = x - 0x38000000u;
+    const uint32_t rem = r & 0x1fffu;
+    r >>= 13;
+    if (rem > 0x1000u || (rem == 0x1000u && (r & 1u))) r++;
+    return sign | r;
+#endif
+}
+
+// ---- scalar helpers -----------------------------------------------------------------------------
+GS_HD float lerpf(float a, float b, float t) { return fmaf(t, b - a, a); }
+GS_HD float sat(float x) { return fminf(fmaxf(x, 0.0f), 1.0f); }
+GS_HD float sgn(float x) { return (x > 0.0f) ? 1.0f : ((x < 0.0f) ? -1.0f : 0.0f); }
+GS_HD float dot3f(float ax, float ay, float az, float bx, float by, float bz) { return fmaf(az, bz, fmaf(ay, by, ax * bx)); }
+GS_HD float dot2f(float ax, float ay, float bx, float by) { return fmaf(ay, by, ax * bx); }
+// row r of mul(M, float4(v,1)) for a matrix stored as rows of 4
+GS_HD float mrow(const float* m, int r, float x, float y, float z) {
+    return fmaf(m[r * 4 + 2], z, fmaf(m[r * 4 + 1], y, fmaf(m[r * 4 + 0], x, m[r * 4 + 3])));
+}
+GS_HD float mrow3(const float* m, int r, float x, float y, float z) {
+    return fmaf(m[r * 4 + 2], z, fmaf(m[r * 4 + 1], y, m[r * 4 + 0] * x));
+}
+
+GS_HD uint32_t FloatToSortableUint(float f) {
+    const uint32_t fu = f2u(f);
+    const uint32_t mask = (uint32_t)(-(int32_t)(fu >> 31)) | 0x80000000u;
+    return fu ^ mask;
+}
+
+// ---- raw loads (2-byte aligned addresses, stitched from aligned dwords like the HLSL) -------------
+GS_HD uint32_t ld32a(const uint8_t* p, uint64_t a) { return *(const uint32_t*)(p + a); }            // a % 4 == 0
+GS_HD uint32_t LoadUInt(const uint8_t* p, uint64_t a) {
+    const uint64_t aa = a & ~(uint64_t)3;
+    uint32_t v = ld32a(p, aa);
+    if (a != aa) { const uint32_t v1 = ld32a(p, aa + 4); v = (v >> 16) | (v1 << 16); }
+    return v;
+}
+GS_HD uint32_t LoadUShort(const uint8_t* p, uint64_t a) {
+    const uint64_t aa = a & ~(uint64_t)3;
+    uint32_t v = ld32a(p, aa);
+    if (a != aa) v >>= 16;
+    return v & 0xffffu;
+}
+
+#define GS_R63 (1.0f / 63.0f)
+#define GS_R31 (1.0f / 31.0f)
+#define GS_R2047 (1.0f / 2047.0f)
+#define GS_R1023 (1.0f / 1023.0f)
+#define GS_R65535 (1.0f / 65535.0f)
+#define GS_R255 (1.0f / 255.0f)
+
+struct V3 { float x, y, z; };
+struct V4 { float x, y, z, w; };
+
+GS_HD V3 Dec_6_5_5(uint32_t e) { return { (float)(e & 63) * GS_R63, (float)((e >> 6) & 31) * GS_R31, (float)((e >> 11) & 31) * GS_R31 }; }
+GS_HD V3 Dec_5_6_5(uint32_t e) { return { (float)(e & 31) * GS_R31, (float)((e >> 5) & 63) * GS_R63, (float)((e >> 11) & 31) * GS_R31 }; }
+GS_HD V3 Dec_11_10_11(uint32_t e) { return { (float)(e & 2047) * GS_R2047, (float)((e >> 11) & 1023) * GS_R1023, (float)((e >> 21) & 2047) * GS_R2047 }; }
+GS_HD V3 Dec_16_16_16(uint32_t e0, uint32_t e1) { return { (float)(e0 & 65535) * GS_R65535, (float)(e0 >> 16) * GS_R65535, (float)(e1 & 65535) * GS_R65535 }; }
+
+GS_HD uint32_t vecStride(uint32_t fmt) { return fmt == 0 ? 12u : (fmt == 1 ? 6u : (fmt == 2 ? 4u : 2u)); }
+
+GS_HD V3 LoadVec(const uint8_t* buf, uint64_t a, uint32_t fmt) {
+    if (fmt == 0) return { u2f(LoadUInt(buf, a)), u2f(LoadUInt(buf, a + 4)), u2f(LoadUInt(buf, a + 8)) };
+    if (fmt == 1) return Dec_16_16_16(LoadUInt(buf, a), LoadUShort(buf, a + 4));
+    if (fmt == 2) return Dec_11_10_11(LoadUInt(buf, a));
+    return Dec_6_5_5(LoadUShort(buf, a));
+}
+
+struct ChunkRaw { uint32_t w[16]; };    // colR,colG,colB,colA, posX(2),posY(2),posZ(2), sclX..Z, shR..B
+GS_HD ChunkRaw LoadChunk(const uint8_t* chunk, uint32_t ci) {
+    ChunkRaw c;
+    const uint32_t* p = (const uint32_t*)(chunk + (uint64_t)ci * 64);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) c.w[k] = p[k];     // uniform per 256-splat block: becomes one scalar s_load_dwordx16
+    return c;
+}
+
+// LoadSplatPos (GaussianSplatting.hlsl:394-421)
+GS_HD V3 LoadSplatPos(const AssetView& a, uint32_t idx) {
+    V3 p = LoadVec(a.pos, (uint64_t)idx * vecStride(a.posFmt), a.posFmt);
+    const uint32_t ci = idx >> 8;
+    if (ci < a.chunkCount) {
+        const uint8_t* c = a.chunk + (uint64_t)ci * 64;
+        p.x = lerpf(u2f(ld32a(c, 16)), u2f(ld32a(c, 20)), p.x);
+        p.y = lerpf(u2f(ld32a(c, 24)), u2f(ld32a(c, 28)), p.y);
+        p.z = lerpf(u2f(ld32a(c, 32)), u2f(ld32a(c, 36)), p.z);
+    }
+    return p;
+}
+
+// CSCalcDistances body (SplatUtilities.compute:76-81): key of the splat `origIdx` under sort-matrix row 2
+GS_HD uint32_t SortKey(const AssetView& a, uint32_t origIdx, float m20, float m21, float m22, float m23) {
+    const V3 p = LoadSplatPos(a, origIdx);
+    const float z = fmaf(m22, p.z, fmaf(m21, p.y, fmaf(m20, p.x, m23)));
+    return FloatToSortableUint(z);
+}
+
+GS_HD void SplatIndexToPixelIndex(uint32_t idx, uint32_t& x, uint32_t& y) {
+    uint32_t t = idx;
+    t = (t & 0xFF) | ((t & 0xFE) << 7);
+    t &= 0x5555;
+    t = (t ^ (t >> 1)) & 0x3333;
+    t = (t ^ (t >> 2)) & 0x0f0f;
+    const uint32_t tile = idx >> 8;
+    x = (tile & 127u) * 16 + (t & 0xF);
+    y = (tile >> 7) * 16 + (t >> 8);
+}
+
+GS_HD float InvSquareCentered01(float x) {
+    x -= 0.5f;
+    x *= 0.5f;
+    x = sqrtf(fabsf(x)) * sgn(x);
+    return x + 0.5f;
+}
+
+GS_HD V4 DecodeRotation(uint32_t enc) {
+    const float px = (float)(enc & 1023) * GS_R1023, py = (float)((enc >> 10) & 1023) * GS_R1023, pz = (float)((enc >> 20) & 1023) * GS_R1023;
+    const uint32_t idx = enc >> 30;
+    const float SQRT2 = 1.41421356237f, INV_SQRT2 = 0.70710678118f;
+    const float qx = fmaf(px, SQRT2, -INV_SQRT2), qy = fmaf(py, SQRT2, -INV_SQRT2), qz = fmaf(pz, SQRT2, -INV_SQRT2);
+    const float qw = sqrtf(1.0f - sat(dot3f(qx, qy, qz, qx, qy, qz)));
+    V4 q = { qx, qy, qz, qw };
+    if (idx == 0) q = { qw, qx, qy, qz };
+    if (idx == 1) q = { qx, qw, qy, qz };
+    if (idx == 2) q = { qx, qy, qw, qz };
+    return q;
+}
+
+// SH coefficient k (1..15) of the splat whose SH record starts at `sp`, before chunk de-normalisation
+GS_HD V3 LoadSH(const uint8_t* sp, uint32_t shFormat, int k) {
+    if (shFormat == 0) return { u2f(ld32a(sp, (k - 1) * 12)), u2f(ld32a(sp, (k - 1) * 12 + 4)), u2f(ld32a(sp, (k - 1) * 12 + 8)) };
+    if (shFormat == 2) return Dec_11_10_11(ld32a(sp, (k - 1) * 4));
+    if (shFormat == 3) return Dec_5_6_5(LoadUShort(sp, (uint64_t)(k - 1) * 2));
+    // fp16 (Float16 and Cluster* tables)
+    return { f16tof32(LoadUShort(sp, (uint64_t)(k - 1) * 6)), f16tof32(LoadUShort(sp, (uint64_t)(k - 1) * 6 + 2)), f16tof32(LoadUShort(sp, (uint64_t)(k - 1) * 6 + 4)) };
+}
+
+GS_HD uint32_t shStrideOf(uint32_t shFormat) { return shFormat == 0 ? 192u : (shFormat == 2 ? 60u : (shFormat == 3 ? 32u : 96u)); }
+
+#define GS_SH_C1 0.4886025f
+
+// CSCalcViewData for one splat (SplatUtilities.compute:189-252), cutouts/deleted bits absent.
+// SH coefficients are consumed in order sh1..sh15 by three fmaf chains (degree 1, 2, 3), so they are decoded
+// one at a time instead of being held in 45 registers.
+GS_HD ViewData CalcViewData(const AssetView& a, const FrameConsts& P, uint32_t idx) {
+    ViewData view;
+    view.pos[0] = view.pos[1] = view.pos[2] = view.pos[3] = 0.0f;
+    view.axis1[0] = view.axis1[1] = view.axis2[0] = view.axis2[1] = 0.0f;
+    view.color[0] = view.color[1] = 0u;
+
+    // ---- LoadSplatData: position first (needed for the early out)
+    V3 pos = LoadVec(a.pos, (uint64_t)idx * vecStride(a.posFmt), a.posFmt);
+    const uint32_t ci = idx >> 8;
+    const bool chunked = ci < a.chunkCount;
+    ChunkRaw ck;
+    if (chunked) {
+        ck = LoadChunk(a.chunk, ci);
+        pos.x = lerpf(u2f(ck.w[4]), u2f(ck.w[5]), pos.x);
+        pos.y = lerpf(u2f(ck.w[6]), u2f(ck.w[7]), pos.y);
+        pos.z = lerpf(u2f(ck.w[8]), u2f(ck.w[9]), pos.z);
+    }
+    const float wx = mrow(P.o2w, 0, pos.x, pos.y, pos.z), wy = mrow(P.o2w, 1, pos.x, pos.y, pos.z), wz = mrow(P.o2w, 2, pos.x, pos.y, pos.z);
+    view.pos[0] = mrow(P.vp, 0, wx, wy, wz);
+    view.pos[1] = mrow(P.vp, 1, wx, wy, wz);
+    view.pos[2] = mrow(P.vp, 2, wx, wy, wz);
+    view.pos[3] = mrow(P.vp, 3, wx, wy, wz);
+    if (!(view.pos[3] > 0.0f)) return view;                       // behindCam
+
+    // ---- rotation / scale
+    uint32_t otherStride = 4 + vecStride(a.scaleFmt);
+    if (a.shFmt > 3) otherStride += 2;
+    const uint64_t otherAddr = (uint64_t)idx * otherStride;
+    const V4 q = DecodeRotation(LoadUInt(a.other, otherAddr));
+    V3 scale = LoadVec(a.other, otherAddr + 4, a.scaleFmt);
+
+    // ---- colour texel
+    uint32_t tx, ty;
+    SplatIndexToPixelIndex(idx, tx, ty);
+    const uint64_t texel = (uint64_t)ty * 2048 + tx;
+    V4 col;
+    if (a.colorFmt == 0) {
+        const uint8_t* c = a.color + texel * 16;
+        col = { u2f(ld32a(c, 0)), u2f(ld32a(c, 4)), u2f(ld32a(c, 8)), u2f(ld32a(c, 12)) };
+    } else if (a.colorFmt == 1) {
+        const uint32_t lo = ld32a(a.color, texel * 8), hi = ld32a(a.color, texel * 8 + 4);
+        col = { f16tof32(lo), f16tof32(lo >> 16), f16tof32(hi), f16tof32(hi >> 16) };
+    } else {
+        const uint32_t e = ld32a(a.color, texel * 4);
+        col = { (float)(e & 255) * GS_R255, (float)((e >> 8) & 255) * GS_R255, (float)((e >> 16) & 255) * GS_R255, (float)(e >> 24) * GS_R255 };
+    }
+
+    V3 shMin = { 0, 0, 0 }, shMax = { 0, 0, 0 };
+    bool shLerp = false;
+    if (chunked) {
+        scale.x = lerpf(f16tof32(ck.w[10]), f16tof32(ck.w[10] >> 16), scale.x);
+        scale.y = lerpf(f16tof32(ck.w[11]), f16tof32(ck.w[11] >> 16), scale.y);
+        scale.z = lerpf(f16tof32(ck.w[12]), f16tof32(ck.w[12] >> 16), scale.z);
+        scale.x *= scale.x; scale.y *= scale.y; scale.z *= scale.z;
+        scale.x *= scale.x; scale.y *= scale.y; scale.z *= scale.z;
+        scale.x *= scale.x; scale.y *= scale.y; scale.z *= scale.z;
+        col.x = lerpf(f16tof32(ck.w[0]), f16tof32(ck.w[0] >> 16), col.x);
+        col.y = lerpf(f16tof32(ck.w[1]), f16tof32(ck.w[1] >> 16), col.y);
+        col.z = lerpf(f16tof32(ck.w[2]), f16tof32(ck.w[2] >> 16), col.z);
+        col.w = lerpf(f16tof32(ck.w[3]), f16tof32(ck.w[3] >> 16), col.w);
+        col.w = InvSquareCentered01(col.w);
+        shMin = { f16tof32(ck.w[13]), f16tof32(ck.w[14]), f16tof32(ck.w[15]) };
+        shMax = { f16tof32(ck.w[13] >> 16), f16tof32(ck.w[14] >> 16), f16tof32(ck.w[15] >> 16) };
+        shLerp = a.shFmt > 0 && a.shFmt <= 3;
+    }
+
+    // ---- CalcMatrixFromRotationScale + CalcCovariance3D
+    const float x = q.x, y = q.y, z = q.z, w = q.w;
+    const float r00 = fmaf(-2.0f, fmaf(z, z, y * y), 1.0f), r01 = 2.0f * fmaf(-w, z, x * y), r02 = 2.0f * fmaf(w, y, x * z);
+    const float r10 = 2.0f * fmaf(w, z, x * y), r11 = fmaf(-2.0f, fmaf(z, z, x * x), 1.0f), r12 = 2.0f * fmaf(-w, x, y * z);
+    const float r20 = 2.0f * fmaf(-w, y, x * z), r21 = 2.0f * fmaf(w, x, y * z), r22 = fmaf(-2.0f, fmaf(y, y, x * x), 1.0f);
+    const float m00 = r00 * scale.x, m01 = r01 * scale.y, m02 = r02 * scale.z;
+    const float m10 = r10 * scale.x, m11 = r11 * scale.y, m12 = r12 * scale.z;
+    const float m20 = r20 * scale.x, m21 = r21 * scale.y, m22 = r22 * scale.z;
+    const float ss2 = P.splatScale * P.splatScale;
+    const float c00 = dot3f(m00, m01, m02, m00, m01, m02) * ss2, c01 = dot3f(m00, m01, m02, m10, m11, m12) * ss2, c02 = dot3f(m00, m01, m02, m20, m21, m22) * ss2;
+    const float c11 = dot3f(m10, m11, m12, m10, m11, m12) * ss2, c12 = dot3f(m10, m11, m12, m20, m21, m22) * ss2, c22 = dot3f(m20, m21, m22, m20, m21, m22) * ss2;
+
+    // ---- CalcCovariance2D
+    float vx = mrow(P.mv, 0, pos.x, pos.y, pos.z), vy = mrow(P.mv, 1, pos.x, pos.y, pos.z);
+    const float vz = mrow(P.mv, 2, pos.x, pos.y, pos.z);
+    const float aspect = P.p00 / P.p11;
+    const float tanFovX = 1.0f / P.p00;
+    const float tanFovY = 1.0f / (P.p11 * aspect);
+    const float limX = 1.3f * tanFovX, limY = 1.3f * tanFovY;
+    vx = fminf(fmaxf(vx / vz, -limX), limX) * vz;
+    vy = fminf(fmaxf(vy / vz, -limY), limY) * vz;
+    const float focal = P.screenW * P.p00 / 2.0f;
+    const float zz2 = vz * vz;
+    const float J00 = focal / vz, J02 = -(focal * vx) / zz2;
+    const float J11 = J00, J12 = -(focal * vy) / zz2;
+    const float T00 = fmaf(J02, P.mv[8], J00 * P.mv[0]), T01 = fmaf(J02, P.mv[9], J00 * P.mv[1]), T02 = fmaf(J02, P.mv[10], J00 * P.mv[2]);
+    const float T10 = fmaf(J12, P.mv[8], J11 * P.mv[4]), T11 = fmaf(J12, P.mv[9], J11 * P.mv[5]), T12 = fmaf(J12, P.mv[10], J11 * P.mv[6]);
+    // VT[i][j] = sum_k V[i][k] * T[j][k]
+    const float VT00 = dot3f(c00, c01, c02, T00, T01, T02), VT01 = dot3f(c00, c01, c02, T10, T11, T12);
+    const float VT10 = dot3f(c01, c11, c12, T00, T01, T02), VT11 = dot3f(c01, c11, c12, T10, T11, T12);
+    const float VT20 = dot3f(c02, c12, c22, T00, T01, T02), VT21 = dot3f(c02, c12, c22, T10, T11, T12);
+    const float cov00 = dot3f(T00, T01, T02, VT00, VT10, VT20) + 0.3f;
+    const float cov01 = dot3f(T00, T01, T02, VT01, VT11, VT21);
+    const float cov11 = dot3f(T10, T11, T12, VT01, VT11, VT21) + 0.3f;
+
+    // ---- DecomposeCovariance (#else branch)
+    const float mid = 0.5f * (cov00 + cov11);
+    const float hx = (cov00 - cov11) / 2.0f;
+    const float radius = sqrtf(dot2f(hx, cov01, hx, cov01));
+    const float lambda1 = mid + radius;
+    const float lambda2 = fmaxf(mid - radius, 0.1f);
+    float dvx = cov01, dvy = lambda1 - cov00;
+    const float invLen = 1.0f / sqrtf(dot2f(dvx, dvy, dvx, dvy));
+    dvx *= invLen; dvy *= invLen;
+    dvy = -dvy;
+    const float s1 = fminf(sqrtf(2.0f * lambda1), 4096.0f), s2 = fminf(sqrtf(2.0f * lambda2), 4096.0f);
+    view.axis1[0] = s1 * dvx; view.axis1[1] = s1 * dvy;
+    view.axis2[0] = s2 * dvy; view.axis2[1] = s2 * (-dvx);
+
+    // ---- view direction in object space, SH basis
+    const float dwx = P.camx - wx, dwy = P.camy - wy, dwz = P.camz - wz;
+    float ox = mrow3(P.w2o, 0, dwx, dwy, dwz), oy = mrow3(P.w2o, 1, dwx, dwy, dwz), oz = mrow3(P.w2o, 2, dwx, dwy, dwz);
+    const float invN = 1.0f / sqrtf(dot3f(ox, oy, oz, ox, oy, oz));
+    ox *= invN; oy *= invN; oz *= invN;
+    const float dx = -ox, dy = -oy, dz = -oz;
+
+    const bool onlySH = P.shOnly != 0;
+    float r = onlySH ? 0.5f : col.x, g = onlySH ? 0.5f : col.y, b = onlySH ? 0.5f : col.z;
+    if (P.shOrder >= 1) {
+        uint32_t shIndex = idx;
+        if (a.shFmt > 3) shIndex = LoadUShort(a.other, otherAddr + otherStride - 2);
+        const uint8_t* sp = a.sh + (uint64_t)shIndex * shStrideOf(a.shFmt);
+        auto SHK = [&](int k) -> V3 {
+            V3 s = LoadSH(sp, a.shFmt, k);
+            if (shLerp) { s.x = lerpf(shMin.x, shMax.x, s.x); s.y = lerpf(shMin.y, shMax.y, s.y); s.z = lerpf(shMin.z, shMax.z, s.z); }
+            return s;
+        };
+        {   // degree 1: res += C1 * (-sh1*y + sh2*z - sh3*x)
+            const V3 s1v = SHK(1), s2v = SHK(2), s3v = SHK(3);
+            float tr = (-s1v.x) * dy, tg = (-s1v.y) * dy, tb = (-s1v.z) * dy;
+            tr = fmaf(s2v.x, dz, tr); tg = fmaf(s2v.y, dz, tg); tb = fmaf(s2v.z, dz, tb);
+            tr = fmaf(-s3v.x, dx, tr); tg = fmaf(-s3v.y, dx, tg); tb = fmaf(-s3v.z, dx, tb);
+            r = fmaf(GS_SH_C1, tr, r); g = fmaf(GS_SH_C1, tg, g); b = fmaf(GS_SH_C1, tb, b);
+        }
+        if (P.shOrder >= 2) {
+            const float xx = dx * dx, yy = dy * dy, zz = dz * dz;
+            const float xy = dx * dy, yz = dy * dz, xz = dx * dz;
+            {
+                const float b4 = 1.0925484f * xy, b5 = -1.0925484f * yz, b6 = 0.3153916f * (fmaf(2.0f, zz, -xx) - yy),
+                            b7 = -1.0925484f * xz, b8 = 0.5462742f * (xx - yy);
+                V3 s = SHK(4);
+                float ar = b4 * s.x, ag = b4 * s.y, ab = b4 * s.z;
+                s = SHK(5); ar = fmaf(b5, s.x, ar); ag = fmaf(b5, s.y, ag); ab = fmaf(b5, s.z, ab);
+                s = SHK(6); ar = fmaf(b6, s.x, ar); ag = fmaf(b6, s.y, ag); ab = fmaf(b6, s.z, ab);
+                s = SHK(7); ar = fmaf(b7, s.x, ar); ag = fmaf(b7, s.y, ag); ab = fmaf(b7, s.z, ab);
+                s = SHK(8); ar = fmaf(b8, s.x, ar); ag = fmaf(b8, s.y, ag); ab = fmaf(b8, s.z, ab);
+                r += ar; g += ag; b += ab;
+            }
+            if (P.shOrder >= 3) {
+                const float b9 = (-0.5900436f * dy) * fmaf(3.0f, xx, -yy);
+                const float b10 = (2.8906114f * xy) * dz;
+                const float b11 = (-0.4570458f * dy) * (fmaf(4.0f, zz, -xx) - yy);
+                const float b12 = (0.3731763f * dz) * (fmaf(2.0f, zz, -3.0f * xx) - 3.0f * yy);
+                const float b13 = (-0.4570458f * dx) * (fmaf(4.0f, zz, -xx) - yy);
+                const float b14 = (1.4453057f * dz) * (xx - yy);
+                const float b15 = (-0.5900436f * dx) * fmaf(-3.0f, yy, xx);
+                V3 s = SHK(9);
+                float ar = b9 * s.x, ag = b9 * s.y, ab = b9 * s.z;
+                s = SHK(10); ar = fmaf(b10, s.x, ar); ag = fmaf(b10, s.y, ag); ab = fmaf(b10, s.z, ab);
+                s = SHK(11); ar = fmaf(b11, s.x, ar); ag = fmaf(b11, s.y, ag); ab = fmaf(b11, s.z, ab);
+                s = SHK(12); ar = fmaf(b12, s.x, ar); ag = fmaf(b12, s.y, ag); ab = fmaf(b12, s.z, ab);
+                s = SHK(13); ar = fmaf(b13, s.x, ar); ag = fmaf(b13, s.y, ag); ab = fmaf(b13, s.z, ab);
+                s = SHK(14); ar = fmaf(b14, s.x, ar); ag = fmaf(b14, s.y, ag); ab = fmaf(b14, s.z, ab);
+                s = SHK(15); ar = fmaf(b15, s.x, ar); ag = fmaf(b15, s.y, ag); ab = fmaf(b15, s.z, ab);
+                r += ar; g += ag; b += ab;
+            }
+        }
+    }
+    r = fmaxf(r, 0.0f); g = fmaxf(g, 0.0f); b = fmaxf(b, 0.0f);
+    const float al = fminf(col.w * P.opacityScale, 65000.0f);
+    view.color[0] = (f32tof16(r) << 16) | f32tof16(g);
+    view.color[1] = (f32tof16(b) << 16) | f32tof16(al);
+    return view;
+}
+
+} // namespace gsm
