@@ -1,0 +1,46 @@
+// Test-only: compiles the kernels' arithmetic header (csrc/gs_device_math.h) for the HOST so that it can be
+// compared with the oracle bit for bit on a box without a GPU.  Never part of the shipped library.
+#include "../include/gsplat_c.h"
+#include "../unitygaussiansplatting_amd/csrc/gs_device_math.h"
+
+static gsm::AssetView mk(const gs_asset_desc* d) {
+    gsm::AssetView a;
+    a.pos = (const uint8_t*)d->pos_data; a.other = (const uint8_t*)d->other_data; a.color = (const uint8_t*)d->color_data;
+    a.sh = (const uint8_t*)d->sh_data; a.chunk = (const uint8_t*)d->chunk_data;
+    a.n = d->splat_count; a.posFmt = d->pos_format; a.scaleFmt = d->scale_format; a.colorFmt = d->color_format; a.shFmt = d->sh_format;
+    a.chunkCount = (d->chunk_data && d->chunk_size) ? (uint32_t)(d->chunk_size / 64) : 0;
+    return a;
+}
+static gsm::FrameConsts fl(const gs_frame_params* p) {
+    gsm::FrameConsts c;
+    memcpy(c.mv, p->matrix_mv, 48); memcpy(c.o2w, p->matrix_object_to_world, 48); memcpy(c.w2o, p->matrix_world_to_object, 48);
+    memcpy(c.vp, p->matrix_vp, 64);
+    c.p00 = p->proj_m00; c.p11 = p->proj_m11; c.screenW = p->screen_w; c.screenH = p->screen_h;
+    c.camx = p->cam_pos_world[0]; c.camy = p->cam_pos_world[1]; c.camz = p->cam_pos_world[2];
+    c.splatScale = p->splat_scale; c.opacityScale = p->opacity_scale; c.shOrder = p->sh_order; c.shOnly = p->sh_only;
+    c.nearClip = p->near_clip; c.farClip = p->far_clip;
+    return c;
+}
+extern "C" {
+void hm_calc_view(const gs_asset_desc* d, const gs_frame_params* p, void* out) {
+    const gsm::AssetView a = mk(d); const gsm::FrameConsts c = fl(p);
+    gsm::ViewData* o = (gsm::ViewData*)out;
+    for (uint32_t i = 0; i < a.n; ++i) o[i] = gsm::CalcViewData(a, c, i);
+}
+void hm_calc_distances(const gs_asset_desc* d, const uint32_t* order, const float* m, uint32_t* keys) {
+    const gsm::AssetView a = mk(d);
+    for (uint32_t i = 0; i < a.n; ++i) keys[i] = gsm::SortKey(a, order[i], m[8], m[9], m[10], m[11]);
+}
+// footprints: out[i] = {tx0,tx1,ty0,ty1, ok}; centres: cxy[i] = {cx,cy}
+void hm_prepare(const void* view, uint32_t n, const gs_frame_params* p, int32_t* out, float* cxy) {
+    const gsm::ViewData* v = (const gsm::ViewData*)view;
+    for (uint32_t i = 0; i < n; ++i) {
+        gsm::SplatFootprint fp;
+        const bool ok = gsm::PrepareSplat(v[i], p->screen_w, p->screen_h, p->near_clip, p->far_clip, fp);
+        out[i * 5 + 0] = fp.tx0; out[i * 5 + 1] = fp.tx1; out[i * 5 + 2] = fp.ty0; out[i * 5 + 3] = fp.ty1; out[i * 5 + 4] = ok;
+        cxy[i * 2] = fp.cx; cxy[i * 2 + 1] = fp.cy;
+    }
+}
+uint32_t hm_f32tof16(float f) { return gsm::f32tof16(f); }
+float hm_f16tof32(uint32_t h) { return gsm::f16tof32(h); }
+}

@@ -1,0 +1,507 @@
+// gs_api.hip -- the C-ABI of include/gsplat_c.h: object lifetime, argument validation, stream sequencing.
+// Mirrors what GaussianSplatRenderer.cs / GpuSorting.cs do on Unity's main thread (buffer creation :373-445,
+// dispatch order :108-211,579-639, disposal :527-577); every kernel lives in gs_sort/gs_view/gs_raster.hip.
+#include <stdarg.h>
+
+#include <new>
+
+#include "gs_common.h"
+
+namespace gs {
+
+static thread_local char g_err[512] = "";
+
+void set_error_detail(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+int32_t fail(int32_t code, const char* what) {
+    set_error_detail("%s", what);
+    return code;
+}
+int32_t fail_hip(hipError_t e, const char* what, const char* file, int line) {
+    set_error_detail("%s failed: %s (%s:%d)", what, hipGetErrorString(e), file, line);
+    return e == hipErrorOutOfMemory ? GS_ERR_OUT_OF_MEMORY : GS_ERR_HIP;
+}
+
+} // namespace gs
+
+using namespace gs;
+
+static int32_t bind_device(gs_context* ctx) {
+    GS_HIP(hipSetDevice(ctx->device));
+    return GS_OK;
+}
+
+extern "C" {
+
+int32_t gs_abi_version(void) { return GS_ABI_VERSION; }
+
+const char* gs_error_string(int32_t err) {
+    switch (err) {
+        case GS_OK: return "ok";
+        case GS_ERR_INVALID_ARGUMENT: return "invalid argument";
+        case GS_ERR_HIP: return "HIP runtime error";
+        case GS_ERR_UNSUPPORTED_FORMAT: return "unsupported format";
+        case GS_ERR_OUT_OF_MEMORY: return "out of device memory";
+        case GS_ERR_INVALID_ASSET: return "invalid asset (blob sizes do not match splat count / formats)";
+        case GS_ERR_PAIR_OVERFLOW: return "tile-pair buffer overflow (buffer was grown; render the frame again)";
+        case GS_ERR_SORT_TIMEOUT: return "sort look-back timed out";
+        case GS_ERR_NO_DEVICE: return "no HIP device";
+        default: return "unknown error";
+    }
+}
+const char* gs_last_error_string(void) { return g_err; }
+
+// ---- context ---------------------------------------------------------------------------------------------
+int32_t gs_context_create(int32_t device, void* hip_stream, gs_context** out) {
+    if (!out) return fail(GS_ERR_INVALID_ARGUMENT, "out is null");
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return fail(GS_ERR_NO_DEVICE, "no HIP device visible");
+    if (device < 0 || device >= count) return fail(GS_ERR_INVALID_ARGUMENT, "device index out of range");
+    gs_context* ctx = new (std::nothrow) gs_context();
+    if (!ctx) return fail(GS_ERR_OUT_OF_MEMORY, "host allocation");
+    ctx->device = device;
+    if (hipSetDevice(device) != hipSuccess) { delete ctx; return fail(GS_ERR_HIP, "hipSetDevice"); }
+    if (hipGetDeviceProperties(&ctx->props, device) != hipSuccess) { delete ctx; return fail(GS_ERR_HIP, "hipGetDeviceProperties"); }
+    ctx->cuCount = ctx->props.multiProcessorCount > 0 ? ctx->props.multiProcessorCount : 256;
+    if (hip_stream) { ctx->stream = (hipStream_t)hip_stream; ctx->ownStream = false; }
+    else {
+        if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return fail(GS_ERR_HIP, "hipStreamCreate"); }
+        ctx->ownStream = true;
+    }
+    *out = ctx;
+    return GS_OK;
+}
+
+int32_t gs_context_destroy(gs_context* ctx) {
+    if (!ctx) return GS_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->ownStream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return GS_OK;
+}
+
+int32_t gs_context_synchronize(gs_context* ctx) {
+    if (!ctx) return fail(GS_ERR_INVALID_ARGUMENT, "ctx is null");
+    GS_TRY(bind_device(ctx));
+    GS_HIP(hipStreamSynchronize(ctx->stream));
+    return GS_OK;
+}
+
+int32_t gs_context_device_info(gs_context* ctx, char* name_out, size_t name_cap, int32_t* cu_count, uint64_t* hbm_bytes) {
+    if (!ctx) return fail(GS_ERR_INVALID_ARGUMENT, "ctx is null");
+    if (name_out && name_cap) { snprintf(name_out, name_cap, "%s (%s)", ctx->props.name, ctx->props.gcnArchName); }
+    if (cu_count) *cu_count = ctx->cuCount;
+    if (hbm_bytes) *hbm_bytes = (uint64_t)ctx->props.totalGlobalMem;
+    return GS_OK;
+}
+
+// ---- asset -----------------------------------------------------------------------------------------------
+static uint64_t sh_item_size(uint32_t f) { return f == 0 ? 192 : (f == 2 ? 60 : (f == 3 ? 32 : 96)); }
+static uint64_t sh_count(uint32_t f, uint64_t n) {
+    switch (f) { case 4: return 65536; case 5: return 32768; case 6: return 16384; case 7: return 8192; case 8: return 4096; default: return n; }
+}
+
+int32_t gs_asset_create(gs_context* ctx, const gs_asset_desc* d, gs_asset** out) {
+    if (!ctx || !d || !out) return fail(GS_ERR_INVALID_ARGUMENT, "null argument");
+    *out = nullptr;
+    if (d->splat_count == 0) return fail(GS_ERR_INVALID_ASSET, "splat_count is 0");
+    if (d->pos_format > 3 || d->scale_format > 3 || d->color_format > 3 || d->sh_format > 8) return fail(GS_ERR_INVALID_ARGUMENT, "format enum out of range");
+    if (d->color_format == GS_COLOR_BC7) return fail(GS_ERR_UNSUPPORTED_FORMAT, "BC7 colour is not supported");
+    if (!d->pos_data || !d->other_data || !d->color_data || !d->sh_data) return fail(GS_ERR_INVALID_ASSET, "a required blob is null");
+    const uint64_t n = d->splat_count;
+    const uint64_t vs[4] = {12, 6, 4, 2};
+    const uint64_t cs[3] = {16, 8, 4};
+    const uint64_t otherStride = 4 + vs[d->scale_format] + (d->sh_format > 3 ? 2 : 0);
+    const uint64_t texH = ((n + 2047) / 2048 + 15) / 16 * 16;
+    const uint64_t need[5] = { n * vs[d->pos_format], n * otherStride, 2048 * texH * cs[d->color_format],
+                               sh_count(d->sh_format, n) * sh_item_size(d->sh_format), 0 };
+    const uint64_t have[5] = { d->pos_size, d->other_size, d->color_size, d->sh_size, d->chunk_size };
+    const void* src[5] = { d->pos_data, d->other_data, d->color_data, d->sh_data, d->chunk_data };
+    for (int k = 0; k < 4; ++k)
+        if (have[k] < need[k]) { set_error_detail("blob %d too small: %llu < %llu", k, (unsigned long long)have[k], (unsigned long long)need[k]); return GS_ERR_INVALID_ASSET; }
+    uint32_t chunkCount = 0;
+    if (d->chunk_data && d->chunk_size) {
+        chunkCount = (uint32_t)(d->chunk_size / 64);
+        if ((uint64_t)chunkCount < (n + 255) / 256) return fail(GS_ERR_INVALID_ASSET, "chunk blob too small");
+    }
+    GS_TRY(bind_device(ctx));
+    gs_asset* a = new (std::nothrow) gs_asset();
+    if (!a) return fail(GS_ERR_OUT_OF_MEMORY, "host allocation");
+    a->ctx = ctx;
+    a->owned = d->memory_kind == 0;
+    for (int k = 0; k < 5; ++k) {
+        a->sizes[k] = have[k];
+        if (!src[k] || have[k] == 0) { a->blobs[k] = nullptr; a->sizes[k] = 0; continue; }
+        if (a->owned) {
+            // +16 B: the 2-byte-aligned dword stitching of LoadUInt may touch the dword after the last record
+            hipError_t e = hipMalloc(&a->blobs[k], have[k] + 16);
+            if (e == hipSuccess) e = hipMemsetAsync((uint8_t*)a->blobs[k] + have[k], 0, 16, ctx->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(a->blobs[k], src[k], have[k], hipMemcpyHostToDevice, ctx->stream);
+            if (e != hipSuccess) { gs_asset_destroy(a); return fail_hip(e, "asset upload", __FILE__, __LINE__); }
+        } else {
+            a->blobs[k] = const_cast<void*>(src[k]);
+        }
+    }
+    if (a->owned) { hipError_t e = hipStreamSynchronize(ctx->stream); if (e != hipSuccess) { gs_asset_destroy(a); return fail_hip(e, "asset upload sync", __FILE__, __LINE__); } }
+    a->view.pos = (const uint8_t*)a->blobs[0]; a->view.other = (const uint8_t*)a->blobs[1]; a->view.color = (const uint8_t*)a->blobs[2];
+    a->view.sh = (const uint8_t*)a->blobs[3]; a->view.chunk = (const uint8_t*)a->blobs[4];
+    a->view.n = d->splat_count; a->view.posFmt = d->pos_format; a->view.scaleFmt = d->scale_format;
+    a->view.colorFmt = d->color_format; a->view.shFmt = d->sh_format; a->view.chunkCount = chunkCount;
+    *out = a;
+    return GS_OK;
+}
+
+int32_t gs_asset_destroy(gs_asset* a) {
+    if (!a) return GS_OK;
+    (void)hipSetDevice(a->ctx->device);
+    if (a->owned) for (int k = 0; k < 5; ++k) if (a->blobs[k]) (void)hipFree(a->blobs[k]);
+    delete a;
+    return GS_OK;
+}
+
+int32_t gs_asset_splat_count(const gs_asset* a, uint32_t* out) {
+    if (!a || !out) return fail(GS_ERR_INVALID_ARGUMENT, "null argument");
+    *out = a->view.n;
+    return GS_OK;
+}
+
+int32_t gs_asset_device_blobs(const gs_asset* a, void* ptrs[5], uint64_t sizes[5]) {
+    if (!a || !ptrs || !sizes) return fail(GS_ERR_INVALID_ARGUMENT, "null argument");
+    for (int k = 0; k < 5; ++k) { ptrs[k] = a->blobs[k]; sizes[k] = a->sizes[k]; }
+    return GS_OK;
+}
+
+// ---- renderer --------------------------------------------------------------------------------------------
+int32_t gs_renderer_create(gs_context* ctx, gs_asset* asset, gs_renderer** out) {
+    if (!ctx || !asset || !out) return fail(GS_ERR_INVALID_ARGUMENT, "null argument");
+    *out = nullptr;
+    if (asset->ctx != ctx) return fail(GS_ERR_INVALID_ARGUMENT, "asset belongs to another context");
+    GS_TRY(bind_device(ctx));
+    gs_renderer* r = new (std::nothrow) gs_renderer();
+    if (!r) return fail(GS_ERR_OUT_OF_MEMORY, "host allocation");
+    r->ctx = ctx; r->asset = asset; r->n = asset->view.n;
+    for (int k = 0; k < 10; ++k) r->evValid[k] = false;
+    int32_t rc = GS_OK;
+    auto chk = [&](hipError_t e, const char* what) { if (rc == GS_OK && e != hipSuccess) rc = fail_hip(e, what, __FILE__, __LINE__); };
+    chk(hipMalloc((void**)&r->view, (size_t)r->n * sizeof(gsm::ViewData) + 64), "alloc view");
+    chk(hipMalloc((void**)&r->distances, (size_t)(r->n + 16) * 4), "alloc distances");
+    chk(hipMalloc((void**)&r->order, (size_t)(r->n + 16) * 4), "alloc order");
+    chk(hipMalloc((void**)&r->depthControl, sizeof(SortControl)), "alloc sort control");
+    if (rc == GS_OK) rc = sort_state_create(ctx, r->depthSort, r->n);
+    if (rc == GS_OK) rc = renderer_alloc_raster(r);
+    if (rc == GS_OK) rc = enqueue_set_indices(ctx, r->order, r->n);
+    if (rc == GS_OK) chk(hipMemsetAsync(r->view, 0, (size_t)r->n * sizeof(gsm::ViewData), ctx->stream), "clear view");
+    if (rc != GS_OK) { gs_renderer_destroy(r); return rc; }
+    *out = r;
+    return GS_OK;
+}
+
+int32_t gs_renderer_destroy(gs_renderer* r) {
+    if (!r) return GS_OK;
+    (void)hipSetDevice(r->ctx->device);
+    (void)hipStreamSynchronize(r->ctx->stream);
+    if (r->view) (void)hipFree(r->view);
+    if (r->distances) (void)hipFree(r->distances);
+    if (r->order) (void)hipFree(r->order);
+    if (r->depthControl) (void)hipFree(r->depthControl);
+    sort_state_destroy(r->depthSort);
+    renderer_free_raster(r);
+    if (r->evCreated) for (int k = 0; k < 10; ++k) (void)hipEventDestroy(r->ev[k]);
+    delete r;
+    return GS_OK;
+}
+
+int32_t gs_renderer_reset_order(gs_renderer* r) {
+    if (!r) return fail(GS_ERR_INVALID_ARGUMENT, "renderer is null");
+    GS_TRY(bind_device(r->ctx));
+    return enqueue_set_indices(r->ctx, r->order, r->n);
+}
+
+static void rec_ev(gs_renderer* r, int k) {
+    if (r->profiling) { (void)hipEventRecord(r->ev[k], r->ctx->stream); r->evValid[k] = true; }
+}
+
+int32_t gs_renderer_sort(gs_renderer* r, const float m[16]) {
+    if (!r || !m) return fail(GS_ERR_INVALID_ARGUMENT, "null argument");
+    GS_TRY(bind_device(r->ctx));
+    rec_ev(r, 0);
+    GS_TRY(enqueue_calc_distances(r->ctx, r->asset->view, r->order, m, r->distances, r->depthControl, r->n));
+    rec_ev(r, 1);
+    GS_TRY(enqueue_sort_passes(r->ctx, r->depthSort, r->depthControl, r->distances, r->order, r->n, nullptr, 4));
+    rec_ev(r, 2);
+    return GS_OK;
+}
+
+int32_t gs_renderer_calc_view(gs_renderer* r, const gs_frame_params* p) {
+    if (!r || !p) return fail(GS_ERR_INVALID_ARGUMENT, "null argument");
+    GS_TRY(bind_device(r->ctx));
+    rec_ev(r, 7);
+    GS_TRY(enqueue_calc_view(r->ctx, r->asset->view, p, r->view));
+    rec_ev(r, 8);
+    return GS_OK;
+}
+
+// host-side read of the previous frame's pair count: grow the pair buffers before they overflow again
+static int32_t maybe_grow_pairs(gs_renderer* r) {
+    if (!r->frameInFlight) return GS_OK;
+    if (hipStreamQuery(r->ctx->stream) != hipSuccess) return GS_OK;       // still running: decide next time
+    if (r->hostBin->pairCount > r->pairCapacity) {
+        unsigned long long want = r->hostBin->pairCount + r->hostBin->pairCount / 4;
+        return gs_renderer_reserve_pairs(r, want);
+    }
+    return GS_OK;
+}
+
+int32_t gs_renderer_draw(gs_renderer* r, const gs_frame_params* p, gs_target* rt) {
+    if (!r || !p || !rt) return fail(GS_ERR_INVALID_ARGUMENT, "null argument");
+    if (rt->ctx != r->ctx) return fail(GS_ERR_INVALID_ARGUMENT, "target belongs to another context");
+    if ((uint32_t)p->screen_w != rt->width || (uint32_t)p->screen_h != rt->height) return fail(GS_ERR_INVALID_ARGUMENT, "screen_w/h do not match the target");
+    GS_TRY(bind_device(r->ctx));
+    GS_TRY(maybe_grow_pairs(r));
+    for (int k = 3; k <= 6; ++k) r->evValid[k] = r->profiling;
+    return enqueue_draw(r, p, rt);
+}
+
+int32_t gs_renderer_render(gs_renderer* r, const float m[16], const gs_frame_params* p, gs_target* rt, int32_t do_sort) {
+    if (!r || !p || !rt) return fail(GS_ERR_INVALID_ARGUMENT, "null argument");
+    if (do_sort) { if (!m) return fail(GS_ERR_INVALID_ARGUMENT, "matrix_sort is null"); GS_TRY(gs_renderer_sort(r, m)); }
+    GS_TRY(gs_renderer_calc_view(r, p));
+    GS_TRY(gs_target_clear(rt));
+    return gs_renderer_draw(r, p, rt);
+}
+
+int32_t gs_renderer_set_blend_mode(gs_renderer* r, int32_t mode) {
+    if (!r || (mode != 0 && mode != 1)) return fail(GS_ERR_INVALID_ARGUMENT, "blend mode must be 0 or 1");
+    r->blendMode = mode;
+    return GS_OK;
+}
+
+int32_t gs_renderer_set_profiling(gs_renderer* r, int32_t enabled) {
+    if (!r) return fail(GS_ERR_INVALID_ARGUMENT, "renderer is null");
+    GS_TRY(bind_device(r->ctx));
+    if (enabled && !r->evCreated) {
+        for (int k = 0; k < 10; ++k) GS_HIP(hipEventCreate(&r->ev[k]));
+        r->evCreated = true;
+    }
+    r->profiling = enabled != 0;
+    for (int k = 0; k < 10; ++k) r->evValid[k] = false;
+    return GS_OK;
+}
+
+int32_t gs_renderer_reserve_pairs(gs_renderer* r, uint64_t cap) {
+    if (!r) return fail(GS_ERR_INVALID_ARGUMENT, "renderer is null");
+    if (cap <= r->pairCapacity) return GS_OK;
+    if (cap > 0xfffffff0ull) cap = 0xfffffff0ull;
+    if (cap <= r->pairCapacity) return GS_OK;
+    GS_TRY(bind_device(r->ctx));
+    GS_HIP(hipStreamSynchronize(r->ctx->stream));
+    if (r->pairKeys) (void)hipFree(r->pairKeys);
+    if (r->pairVals) (void)hipFree(r->pairVals);
+    r->pairKeys = r->pairVals = nullptr;
+    sort_state_destroy(r->pairSort);
+    r->pairCapacity = cap;
+    GS_HIP(hipMalloc((void**)&r->pairKeys, (size_t)(cap + 16) * 4));
+    GS_HIP(hipMalloc((void**)&r->pairVals, (size_t)(cap + 16) * 4));
+    GS_TRY(sort_state_create(r->ctx, r->pairSort, (uint32_t)cap));
+    return GS_OK;
+}
+
+static int32_t download(gs_context* ctx, void* dst, const void* src, size_t bytes) {
+    GS_TRY(bind_device(ctx));
+    GS_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    GS_HIP(hipStreamSynchronize(ctx->stream));
+    return GS_OK;
+}
+
+int32_t gs_renderer_download_order(gs_renderer* r, uint32_t* out, size_t count) {
+    if (!r || !out || count > r->n) return fail(GS_ERR_INVALID_ARGUMENT, "bad argument");
+    return download(r->ctx, out, r->order, count * 4);
+}
+int32_t gs_renderer_download_distances(gs_renderer* r, uint32_t* out, size_t count) {
+    if (!r || !out || count > r->n) return fail(GS_ERR_INVALID_ARGUMENT, "bad argument");
+    return download(r->ctx, out, r->distances, count * 4);
+}
+int32_t gs_renderer_upload_order(gs_renderer* r, const uint32_t* in, size_t count) {
+    if (!r || !in || count != r->n) return fail(GS_ERR_INVALID_ARGUMENT, "bad argument");
+    GS_TRY(bind_device(r->ctx));
+    GS_HIP(hipMemcpyAsync(r->order, in, count * 4, hipMemcpyHostToDevice, r->ctx->stream));
+    GS_HIP(hipStreamSynchronize(r->ctx->stream));
+    return GS_OK;
+}
+int32_t gs_renderer_download_view(gs_renderer* r, void* out, size_t bytes) {
+    if (!r || !out || bytes > (size_t)r->n * sizeof(gsm::ViewData)) return fail(GS_ERR_INVALID_ARGUMENT, "bad argument");
+    return download(r->ctx, out, r->view, bytes);
+}
+
+int32_t gs_renderer_frame_stats(gs_renderer* r, gs_frame_stats* out) {
+    if (!r || !out) return fail(GS_ERR_INVALID_ARGUMENT, "null argument");
+    GS_TRY(bind_device(r->ctx));
+    GS_HIP(hipStreamSynchronize(r->ctx->stream));
+    uint32_t depthErr = 0;
+    GS_HIP(hipMemcpy(&depthErr, &r->depthControl->error, 4, hipMemcpyDeviceToHost));
+    memset(out, 0, sizeof(*out));
+    out->pair_capacity = r->pairCapacity;
+    out->tiles_x = r->lastTilesX; out->tiles_y = r->lastTilesY;
+    if (r->frameInFlight) {
+        out->tile_pairs = r->hostBin->pairCount;
+        out->visible_splats = r->hostBin->visible;
+        out->sort_error = depthErr | r->hostSortErr->error | (r->hostBin->error & 2u);
+    } else out->sort_error = depthErr;
+    if (out->sort_error) return fail(GS_ERR_SORT_TIMEOUT, "a bounded look-back spin expired");
+    if (r->frameInFlight && out->tile_pairs > r->pairCapacity) {
+        const unsigned long long want = out->tile_pairs + out->tile_pairs / 4;
+        GS_TRY(gs_renderer_reserve_pairs(r, want));
+        out->pair_capacity = r->pairCapacity;
+        r->frameInFlight = false;
+        return fail(GS_ERR_PAIR_OVERFLOW, "tile-pair buffer overflowed this frame; it has been grown, render again");
+    }
+    return GS_OK;
+}
+
+int32_t gs_renderer_stage_times(gs_renderer* r, gs_stage_times* out) {
+    if (!r || !out) return fail(GS_ERR_INVALID_ARGUMENT, "null argument");
+    memset(out, 0, sizeof(*out));
+    if (!r->evCreated) return fail(GS_ERR_INVALID_ARGUMENT, "profiling was never enabled");
+    GS_TRY(bind_device(r->ctx));
+    GS_HIP(hipStreamSynchronize(r->ctx->stream));
+    auto el = [&](int a, int b) -> float {
+        float ms = 0.f;
+        if (r->evValid[a] && r->evValid[b] && hipEventElapsedTime(&ms, r->ev[a], r->ev[b]) == hipSuccess) return ms;
+        return 0.f;
+    };
+    out->calc_distances_ms = el(0, 1);
+    out->sort_ms = el(1, 2);
+    out->calc_view_ms = el(7, 8);
+    out->bin_ms = el(3, 4);
+    out->pair_sort_ms = el(4, 5);
+    out->blend_ms = el(5, 6);
+    out->resolve_ms = r->resolveMs;
+    out->total_ms = out->calc_distances_ms + out->sort_ms + out->calc_view_ms + out->bin_ms + out->pair_sort_ms + out->blend_ms;
+    return GS_OK;
+}
+
+// ---- target ----------------------------------------------------------------------------------------------
+int32_t gs_target_create(gs_context* ctx, uint32_t w, uint32_t h, gs_target** out) {
+    if (!ctx || !out || w == 0 || h == 0 || w > 65536 || h > 65536) return fail(GS_ERR_INVALID_ARGUMENT, "bad argument");
+    *out = nullptr;
+    GS_TRY(bind_device(ctx));
+    gs_target* t = new (std::nothrow) gs_target();
+    if (!t) return fail(GS_ERR_OUT_OF_MEMORY, "host allocation");
+    t->ctx = ctx; t->width = w; t->height = h;
+    hipError_t e = hipMalloc((void**)&t->rgba16f, (size_t)w * h * 8);
+    if (e == hipSuccess) e = hipMemsetAsync(t->rgba16f, 0, (size_t)w * h * 8, ctx->stream);
+    if (e != hipSuccess) { delete t; return fail_hip(e, "alloc target", __FILE__, __LINE__); }
+    *out = t;
+    return GS_OK;
+}
+
+int32_t gs_target_destroy(gs_target* t) {
+    if (!t) return GS_OK;
+    (void)hipSetDevice(t->ctx->device);
+    (void)hipStreamSynchronize(t->ctx->stream);
+    if (t->rgba16f) (void)hipFree(t->rgba16f);
+    if (t->resolved) (void)hipFree(t->resolved);
+    if (t->resolved8) (void)hipFree(t->resolved8);
+    delete t;
+    return GS_OK;
+}
+
+int32_t gs_target_clear(gs_target* t) {
+    if (!t) return fail(GS_ERR_INVALID_ARGUMENT, "target is null");
+    GS_TRY(bind_device(t->ctx));
+    GS_HIP(hipMemsetAsync(t->rgba16f, 0, (size_t)t->width * t->height * 8, t->ctx->stream));
+    return GS_OK;
+}
+
+int32_t gs_target_download(gs_target* t, void* out, size_t bytes) {
+    if (!t || !out || bytes > (size_t)t->width * t->height * 8) return fail(GS_ERR_INVALID_ARGUMENT, "bad argument");
+    return download(t->ctx, out, t->rgba16f, bytes);
+}
+
+int32_t gs_target_resolve(gs_target* t, const float bg[4], float* out32, uint8_t* out8) {
+    if (!t || !bg) return fail(GS_ERR_INVALID_ARGUMENT, "null argument");
+    GS_TRY(bind_device(t->ctx));
+    GS_TRY(enqueue_resolve(t, bg));
+    const size_t px = (size_t)t->width * t->height;
+    if (out32) GS_HIP(hipMemcpyAsync(out32, t->resolved, px * 16, hipMemcpyDeviceToHost, t->ctx->stream));
+    if (out8) GS_HIP(hipMemcpyAsync(out8, t->resolved8, px * 4, hipMemcpyDeviceToHost, t->ctx->stream));
+    if (out32 || out8) GS_HIP(hipStreamSynchronize(t->ctx->stream));
+    return GS_OK;
+}
+
+int32_t gs_target_device_ptr(gs_target* t, void** rgba16f_dev, void** resolved_dev) {
+    if (!t) return fail(GS_ERR_INVALID_ARGUMENT, "target is null");
+    if (rgba16f_dev) *rgba16f_dev = t->rgba16f;
+    if (resolved_dev) *resolved_dev = t->resolved;
+    return GS_OK;
+}
+
+// ---- stand-alone sorter (GpuSorting) ---------------------------------------------------------------------
+int32_t gs_sorter_create(gs_context* ctx, uint32_t max_count, gs_sorter** out) {
+    if (!ctx || !out || max_count == 0) return fail(GS_ERR_INVALID_ARGUMENT, "bad argument");
+    *out = nullptr;
+    GS_TRY(bind_device(ctx));
+    gs_sorter* s = new (std::nothrow) gs_sorter();
+    if (!s) return fail(GS_ERR_OUT_OF_MEMORY, "host allocation");
+    s->ctx = ctx;
+    int32_t rc = sort_state_create(ctx, s->st, max_count);
+    if (rc == GS_OK && hipMalloc((void**)&s->control, sizeof(SortControl)) != hipSuccess) rc = fail(GS_ERR_OUT_OF_MEMORY, "alloc sort control");
+    if (rc != GS_OK) { gs_sorter_destroy(s); return rc; }
+    *out = s;
+    return GS_OK;
+}
+
+int32_t gs_sorter_destroy(gs_sorter* s) {
+    if (!s) return GS_OK;
+    (void)hipSetDevice(s->ctx->device);
+    (void)hipStreamSynchronize(s->ctx->stream);
+    sort_state_destroy(s->st);
+    if (s->control) (void)hipFree(s->control);
+    if (s->tmpKeys) (void)hipFree(s->tmpKeys);
+    if (s->tmpVals) (void)hipFree(s->tmpVals);
+    delete s;
+    return GS_OK;
+}
+
+int32_t gs_sorter_dispatch(gs_sorter* s, void* keys_dev, void* values_dev, uint32_t count, uint32_t key_bits) {
+    if (!s || !keys_dev || !values_dev) return fail(GS_ERR_INVALID_ARGUMENT, "null argument");
+    if (key_bits < 1 || key_bits > 32) return fail(GS_ERR_INVALID_ARGUMENT, "key_bits must be in [1,32]");
+    if (count > s->st.maxCount) return fail(GS_ERR_INVALID_ARGUMENT, "count exceeds the sorter's capacity");
+    if (count == 0) return GS_OK;
+    GS_TRY(bind_device(s->ctx));
+    const int passes = (int)((key_bits + 7) / 8);
+    const uint32_t lastBits = key_bits - 8u * (uint32_t)(passes - 1);
+    const uint32_t lastMask = (1u << lastBits) - 1u;
+    GS_TRY(enqueue_histogram(s->ctx, (const uint32_t*)keys_dev, count, nullptr, passes, lastMask, s->control));
+    return enqueue_sort_passes(s->ctx, s->st, s->control, (uint32_t*)keys_dev, (uint32_t*)values_dev, count, nullptr, passes, lastMask);
+}
+
+int32_t gs_sorter_sort_host(gs_sorter* s, uint32_t* keys, uint32_t* values, uint32_t count, uint32_t key_bits) {
+    if (!s || !keys || !values) return fail(GS_ERR_INVALID_ARGUMENT, "null argument");
+    if (count > s->st.maxCount) return fail(GS_ERR_INVALID_ARGUMENT, "count exceeds the sorter's capacity");
+    if (count == 0) return GS_OK;
+    GS_TRY(bind_device(s->ctx));
+    if (!s->tmpKeys) {
+        GS_HIP(hipMalloc((void**)&s->tmpKeys, (size_t)(s->st.maxCount + 16) * 4));
+        GS_HIP(hipMalloc((void**)&s->tmpVals, (size_t)(s->st.maxCount + 16) * 4));
+    }
+    hipStream_t st = s->ctx->stream;
+    GS_HIP(hipMemcpyAsync(s->tmpKeys, keys, (size_t)count * 4, hipMemcpyHostToDevice, st));
+    GS_HIP(hipMemcpyAsync(s->tmpVals, values, (size_t)count * 4, hipMemcpyHostToDevice, st));
+    GS_TRY(gs_sorter_dispatch(s, s->tmpKeys, s->tmpVals, count, key_bits));
+    GS_HIP(hipMemcpyAsync(keys, s->tmpKeys, (size_t)count * 4, hipMemcpyDeviceToHost, st));
+    GS_HIP(hipMemcpyAsync(values, s->tmpVals, (size_t)count * 4, hipMemcpyDeviceToHost, st));
+    uint32_t err = 0;
+    GS_HIP(hipMemcpyAsync(&err, &s->control->error, 4, hipMemcpyDeviceToHost, st));
+    GS_HIP(hipStreamSynchronize(st));
+    if (err) return fail(GS_ERR_SORT_TIMEOUT, "a bounded look-back spin expired");
+    return GS_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,166 @@
+// gs_common.h -- host-side object layouts and helpers shared by the .hip translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/gsplat_c.h"
+#include "gs_device_math.h"
+
+namespace gs {
+
+// thread-local error detail -------------------------------------------------------------------------
+void set_error_detail(const char* fmt, ...);
+int32_t fail(int32_t code, const char* what);
+int32_t fail_hip(hipError_t e, const char* what, const char* file, int line);
+
+#define GS_HIP(call)                                                        \
+    do {                                                                    \
+        hipError_t _e = (call);                                             \
+        if (_e != hipSuccess) return gs::fail_hip(_e, #call, __FILE__, __LINE__); \
+    } while (0)
+
+#define GS_TRY(call)                    \
+    do {                                \
+        int32_t _r = (call);            \
+        if (_r != GS_OK) return _r;     \
+    } while (0)
+
+constexpr int kTile = 16;                 // compositor tile edge, pixels
+constexpr int kSortThreads = 256;
+constexpr int kSortKPT = 16;              // keys per thread
+constexpr int kSortPart = kSortThreads * kSortKPT;   // 4096 keys per partition
+constexpr int kBinThreads = 256;
+constexpr int kBinItems = 4;              // sorted positions per thread
+constexpr int kBinPart = kBinThreads * kBinItems;
+
+// 32-byte per-sorted-position record consumed by the blend kernel
+struct alignas(16) SplatRec {
+    float cx, cy;           // centre, pixels (y down)
+    float a1x, a1y;         // axis1, pixels
+    float a2x, a2y;         // axis2, pixels
+    uint32_t color0;        // f16 r << 16 | f16 g
+    uint32_t color1;        // f16 b << 16 | f16 a
+};
+static_assert(sizeof(SplatRec) == 32, "SplatRec is 32 B");
+
+// Onesweep look-back state for one sort (shared by all passes: every pass uses a fresh epoch)
+struct SortState {
+    uint32_t* altKeys = nullptr;
+    uint32_t* altVals = nullptr;
+    unsigned long long* status = nullptr;   // maxParts x 256 words {epoch:30 | flag:2 | value:32}
+    uint32_t maxCount = 0;
+    uint32_t maxParts = 0;
+    uint32_t epoch = 0;                     // last epoch used on `status` (30 bits, never 0)
+};
+
+// small per-sort control block (zeroed by one memset before each sort)
+struct SortControl {
+    uint32_t hist[4 * 256];       // digit histograms, then exclusive offsets
+    uint32_t tickets[4];          // partition tickets, one per pass
+    uint32_t error;               // != 0: bounded spin expired
+    uint32_t pad[3];
+};
+
+struct BinControl {
+    unsigned long long pairCount; // P: total pairs this frame (may exceed capacity => overflow)
+    uint32_t ticket;
+    uint32_t visible;
+    uint32_t pairCountClamped;    // min(P, capacity), what the pair sort / ranges / blend see
+    uint32_t error;
+    uint32_t pad[2];
+};
+
+} // namespace gs
+
+struct gs_context {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool ownStream = false;
+    int cuCount = 0;
+    hipDeviceProp_t props;
+};
+
+struct gs_asset {
+    gs_context* ctx = nullptr;
+    gsm::AssetView view{};
+    void* blobs[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    uint64_t sizes[5] = {0, 0, 0, 0, 0};
+    bool owned = true;
+};
+
+struct gs_sorter {
+    gs_context* ctx = nullptr;
+    gs::SortState st;
+    gs::SortControl* control = nullptr;     // device
+    uint32_t* tmpKeys = nullptr;            // for sort_host
+    uint32_t* tmpVals = nullptr;
+};
+
+struct gs_target {
+    gs_context* ctx = nullptr;
+    uint32_t width = 0, height = 0;
+    uint16_t* rgba16f = nullptr;            // W*H*4 halfs
+    float* resolved = nullptr;              // W*H*4 floats, lazily allocated
+    uint8_t* resolved8 = nullptr;
+};
+
+struct gs_renderer {
+    gs_context* ctx = nullptr;
+    gs_asset* asset = nullptr;
+    uint32_t n = 0;
+    // reference buffers (GaussianSplatRenderer.cs:407,431-432)
+    gsm::ViewData* view = nullptr;          // m_GpuView
+    uint32_t* distances = nullptr;          // m_GpuSortDistances
+    uint32_t* order = nullptr;              // m_GpuSortKeys (_OrderBuffer)
+    gs::SortState depthSort;
+    gs::SortControl* depthControl = nullptr;
+    // compositor buffers
+    gs::SplatRec* recs = nullptr;           // N x 32 B, indexed by sorted position
+    uint32_t* pairKeys = nullptr;           // tile ids
+    uint32_t* pairVals = nullptr;           // sorted positions
+    gs::SortState pairSort;
+    uint64_t pairCapacity = 0;
+    // per-frame zero arena: [BinControl | SortControl(pair) | binStatus | tileStart | tileEnd]
+    uint8_t* frameArena = nullptr;
+    size_t frameArenaBytes = 0;
+    size_t offBinStatus = 0, offTileStart = 0, offTileEnd = 0, offPairControl = 0;
+    uint32_t arenaTiles = 0;                // tiles the arena was sized for
+    uint32_t binParts = 0;
+    int blendMode = 0;
+    bool profiling = false;
+    hipEvent_t ev[10];
+    bool evCreated = false;
+    bool evValid[10];
+    // host copy of last frame's control (pinned), read lazily
+    gs::BinControl* hostBin = nullptr;
+    gs::SortControl* hostSortErr = nullptr;
+    uint32_t lastTilesX = 0, lastTilesY = 0;
+    bool frameInFlight = false;
+    float resolveMs = 0.f;
+};
+
+namespace gs {
+// sort entry points (gs_sort.hip)
+int32_t sort_state_create(gs_context* ctx, SortState& st, uint32_t maxCount);
+void sort_state_destroy(SortState& st);
+// CSCalcDistances + fused 4x256 histogram
+int32_t enqueue_calc_distances(gs_context* ctx, const gsm::AssetView& a, const uint32_t* order, const float* matSort,
+                               uint32_t* keys, SortControl* control, uint32_t n);
+int32_t enqueue_histogram(gs_context* ctx, const uint32_t* keys, uint32_t n, const uint32_t* nPtr, int passes, uint32_t lastMask,
+                          SortControl* control);
+// scan + `passes` Onesweep passes.  Histograms must already be in control->hist.  Result ends in (keys, vals) when
+// passes is even, otherwise it is copied back.
+int32_t enqueue_sort_passes(gs_context* ctx, SortState& st, SortControl* control, uint32_t* keys, uint32_t* vals,
+                            uint32_t nUpper, const uint32_t* nPtr, int passes, uint32_t lastMask = 255u);
+int32_t enqueue_set_indices(gs_context* ctx, uint32_t* order, uint32_t n);
+// view (gs_view.hip)
+int32_t enqueue_calc_view(gs_context* ctx, const gsm::AssetView& a, const gs_frame_params* p, gsm::ViewData* out);
+void flatten_params(const gs_frame_params* p, gsm::FrameConsts& c);
+// raster (gs_raster.hip)
+int32_t renderer_alloc_raster(gs_renderer* r);
+void renderer_free_raster(gs_renderer* r);
+int32_t enqueue_draw(gs_renderer* r, const gs_frame_params* p, gs_target* rt);
+int32_t enqueue_resolve(gs_target* t, const float bg[4]);
+} // namespace gs

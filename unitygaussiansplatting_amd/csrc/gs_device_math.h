@@ -419,4 +419,52 @@ GS_HD ViewData CalcViewData(const AssetView& a, const FrameConsts& P, uint32_t i
     return view;
 }
 
+// ---- compositor set-up: which splats are drawn, where, and which 16x16 tiles they can touch -----------
+// Restates the vertex stage of RenderGaussianSplats.shader:35-77 plus the fixed-function clipping it relies
+// on (DESIGN.md "compositor semantics"); must stay in step with prepare() in oracle/gs_oracle.cpp.
+GS_HD bool finite32(float x) { return fabsf(x) <= 3.4028234663852886e38f; }
+
+GS_HD void PixRange(float c, float e, float size, int& lo, int& hi) {
+    float flo = ceilf((c - e) - 0.5f), fhi = floorf((c + e) - 0.5f);
+    flo = fmaxf(flo, 0.0f); fhi = fminf(fhi, size - 1.0f);
+    if (!(flo <= fhi)) { lo = 1; hi = 0; return; }
+    lo = (int)flo; hi = (int)fhi;
+}
+
+struct SplatFootprint {
+    float cx, cy;               // centre in pixels, y down
+    int tx0, tx1, ty0, ty1;     // inclusive tile rect (tx0 > tx1: nothing to draw)
+};
+
+GS_HD bool PrepareSplat(const ViewData& v, float W, float H, float nearClip, float farClip, SplatFootprint& fp) {
+    fp.tx0 = 1; fp.tx1 = 0; fp.ty0 = 1; fp.ty1 = 0; fp.cx = 0.0f; fp.cy = 0.0f;
+    const float w = v.pos[3];
+    if (!(w > 0.0f)) return false;
+    if (!(w >= nearClip && w <= farClip)) return false;
+    if (!(finite32(v.axis1[0]) && finite32(v.axis1[1]) && finite32(v.axis2[0]) && finite32(v.axis2[1]))) return false;
+    const float a = f16tof32(v.color[1]);
+    if (!(a >= 1.0f / 255.0f)) return false;
+    const float invw = 1.0f / w;
+    fp.cx = fmaf(0.5f * (v.pos[0] * invw), W, 0.5f * W);
+    fp.cy = fmaf(-0.5f * (v.pos[1] * invw), H, 0.5f * H);
+    if (!(finite32(fp.cx) && finite32(fp.cy))) return false;
+    const float a1x = v.axis1[0], a1y = v.axis1[1], a2x = v.axis2[0], a2y = v.axis2[1];
+    const float inv1 = 1.0f / dot2f(a1x, a1y, a1x, a1y), inv2 = 1.0f / dot2f(a2x, a2y, a2x, a2y);
+    if (!(finite32(inv1) && finite32(inv2))) return false;
+    const float exr = 2.0f * (fabsf(a1x) + fabsf(a2x)), eyr = 2.0f * (fabsf(a1y) + fabsf(a2y));
+    const float slack = 0.01f;
+    int x0, x1, y0, y1;
+    PixRange(fp.cx, exr + slack, W, x0, x1);
+    PixRange(fp.cy, eyr + slack, H, y0, y1);
+    if (x0 > x1 || y0 > y1) return false;
+    const float r2 = fmaf(logf(255.0f * a), 1.0001f, 1.0e-4f);
+    const float rr = sqrtf(fmaxf(r2, 0.0f));
+    const float exe = rr * sqrtf(dot2f(a1x, a2x, a1x, a2x)), eye = rr * sqrtf(dot2f(a1y, a2y, a1y, a2y));
+    PixRange(fp.cx, fminf(exr, exe) + slack, W, x0, x1);
+    PixRange(fp.cy, fminf(eyr, eye) + slack, H, y0, y1);
+    if (x0 > x1 || y0 > y1) return true;         // drawn by the reference, but every fragment is below 1/255
+    fp.tx0 = x0 >> 4; fp.tx1 = x1 >> 4; fp.ty0 = y0 >> 4; fp.ty1 = y1 >> 4;
+    return true;
+}
+
 } // namespace gsm

@@ -1,0 +1,459 @@
+// gs_raster.hip -- the splat "draw call" and the composite, re-expressed as compute for gfx950.
+//
+// Replaces RenderGaussianSplats.shader (instanced quad VS :35-77, gaussian FS :79-108, fixed-function
+// "Blend OneMinusDstAlpha One" :10-12 into an RGBA16F target, GaussianSplatRenderer.cs:156-166,194-196) and
+// GaussianComposite.shader:25-39.  MI355X has no rasteriser/ROP, so the draw is:
+//   1. bin_emit:   for sorted position i (front to back): gather view[order[i]], cull, write a 32-byte record
+//                  rec[i], and emit one (tile, i) pair per overlapped 16x16 tile.  Pair offsets come from a
+//                  single-pass chained scan (decoupled look-back) so pairs are emitted in i order.
+//   2. pair sort:  STABLE Onesweep sort of the pairs by tile id only (2 passes for <= 65536 tiles): every
+//                  tile's list is then already depth ordered -- no per-tile depth sort.
+//   3. ranges:     tile -> [start, end) in the sorted pair array.
+//   4. blend:      one 256-thread workgroup per tile, one pixel per lane, each wave owns an 8x8 quadrant.
+//                  The tile's list is streamed in batches of 256 records staged in LDS; each wave culls the
+//                  batch against its quadrant with a ballot and walks only the survivors, broadcasting the
+//                  record through v_readlane (scalar operands), blending front-to-back in registers.
+// Semantics (DESIGN.md "compositor semantics") are those of the reference rasteriser: oriented quad |q|<=2,
+// alpha = saturate(exp(-|q|^2) * a), discard < 1/255, dst = src*(1-dst.a) + dst, fp16 rounding per blend.
+#include "gs_common.h"
+
+namespace gs {
+
+namespace {
+
+struct RasterConsts {
+    float W, H, nearClip, farClip;
+    uint32_t tilesX, tilesY, width, height;
+};
+
+constexpr unsigned long long BFLAG_AGG = 1ull << 62, BFLAG_INCL = 2ull << 62, BVAL_MASK = (1ull << 62) - 1ull;
+constexpr uint32_t BIN_SPIN_LIMIT = 1u << 24;
+constexpr int BIG_SPLAT = 32;      // splats covering more tiles than this are emitted cooperatively
+
+// broadcast lane `b` (wave-uniform) of x to every lane through v_readlane_b32: the result is a scalar operand
+__device__ __forceinline__ float rl(float x, int b) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), b)); }
+
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = __shfl_up(v, o, 64);
+        if (lane >= o) v += t;
+    }
+    return v;
+}
+
+__device__ __forceinline__ void emit_pair(uint32_t* __restrict__ pairKeys, uint32_t* __restrict__ pairVals, uint32_t* s_hist,
+                                          unsigned long long off, uint32_t capacity, uint32_t tile, uint32_t i) {
+    if (off < (unsigned long long)capacity) {
+        pairKeys[off] = tile;
+        pairVals[off] = i;
+        atomicAdd(&s_hist[tile & 255u], 1u);
+        atomicAdd(&s_hist[256u + ((tile >> 8) & 255u)], 1u);
+        atomicAdd(&s_hist[512u + ((tile >> 16) & 255u)], 1u);
+    }
+}
+
+__global__ __launch_bounds__(kBinThreads) void bin_emit_kernel(const gsm::ViewData* __restrict__ view, const uint32_t* __restrict__ order,
+                                                                uint32_t n, RasterConsts rc, SplatRec* __restrict__ recs,
+                                                                uint32_t* __restrict__ pairKeys, uint32_t* __restrict__ pairVals,
+                                                                uint32_t capacity, BinControl* ctl, unsigned long long* binStatus,
+                                                                uint32_t* pairHist) {
+    __shared__ uint32_t s_hist[3 * 256];
+    __shared__ uint32_t s_wtot[4];
+    __shared__ uint32_t s_part;
+    __shared__ unsigned long long s_base;
+    __shared__ uint32_t s_qn;
+    __shared__ uint32_t s_qi[kBinThreads];
+    __shared__ uint32_t s_qrect[kBinThreads];       // tx0 | ty0 << 16
+    __shared__ uint32_t s_qdim[kBinThreads];        // tiles wide | count << 8 ... (count kept separately)
+    __shared__ uint32_t s_qcnt[kBinThreads];
+    __shared__ unsigned long long s_qoff[kBinThreads];
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    if (tid == 0) s_part = __hip_atomic_fetch_add(&ctl->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int j = tid; j < 3 * 256; j += kBinThreads) s_hist[j] = 0;
+    __syncthreads();
+    const uint32_t part = s_part;
+    const uint32_t numParts = (n + kBinPart - 1) / kBinPart;
+    if (part >= numParts) return;
+    const uint32_t base = part * (uint32_t)kBinPart;
+
+    // ---- per sorted position: gather the view record, cull, footprint, write rec[i] ------------------------
+    int tx0[kBinItems], ty0[kBinItems], tw[kBinItems];
+    uint32_t cnt[kBinItems];
+    uint32_t visible = 0;
+#pragma unroll
+    for (int k = 0; k < kBinItems; ++k) {
+        const uint32_t i = base + (uint32_t)k * kBinThreads + tid;
+        cnt[k] = 0; tx0[k] = 0; ty0[k] = 0; tw[k] = 1;
+        if (i < n) {
+            const uint32_t s = order[i];
+            const uint2* vp = (const uint2*)(view + s);           // 40-byte records: 8-byte aligned
+            const uint2 q0 = vp[0], q1 = vp[1], q2 = vp[2], q3 = vp[3], q4 = vp[4];
+            gsm::ViewData v;
+            v.pos[0] = gsm::u2f(q0.x); v.pos[1] = gsm::u2f(q0.y); v.pos[2] = gsm::u2f(q1.x); v.pos[3] = gsm::u2f(q1.y);
+            v.axis1[0] = gsm::u2f(q2.x); v.axis1[1] = gsm::u2f(q2.y); v.axis2[0] = gsm::u2f(q3.x); v.axis2[1] = gsm::u2f(q3.y);
+            v.color[0] = q4.x; v.color[1] = q4.y;
+            gsm::SplatFootprint fp;
+            const bool ok = gsm::PrepareSplat(v, rc.W, rc.H, rc.nearClip, rc.farClip, fp);
+            if (ok && fp.tx0 <= fp.tx1) {
+                tx0[k] = fp.tx0; ty0[k] = fp.ty0; tw[k] = fp.tx1 - fp.tx0 + 1;
+                cnt[k] = (uint32_t)tw[k] * (uint32_t)(fp.ty1 - fp.ty0 + 1);
+                visible++;
+            }
+            float4 r0, r1;
+            r0.x = fp.cx; r0.y = fp.cy; r0.z = v.axis1[0]; r0.w = v.axis1[1];
+            r1.x = v.axis2[0]; r1.y = v.axis2[1]; r1.z = gsm::u2f(v.color[0]); r1.w = gsm::u2f(v.color[1]);
+            float4* rp = (float4*)(recs + i);
+            rp[0] = r0; rp[1] = r1;
+        }
+    }
+
+    // ---- block-wide exclusive scan of the pair counts in i order (round k, then thread) -----------------------
+    uint32_t off[kBinItems];
+    uint32_t running = 0;
+#pragma unroll
+    for (int k = 0; k < kBinItems; ++k) {
+        const uint32_t incl = wave_incl_scan_u32(cnt[k], lane);
+        if (lane == 63) s_wtot[w] = incl;
+        __syncthreads();
+        uint32_t wbase = 0, tot = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const uint32_t t = s_wtot[j]; wbase += (j < w) ? t : 0u; tot += t; }
+        off[k] = running + wbase + incl - cnt[k];
+        running += tot;
+        __syncthreads();
+    }
+    const uint32_t blockTotal = running;
+
+    // ---- chained scan across partitions (one lane looks back) ---------------------------------------------------
+    if (tid == 0) {
+        unsigned long long* my = binStatus + part;
+        __hip_atomic_store(my, (part == 0 ? BFLAG_INCL : BFLAG_AGG) | (unsigned long long)blockTotal, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned long long excl = 0;
+        if (part > 0) {
+            int q = (int)part - 1;
+            uint32_t spins = 0;
+            for (;;) {
+                const unsigned long long s = __hip_atomic_load(binStatus + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (s & (BFLAG_AGG | BFLAG_INCL)) {
+                    excl += s & BVAL_MASK;
+                    if (s & BFLAG_INCL) break;
+                    --q;
+                    continue;
+                }
+                if (++spins > BIN_SPIN_LIMIT) { atomicOr(&ctl->error, 2u); break; }
+                __builtin_amdgcn_s_sleep(2);
+            }
+            __hip_atomic_store(my, BFLAG_INCL | (excl + blockTotal), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        s_base = excl;
+        if (part == numParts - 1) {
+            const unsigned long long total = excl + blockTotal;
+            ctl->pairCount = total;
+            ctl->pairCountClamped = (uint32_t)(total < (unsigned long long)capacity ? total : (unsigned long long)capacity);
+            if (total > (unsigned long long)capacity) atomicOr(&ctl->error, 1u);
+        }
+    }
+    __syncthreads();
+    const unsigned long long blockBase = s_base;
+
+    // ---- emit (tile, i) pairs: small footprints by their own lane, big ones by the whole workgroup -------------
+#pragma unroll
+    for (int k = 0; k < kBinItems; ++k) {
+        const uint32_t i = base + (uint32_t)k * kBinThreads + tid;
+        if (tid == 0) s_qn = 0;
+        __syncthreads();
+        if (cnt[k] > 0) {
+            const unsigned long long o = blockBase + off[k];
+            if (cnt[k] <= (uint32_t)BIG_SPLAT) {
+                uint32_t j = 0;
+                for (int ty = 0; j < cnt[k]; ++ty)
+                    for (int tx = 0; tx < tw[k]; ++tx, ++j)
+                        emit_pair(pairKeys, pairVals, s_hist, o + j, capacity, (uint32_t)(ty0[k] + ty) * rc.tilesX + (uint32_t)(tx0[k] + tx), i);
+            } else {
+                const uint32_t slot = atomicAdd(&s_qn, 1u);
+                s_qi[slot] = i; s_qrect[slot] = (uint32_t)tx0[k] | ((uint32_t)ty0[k] << 16);
+                s_qdim[slot] = (uint32_t)tw[k]; s_qcnt[slot] = cnt[k]; s_qoff[slot] = o;
+            }
+        }
+        __syncthreads();
+        const uint32_t qn = s_qn;
+        for (uint32_t e = 0; e < qn; ++e) {
+            const uint32_t qi = s_qi[e], qr = s_qrect[e], qw = s_qdim[e], qc = s_qcnt[e];
+            const unsigned long long qo = s_qoff[e];
+            const uint32_t qx0 = qr & 0xffffu, qy0 = qr >> 16;
+            for (uint32_t j = tid; j < qc; j += kBinThreads) {
+                const uint32_t ty = j / qw, tx = j - ty * qw;
+                emit_pair(pairKeys, pairVals, s_hist, qo + j, capacity, (qy0 + ty) * rc.tilesX + (qx0 + tx), qi);
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- flush the pair-sort digit histograms, count visible splats ----------------------------------------------
+    for (int j = tid; j < 3 * 256; j += kBinThreads) {
+        const uint32_t c = s_hist[j];
+        if (c) atomicAdd(&pairHist[j], c);
+    }
+    const unsigned long long vb = __ballot(visible != 0);
+    (void)vb;
+    uint32_t vsum = visible;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) vsum += __shfl_down(vsum, o, 64);
+    if (lane == 0 && vsum) atomicAdd(&ctl->visible, vsum);
+}
+
+// tile -> [start, end) in the tile-sorted pair array
+__global__ __launch_bounds__(256) void tile_ranges_kernel(const uint32_t* __restrict__ pairKeys, const uint32_t* nPtr,
+                                                          uint32_t* __restrict__ tileStart, uint32_t* __restrict__ tileEnd, uint32_t numTiles) {
+    const uint32_t n = *nPtr;
+    for (uint32_t j = blockIdx.x * 256u + threadIdx.x; j < n; j += gridDim.x * 256u) {
+        const uint32_t t = pairKeys[j];
+        if (t >= numTiles) continue;
+        if (j == 0 || pairKeys[j - 1] != t) tileStart[t] = j;
+        if (j == n - 1 || pairKeys[j + 1] != t) tileEnd[t] = j + 1;
+    }
+}
+
+// XCD-aware bijective block -> tile map: consecutive tiles (which share splat records) stay on one XCD's L2
+__device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t total) {
+    const uint32_t q = total >> 3, r = total & 7u, xcd = b & 7u, k = b >> 3;
+    return (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + k;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void blend_kernel(const uint32_t* __restrict__ pairVals, const uint32_t* __restrict__ tileStart,
+                                                    const uint32_t* __restrict__ tileEnd, const SplatRec* __restrict__ recs,
+                                                    uint16_t* __restrict__ rt, RasterConsts rc) {
+    __shared__ float4 s_r0[256];
+    __shared__ float4 s_r1[256];
+    __shared__ int s_done;
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const uint32_t tile = xcd_remap(blockIdx.x, rc.tilesX * rc.tilesY);
+    const uint32_t tx = tile % rc.tilesX, ty = tile / rc.tilesX;
+    const uint32_t start = tileStart[tile], end = tileEnd[tile];
+    if (start >= end) return;                                  // nothing lands on this tile: target unchanged
+
+    const int qx0 = (int)tx * 16 + (w & 1) * 8, qy0 = (int)ty * 16 + (w >> 1) * 8;
+    const int px = qx0 + (lane & 7), py = qy0 + (lane >> 3);
+    const bool inside = px < (int)rc.width && py < (int)rc.height;
+    const float fx = (float)px + 0.5f, fy = (float)py + 0.5f;
+    const float qminx = (float)qx0 + 0.5f, qmaxx = (float)qx0 + 7.5f, qminy = (float)qy0 + 0.5f, qmaxy = (float)qy0 + 7.5f;
+
+    float Cr = 0.f, Cg = 0.f, Cb = 0.f, A = 0.f;
+    uint2* dst = (uint2*)(rt + ((size_t)py * rc.width + (size_t)px) * 4);
+    if (inside) {
+        const uint2 d = *dst;
+        Cr = gsm::f16tof32(d.x); Cg = gsm::f16tof32(d.x >> 16); Cb = gsm::f16tof32(d.y); A = gsm::f16tof32(d.y >> 16);
+    }
+    if (tid == 0) s_done = 0;
+    bool waveDone = false;
+
+    for (uint32_t bs = start; bs < end; bs += 256u) {
+        __syncthreads();
+        if (s_done == 4) break;
+        const uint32_t cnt = min(256u, end - bs);
+        if ((uint32_t)tid < cnt) {
+            const uint32_t i = pairVals[bs + tid];
+            const float4* rp = (const float4*)(recs + i);
+            s_r0[tid] = rp[0];
+            s_r1[tid] = rp[1];
+        }
+        __syncthreads();
+        if (!waveDone) {
+            for (uint32_t c = 0; c < cnt; c += 64u) {
+                const uint32_t j = c + lane;
+                const bool has = j < cnt;
+                float4 r0 = make_float4(0.f, 0.f, 1.f, 0.f), r1 = make_float4(0.f, 1.f, 0.f, 0.f);
+                if (has) { r0 = s_r0[j]; r1 = s_r1[j]; }
+                // per-record quantities, computed by the lane that holds the record
+                const float ex = 2.0f * (fabsf(r0.z) + fabsf(r1.x)) + 0.01f, ey = 2.0f * (fabsf(r0.w) + fabsf(r1.y)) + 0.01f;
+                const bool hit = has && (r0.x + ex >= qminx) && (r0.x - ex <= qmaxx) && (r0.y + ey >= qminy) && (r0.y - ey <= qmaxy);
+                const float inv1 = 1.0f / gsm::dot2f(r0.z, r0.w, r0.z, r0.w);
+                const float inv2 = 1.0f / gsm::dot2f(r1.x, r1.y, r1.x, r1.y);
+                const uint32_t c0 = gsm::f2u(r1.z), c1 = gsm::f2u(r1.w);
+                const float colr = gsm::f16tof32(c0 >> 16), colg = gsm::f16tof32(c0), colb = gsm::f16tof32(c1 >> 16), cola = gsm::f16tof32(c1);
+                unsigned long long mask = __ballot(hit);
+                while (mask) {
+                    const int b = __ffsll((long long)mask) - 1;
+                    mask &= mask - 1ull;
+                    const float cx = rl(r0.x, b), cy = rl(r0.y, b);
+                    const float a1x = rl(r0.z, b), a1y = rl(r0.w, b);
+                    const float a2x = rl(r1.x, b), a2y = rl(r1.y, b);
+                    const float i1 = rl(inv1, b), i2 = rl(inv2, b);
+                    const float sr = rl(colr, b), sg = rl(colg, b), sb = rl(colb, b), sa = rl(cola, b);
+                    const float dx = fx - cx, dy = fy - cy;
+                    const float q1 = fmaf(dy, a1y, dx * a1x) * i1;
+                    const float q2 = fmaf(dy, a2y, dx * a2x) * i2;
+                    const float power = -fmaf(q2, q2, q1 * q1);
+                    float alpha = __expf(power);
+                    alpha = gsm::sat(alpha * sa);
+                    bool live = (fabsf(q1) <= 2.0f) && (fabsf(q2) <= 2.0f) && (alpha >= 1.0f / 255.0f);
+                    if (MODE == 1) live = live && !((1.0f - A) < (1.0f / 4096.0f));
+                    if (live) {
+                        const float t = 1.0f - A;
+                        float nr = fmaf(sr * alpha, t, Cr), ng = fmaf(sg * alpha, t, Cg), nb = fmaf(sb * alpha, t, Cb), na = fmaf(alpha, t, A);
+                        if (MODE == 0) {
+                            nr = gsm::f16tof32(gsm::f32tof16(nr)); ng = gsm::f16tof32(gsm::f32tof16(ng));
+                            nb = gsm::f16tof32(gsm::f32tof16(nb)); na = gsm::f16tof32(gsm::f32tof16(na));
+                        }
+                        Cr = nr; Cg = ng; Cb = nb; A = na;
+                    }
+                }
+                const bool pixDone = !inside || (MODE == 0 ? (A == 1.0f) : ((1.0f - A) < (1.0f / 4096.0f)));
+                if (__all(pixDone)) {
+                    waveDone = true;
+                    if (lane == 0) atomicAdd(&s_done, 1);
+                    break;
+                }
+            }
+        }
+    }
+    if (inside) {
+        uint2 o;
+        o.x = gsm::f32tof16(Cr) | (gsm::f32tof16(Cg) << 16);
+        o.y = gsm::f32tof16(Cb) | (gsm::f32tof16(A) << 16);
+        *dst = o;
+    }
+}
+
+// GaussianComposite.shader:25-39 + "Blend SrcAlpha OneMinusSrcAlpha" over a constant background
+__global__ __launch_bounds__(256) void resolve_kernel(const uint16_t* __restrict__ rt, uint32_t numPix, float bgr, float bgg, float bgb,
+                                                      float bga, float* __restrict__ out32, uint8_t* __restrict__ out8) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= numPix) return;
+    const uint2 d = ((const uint2*)rt)[i];
+    const float C[3] = { gsm::f16tof32(d.x), gsm::f16tof32(d.x >> 16), gsm::f16tof32(d.y) };
+    const float A = gsm::f16tof32(d.y >> 16);
+    const float bg[4] = { bgr, bgg, bgb, bga };
+    float o[4];
+    if (!(A > 0.0f)) { o[0] = bgr; o[1] = bgg; o[2] = bgb; o[3] = bga; }
+    else {
+        const float invA = 1.0f / A;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float s = C[c] * invA;
+            const float lin = s * fmaf(s, fmaf(s, 0.305306011f, 0.682171111f), 0.012522878f);   // UnityCG GammaToLinearSpace
+            o[c] = fmaf(A, lin - bg[c], bg[c]);
+        }
+        o[3] = fmaf(A, 1.0f - bga, bga);
+    }
+    ((float4*)out32)[i] = make_float4(o[0], o[1], o[2], o[3]);
+    if (out8) {
+        uint32_t pk = 0;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float l = gsm::sat(o[c]);
+            const float s = (l <= 0.0031308f) ? 12.92f * l : fmaf(1.055f, powf(l, 1.0f / 2.4f), -0.055f);
+            pk |= (uint32_t)floorf(fmaf(gsm::sat(s), 255.0f, 0.5f)) << (8 * c);
+        }
+        pk |= (uint32_t)floorf(fmaf(gsm::sat(o[3]), 255.0f, 0.5f)) << 24;
+        ((uint32_t*)out8)[i] = pk;
+    }
+}
+
+inline uint32_t div_up(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
+inline size_t align_up(size_t a, size_t b) { return (a + b - 1) / b * b; }
+
+int32_t ensure_arena(gs_renderer* r, uint32_t numTiles) {
+    if (r->frameArena && numTiles <= r->arenaTiles) return GS_OK;
+    if (r->frameArena) { GS_HIP(hipStreamSynchronize(r->ctx->stream)); (void)hipFree(r->frameArena); r->frameArena = nullptr; }
+    size_t off = 0;
+    off = align_up(sizeof(BinControl), 256);
+    r->offPairControl = off; off += align_up(sizeof(SortControl), 256);
+    r->offBinStatus = off;   off += align_up((size_t)r->binParts * 8, 256);
+    r->offTileStart = off;   off += align_up((size_t)numTiles * 4, 256);
+    r->offTileEnd = off;     off += align_up((size_t)numTiles * 4, 256);
+    r->frameArenaBytes = off;
+    r->arenaTiles = numTiles;
+    GS_HIP(hipMalloc((void**)&r->frameArena, off));
+    return GS_OK;
+}
+
+} // namespace
+
+int32_t renderer_alloc_raster(gs_renderer* r) {
+    gs_context* ctx = r->ctx;
+    r->binParts = div_up(r->n, kBinPart);
+    GS_HIP(hipMalloc((void**)&r->recs, (size_t)r->n * sizeof(SplatRec)));
+    if (r->pairCapacity == 0) {
+        unsigned long long cap = (unsigned long long)r->n * 8ull;
+        if (cap < (1ull << 22)) cap = 1ull << 22;
+        if (cap > 0xfffffff0ull) cap = 0xfffffff0ull;
+        r->pairCapacity = cap;
+    }
+    GS_HIP(hipMalloc((void**)&r->pairKeys, (size_t)(r->pairCapacity + 16) * 4));
+    GS_HIP(hipMalloc((void**)&r->pairVals, (size_t)(r->pairCapacity + 16) * 4));
+    GS_TRY(sort_state_create(ctx, r->pairSort, (uint32_t)r->pairCapacity));
+    GS_HIP(hipHostMalloc((void**)&r->hostBin, sizeof(BinControl) + sizeof(SortControl), hipHostMallocDefault));
+    memset(r->hostBin, 0, sizeof(BinControl) + sizeof(SortControl));
+    r->hostSortErr = (SortControl*)((uint8_t*)r->hostBin + sizeof(BinControl));
+    return GS_OK;
+}
+
+void renderer_free_raster(gs_renderer* r) {
+    if (r->recs) (void)hipFree(r->recs);
+    if (r->pairKeys) (void)hipFree(r->pairKeys);
+    if (r->pairVals) (void)hipFree(r->pairVals);
+    sort_state_destroy(r->pairSort);
+    if (r->frameArena) (void)hipFree(r->frameArena);
+    if (r->hostBin) (void)hipHostFree(r->hostBin);
+    r->recs = nullptr; r->pairKeys = r->pairVals = nullptr; r->frameArena = nullptr; r->hostBin = nullptr;
+}
+
+int32_t enqueue_draw(gs_renderer* r, const gs_frame_params* p, gs_target* rt) {
+    gs_context* ctx = r->ctx;
+    hipStream_t st = ctx->stream;
+    RasterConsts rc;
+    rc.W = (float)rt->width; rc.H = (float)rt->height; rc.nearClip = p->near_clip; rc.farClip = p->far_clip;
+    rc.width = rt->width; rc.height = rt->height;
+    rc.tilesX = div_up(rt->width, kTile); rc.tilesY = div_up(rt->height, kTile);
+    const uint32_t numTiles = rc.tilesX * rc.tilesY;
+    if (numTiles > (1u << 24)) return fail(GS_ERR_INVALID_ARGUMENT, "target too large (more than 2^24 tiles)");
+    GS_TRY(ensure_arena(r, numTiles));
+    r->lastTilesX = rc.tilesX; r->lastTilesY = rc.tilesY;
+
+    BinControl* binCtl = (BinControl*)r->frameArena;
+    SortControl* pairCtl = (SortControl*)(r->frameArena + r->offPairControl);
+    unsigned long long* binStatus = (unsigned long long*)(r->frameArena + r->offBinStatus);
+    uint32_t* tileStart = (uint32_t*)(r->frameArena + r->offTileStart);
+    uint32_t* tileEnd = (uint32_t*)(r->frameArena + r->offTileEnd);
+    const uint32_t cap = (uint32_t)r->pairCapacity;
+
+    GS_HIP(hipMemsetAsync(r->frameArena, 0, r->frameArenaBytes, st));
+    if (r->profiling) GS_HIP(hipEventRecord(r->ev[3], st));
+    hipLaunchKernelGGL(bin_emit_kernel, dim3(r->binParts), dim3(kBinThreads), 0, st, r->view, r->order, r->n, rc, r->recs, r->pairKeys,
+                       r->pairVals, cap, binCtl, binStatus, pairCtl->hist);
+    if (r->profiling) GS_HIP(hipEventRecord(r->ev[4], st));
+    const int passes = numTiles <= 256 ? 1 : (numTiles <= 65536 ? 2 : 3);
+    GS_TRY(enqueue_sort_passes(ctx, r->pairSort, pairCtl, r->pairKeys, r->pairVals, cap, &binCtl->pairCountClamped, passes));
+    hipLaunchKernelGGL(tile_ranges_kernel, dim3(max(1u, min(div_up(cap, 256), (uint32_t)ctx->cuCount * 8u))), dim3(256), 0, st, r->pairKeys,
+                       &binCtl->pairCountClamped, tileStart, tileEnd, numTiles);
+    if (r->profiling) GS_HIP(hipEventRecord(r->ev[5], st));
+    if (r->blendMode == 0)
+        hipLaunchKernelGGL(blend_kernel<0>, dim3(numTiles), dim3(256), 0, st, r->pairVals, tileStart, tileEnd, r->recs, rt->rgba16f, rc);
+    else
+        hipLaunchKernelGGL(blend_kernel<1>, dim3(numTiles), dim3(256), 0, st, r->pairVals, tileStart, tileEnd, r->recs, rt->rgba16f, rc);
+    if (r->profiling) GS_HIP(hipEventRecord(r->ev[6], st));
+    GS_HIP(hipGetLastError());
+    GS_HIP(hipMemcpyAsync(r->hostBin, binCtl, sizeof(BinControl), hipMemcpyDeviceToHost, st));
+    GS_HIP(hipMemcpyAsync(&r->hostSortErr->error, &pairCtl->error, 4, hipMemcpyDeviceToHost, st));
+    r->frameInFlight = true;
+    return GS_OK;
+}
+
+int32_t enqueue_resolve(gs_target* t, const float bg[4]) {
+    const uint32_t numPix = t->width * t->height;
+    if (!t->resolved) {
+        GS_HIP(hipMalloc((void**)&t->resolved, (size_t)numPix * 16));
+        GS_HIP(hipMalloc((void**)&t->resolved8, (size_t)numPix * 4));
+    }
+    hipLaunchKernelGGL(resolve_kernel, dim3(div_up(numPix, 256)), dim3(256), 0, t->ctx->stream, t->rgba16f, numPix, bg[0], bg[1], bg[2], bg[3],
+                       t->resolved, t->resolved8);
+    GS_HIP(hipGetLastError());
+    return GS_OK;
+}
+
+} // namespace gs

@@ -1,0 +1,348 @@
+// gs_sort.hip -- CSSetIndices, CSCalcDistances and the device radix sort, re-designed for gfx950.
+//
+// Replaces (semantics only -- the structure is new):
+//   SplatUtilities.compute:59-82      CSSetIndices, CSCalcDistances
+//   DeviceRadixSort.hlsl:42,163,428,451 + SortCommon.hlsl   InitDeviceRadixSort / Upsweep / Scan / Downsweep
+//   GpuSorting.cs:142-198             the 13-dispatch reduce-then-scan driver
+// with a Onesweep LSD radix sort (8-bit digits): ONE histogram sweep for all passes (fused into the key
+// generation) + one chained-scan binning kernel per pass with decoupled look-back.  Contract kept:
+// stable, ascending, (uint32 key, uint32 payload) pairs (KEY_UINT PAYLOAD_UINT SHOULD_ASCEND SORT_PAIRS).
+//
+// gfx950 specifics: 64-lane waves -- ranking is a wave-level multi-split from 8 __ballot()s per key (one per
+// digit bit) and a 64-bit popcount below the lane; per-wave digit histograms live in LDS; inter-workgroup
+// look-back words are single 8-byte {epoch, flag, value} granules written/read with relaxed AGENT-scope atomics
+// (the per-XCD L2s are not coherent, see MI355X_MICROARCH.md "inter-workgroup visibility"; the granule carries
+// its own tag so no fence is needed and no status memset between passes: each pass uses a fresh epoch).
+// Partitions are handed out by an atomic ticket inside a persistent grid, so a workgroup only ever waits on
+// partitions that are already running; every spin is bounded and reports GS_ERR_SORT_TIMEOUT instead of hanging.
+#include "gs_common.h"
+
+namespace gs {
+
+namespace {
+
+constexpr int RADIX = 256;
+constexpr int THREADS = kSortThreads;
+constexpr int WAVES = THREADS / 64;
+constexpr int KPT = kSortKPT;
+constexpr int PART = kSortPart;
+constexpr uint32_t SPIN_LIMIT = 1u << 24;
+
+constexpr unsigned long long FLAG_AGG = 1ull, FLAG_INCL = 2ull;
+
+__device__ __forceinline__ unsigned long long pack_status(uint32_t epoch, unsigned long long flag, uint32_t value) {
+    return ((unsigned long long)epoch << 34) | (flag << 32) | (unsigned long long)value;
+}
+__device__ __forceinline__ unsigned long long ld_status(const unsigned long long* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_status(unsigned long long* p, unsigned long long v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = __shfl_up(v, o, 64);
+        if (lane >= o) v += t;
+    }
+    return v;
+}
+
+// add 1 to an LDS histogram bin; wave-aggregated when the whole wave hits one bin (the common case for the
+// high digits of depth keys, where a per-lane ds_add would serialise 64 deep on one address)
+__device__ __forceinline__ void lds_hist_add(uint32_t* h, uint32_t d) {
+    const uint32_t first = __builtin_amdgcn_readfirstlane(d);
+    const unsigned long long act = __ballot(1);
+    if (__all(d == first)) {
+        if ((int)(threadIdx.x & 63) == __ffsll((long long)act) - 1) atomicAdd(&h[first], (uint32_t)__popcll(act));
+    } else {
+        atomicAdd(&h[d], 1u);
+    }
+}
+
+__global__ __launch_bounds__(1024) void set_indices_kernel(uint32_t* order, uint32_t n) {
+    const uint32_t i = blockIdx.x * 1024u + threadIdx.x;
+    if (i < n) order[i] = i;
+}
+
+// CSCalcDistances fused with the 4 digit histograms of the Onesweep sort.
+__global__ __launch_bounds__(256) void calc_distances_kernel(gsm::AssetView a, const uint32_t* __restrict__ order,
+                                                             float m20, float m21, float m22, float m23,
+                                                             uint32_t* __restrict__ keys, uint32_t* __restrict__ hist, uint32_t n) {
+    __shared__ uint32_t s_h[4 * RADIX];
+    for (int j = threadIdx.x; j < 4 * RADIX; j += 256) s_h[j] = 0;
+    __syncthreads();
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+        const uint32_t origIdx = order[i];
+        const uint32_t key = gsm::SortKey(a, origIdx, m20, m21, m22, m23);
+        keys[i] = key;
+        lds_hist_add(s_h, key & 255u);
+        lds_hist_add(s_h + RADIX, (key >> 8) & 255u);
+        lds_hist_add(s_h + 2 * RADIX, (key >> 16) & 255u);
+        lds_hist_add(s_h + 3 * RADIX, key >> 24);
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < 4 * RADIX; j += 256) {
+        const uint32_t c = s_h[j];
+        if (c) atomicAdd(&hist[j], c);
+    }
+}
+
+// stand-alone histogram (gs_sorter path): `passes` digit histograms of keys[0..n)
+__global__ __launch_bounds__(256) void histogram_kernel(const uint32_t* __restrict__ keys, uint32_t nImm, const uint32_t* nPtr,
+                                                        int passes, uint32_t lastMask, uint32_t* __restrict__ hist) {
+    __shared__ uint32_t s_h[4 * RADIX];
+    for (int j = threadIdx.x; j < 4 * RADIX; j += 256) s_h[j] = 0;
+    __syncthreads();
+    const uint32_t n = nPtr ? min(*nPtr, nImm) : nImm;
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+        const uint32_t key = keys[i];
+        for (int p = 0; p < passes; ++p) lds_hist_add(s_h + p * RADIX, (key >> (8 * p)) & (p == passes - 1 ? lastMask : 255u));
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < passes * RADIX; j += 256) {
+        const uint32_t c = s_h[j];
+        if (c) atomicAdd(&hist[j], c);
+    }
+}
+
+// in-place exclusive scan of each 256-bin histogram (one 256-thread group per pass)
+__global__ __launch_bounds__(1024) void scan_hist_kernel(uint32_t* hist, int passes) {
+    __shared__ uint32_t s_w[16];
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const bool live = (t >> 8) < passes;
+    const uint32_t v = live ? hist[t] : 0u;
+    const uint32_t incl = wave_incl_scan(v, lane);
+    if (lane == 63) s_w[w] = incl;
+    __syncthreads();
+    uint32_t base = 0;
+    for (int k = (w & ~3); k < w; ++k) base += s_w[k];
+    if (live) hist[t] = base + incl - v;
+}
+
+// One Onesweep pass: reads (keysIn, valsIn), writes (keysOut, valsOut) stably partitioned by digit (key>>shift)&255.
+__global__ __launch_bounds__(THREADS) void onesweep_kernel(const uint32_t* __restrict__ keysIn, const uint32_t* __restrict__ valsIn,
+                                                           uint32_t* __restrict__ keysOut, uint32_t* __restrict__ valsOut,
+                                                           const uint32_t* __restrict__ histExcl, unsigned long long* status,
+                                                           uint32_t* ticket, uint32_t* error, uint32_t nImm, const uint32_t* nPtr,
+                                                           uint32_t shift, uint32_t epoch, uint32_t digitMask) {
+    __shared__ uint32_t s_hist[WAVES * RADIX];   // per-wave digit counts -> wave-exclusive offsets
+    __shared__ uint32_t s_lbase[RADIX];          // exclusive digit offsets inside the partition
+    __shared__ uint32_t s_gbase[RADIX];          // global index of local slot j with digit d = s_gbase[d] + j
+    __shared__ uint32_t s_buf[PART];
+    __shared__ uint32_t s_wtot[WAVES];
+    __shared__ uint32_t s_part;
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const uint32_t n = nPtr ? min(*nPtr, nImm) : nImm;
+    const uint32_t numParts = (n + PART - 1) / PART;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+
+    for (;;) {
+        __syncthreads();                                    // previous partition's LDS reads are finished
+        if (tid == 0) s_part = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int k = 0; k < WAVES; ++k) s_hist[k * RADIX + tid] = 0;
+        __syncthreads();
+        const uint32_t part = s_part;
+        if (part >= numParts) break;
+
+        const uint32_t partBase = part * (uint32_t)PART;
+        const uint32_t valid = min((uint32_t)PART, n - partBase);
+        const uint32_t waveBase = partBase + (uint32_t)w * (64u * KPT);
+
+        // ---- load: wave-striped, item (w,k,lane) has global index waveBase + k*64 + lane --------------
+        uint32_t key[KPT], val[KPT];
+#pragma unroll
+        for (int k = 0; k < KPT; ++k) {
+            const uint32_t gi = waveBase + (uint32_t)k * 64u + lane;
+            key[k] = (gi < n) ? keysIn[gi] : 0xffffffffu;     // tail dummies sort last and are never written
+        }
+#pragma unroll
+        for (int k = 0; k < KPT; ++k) {
+            const uint32_t gi = waveBase + (uint32_t)k * 64u + lane;
+            val[k] = (gi < n) ? valsIn[gi] : 0u;
+        }
+
+        // ---- rank inside the wave: multi-split by 8 ballots, running per-wave LDS histogram ------------
+        uint32_t rank[KPT];
+        uint32_t* wh = s_hist + w * RADIX;
+#pragma unroll
+        for (int k = 0; k < KPT; ++k) {
+            const uint32_t d = (key[k] >> shift) & digitMask;
+            unsigned long long m = ~0ull;
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                const bool bit = (d >> b) & 1u;
+                const unsigned long long bal = __ballot(bit);
+                m &= bit ? bal : ~bal;
+            }
+            const uint32_t lower = (uint32_t)__popcll(m & lt);
+            const uint32_t cnt = (uint32_t)__popcll(m);
+            const uint32_t pre = wh[d];
+            __builtin_amdgcn_wave_barrier();
+            if (lower == 0) wh[d] = pre + cnt;
+            __builtin_amdgcn_wave_barrier();
+            rank[k] = pre + lower;
+        }
+        __syncthreads();
+
+        // ---- partition digit counts, wave-exclusive offsets, local exclusive scan over digits --------
+        uint32_t total = 0;
+#pragma unroll
+        for (int k = 0; k < WAVES; ++k) {
+            const uint32_t c = s_hist[k * RADIX + tid];
+            s_hist[k * RADIX + tid] = total;
+            total += c;
+        }
+        // publish this partition's digit count right away (decoupled look-back: successors need only this)
+        unsigned long long* myStatus = status + (size_t)part * RADIX + tid;
+        st_status(myStatus, pack_status(epoch, part == 0 ? FLAG_INCL : FLAG_AGG, total));
+
+        const uint32_t incl = wave_incl_scan(total, lane);
+        if (lane == 63) s_wtot[w] = incl;
+        __syncthreads();
+        uint32_t wbase = 0;
+#pragma unroll
+        for (int k = 0; k < WAVES; ++k) wbase += (k < w) ? s_wtot[k] : 0u;
+        const uint32_t lbase = wbase + incl - total;
+        s_lbase[tid] = lbase;
+
+        // ---- look back over earlier partitions for digit `tid` -----------------------------------------
+        uint32_t exclPrefix = 0;
+        if (part > 0) {
+            int q = (int)part - 1;
+            uint32_t spins = 0;
+            for (;;) {
+                const unsigned long long s = ld_status(status + (size_t)q * RADIX + tid);
+                const uint32_t e = (uint32_t)(s >> 34);
+                const uint32_t f = (uint32_t)(s >> 32) & 3u;
+                if (e == epoch && f != 0) {
+                    exclPrefix += (uint32_t)s;
+                    if (f == (uint32_t)FLAG_INCL) break;
+                    --q;                                   // partition 0 always publishes INCL, so q never drops below 0
+                    continue;
+                }
+                if (++spins > SPIN_LIMIT) { atomicOr(error, 1u); break; }
+                __builtin_amdgcn_s_sleep(2);
+            }
+            st_status(myStatus, pack_status(epoch, FLAG_INCL, exclPrefix + total));
+        }
+        s_gbase[tid] = histExcl[tid] + exclPrefix - lbase;
+        __syncthreads();
+
+        // ---- scatter keys through LDS so that global writes are runs of equal digits -------------------
+        uint32_t pos[KPT];
+#pragma unroll
+        for (int k = 0; k < KPT; ++k) {
+            const uint32_t d = (key[k] >> shift) & digitMask;
+            pos[k] = s_lbase[d] + wh[d] + rank[k];
+            s_buf[pos[k]] = key[k];
+        }
+        __syncthreads();
+        uint32_t gidx[KPT];
+#pragma unroll
+        for (int k = 0; k < KPT; ++k) {
+            const uint32_t j = (uint32_t)tid + (uint32_t)k * THREADS;
+            gidx[k] = 0xffffffffu;
+            if (j < valid) {
+                const uint32_t kk = s_buf[j];
+                const uint32_t gi = s_gbase[(kk >> shift) & digitMask] + j;
+                keysOut[gi] = kk;
+                gidx[k] = gi;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < KPT; ++k) s_buf[pos[k]] = val[k];
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < KPT; ++k) {
+            const uint32_t j = (uint32_t)tid + (uint32_t)k * THREADS;
+            if (j < valid) valsOut[gidx[k]] = s_buf[j];
+        }
+    }
+}
+
+__global__ void copy_pairs_kernel(const uint32_t* __restrict__ ks, const uint32_t* __restrict__ vs, uint32_t* __restrict__ kd,
+                                  uint32_t* __restrict__ vd, uint32_t nImm, const uint32_t* nPtr) {
+    const uint32_t n = nPtr ? min(*nPtr, nImm) : nImm;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) { kd[i] = ks[i]; vd[i] = vs[i]; }
+}
+
+inline uint32_t div_up(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
+
+} // namespace
+
+int32_t sort_state_create(gs_context* ctx, SortState& st, uint32_t maxCount) {
+    (void)ctx;
+    st.maxCount = maxCount;
+    st.maxParts = div_up(maxCount > 0 ? maxCount : 1, PART);
+    GS_HIP(hipMalloc((void**)&st.altKeys, (size_t)(maxCount + 16) * 4));
+    GS_HIP(hipMalloc((void**)&st.altVals, (size_t)(maxCount + 16) * 4));
+    GS_HIP(hipMalloc((void**)&st.status, (size_t)st.maxParts * RADIX * 8));
+    GS_HIP(hipMemsetAsync(st.status, 0, (size_t)st.maxParts * RADIX * 8, ctx->stream));
+    return GS_OK;
+}
+
+void sort_state_destroy(SortState& st) {
+    if (st.altKeys) (void)hipFree(st.altKeys);
+    if (st.altVals) (void)hipFree(st.altVals);
+    if (st.status) (void)hipFree(st.status);
+    st = SortState();
+}
+
+int32_t enqueue_set_indices(gs_context* ctx, uint32_t* order, uint32_t n) {
+    hipLaunchKernelGGL(set_indices_kernel, dim3(div_up(n, 1024)), dim3(1024), 0, ctx->stream, order, n);
+    GS_HIP(hipGetLastError());
+    return GS_OK;
+}
+
+int32_t enqueue_calc_distances(gs_context* ctx, const gsm::AssetView& a, const uint32_t* order, const float* m, uint32_t* keys,
+                               SortControl* control, uint32_t n) {
+    GS_HIP(hipMemsetAsync(control, 0, sizeof(SortControl), ctx->stream));
+    const uint32_t grid = min(div_up(n, 256), (uint32_t)ctx->cuCount * 4u);
+    hipLaunchKernelGGL(calc_distances_kernel, dim3(grid), dim3(256), 0, ctx->stream, a, order, m[8], m[9], m[10], m[11], keys,
+                       control->hist, n);
+    GS_HIP(hipGetLastError());
+    return GS_OK;
+}
+
+int32_t enqueue_histogram(gs_context* ctx, const uint32_t* keys, uint32_t n, const uint32_t* nPtr, int passes, uint32_t lastMask, SortControl* control) {
+    GS_HIP(hipMemsetAsync(control, 0, sizeof(SortControl), ctx->stream));
+    const uint32_t grid = max(1u, min(div_up(n, 256), (uint32_t)ctx->cuCount * 4u));
+    hipLaunchKernelGGL(histogram_kernel, dim3(grid), dim3(256), 0, ctx->stream, keys, n, nPtr, passes, lastMask, control->hist);
+    GS_HIP(hipGetLastError());
+    return GS_OK;
+}
+
+int32_t enqueue_sort_passes(gs_context* ctx, SortState& st, SortControl* control, uint32_t* keys, uint32_t* vals, uint32_t nUpper,
+                            const uint32_t* nPtr, int passes, uint32_t lastMask) {
+    if (passes < 1 || passes > 4) return fail(GS_ERR_INVALID_ARGUMENT, "sort passes");
+    if (nUpper > st.maxCount) return fail(GS_ERR_INVALID_ARGUMENT, "sort count exceeds sorter capacity");
+    if (nUpper == 0) return GS_OK;
+    hipLaunchKernelGGL(scan_hist_kernel, dim3(1), dim3(1024), 0, ctx->stream, control->hist, passes);
+    const uint32_t parts = div_up(nUpper, PART);
+    const uint32_t grid = max(1u, min(parts, (uint32_t)ctx->cuCount * 4u));
+    uint32_t *ks = keys, *vs = vals, *kd = st.altKeys, *vd = st.altVals;
+    for (int p = 0; p < passes; ++p) {
+        uint32_t epoch = (++st.epoch) & 0x3fffffffu;
+        if (epoch == 0) {   // 30-bit epoch wrapped: wipe the status array (it may hold every old epoch), restart at 1
+            GS_HIP(hipMemsetAsync(st.status, 0, (size_t)st.maxParts * RADIX * 8, ctx->stream));
+            st.epoch = epoch = 1;
+        }
+        hipLaunchKernelGGL(onesweep_kernel, dim3(grid), dim3(THREADS), 0, ctx->stream, ks, vs, kd, vd, control->hist + RADIX * p,
+                           st.status, &control->tickets[p], &control->error, nUpper, nPtr, (uint32_t)(8 * p), epoch, p == passes - 1 ? lastMask : 255u);
+        uint32_t* t = ks; ks = kd; kd = t;
+        t = vs; vs = vd; vd = t;
+    }
+    if (ks != keys) {
+        hipLaunchKernelGGL(copy_pairs_kernel, dim3(max(1u, min(div_up(nUpper, 256), (uint32_t)ctx->cuCount * 8u))), dim3(256), 0,
+                           ctx->stream, ks, vs, keys, vals, nUpper, nPtr);
+    }
+    GS_HIP(hipGetLastError());
+    return GS_OK;
+}
+
+} // namespace gs

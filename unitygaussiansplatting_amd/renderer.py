@@ -1,0 +1,334 @@
+"""Host-side mirror of the reference's renderer API over the C-ABI (include/gsplat_c.h).
+
+Same class, field and method names as /root/reference/package/Runtime/GaussianSplatRenderer.cs
+(GaussianSplatRenderSystem :17-212, GaussianSplatRenderer :214-680) and GpuSorting.cs, minus the Unity
+plumbing (MonoBehaviour, CommandBuffer, materials): where the C# records a dispatch into a CommandBuffer,
+these methods enqueue the corresponding HIP kernels on the context's stream.  A .NET host would be the same
+thin layer over [DllImport("gsplat_hip")] (unitygaussiansplatting_amd/dotnet/GaussianSplatNative.cs).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Tuple
+
+import numpy as np
+
+from . import _lib
+from ._abi import (GS_ERR_PAIR_OVERFLOW, VIEW_DTYPE, gs_frame_params, gs_frame_stats, gs_stage_times, make_asset_desc)
+from ._lib import GsError, check
+from .asset import GaussianSplatAsset, kCurrentVersion
+from .camera import Camera, Transform, frame_params, sort_matrix
+
+
+def _fptr(a: np.ndarray):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+class GpuContext:
+    """One GPU + one HIP stream (the analogue of Unity's graphics device + render thread)."""
+
+    def __init__(self, device: int = 0, stream: Optional[int] = None):
+        self._h = C.c_void_p()
+        check(_lib.lib().gs_context_create(device, C.c_void_p(stream) if stream else None, C.byref(self._h)), "gs_context_create")
+        self.device = device
+
+    def Synchronize(self) -> None:
+        check(_lib.lib().gs_context_synchronize(self._h), "gs_context_synchronize")
+
+    def DeviceInfo(self) -> Tuple[str, int, int]:
+        name = C.create_string_buffer(256)
+        cus = C.c_int32()
+        mem = C.c_uint64()
+        check(_lib.lib().gs_context_device_info(self._h, name, 256, C.byref(cus), C.byref(mem)), "gs_context_device_info")
+        return name.value.decode(), cus.value, mem.value
+
+    def Dispose(self) -> None:
+        if self._h:
+            _lib.lib().gs_context_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.Dispose()
+        except Exception:
+            pass
+
+
+class RenderTarget:
+    """The _GaussianSplatRT temporary: RGBA16F, premultiplied, cleared to 0 (GaussianSplatRenderer.cs:194-196)."""
+
+    def __init__(self, ctx: GpuContext, width: int, height: int):
+        self.ctx, self.width, self.height = ctx, width, height
+        self._h = C.c_void_p()
+        check(_lib.lib().gs_target_create(ctx._h, width, height, C.byref(self._h)), "gs_target_create")
+
+    def Clear(self) -> None:
+        check(_lib.lib().gs_target_clear(self._h), "gs_target_clear")
+
+    def Download(self) -> np.ndarray:
+        out = np.empty((self.height, self.width, 4), np.uint16)
+        check(_lib.lib().gs_target_download(self._h, out.ctypes.data, out.nbytes), "gs_target_download")
+        return out
+
+    def Resolve(self, background=(0.0, 0.0, 0.0, 0.0), want8: bool = True):
+        """GaussianComposite.shader onto a constant background: (linear RGBA float32, sRGB RGBA8)."""
+        bg = np.asarray(background, np.float32)
+        o32 = np.empty((self.height, self.width, 4), np.float32)
+        o8 = np.empty((self.height, self.width, 4), np.uint8) if want8 else None
+        check(_lib.lib().gs_target_resolve(self._h, _fptr(bg), o32.ctypes.data, o8.ctypes.data if want8 else None), "gs_target_resolve")
+        return o32, o8
+
+    def ResolveAsync(self, background=(0.0, 0.0, 0.0, 0.0)) -> None:
+        bg = np.asarray(background, np.float32)
+        check(_lib.lib().gs_target_resolve(self._h, _fptr(bg), None, None), "gs_target_resolve")
+
+    def Dispose(self) -> None:
+        if self._h:
+            _lib.lib().gs_target_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.Dispose()
+        except Exception:
+            pass
+
+
+class GpuSorting:
+    """GpuSorting.cs: stable ascending (uint key, uint payload) device sort.  `SupportResources.Load(count)`
+    is the constructor; `Dispatch` sorts device buffers in place, `DispatchHost` round-trips numpy arrays."""
+
+    def __init__(self, ctx: GpuContext, count: int):
+        self.ctx, self.count = ctx, count
+        self._h = C.c_void_p()
+        check(_lib.lib().gs_sorter_create(ctx._h, count, C.byref(self._h)), "gs_sorter_create")
+
+    @property
+    def Valid(self) -> bool:
+        return bool(self._h)
+
+    def Dispatch(self, keys_dev: int, values_dev: int, count: int, key_bits: int = 32) -> None:
+        check(_lib.lib().gs_sorter_dispatch(self._h, C.c_void_p(keys_dev), C.c_void_p(values_dev), count, key_bits), "gs_sorter_dispatch")
+
+    def DispatchHost(self, keys: np.ndarray, values: np.ndarray, key_bits: int = 32):
+        k = np.ascontiguousarray(keys, np.uint32).copy()
+        v = np.ascontiguousarray(values, np.uint32).copy()
+        check(_lib.lib().gs_sorter_sort_host(self._h, k.ctypes.data, v.ctypes.data, len(k), key_bits), "gs_sorter_sort_host")
+        return k, v
+
+    def Dispose(self) -> None:
+        if self._h:
+            _lib.lib().gs_sorter_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.Dispose()
+        except Exception:
+            pass
+
+
+class GaussianSplatRenderer:
+    """GaussianSplatRenderer component (GaussianSplatRenderer.cs:214-680), render path only."""
+
+    def __init__(self, ctx: GpuContext, asset: Optional[GaussianSplatAsset] = None, transform: Optional[Transform] = None):
+        self.ctx = ctx
+        self.transform = transform or Transform()
+        # serialized fields, :225-244
+        self.m_Asset: Optional[GaussianSplatAsset] = asset
+        self.m_RenderOrder = 0
+        self.m_SplatScale = 1.0
+        self.m_OpacityScale = 1.0
+        self.m_SHOrder = 3
+        self.m_SHOnly = False
+        self.m_SortNthFrame = 1
+        self.m_FrameCounter = 0
+        self.blendMode = 0            # 0 exact (fp16 ROP rounding), 1 fast (fp32 accumulate)
+        self._asset_h = C.c_void_p()
+        self._r_h = C.c_void_p()
+        self._keep: list = []
+        self.m_SplatCount = 0
+        self.m_PrevAsset = None
+        self.m_PrevHash = None
+        self.m_Registered = False
+
+    # -- properties ---------------------------------------------------------------------------------------
+    @property
+    def asset(self):
+        return self.m_Asset
+
+    @property
+    def splatCount(self) -> int:
+        return self.m_SplatCount
+
+    @property
+    def HasValidAsset(self) -> bool:          # :361-368
+        a = self.m_Asset
+        return (a is not None and a.splatCount > 0 and a.formatVersion == kCurrentVersion and a.posData is not None
+                and a.otherData is not None and a.shData is not None and a.colorData is not None)
+
+    @property
+    def HasValidRenderSetup(self) -> bool:    # :369
+        return bool(self._r_h)
+
+    # -- lifetime -------------------------------------------------------------------------------------------
+    def CreateResourcesForAsset(self) -> None:      # :373-424
+        if not self.HasValidAsset:
+            return
+        a = self.m_Asset
+        self._keep = []
+        desc = make_asset_desc(a, self._keep)
+        check(_lib.lib().gs_asset_create(self.ctx._h, C.byref(desc), C.byref(self._asset_h)), "gs_asset_create")
+        self._keep = []                              # data was copied to the GPU
+        check(_lib.lib().gs_renderer_create(self.ctx._h, self._asset_h, C.byref(self._r_h)), "gs_renderer_create")
+        self.m_SplatCount = a.splatCount
+
+    def DisposeResourcesForAsset(self) -> None:     # :527-565
+        l = _lib.lib()
+        if self._r_h:
+            l.gs_renderer_destroy(self._r_h)
+            self._r_h = C.c_void_p()
+        if self._asset_h:
+            l.gs_asset_destroy(self._asset_h)
+            self._asset_h = C.c_void_p()
+        self.m_SplatCount = 0
+
+    def OnEnable(self) -> None:                     # :475-485
+        self.m_FrameCounter = 0
+        self.EnsureSorterAndRegister()
+        self.CreateResourcesForAsset()
+        self.m_PrevAsset = self.m_Asset
+        self.m_PrevHash = self.m_Asset.dataHash if self.m_Asset else None
+
+    def OnDisable(self) -> None:                    # :567-577
+        self.DisposeResourcesForAsset()
+        GaussianSplatRenderSystem.instance.UnregisterSplat(self)
+        self.m_Registered = False
+
+    def EnsureSorterAndRegister(self) -> None:      # :461-473
+        if not self.m_Registered:
+            GaussianSplatRenderSystem.instance.RegisterSplat(self)
+            self.m_Registered = True
+
+    def Update(self) -> None:                       # :641-658 asset hot-reload keyed on dataHash
+        cur = self.m_Asset.dataHash if self.m_Asset else None
+        if self.m_PrevAsset is not self.m_Asset or self.m_PrevHash != cur:
+            self.m_PrevAsset, self.m_PrevHash = self.m_Asset, cur
+            self.DisposeResourcesForAsset()
+            self.CreateResourcesForAsset()
+
+    # -- per frame ------------------------------------------------------------------------------------------
+    def FrameParams(self, cam: Camera) -> gs_frame_params:
+        return frame_params(cam, self.transform, self.m_SplatScale, self.m_OpacityScale, self.m_SHOrder, self.m_SHOnly)
+
+    def ResetOrder(self) -> None:                   # CSSetIndices, :434-438
+        check(_lib.lib().gs_renderer_reset_order(self._r_h), "gs_renderer_reset_order")
+
+    def SortPoints(self, cam: Camera, matrix: Optional[np.ndarray] = None) -> None:     # :612-639
+        if matrix is None:
+            matrix = self.transform.localToWorldMatrix
+        m = np.ascontiguousarray(sort_matrix(cam, matrix), np.float32).reshape(16)
+        check(_lib.lib().gs_renderer_sort(self._r_h, _fptr(m)), "gs_renderer_sort")
+
+    def CalcViewData(self, cam: Camera) -> None:    # :579-610
+        p = self.FrameParams(cam)
+        check(_lib.lib().gs_renderer_calc_view(self._r_h, C.byref(p)), "gs_renderer_calc_view")
+
+    def Draw(self, cam: Camera, rt: RenderTarget) -> None:     # the DrawProcedural of :156-166
+        check(_lib.lib().gs_renderer_set_blend_mode(self._r_h, int(self.blendMode)), "gs_renderer_set_blend_mode")
+        p = self.FrameParams(cam)
+        check(_lib.lib().gs_renderer_draw(self._r_h, C.byref(p), rt._h), "gs_renderer_draw")
+
+    # -- parity / measurement hooks ---------------------------------------------------------------------------
+    def SetProfiling(self, on: bool) -> None:
+        check(_lib.lib().gs_renderer_set_profiling(self._r_h, int(on)), "gs_renderer_set_profiling")
+
+    def ReservePairs(self, n: int) -> None:
+        check(_lib.lib().gs_renderer_reserve_pairs(self._r_h, n), "gs_renderer_reserve_pairs")
+
+    def DownloadOrder(self) -> np.ndarray:
+        out = np.empty(self.m_SplatCount, np.uint32)
+        check(_lib.lib().gs_renderer_download_order(self._r_h, out.ctypes.data, len(out)), "gs_renderer_download_order")
+        return out
+
+    def UploadOrder(self, order: np.ndarray) -> None:
+        o = np.ascontiguousarray(order, np.uint32)
+        check(_lib.lib().gs_renderer_upload_order(self._r_h, o.ctypes.data, len(o)), "gs_renderer_upload_order")
+
+    def DownloadDistances(self) -> np.ndarray:
+        out = np.empty(self.m_SplatCount, np.uint32)
+        check(_lib.lib().gs_renderer_download_distances(self._r_h, out.ctypes.data, len(out)), "gs_renderer_download_distances")
+        return out
+
+    def DownloadView(self) -> np.ndarray:
+        out = np.empty(self.m_SplatCount, VIEW_DTYPE)
+        check(_lib.lib().gs_renderer_download_view(self._r_h, out.ctypes.data, out.nbytes), "gs_renderer_download_view")
+        return out
+
+    def FrameStats(self) -> gs_frame_stats:
+        """Blocks.  Raises GsError(GS_ERR_PAIR_OVERFLOW) if the frame overflowed the pair buffer (it is grown: draw again)."""
+        s = gs_frame_stats()
+        check(_lib.lib().gs_renderer_frame_stats(self._r_h, C.byref(s)), "gs_renderer_frame_stats")
+        return s
+
+    def StageTimes(self) -> gs_stage_times:
+        t = gs_stage_times()
+        check(_lib.lib().gs_renderer_stage_times(self._r_h, C.byref(t)), "gs_renderer_stage_times")
+        return t
+
+    def __del__(self):
+        try:
+            self.DisposeResourcesForAsset()
+        except Exception:
+            pass
+
+
+class GaussianSplatRenderSystem:
+    """GaussianSplatRenderSystem (GaussianSplatRenderer.cs:17-212): per-camera gather, order, sort, draw, composite."""
+    instance: "GaussianSplatRenderSystem" = None  # type: ignore
+
+    def __init__(self):
+        self.m_Splats: List[GaussianSplatRenderer] = []
+        self.m_ActiveSplats: List[GaussianSplatRenderer] = []
+
+    def RegisterSplat(self, r: GaussianSplatRenderer) -> None:      # :25-36
+        if r not in self.m_Splats:
+            self.m_Splats.append(r)
+
+    def UnregisterSplat(self, r: GaussianSplatRenderer) -> None:    # :38-70
+        if r in self.m_Splats:
+            self.m_Splats.remove(r)
+
+    def GatherSplatsForCamera(self, cam: Camera) -> bool:           # :73-105
+        self.m_ActiveSplats = [gs for gs in self.m_Splats if gs.HasValidAsset and gs.HasValidRenderSetup]
+        if not self.m_ActiveSplats:
+            return False
+        w2c = cam.worldToCameraMatrix.astype(np.float64)
+
+        def cam_z(gs):                                              # camTr.InverseTransformPoint(pos).z (Unity: +z forward)
+            p = np.append(np.asarray(gs.transform.position, np.float64), 1.0)
+            return -float((w2c @ p)[2])
+        # orderB.CompareTo(orderA), then posA.z.CompareTo(posB.z): stable sort on (-order, z)
+        self.m_ActiveSplats.sort(key=lambda gs: (-gs.m_RenderOrder, cam_z(gs)))
+        return True
+
+    def SortAndRenderSplats(self, cam: Camera, rt: RenderTarget) -> None:     # :108-169
+        for gs in self.m_ActiveSplats:
+            if gs.m_FrameCounter % gs.m_SortNthFrame == 0:
+                gs.SortPoints(cam, gs.transform.localToWorldMatrix)
+            gs.m_FrameCounter += 1
+            gs.CalcViewData(cam)
+            gs.Draw(cam, rt)
+
+    def OnPreCullCamera(self, cam: Camera, rt: RenderTarget, background=None):     # :187-211
+        """Clear the splat RT, sort/calc/draw every active renderer, then (optionally) composite onto `background`."""
+        if not self.GatherSplatsForCamera(cam):
+            return None
+        rt.Clear()
+        self.SortAndRenderSplats(cam, rt)
+        if background is not None:
+            return rt.Resolve(background)
+        return None
+
+
+GaussianSplatRenderSystem.instance = GaussianSplatRenderSystem()
