@@ -1,0 +1,288 @@
+#!/usr/bin/env python3
+"""bench.py -- frames/s of the splat render hot path on MI355X (BASELINE.json metric).
+
+One "step" = one frame of the reference's per-camera path for one GaussianSplatRenderer:
+    SortPoints (CSCalcDistances + device radix sort)  ->  CalcViewData (CSCalcViewData)
+    ->  clear RT  ->  draw all splats front-to-back  ->  composite (GaussianComposite)
+on the configuration BASELINE.json quotes its metric on: bicycle-*sized* synthetic scene, 6,131,954 splats,
+Medium asset (296 MB), 1200x797 (SURVEY.md section 8d "C2"; the real INRIA model is not available offline).
+All inputs are resident in HBM before the timed region.  The camera orbits by 0.25 degrees per frame.
+
+    python bench.py [--gpus N --steps K --warmup W] [--config C2] [--blend exact|fast] [--cpu-baseline auto|off]
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): view-parallel.  Rank 0 builds the asset, its five
+blobs are broadcast once over RCCL (torch.distributed, backend "nccl"), every rank renders its own camera
+(azimuth rank*45 deg); no per-frame collective.  value = all ranks' splats*frames / max-over-ranks time.
+
+Prints ONE JSON line on rank 0 (see DESIGN.md "measurement" for the byte formulas behind `roofline`).
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import threading
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--config", default="C2", choices=["C1", "C2", "C3", "C4", "C5"])
+    ap.add_argument("--splats", type=int, default=0, help="override the splat count (debugging only; result is labelled)")
+    ap.add_argument("--blend", default="exact", choices=["exact", "fast"])
+    ap.add_argument("--cpu-baseline", default="auto", choices=["auto", "off"])
+    ap.add_argument("--sort-nth-frame", type=int, default=1)
+    return ap.parse_args()
+
+
+def stage_bytes(n, P, W, H, asset, passes_pair):
+    """ALGORITHMIC bytes per launch of each stage (DESIGN.md "measurement")."""
+    from unitygaussiansplatting_amd.asset import GetVectorSize, GetOtherSizeNoSHIndex, GetColorSize
+    b_pos = GetVectorSize(asset.posFormat)
+    sh_item = {0: 192, 1: 96, 2: 60, 3: 32}.get(int(asset.shFormat), 96)
+    chunk = 64.0 / 256.0 if asset.chunkCount else 0.0
+    b_asset = b_pos + GetOtherSizeNoSHIndex(asset.scaleFormat) + GetColorSize(asset.colorFormat) + sh_item + chunk
+    return {
+        "calc_distances": n * (4 + b_pos + chunk + 4),           # prev order + gathered pos + key out
+        "sort": n * 16 * 4,                                      # 4 Onesweep passes x (key+payload read + write); histogram is fused into calc_distances
+        "calc_view": n * (b_asset + 40),                         # asset record in, 40-byte view record out
+        "bin": n * (4 + 40 + 32) + P * 8,                        # order + view gather + 32-byte record out, (tile,i) pairs out
+        "pair_sort": P * 16 * passes_pair + P * 4,               # Onesweep passes over the pairs + tile-range scan of the keys
+        "blend": P * (4 + 32) + W * H * 16,                      # pair index + record per pair, RT read + write
+        "resolve": W * H * (8 + 16 + 4),                         # RGBA16F in, float RGBA + RGBA8 out
+    }
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        args.gpus = world
+
+    # torch is plumbing here (device memory for the broadcast blobs, barrier, synchronize); its first import on a
+    # fresh box takes a minute or two, so it is overlapped with building the synthetic scene.
+    holder = {}
+
+    def _imp():
+        import torch
+        holder["torch"] = torch
+    th = threading.Thread(target=_imp)
+    th.start()
+
+    from unitygaussiansplatting_amd import camera, creator, scenes
+    from unitygaussiansplatting_amd._abi import gs_asset_desc
+    from unitygaussiansplatting_amd import _lib
+    from unitygaussiansplatting_amd._lib import GsError, check
+    from unitygaussiansplatting_amd.renderer import GaussianSplatRenderer, GpuContext, RenderTarget
+    from unitygaussiansplatting_amd.asset import ColorFormat, GaussianSplatAsset, SHFormat, VectorFormat
+
+    cfg = scenes.CONFIGS[args.config]
+    t_build = time.perf_counter()
+    asset = None
+    if rank == 0:
+        raw = scenes.make_config_splats(cfg, args.splats)
+        asset = creator.CreateAssetFromSplats(raw, cfg.quality, name=cfg.key)
+        del raw
+    th.join()
+    torch = holder["torch"]
+    t_build = time.perf_counter() - t_build
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (torch.cuda.is_available() is False); there is no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    # ---- asset residency: blobs live in torch CUDA tensors; rank 0's are broadcast over RCCL/xGMI ------------
+    from unitygaussiansplatting_amd import parallel
+    t0 = time.perf_counter()
+    meta, blobs = parallel.broadcast_asset(asset, torch, dist, rank, world, torch.device("cuda", local_rank))
+    torch.cuda.synchronize()
+    t_bcast = time.perf_counter() - t0
+
+    ctx = GpuContext(local_rank)
+    r = GaussianSplatRenderer(ctx)
+    asset_meta = parallel.asset_from_meta(meta)          # formats/count only (no host blobs on ranks > 0)
+    r.m_Asset = asset if asset is not None else asset_meta
+    r.m_SortNthFrame = args.sort_nth_frame
+    parallel.attach_device_asset(r, meta, blobs)         # gs_asset_create(memory_kind = device) + gs_renderer_create
+    r.blendMode = 0 if args.blend == "exact" else 1
+    W, H = cfg.width, cfg.height
+    rt = RenderTarget(ctx, W, H)
+    n = meta["splatCount"]
+
+    def cam_at(frame):
+        az = rank * 45.0 + 0.25 * frame
+        return camera.Camera(position=scenes.orbit_eye(cfg.eye_radius, cfg.eye_elev_deg, az), pixelWidth=W, pixelHeight=H,
+                             fieldOfView=cfg.fov_y)
+
+    def frame(i, cam):
+        if i % r.m_SortNthFrame == 0:
+            r.SortPoints(cam)
+        r.CalcViewData(cam)
+        rt.Clear()
+        r.Draw(cam, rt)
+        rt.ResolveAsync((0.0, 0.0, 0.0, 1.0))
+
+    def full_sync():
+        ctx.Synchronize()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    # ---- warm-up (also sizes the pair buffer: an overflowing frame grows it and is re-run) -------------------
+    fi = 0
+    for _ in range(max(args.warmup, 1)):
+        frame(fi, cam_at(fi))
+        try:
+            r.FrameStats()
+        except GsError as e:
+            if e.code != -6:
+                raise
+            frame(fi, cam_at(fi))
+            r.FrameStats()
+        fi += 1
+    # the orbit over the timed region may need more pairs than the warm-up saw: leave 50 % headroom
+    st = r.FrameStats()
+    r.ReservePairs(int(st.tile_pairs * 1.5) + (1 << 20))
+
+    # ---- timed region ------------------------------------------------------------------------------------
+    r.SetProfiling(min(args.steps, 1024))
+    full_sync()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        frame(fi + k, cam_at(fi + k))
+    ctx.Synchronize()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    st = r.FrameStats()                   # raises if the last frame overflowed / a sort spin expired
+    stage = r.StageTimes()
+    r.SetProfiling(0)
+    if dist is not None:
+        tmax = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    ms_per_step = elapsed / args.steps * 1e3
+    msplats = n * args.steps * world / elapsed / 1e6
+
+    if rank == 0:
+        P = int(st.tile_pairs)
+        numTiles = st.tiles_x * st.tiles_y
+        passes_pair = 1 if numTiles <= 256 else (2 if numTiles <= 65536 else 3)
+        # resolve is timed separately (it is a target method, outside the renderer's event ring)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ctx.Synchronize()
+        t_r = time.perf_counter()
+        for _ in range(20):
+            rt.ResolveAsync((0.0, 0.0, 0.0, 1.0))
+        ctx.Synchronize()
+        resolve_ms = (time.perf_counter() - t_r) / 20 * 1e3
+        sb = stage_bytes(n, P, W, H, r.m_Asset, passes_pair)
+        times = {"calc_distances": stage.calc_distances_ms, "sort": stage.sort_ms, "calc_view": stage.calc_view_ms,
+                 "bin": stage.bin_ms, "pair_sort": stage.pair_sort_ms, "blend": stage.blend_ms, "resolve": resolve_ms}
+        stages = {}
+        for k, ms in times.items():
+            gbs = sb[k] / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+            stages[k] = {"ms": round(ms, 4), "alg_MB": round(sb[k] / 1e6, 2), "GBps": round(gbs, 1), "hbm_frac": round(gbs / HBM_PEAK_GBS, 4)}
+        dom = max((k for k in times if k != "resolve"), key=lambda k: times[k])
+        kernel_of = {"calc_distances": "calc_distances_kernel", "sort": "onesweep_kernel (x4)", "calc_view": "calc_view_kernel",
+                     "bin": "bin_emit_kernel", "pair_sort": "onesweep_kernel (pairs)", "blend": "blend_kernel"}
+        dom_launches = 4 if dom == "sort" else (passes_pair if dom == "pair_sort" else 1)
+        dom_ms = times[dom] / dom_launches
+        dom_bytes = (sb[dom] - (P * 4 if dom == "pair_sort" else 0)) / dom_launches
+        achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        frame_bytes = sum(sb.values())
+        roofline = {"bound": "hbm", "kernel": kernel_of[dom], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                    "alg_bytes_per_launch": int(dom_bytes), "avg_launch_ms": round(dom_ms, 4), "frames_averaged": int(stage.frames),
+                    "whole_frame": {"alg_MB": round(frame_bytes / 1e6, 1), "GBps": round(frame_bytes / (ms_per_step * 1e-3) / 1e9, 1),
+                                    "hbm_frac": round(frame_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}}
+
+        cpu = None
+        parity = None
+        if world == 1 and args.cpu_baseline == "auto":
+            cpu, parity = cpu_baseline(asset, r, rt, cam_at(fi + args.steps - 1), n, W, H, r.blendMode)
+
+        ref_msplats = 6_131_954 / 6.8e-3 / 1e6      # 6.8 ms/frame, RTX 3080 Ti, real bicycle scene
+        out = {
+            "metric": "Msplats/s rendered (sort+view+composite), bicycle-sized 6.1M splats @1200x797; ms/frame in ms_per_step",
+            "value": round(msplats, 2), "unit": "Msplats/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": round(msplats / world / ref_msplats, 3) if args.config == "C2" and not args.splats else None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": cfg.label + (f" [splat count overridden to {n}]" if args.splats else ""),
+                       "splats": n, "resolution": [W, H], "asset_MB": round(sum(b.numel() for b in blobs if b is not None) / 1e6, 1),
+                       "blend": args.blend, "sort_nth_frame": args.sort_nth_frame, "tile_pairs_P": P, "visible_splats": int(st.visible_splats),
+                       "parallelism": f"view-parallel x{world} (one camera per GPU, asset broadcast once over RCCL)" if world > 1 else "single GPU",
+                       "baseline_note": "vs_baseline = per-GPU Msplats/s / 901.8 (reference: 6.8 ms/frame on RTX 3080 Ti, real INRIA bicycle, BASELINE.md)"},
+            "roofline": roofline, "stages": stages, "cpu_baseline": cpu, "parity_vs_oracle": parity,
+            "setup_s": {"scene_build": round(t_build, 1), "asset_broadcast": round(t_bcast, 3)},
+        }
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(asset, r, rt, cam, n, W, H, mode):
+    """The oracle (CPU restatement of the reference shaders, oracle/gs_oracle.cpp) timed on the host cores for one
+    whole frame of the same workload, and used as the checker for the GPU frame of the same camera."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    from unitygaussiansplatting_amd import camera
+    orc = O.Oracle(asset)
+    cores = int(O.lib().gso_num_threads())
+    P = r.FrameParams(cam)
+    ms = camera.sort_matrix(cam, r.transform.localToWorldMatrix)
+    orc.sort(ms)                                    # warm the page cache / thread pool; also the previous-frame order
+    t0 = time.perf_counter()
+    orc.sort(ms)
+    t1 = time.perf_counter()
+    orc.calc_view(P)
+    t2 = time.perf_counter()
+    ref = orc.draw(P, mode)
+    t3 = time.perf_counter()
+    O.resolve(ref, (0, 0, 0, 1))
+    t4 = time.perf_counter()
+    total = t4 - t0
+    # same camera on the GPU, then compare
+    r.ResetOrder()
+    r.SortPoints(cam); r.SortPoints(cam)
+    r.CalcViewData(cam)
+    rt.Clear()
+    r.Draw(cam, rt)
+    r.FrameStats()
+    img = rt.Download()
+    a, b = O.f16_to_f32(img), O.f16_to_f32(ref)
+    d = np.abs(a - b)
+    order_equal = bool(np.array_equal(r.DownloadOrder(), orc.order))
+    parity = {"order_bit_exact": order_equal, "rt_max_abs": float(d.max()), "rt_mean_abs": float(d.mean()),
+              "rt_pixels_bit_equal": float((img == ref).all(axis=2).mean())}
+    cpu = {"value": round(n / total / 1e6, 3), "unit": "Msplats/s", "cores": cores, "kind": "port",
+           "sample": f"1 whole frame of the same workload ({n} splats, {W}x{H}): sort {t1 - t0:.2f}s + view {t2 - t1:.2f}s + "
+                     f"composite {t3 - t2:.2f}s + resolve {t4 - t3:.2f}s = {total:.2f}s on {cores} OpenMP threads",
+           "ms_per_frame": round(total * 1e3, 1)}
+    return cpu, parity
+
+
+if __name__ == "__main__":
+    main()

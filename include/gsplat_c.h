@@ -100,7 +100,8 @@ typedef struct gs_frame_stats {
 } gs_frame_stats;
 
 /* hipEvent-timed stage durations of the last frame, ms (the four ProfilerMarkers of
- * GaussianSplatRenderer.cs:20-22,287 split further).  Only valid after gs_renderer_set_profiling(r,1). */
+ * GaussianSplatRenderer.cs:20-22,287 split further), averaged over the frames recorded since the last call.
+ * Only valid after gs_renderer_set_profiling(r, frames > 0). */
 typedef struct gs_stage_times {
     float calc_distances_ms;   /* CSCalcDistances (+ fused digit histograms) */
     float sort_ms;             /* 4 Onesweep passes */
@@ -110,6 +111,7 @@ typedef struct gs_stage_times {
     float blend_ms;            /* per-tile front-to-back composite (RenderGaussianSplats.shader) */
     float resolve_ms;          /* GaussianComposite.shader */
     float total_ms;
+    uint32_t frames;           /* number of frames the averages cover */
 } gs_stage_times;
 
 int32_t gs_abi_version(void);
@@ -152,7 +154,9 @@ int32_t gs_renderer_render(gs_renderer* r, const float matrix_sort[16], const gs
 /* 0 (default): "exact" -- accumulate in fp16 (RTNE after every blend, like the RGBA16F ROP).
  * 1: "fast" -- accumulate in fp32, stop a pixel when 1-A < 1/4096. */
 int32_t gs_renderer_set_blend_mode(gs_renderer* r, int32_t mode);
-int32_t gs_renderer_set_profiling(gs_renderer* r, int32_t enabled);
+/* frames = 0: off.  frames > 0: keep a ring of `frames` per-frame hipEvent sets (no host sync while rendering);
+ * a frame ends at gs_renderer_draw.  gs_renderer_stage_times averages over the ring and resets it. */
+int32_t gs_renderer_set_profiling(gs_renderer* r, int32_t frames);
 int32_t gs_renderer_reserve_pairs(gs_renderer* r, uint64_t pair_capacity);
 /* blocking readbacks (parity hooks; synchronise the stream) */
 int32_t gs_renderer_download_order(gs_renderer* r, uint32_t* out, size_t count);        /* _OrderBuffer / m_GpuSortKeys */

@@ -26,6 +26,18 @@ int32_t fail_hip(hipError_t e, const char* what, const char* file, int line) {
     return e == hipErrorOutOfMemory ? GS_ERR_OUT_OF_MEMORY : GS_ERR_HIP;
 }
 
+void prof_record(gs_renderer* r, int k) {
+    if (!r->profiling || !r->ev) return;
+    const int idx = r->profCur * kEvPerFrame + k;
+    if (hipEventRecord(r->ev[idx], r->ctx->stream) == hipSuccess) r->evValid[idx] = 1;
+}
+void prof_end_frame(gs_renderer* r) {
+    if (!r->profiling || !r->ev) return;
+    r->profCompleted++;
+    r->profCur = (r->profCur + 1) % r->profCapacity;
+    memset(r->evValid + (size_t)r->profCur * kEvPerFrame, 0, kEvPerFrame);
+}
+
 } // namespace gs
 
 using namespace gs;
@@ -186,7 +198,6 @@ int32_t gs_renderer_create(gs_context* ctx, gs_asset* asset, gs_renderer** out) 
     gs_renderer* r = new (std::nothrow) gs_renderer();
     if (!r) return fail(GS_ERR_OUT_OF_MEMORY, "host allocation");
     r->ctx = ctx; r->asset = asset; r->n = asset->view.n;
-    for (int k = 0; k < 10; ++k) r->evValid[k] = false;
     int32_t rc = GS_OK;
     auto chk = [&](hipError_t e, const char* what) { if (rc == GS_OK && e != hipSuccess) rc = fail_hip(e, what, __FILE__, __LINE__); };
     chk(hipMalloc((void**)&r->view, (size_t)r->n * sizeof(gsm::ViewData) + 64), "alloc view");
@@ -212,7 +223,7 @@ int32_t gs_renderer_destroy(gs_renderer* r) {
     if (r->depthControl) (void)hipFree(r->depthControl);
     sort_state_destroy(r->depthSort);
     renderer_free_raster(r);
-    if (r->evCreated) for (int k = 0; k < 10; ++k) (void)hipEventDestroy(r->ev[k]);
+    if (r->ev) { for (int k = 0; k < r->profCapacity * kEvPerFrame; ++k) (void)hipEventDestroy(r->ev[k]); delete[] r->ev; delete[] r->evValid; }
     delete r;
     return GS_OK;
 }
@@ -223,9 +234,7 @@ int32_t gs_renderer_reset_order(gs_renderer* r) {
     return enqueue_set_indices(r->ctx, r->order, r->n);
 }
 
-static void rec_ev(gs_renderer* r, int k) {
-    if (r->profiling) { (void)hipEventRecord(r->ev[k], r->ctx->stream); r->evValid[k] = true; }
-}
+static void rec_ev(gs_renderer* r, int k) { gs::prof_record(r, k); }
 
 int32_t gs_renderer_sort(gs_renderer* r, const float m[16]) {
     if (!r || !m) return fail(GS_ERR_INVALID_ARGUMENT, "null argument");
@@ -264,7 +273,6 @@ int32_t gs_renderer_draw(gs_renderer* r, const gs_frame_params* p, gs_target* rt
     if ((uint32_t)p->screen_w != rt->width || (uint32_t)p->screen_h != rt->height) return fail(GS_ERR_INVALID_ARGUMENT, "screen_w/h do not match the target");
     GS_TRY(bind_device(r->ctx));
     GS_TRY(maybe_grow_pairs(r));
-    for (int k = 3; k <= 6; ++k) r->evValid[k] = r->profiling;
     return enqueue_draw(r, p, rt);
 }
 
@@ -282,15 +290,21 @@ int32_t gs_renderer_set_blend_mode(gs_renderer* r, int32_t mode) {
     return GS_OK;
 }
 
-int32_t gs_renderer_set_profiling(gs_renderer* r, int32_t enabled) {
-    if (!r) return fail(GS_ERR_INVALID_ARGUMENT, "renderer is null");
+int32_t gs_renderer_set_profiling(gs_renderer* r, int32_t frames) {
+    if (!r || frames < 0 || frames > 4096) return fail(GS_ERR_INVALID_ARGUMENT, "frames must be in [0, 4096]");
     GS_TRY(bind_device(r->ctx));
-    if (enabled && !r->evCreated) {
-        for (int k = 0; k < 10; ++k) GS_HIP(hipEventCreate(&r->ev[k]));
-        r->evCreated = true;
+    if (frames > r->profCapacity) {
+        GS_HIP(hipStreamSynchronize(r->ctx->stream));
+        if (r->ev) { for (int k = 0; k < r->profCapacity * kEvPerFrame; ++k) (void)hipEventDestroy(r->ev[k]); delete[] r->ev; delete[] r->evValid; r->ev = nullptr; }
+        r->ev = new (std::nothrow) hipEvent_t[(size_t)frames * kEvPerFrame];
+        r->evValid = new (std::nothrow) uint8_t[(size_t)frames * kEvPerFrame];
+        if (!r->ev || !r->evValid) return fail(GS_ERR_OUT_OF_MEMORY, "host allocation");
+        r->profCapacity = frames;
+        for (int k = 0; k < frames * kEvPerFrame; ++k) GS_HIP(hipEventCreate(&r->ev[k]));
     }
-    r->profiling = enabled != 0;
-    for (int k = 0; k < 10; ++k) r->evValid[k] = false;
+    r->profiling = frames > 0;
+    r->profCur = 0; r->profCompleted = 0;
+    if (r->evValid) memset(r->evValid, 0, (size_t)r->profCapacity * kEvPerFrame);
     return GS_OK;
 }
 
@@ -367,22 +381,31 @@ int32_t gs_renderer_frame_stats(gs_renderer* r, gs_frame_stats* out) {
 int32_t gs_renderer_stage_times(gs_renderer* r, gs_stage_times* out) {
     if (!r || !out) return fail(GS_ERR_INVALID_ARGUMENT, "null argument");
     memset(out, 0, sizeof(*out));
-    if (!r->evCreated) return fail(GS_ERR_INVALID_ARGUMENT, "profiling was never enabled");
+    if (!r->ev) return fail(GS_ERR_INVALID_ARGUMENT, "profiling was never enabled");
     GS_TRY(bind_device(r->ctx));
     GS_HIP(hipStreamSynchronize(r->ctx->stream));
-    auto el = [&](int a, int b) -> float {
-        float ms = 0.f;
-        if (r->evValid[a] && r->evValid[b] && hipEventElapsedTime(&ms, r->ev[a], r->ev[b]) == hipSuccess) return ms;
-        return 0.f;
+    // average every stage over the completed slots of the ring (the slot in progress is included if it holds events)
+    const int slots = r->profCompleted < r->profCapacity ? r->profCompleted + 1 : r->profCapacity;
+    auto avg = [&](int a, int b) -> float {
+        double sum = 0.0; int cnt = 0;
+        for (int sidx = 0; sidx < slots; ++sidx) {
+            const int base = sidx * kEvPerFrame;
+            float ms = 0.f;
+            if (r->evValid[base + a] && r->evValid[base + b] && hipEventElapsedTime(&ms, r->ev[base + a], r->ev[base + b]) == hipSuccess) { sum += ms; cnt++; }
+        }
+        return cnt ? (float)(sum / cnt) : 0.f;
     };
-    out->calc_distances_ms = el(0, 1);
-    out->sort_ms = el(1, 2);
-    out->calc_view_ms = el(7, 8);
-    out->bin_ms = el(3, 4);
-    out->pair_sort_ms = el(4, 5);
-    out->blend_ms = el(5, 6);
-    out->resolve_ms = r->resolveMs;
+    out->calc_distances_ms = avg(0, 1);
+    out->sort_ms = avg(1, 2);
+    out->calc_view_ms = avg(7, 8);
+    out->bin_ms = avg(3, 4);
+    out->pair_sort_ms = avg(4, 5);
+    out->blend_ms = avg(5, 6);
+    out->resolve_ms = 0.f;
     out->total_ms = out->calc_distances_ms + out->sort_ms + out->calc_view_ms + out->bin_ms + out->pair_sort_ms + out->blend_ms;
+    out->frames = (uint32_t)(r->profCompleted < r->profCapacity ? r->profCompleted : r->profCapacity);
+    r->profCur = 0; r->profCompleted = 0;
+    memset(r->evValid, 0, (size_t)r->profCapacity * kEvPerFrame);
     return GS_OK;
 }
 

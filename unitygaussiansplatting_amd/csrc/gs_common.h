@@ -34,6 +34,7 @@ constexpr int kSortPart = kSortThreads * kSortKPT;   // 4096 keys per partition
 constexpr int kBinThreads = 256;
 constexpr int kBinItems = 4;              // sorted positions per thread
 constexpr int kBinPart = kBinThreads * kBinItems;
+constexpr int kEvPerFrame = 10;           // hipEvents per profiled frame
 
 // 32-byte per-sorted-position record consumed by the blend kernel
 struct alignas(16) SplatRec {
@@ -129,10 +130,11 @@ struct gs_renderer {
     uint32_t arenaTiles = 0;                // tiles the arena was sized for
     uint32_t binParts = 0;
     int blendMode = 0;
+    // profiling: a ring of per-frame hipEvent sets (slot advances at the end of gs_renderer_draw)
     bool profiling = false;
-    hipEvent_t ev[10];
-    bool evCreated = false;
-    bool evValid[10];
+    hipEvent_t* ev = nullptr;               // profCapacity x kEvPerFrame
+    uint8_t* evValid = nullptr;
+    int profCapacity = 0, profCur = 0, profCompleted = 0;
     // host copy of last frame's control (pinned), read lazily
     gs::BinControl* hostBin = nullptr;
     gs::SortControl* hostSortErr = nullptr;
@@ -142,6 +144,8 @@ struct gs_renderer {
 };
 
 namespace gs {
+void prof_record(gs_renderer* r, int k);   // gs_api.hip: record event k of the current profiling slot
+void prof_end_frame(gs_renderer* r);
 // sort entry points (gs_sort.hip)
 int32_t sort_state_create(gs_context* ctx, SortState& st, uint32_t maxCount);
 void sort_state_destroy(SortState& st);

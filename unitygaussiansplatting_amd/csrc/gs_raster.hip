@@ -423,24 +423,25 @@ int32_t enqueue_draw(gs_renderer* r, const gs_frame_params* p, gs_target* rt) {
     const uint32_t cap = (uint32_t)r->pairCapacity;
 
     GS_HIP(hipMemsetAsync(r->frameArena, 0, r->frameArenaBytes, st));
-    if (r->profiling) GS_HIP(hipEventRecord(r->ev[3], st));
+    prof_record(r, 3);
     hipLaunchKernelGGL(bin_emit_kernel, dim3(r->binParts), dim3(kBinThreads), 0, st, r->view, r->order, r->n, rc, r->recs, r->pairKeys,
                        r->pairVals, cap, binCtl, binStatus, pairCtl->hist);
-    if (r->profiling) GS_HIP(hipEventRecord(r->ev[4], st));
+    prof_record(r, 4);
     const int passes = numTiles <= 256 ? 1 : (numTiles <= 65536 ? 2 : 3);
     GS_TRY(enqueue_sort_passes(ctx, r->pairSort, pairCtl, r->pairKeys, r->pairVals, cap, &binCtl->pairCountClamped, passes));
     hipLaunchKernelGGL(tile_ranges_kernel, dim3(max(1u, min(div_up(cap, 256), (uint32_t)ctx->cuCount * 8u))), dim3(256), 0, st, r->pairKeys,
                        &binCtl->pairCountClamped, tileStart, tileEnd, numTiles);
-    if (r->profiling) GS_HIP(hipEventRecord(r->ev[5], st));
+    prof_record(r, 5);
     if (r->blendMode == 0)
         hipLaunchKernelGGL(blend_kernel<0>, dim3(numTiles), dim3(256), 0, st, r->pairVals, tileStart, tileEnd, r->recs, rt->rgba16f, rc);
     else
         hipLaunchKernelGGL(blend_kernel<1>, dim3(numTiles), dim3(256), 0, st, r->pairVals, tileStart, tileEnd, r->recs, rt->rgba16f, rc);
-    if (r->profiling) GS_HIP(hipEventRecord(r->ev[6], st));
+    prof_record(r, 6);
     GS_HIP(hipGetLastError());
     GS_HIP(hipMemcpyAsync(r->hostBin, binCtl, sizeof(BinControl), hipMemcpyDeviceToHost, st));
     GS_HIP(hipMemcpyAsync(&r->hostSortErr->error, &pairCtl->error, 4, hipMemcpyDeviceToHost, st));
     r->frameInFlight = true;
+    prof_end_frame(r);
     return GS_OK;
 }
 

@@ -1,0 +1,88 @@
+"""Multi-view rendering across GPUs: one camera per GPU, shared splat buffers broadcast once.
+
+The reference is single-GPU, single-process; this layer is new.  The path shards
+naturally by *view*: every GPU holds a replica of the immutable asset blobs and runs the whole per-camera path
+(sort -> view data -> composite) on its own camera, so there is NO per-frame collective.  The only exchange is
+at load time: rank `root` broadcasts the five GaussianSplatAsset blobs (pos / other / color / sh / chunk) to
+every rank with torch.distributed (backend "nccl" = RCCL over xGMI on MI355X; "gloo" in the CPU tests), and the
+renderer adopts the received device buffers without a copy (gs_asset_desc.memory_kind = 1).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from .asset import ColorFormat, GaussianSplatAsset, SHFormat, VectorFormat
+
+BLOB_NAMES = ("posData", "otherData", "colorData", "shData", "chunkData")
+
+
+def assign_views(num_views: int, world_size: int) -> List[List[int]]:
+    """View k is rendered by rank k % world_size (C5: 8 views -> 8 GPUs, one each)."""
+    return [[v for v in range(num_views) if v % world_size == rk] for rk in range(world_size)]
+
+
+def asset_meta(asset: GaussianSplatAsset) -> dict:
+    return dict(splatCount=asset.splatCount, posFormat=int(asset.posFormat), scaleFormat=int(asset.scaleFormat),
+                colorFormat=int(asset.colorFormat), shFormat=int(asset.shFormat), formatVersion=asset.formatVersion,
+                dataHash=asset.dataHash, name=asset.name, boundsMin=tuple(asset.boundsMin), boundsMax=tuple(asset.boundsMax),
+                sizes=[0 if getattr(asset, nm) is None else int(len(getattr(asset, nm))) for nm in BLOB_NAMES])
+
+
+def asset_from_meta(meta: dict, blobs: Optional[Sequence[Optional[np.ndarray]]] = None) -> GaussianSplatAsset:
+    a = GaussianSplatAsset(splatCount=meta["splatCount"], posFormat=VectorFormat(meta["posFormat"]),
+                           scaleFormat=VectorFormat(meta["scaleFormat"]), shFormat=SHFormat(meta["shFormat"]),
+                           colorFormat=ColorFormat(meta["colorFormat"]), formatVersion=meta["formatVersion"],
+                           dataHash=meta["dataHash"], name=meta["name"], boundsMin=meta["boundsMin"], boundsMax=meta["boundsMax"])
+    if blobs is not None:
+        for nm, b in zip(BLOB_NAMES, blobs):
+            setattr(a, nm, b)
+    else:                                   # placeholders so HasValidAsset-style checks see "data lives on the GPU"
+        for nm, sz in zip(BLOB_NAMES, meta["sizes"]):
+            setattr(a, nm, np.zeros(0, np.uint8) if sz else None)
+    return a
+
+
+def broadcast_asset(asset: Optional[GaussianSplatAsset], torch, dist, rank: int, world: int, device, root: int = 0):
+    """Returns (meta, [5 uint8 tensors on `device` or None]).  On `root`, `asset` must be given; elsewhere it is ignored.
+    One broadcast per blob (296 MB for the bicycle-sized Medium asset; 5 large messages, not thousands of small ones)."""
+    meta_box = [asset_meta(asset) if rank == root else None]
+    if dist is not None and world > 1:
+        dist.broadcast_object_list(meta_box, src=root)
+    meta = meta_box[0]
+    blobs = []
+    for nm, sz in zip(BLOB_NAMES, meta["sizes"]):
+        if sz == 0:
+            blobs.append(None)
+            continue
+        # +16 bytes of zero padding: the 2-byte-aligned dword stitching of the decoder may touch the dword after the last record
+        t = torch.zeros(sz + 16, dtype=torch.uint8, device=device)
+        if rank == root:
+            src = np.ascontiguousarray(getattr(asset, nm), dtype=np.uint8)
+            t[:sz].copy_(torch.from_numpy(src))
+        if dist is not None and world > 1:
+            dist.broadcast(t, src=root)
+        blobs.append(t)
+    return meta, blobs
+
+
+def attach_device_asset(renderer, meta: dict, blobs) -> None:
+    """CreateResourcesForAsset for blobs that already live on the renderer's GPU (borrowed, not copied)."""
+    from . import _lib
+    from ._abi import gs_asset_desc
+    from ._lib import check
+    d = gs_asset_desc()
+    d.splat_count = meta["splatCount"]
+    d.pos_format, d.scale_format = meta["posFormat"], meta["scaleFormat"]
+    d.color_format, d.sh_format = meta["colorFormat"], meta["shFormat"]
+    d.memory_kind = 1
+    for nm, t, sz in zip(("pos", "other", "color", "sh", "chunk"), blobs, meta["sizes"]):
+        setattr(d, nm + "_data", None if t is None else t.data_ptr())
+        setattr(d, nm + "_size", 0 if t is None else sz)
+    renderer._device_blobs = blobs            # keep the tensors alive as long as the renderer
+    check(_lib.lib().gs_asset_create(renderer.ctx._h, C.byref(d), C.byref(renderer._asset_h)), "gs_asset_create")
+    check(_lib.lib().gs_renderer_create(renderer.ctx._h, renderer._asset_h, C.byref(renderer._r_h)), "gs_renderer_create")
+    renderer.m_SplatCount = meta["splatCount"]
+    renderer.m_PrevAsset, renderer.m_PrevHash = renderer.m_Asset, meta["dataHash"]

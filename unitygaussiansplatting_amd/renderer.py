@@ -240,8 +240,9 @@ class GaussianSplatRenderer:
         check(_lib.lib().gs_renderer_draw(self._r_h, C.byref(p), rt._h), "gs_renderer_draw")
 
     # -- parity / measurement hooks ---------------------------------------------------------------------------
-    def SetProfiling(self, on: bool) -> None:
-        check(_lib.lib().gs_renderer_set_profiling(self._r_h, int(on)), "gs_renderer_set_profiling")
+    def SetProfiling(self, frames: int) -> None:
+        """frames = 0 off; > 0: ring of per-frame hipEvent sets, averaged by StageTimes()."""
+        check(_lib.lib().gs_renderer_set_profiling(self._r_h, int(frames)), "gs_renderer_set_profiling")
 
     def ReservePairs(self, n: int) -> None:
         check(_lib.lib().gs_renderer_reserve_pairs(self._r_h, n), "gs_renderer_reserve_pairs")
