@@ -1,0 +1,33 @@
+"""Shared helpers for the tests: small deterministic scenes and cameras."""
+from __future__ import annotations
+
+import functools
+
+import numpy as np
+
+from unitygaussiansplatting_amd import camera, creator, scenes
+
+
+@functools.lru_cache(maxsize=16)
+def small_asset(n: int = 20000, seed: int = 5, quality: str = "Medium", extent: float = 3.0, **fmt):
+    raw = scenes.make_splats(n, seed, extent)
+    return creator.CreateAssetFromSplats(raw, quality, name=f"t{n}_{seed}_{quality}", **fmt)
+
+
+def default_camera(W=320, H=200, az=25.0, elev=10.0, radius=6.0, fov=39.0965):
+    return camera.Camera(position=scenes.orbit_eye(radius, elev, az), pixelWidth=W, pixelHeight=H, fieldOfView=fov)
+
+
+def psnr8(a: np.ndarray, b: np.ndarray) -> float:
+    """GaussianSplatValidator.cs:202-204: PSNR = 20 log10(255) - 10 log10(rmse^2) on 8-bit images."""
+    d = a.astype(np.float64) - b.astype(np.float64)
+    mse = float((d * d).mean())
+    if mse == 0.0:
+        return float("inf")
+    return 20.0 * np.log10(255.0) - 10.0 * np.log10(mse)
+
+
+def diff_pixels(a: np.ndarray, b: np.ndarray, thr: int = 3) -> int:
+    """GaussianSplatValidator.cs:171-199: pixels whose abs diff x5 >= 15, i.e. any channel differing by >= 3/255."""
+    d = np.abs(a.astype(np.int32) - b.astype(np.int32))[..., :3].max(axis=-1)
+    return int((d >= thr).sum())

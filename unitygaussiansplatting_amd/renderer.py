@@ -9,6 +9,7 @@ thin layer over [DllImport("gsplat_hip")] (unitygaussiansplatting_amd/dotnet/Gau
 from __future__ import annotations
 
 import ctypes as C
+import weakref
 from typing import List, Optional, Tuple
 
 import numpy as np
@@ -31,6 +32,10 @@ class GpuContext:
         self._h = C.c_void_p()
         check(_lib.lib().gs_context_create(device, C.c_void_p(stream) if stream else None, C.byref(self._h)), "gs_context_create")
         self.device = device
+        self._children = weakref.WeakSet()      # targets / sorters / renderers: disposed before the context is
+
+    def _adopt(self, child) -> None:
+        self._children.add(child)
 
     def Synchronize(self) -> None:
         check(_lib.lib().gs_context_synchronize(self._h), "gs_context_synchronize")
@@ -44,6 +49,8 @@ class GpuContext:
 
     def Dispose(self) -> None:
         if self._h:
+            for ch in list(self._children):     # a child must never outlive its context (it holds a raw pointer to it)
+                ch.Dispose()
             _lib.lib().gs_context_destroy(self._h)
             self._h = C.c_void_p()
 
@@ -61,6 +68,7 @@ class RenderTarget:
         self.ctx, self.width, self.height = ctx, width, height
         self._h = C.c_void_p()
         check(_lib.lib().gs_target_create(ctx._h, width, height, C.byref(self._h)), "gs_target_create")
+        ctx._adopt(self)
 
     def Clear(self) -> None:
         check(_lib.lib().gs_target_clear(self._h), "gs_target_clear")
@@ -102,6 +110,7 @@ class GpuSorting:
         self.ctx, self.count = ctx, count
         self._h = C.c_void_p()
         check(_lib.lib().gs_sorter_create(ctx._h, count, C.byref(self._h)), "gs_sorter_create")
+        ctx._adopt(self)
 
     @property
     def Valid(self) -> bool:
@@ -151,6 +160,10 @@ class GaussianSplatRenderer:
         self.m_PrevAsset = None
         self.m_PrevHash = None
         self.m_Registered = False
+        ctx._adopt(self)
+
+    def Dispose(self) -> None:
+        self.DisposeResourcesForAsset()
 
     # -- properties ---------------------------------------------------------------------------------------
     @property
