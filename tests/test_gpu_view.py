@@ -3,7 +3,7 @@ import numpy as np
 import pytest
 
 import oracle_lib as O
-from common import default_camera, small_asset
+from common import default_camera, small_asset, views_equal
 from unitygaussiansplatting_amd import asset as A
 from unitygaussiansplatting_amd import camera
 from unitygaussiansplatting_amd.renderer import GaussianSplatRenderer
@@ -48,7 +48,7 @@ def test_behind_camera_and_nan_axes_records(gpu_ctx):
     r.CalcViewData(cam)
     got = r.DownloadView()
     want = O.Oracle(a).calc_view(r.FrameParams(cam))
-    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    assert views_equal(got, want)
     assert np.isnan(got["axis1"][0]).all() and got["pos"][2, 3] <= 0 and (got["color"][2] == 0).all()
     r.OnDisable()
 

@@ -1,0 +1,101 @@
+// SPDX-License-Identifier: MIT
+// GaussianSplatNative.cs -- the reference-side binding a maintainer adds to use libgsplat_hip.so from the C# host.
+//
+// This is SOURCE ONLY in this repository: the build image has no dotnet/mono, so it is not compiled here.  It mirrors
+// include/gsplat_c.h 1:1 (the same table is bound and exercised through ctypes in unitygaussiansplatting_amd/_lib.py).
+// Usage inside GaussianSplatRenderer.cs is shown in INTEGRATION.md: each block that records ComputeShader dispatches
+// into a CommandBuffer (CreateResourcesForAsset :373-445, SortPoints :612-639, CalcViewData :579-610, the
+// DrawProcedural of SortAndRenderSplats :156-166, the composite :206-209) becomes one call below.
+using System;
+using System.Runtime.InteropServices;
+
+namespace GaussianSplatting.Runtime
+{
+    public static class GaussianSplatNative
+    {
+        const string Lib = "gsplat_hip";
+
+        public enum Error { Ok = 0, InvalidArgument = -1, Hip = -2, UnsupportedFormat = -3, OutOfMemory = -4, InvalidAsset = -5, PairOverflow = -6, SortTimeout = -7, NoDevice = -8 }
+
+        [StructLayout(LayoutKind.Sequential)]
+        public struct AssetDesc
+        {
+            public uint splatCount, posFormat, scaleFormat, colorFormat, shFormat, memoryKind;
+            public IntPtr posData;   public ulong posSize;
+            public IntPtr otherData; public ulong otherSize;
+            public IntPtr colorData; public ulong colorSize;
+            public IntPtr shData;    public ulong shSize;
+            public IntPtr chunkData; public ulong chunkSize;
+        }
+
+        [StructLayout(LayoutKind.Sequential)]
+        public unsafe struct FrameParams
+        {
+            public fixed float matrixMV[16];
+            public fixed float matrixObjectToWorld[16];
+            public fixed float matrixWorldToObject[16];
+            public fixed float matrixVP[16];
+            public float projM00, projM11;
+            public float screenW, screenH;
+            public fixed float camPosWorld[3];
+            public float splatScale, opacityScale;
+            public uint shOrder, shOnly;
+            public float nearClip, farClip;
+        }
+
+        [StructLayout(LayoutKind.Sequential)]
+        public struct FrameStats { public ulong tilePairs, pairCapacity; public uint visibleSplats, tilesX, tilesY, sortError; }
+
+        [StructLayout(LayoutKind.Sequential)]
+        public struct StageTimes { public float calcDistancesMs, sortMs, calcViewMs, binMs, pairSortMs, blendMs, resolveMs, totalMs; public uint frames; }
+
+        [DllImport(Lib)] public static extern int gs_abi_version();
+        [DllImport(Lib)] public static extern IntPtr gs_error_string(int err);
+        [DllImport(Lib)] public static extern IntPtr gs_last_error_string();
+
+        [DllImport(Lib)] public static extern int gs_context_create(int device, IntPtr hipStream, out IntPtr ctx);
+        [DllImport(Lib)] public static extern int gs_context_destroy(IntPtr ctx);
+        [DllImport(Lib)] public static extern int gs_context_synchronize(IntPtr ctx);
+        [DllImport(Lib)] public static extern int gs_context_device_info(IntPtr ctx, byte[] nameOut, UIntPtr nameCap, out int cuCount, out ulong hbmBytes);
+
+        [DllImport(Lib)] public static extern int gs_asset_create(IntPtr ctx, ref AssetDesc desc, out IntPtr asset);
+        [DllImport(Lib)] public static extern int gs_asset_destroy(IntPtr asset);
+        [DllImport(Lib)] public static extern int gs_asset_splat_count(IntPtr asset, out uint count);
+        [DllImport(Lib)] public static extern int gs_asset_device_blobs(IntPtr asset, [Out] IntPtr[] ptrs5, [Out] ulong[] sizes5);
+
+        [DllImport(Lib)] public static extern int gs_renderer_create(IntPtr ctx, IntPtr asset, out IntPtr renderer);
+        [DllImport(Lib)] public static extern int gs_renderer_destroy(IntPtr renderer);
+        [DllImport(Lib)] public static extern int gs_renderer_reset_order(IntPtr renderer);
+        [DllImport(Lib)] public static extern int gs_renderer_sort(IntPtr renderer, float[] matrixSort16);
+        [DllImport(Lib)] public static extern int gs_renderer_calc_view(IntPtr renderer, ref FrameParams p);
+        [DllImport(Lib)] public static extern int gs_renderer_draw(IntPtr renderer, ref FrameParams p, IntPtr target);
+        [DllImport(Lib)] public static extern int gs_renderer_render(IntPtr renderer, float[] matrixSort16, ref FrameParams p, IntPtr target, int doSort);
+        [DllImport(Lib)] public static extern int gs_renderer_set_blend_mode(IntPtr renderer, int mode);
+        [DllImport(Lib)] public static extern int gs_renderer_set_profiling(IntPtr renderer, int frames);
+        [DllImport(Lib)] public static extern int gs_renderer_reserve_pairs(IntPtr renderer, ulong pairCapacity);
+        [DllImport(Lib)] public static extern int gs_renderer_download_order(IntPtr renderer, uint[] dst, UIntPtr count);
+        [DllImport(Lib)] public static extern int gs_renderer_download_distances(IntPtr renderer, uint[] dst, UIntPtr count);
+        [DllImport(Lib)] public static extern int gs_renderer_upload_order(IntPtr renderer, uint[] src, UIntPtr count);
+        [DllImport(Lib)] public static extern int gs_renderer_download_view(IntPtr renderer, IntPtr dst, UIntPtr bytes);
+        [DllImport(Lib)] public static extern int gs_renderer_frame_stats(IntPtr renderer, out FrameStats stats);
+        [DllImport(Lib)] public static extern int gs_renderer_stage_times(IntPtr renderer, out StageTimes times);
+
+        [DllImport(Lib)] public static extern int gs_target_create(IntPtr ctx, uint width, uint height, out IntPtr target);
+        [DllImport(Lib)] public static extern int gs_target_destroy(IntPtr target);
+        [DllImport(Lib)] public static extern int gs_target_clear(IntPtr target);
+        [DllImport(Lib)] public static extern int gs_target_download(IntPtr target, IntPtr dstRgba16f, UIntPtr bytes);
+        [DllImport(Lib)] public static extern int gs_target_resolve(IntPtr target, float[] backgroundRgba4, IntPtr dstRgba32f, IntPtr dstRgba8);
+        [DllImport(Lib)] public static extern int gs_target_device_ptr(IntPtr target, out IntPtr rgba16fDev, out IntPtr resolvedDev);
+
+        [DllImport(Lib)] public static extern int gs_sorter_create(IntPtr ctx, uint maxCount, out IntPtr sorter);
+        [DllImport(Lib)] public static extern int gs_sorter_destroy(IntPtr sorter);
+        [DllImport(Lib)] public static extern int gs_sorter_dispatch(IntPtr sorter, IntPtr keysDev, IntPtr valuesDev, uint count, uint keyBits);
+        [DllImport(Lib)] public static extern int gs_sorter_sort_host(IntPtr sorter, uint[] keys, uint[] values, uint count, uint keyBits);
+
+        public static void Check(int rc, string where)
+        {
+            if (rc != 0)
+                throw new InvalidOperationException($"{where}: {(Error)rc} ({Marshal.PtrToStringAnsi(gs_last_error_string())})");
+        }
+    }
+}
