@@ -416,7 +416,7 @@ ViewData CalcViewDataOne(const Asset& a, const gs_frame_params& P, uint32_t idx)
 struct Prepared {
     float cx, cy;           // splat centre in pixels (y down)
     float a1x, a1y, a2x, a2y;
-    float inv1, inv2;       // 1/|axis|^2
+    float u1x, u1y, u2x, u2y; // axis_k / |axis_k|^2
     float r, g, b, a;       // colour as the vertex shader unpacks it (f16 -> f32)
     int x0, x1, y0, y1;     // pixel rect of the quad's bounding box, clamped to the screen (x0>x1 => nothing)
     int tx0, tx1, ty0, ty1; // 16x16 tile rect of the *tight* footprint used by the shipped binning kernel
@@ -441,9 +441,10 @@ Prepared prepare(const ViewData& v, const gs_frame_params& P) {
     p.cy = fmaf(-0.5f * (v.pos[1] * invw), H, 0.5f * H);         // (0.5 - 0.5*ndc.y) * H   (image rows top-down)
     if (!(finitef(p.cx) && finitef(p.cy))) return p;
     p.a1x = v.axis1[0]; p.a1y = v.axis1[1]; p.a2x = v.axis2[0]; p.a2y = v.axis2[1];
-    p.inv1 = 1.0f / dot2(p.a1x, p.a1y, p.a1x, p.a1y);
-    p.inv2 = 1.0f / dot2(p.a2x, p.a2y, p.a2x, p.a2y);
-    if (!(finitef(p.inv1) && finitef(p.inv2))) return p;
+    const float inv1 = 1.0f / dot2(p.a1x, p.a1y, p.a1x, p.a1y);
+    const float inv2 = 1.0f / dot2(p.a2x, p.a2y, p.a2x, p.a2y);
+    if (!(finitef(inv1) && finitef(inv2))) return p;
+    p.u1x = p.a1x * inv1; p.u1y = p.a1y * inv1; p.u2x = p.a2x * inv2; p.u2y = p.a2y * inv2;
     // quad = c + qx*axis1 + qy*axis2, q in [-2,2]^2  ->  bounding box half extents
     const float exr = 2.0f * (fabsf(p.a1x) + fabsf(p.a2x));
     const float eyr = 2.0f * (fabsf(p.a1y) + fabsf(p.a2y));
@@ -609,8 +610,8 @@ int32_t gso_draw(const void* view_in, const uint32_t* order, uint32_t n, const g
                 for (int px = p.x0; px <= p.x1; ++px) {
                     const float dx = ((float)px + 0.5f) - p.cx;
                     // interpolated quad coordinate (i.pos of the v2f): q = [axis1 axis2]^-1 * delta, axes orthogonal
-                    const float q1 = fmaf(dy, p.a1y, dx * p.a1x) * p.inv1;
-                    const float q2 = fmaf(dy, p.a2y, dx * p.a2x) * p.inv2;
+                    const float q1 = fmaf(dy, p.u1y, dx * p.u1x);
+                    const float q2 = fmaf(dy, p.u2y, dx * p.u2x);
                     if (!(fabsf(q1) <= 2.0f && fabsf(q2) <= 2.0f)) continue;     // outside the quad
                     float* d = row + (size_t)px * 4;
                     if (mode == 1 && (1.0f - d[3]) < (1.0f / 4096.0f)) continue; // fast mode: pixel finished

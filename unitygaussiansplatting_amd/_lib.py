@@ -9,7 +9,7 @@ import os
 from ._abi import gs_asset_desc, gs_frame_params, gs_frame_stats, gs_stage_times
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgsplat_hip.so")
+LIB_PATH = os.environ.get("GSPLAT_LIB") or os.path.join(_HERE, "libgsplat_hip.so")   # GSPLAT_LIB: A/B a variant build
 
 
 class GsError(RuntimeError):

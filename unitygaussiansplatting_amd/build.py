@@ -31,6 +31,18 @@ def needs_build() -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def build_variant(name: str, defines, verbose: bool = False) -> str:
+    """A/B builds for kernel tuning: unitygaussiansplatting_amd/variants/<name>.so with extra -D flags (select with GSPLAT_LIB)."""
+    out_dir = os.path.join(HERE, "variants")
+    os.makedirs(out_dir, exist_ok=True)
+    out = os.path.join(out_dir, name + ".so")
+    cmd = [hipcc()] + FLAGS + ["-D" + d for d in defines] + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", out]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return out
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not needs_build():
         return LIB

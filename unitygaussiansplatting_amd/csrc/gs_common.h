@@ -36,7 +36,7 @@ constexpr int kBinItems = 4;              // sorted positions per thread
 constexpr int kBinPart = kBinThreads * kBinItems;
 constexpr int kEvPerFrame = 10;           // hipEvents per profiled frame
 
-// 32-byte per-sorted-position record consumed by the blend kernel
+// 32-byte per-splat record consumed by the blend kernel (written by calc_view, splat-index order)
 struct alignas(16) SplatRec {
     float cx, cy;           // centre, pixels (y down)
     float a1x, a1y;         // axis1, pixels
@@ -118,7 +118,10 @@ struct gs_renderer {
     gs::SortState depthSort;
     gs::SortControl* depthControl = nullptr;
     // compositor buffers
-    gs::SplatRec* recs = nullptr;           // N x 32 B, indexed by sorted position
+    gs::SplatRec* recs = nullptr;           // N x 32 B, indexed by splat (written by calc_view)
+    uint2* rects = nullptr;                 // N x 8 B: x = tx0 | ty0 << 16, y = tiles wide | tiles high << 16 (0 = culled)
+    float viewW = 0.f, viewH = 0.f, viewNear = 0.f, viewFar = 0.f;   // what the last calc_view was run with
+    bool viewValid = false;
     uint32_t* pairKeys = nullptr;           // tile ids
     uint32_t* pairVals = nullptr;           // sorted positions
     gs::SortState pairSort;
@@ -160,7 +163,8 @@ int32_t enqueue_sort_passes(gs_context* ctx, SortState& st, SortControl* control
                             uint32_t nUpper, const uint32_t* nPtr, int passes, uint32_t lastMask = 255u);
 int32_t enqueue_set_indices(gs_context* ctx, uint32_t* order, uint32_t n);
 // view (gs_view.hip)
-int32_t enqueue_calc_view(gs_context* ctx, const gsm::AssetView& a, const gs_frame_params* p, gsm::ViewData* out);
+int32_t enqueue_calc_view(gs_context* ctx, const gsm::AssetView& a, const gs_frame_params* p, gsm::ViewData* out, SplatRec* recs,
+                          uint2* rects);
 void flatten_params(const gs_frame_params* p, gsm::FrameConsts& c);
 // raster (gs_raster.hip)
 int32_t renderer_alloc_raster(gs_renderer* r);

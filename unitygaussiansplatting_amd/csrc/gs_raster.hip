@@ -3,9 +3,11 @@
 // Replaces RenderGaussianSplats.shader (instanced quad VS :35-77, gaussian FS :79-108, fixed-function
 // "Blend OneMinusDstAlpha One" :10-12 into an RGBA16F target, GaussianSplatRenderer.cs:156-166,194-196) and
 // GaussianComposite.shader:25-39.  MI355X has no rasteriser/ROP, so the draw is:
-//   1. bin_emit:   for sorted position i (front to back): gather view[order[i]], cull, write a 32-byte record
-//                  rec[i], and emit one (tile, i) pair per overlapped 16x16 tile.  Pair offsets come from a
-//                  single-pass chained scan (decoupled look-back) so pairs are emitted in i order.
+//   0. (gs_view.hip) calc_view culls each splat like the rasteriser would and writes, in splat order, a 32-byte
+//                  record rec[s] (centre, axes, rgba16f) and its inclusive 16x16-tile rectangle rect[s].
+//   1. bin_emit:   for sorted position i (front to back): gather rect[order[i]] (8 B) and emit one (tile, splat)
+//                  pair per overlapped tile.  Pair offsets come from a single-pass chained scan (decoupled
+//                  look-back) so pairs are emitted in i order.
 //   2. pair sort:  STABLE Onesweep sort of the pairs by tile id only (2 passes for <= 65536 tiles): every
 //                  tile's list is then already depth ordered -- no per-tile depth sort.
 //   3. ranges:     tile -> [start, end) in the sorted pair array.
@@ -42,19 +44,49 @@ __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, int lane) {
     return v;
 }
 
-__device__ __forceinline__ void emit_pair(uint32_t* __restrict__ pairKeys, uint32_t* __restrict__ pairVals, uint32_t* s_hist,
-                                          unsigned long long off, uint32_t capacity, uint32_t tile, uint32_t i) {
-    if (off < (unsigned long long)capacity) {
-        pairKeys[off] = tile;
-        pairVals[off] = i;
-        atomicAdd(&s_hist[tile & 255u], 1u);
-        atomicAdd(&s_hist[256u + ((tile >> 8) & 255u)], 1u);
-        atomicAdd(&s_hist[512u + ((tile >> 16) & 255u)], 1u);
+// LDS histogram add for one digit of the pair key.  Lanes of a wave that hit the same bin would serialise inside the
+// LDS atomic unit (64 deep when the digit is constant, as the high digits of a tile id are), so the add is
+// aggregated per distinct value with a ballot loop when few values are present.
+__device__ __forceinline__ void hist_add_aggregated(uint32_t* h, uint32_t d, bool active) {
+    unsigned long long todo = __ballot(active);
+    int guard = 0;
+    while (todo && guard < 4) {                            // up to 4 distinct values are handled by one lane each
+        const int leader = __ffsll((long long)todo) - 1;
+        const uint32_t dv = (uint32_t)__builtin_amdgcn_readlane((int)d, leader);
+        const unsigned long long same = __ballot(active && d == dv);
+        if ((int)(threadIdx.x & 63) == leader) atomicAdd(&h[dv], (uint32_t)__popcll(same));
+        todo &= ~same;
+        active = active && d != dv;
+        ++guard;
     }
+    if (active) atomicAdd(&h[d], 1u);                      // many distinct values left: plain per-lane adds
 }
 
-__global__ __launch_bounds__(kBinThreads) void bin_emit_kernel(const gsm::ViewData* __restrict__ view, const uint32_t* __restrict__ order,
-                                                                uint32_t n, RasterConsts rc, SplatRec* __restrict__ recs,
+template <int PASSES>
+__device__ __forceinline__ void emit_pair(uint32_t* __restrict__ pairKeys, uint32_t* __restrict__ pairVals, uint32_t* s_hist,
+                                          unsigned long long off, uint32_t capacity, uint32_t tile, uint32_t i, bool doit) {
+    const bool w = doit && off < (unsigned long long)capacity;
+#ifndef GS_EXP_NOSTORE
+    if (w) {
+        pairKeys[off] = tile;
+        pairVals[off] = i;
+    }
+#endif
+#ifndef GS_EXP_NOHIST
+    if (w) atomicAdd(&s_hist[tile & 255u], 1u);            // low digit: tiles of different splats, mostly distinct bins
+#ifdef GS_EXP_PLAINHIST
+    if (w && PASSES >= 2) atomicAdd(&s_hist[256u + ((tile >> 8) & 255u)], 1u);
+    if (w && PASSES >= 3) atomicAdd(&s_hist[512u + ((tile >> 16) & 255u)], 1u);
+#else
+    if (PASSES >= 2) hist_add_aggregated(s_hist + 256, (tile >> 8) & 255u, w);
+    if (PASSES >= 3) hist_add_aggregated(s_hist + 512, (tile >> 16) & 255u, w);
+#endif
+#endif
+}
+
+template <int PASSES>
+__global__ __launch_bounds__(kBinThreads) void bin_emit_kernel(const uint2* __restrict__ rects, const uint32_t* __restrict__ order,
+                                                                uint32_t n, RasterConsts rc,
                                                                 uint32_t* __restrict__ pairKeys, uint32_t* __restrict__ pairVals,
                                                                 uint32_t capacity, BinControl* ctl, unsigned long long* binStatus,
                                                                 uint32_t* pairHist) {
@@ -78,34 +110,26 @@ __global__ __launch_bounds__(kBinThreads) void bin_emit_kernel(const gsm::ViewDa
     if (part >= numParts) return;
     const uint32_t base = part * (uint32_t)kBinPart;
 
-    // ---- per sorted position: gather the view record, cull, footprint, write rec[i] ------------------------
+    // ---- per sorted position: gather the splat's tile rectangle (8 B, written by calc_view) ----------------------
     int tx0[kBinItems], ty0[kBinItems], tw[kBinItems];
-    uint32_t cnt[kBinItems];
+    uint32_t cnt[kBinItems], sid[kBinItems];
     uint32_t visible = 0;
+    {
+        uint32_t sidx[kBinItems];
 #pragma unroll
-    for (int k = 0; k < kBinItems; ++k) {
-        const uint32_t i = base + (uint32_t)k * kBinThreads + tid;
-        cnt[k] = 0; tx0[k] = 0; ty0[k] = 0; tw[k] = 1;
-        if (i < n) {
-            const uint32_t s = order[i];
-            const uint2* vp = (const uint2*)(view + s);           // 40-byte records: 8-byte aligned
-            const uint2 q0 = vp[0], q1 = vp[1], q2 = vp[2], q3 = vp[3], q4 = vp[4];
-            gsm::ViewData v;
-            v.pos[0] = gsm::u2f(q0.x); v.pos[1] = gsm::u2f(q0.y); v.pos[2] = gsm::u2f(q1.x); v.pos[3] = gsm::u2f(q1.y);
-            v.axis1[0] = gsm::u2f(q2.x); v.axis1[1] = gsm::u2f(q2.y); v.axis2[0] = gsm::u2f(q3.x); v.axis2[1] = gsm::u2f(q3.y);
-            v.color[0] = q4.x; v.color[1] = q4.y;
-            gsm::SplatFootprint fp;
-            const bool ok = gsm::PrepareSplat(v, rc.W, rc.H, rc.nearClip, rc.farClip, fp);
-            if (ok && fp.tx0 <= fp.tx1) {
-                tx0[k] = fp.tx0; ty0[k] = fp.ty0; tw[k] = fp.tx1 - fp.tx0 + 1;
-                cnt[k] = (uint32_t)tw[k] * (uint32_t)(fp.ty1 - fp.ty0 + 1);
-                visible++;
-            }
-            float4 r0, r1;
-            r0.x = fp.cx; r0.y = fp.cy; r0.z = v.axis1[0]; r0.w = v.axis1[1];
-            r1.x = v.axis2[0]; r1.y = v.axis2[1]; r1.z = gsm::u2f(v.color[0]); r1.w = gsm::u2f(v.color[1]);
-            float4* rp = (float4*)(recs + i);
-            rp[0] = r0; rp[1] = r1;
+        for (int k = 0; k < kBinItems; ++k) {
+            const uint32_t i = base + (uint32_t)k * kBinThreads + tid;
+            sidx[k] = (i < n) ? order[i] : 0xffffffffu;
+        }
+#pragma unroll
+        for (int k = 0; k < kBinItems; ++k) {
+            uint2 rc2 = make_uint2(0u, 0u);
+            if (sidx[k] != 0xffffffffu) rc2 = rects[sidx[k]];
+            sid[k] = sidx[k];
+            tx0[k] = (int)(rc2.x & 0xffffu); ty0[k] = (int)(rc2.x >> 16);
+            tw[k] = (int)(rc2.y & 0xffffu);
+            cnt[k] = (rc2.y & 0xffffu) * (rc2.y >> 16);
+            visible += cnt[k] ? 1u : 0u;
         }
     }
 
@@ -131,7 +155,11 @@ __global__ __launch_bounds__(kBinThreads) void bin_emit_kernel(const gsm::ViewDa
         unsigned long long* my = binStatus + part;
         __hip_atomic_store(my, (part == 0 ? BFLAG_INCL : BFLAG_AGG) | (unsigned long long)blockTotal, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         unsigned long long excl = 0;
+#ifdef GS_EXP_NOLOOKBACK
+        if (false) {
+#else
         if (part > 0) {
+#endif
             int q = (int)part - 1;
             uint32_t spins = 0;
             for (;;) {
@@ -161,20 +189,26 @@ __global__ __launch_bounds__(kBinThreads) void bin_emit_kernel(const gsm::ViewDa
     // ---- emit (tile, i) pairs: small footprints by their own lane, big ones by the whole workgroup -------------
 #pragma unroll
     for (int k = 0; k < kBinItems; ++k) {
-        const uint32_t i = base + (uint32_t)k * kBinThreads + tid;
+        const uint32_t i = sid[k];                 // pair payload = splat index: the blend kernel reads rec[splat]
         if (tid == 0) s_qn = 0;
         __syncthreads();
-        if (cnt[k] > 0) {
+        {
+            const bool small = cnt[k] > 0 && cnt[k] <= (uint32_t)BIG_SPLAT;
             const unsigned long long o = blockBase + off[k];
-            if (cnt[k] <= (uint32_t)BIG_SPLAT) {
-                uint32_t j = 0;
-                for (int ty = 0; j < cnt[k]; ++ty)
-                    for (int tx = 0; tx < tw[k]; ++tx, ++j)
-                        emit_pair(pairKeys, pairVals, s_hist, o + j, capacity, (uint32_t)(ty0[k] + ty) * rc.tilesX + (uint32_t)(tx0[k] + tx), i);
-            } else {
+            if (cnt[k] > (uint32_t)BIG_SPLAT) {
                 const uint32_t slot = atomicAdd(&s_qn, 1u);
                 s_qi[slot] = i; s_qrect[slot] = (uint32_t)tx0[k] | ((uint32_t)ty0[k] << 16);
                 s_qdim[slot] = (uint32_t)tw[k]; s_qcnt[slot] = cnt[k]; s_qoff[slot] = o;
+            }
+            // every lane of the wave walks j = 0 .. (largest small count in the wave) together
+            uint32_t mx = small ? cnt[k] : 0u;
+#pragma unroll
+            for (int sh = 32; sh > 0; sh >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, sh, 64));
+            uint32_t tx = 0, ty = 0;
+            for (uint32_t j = 0; j < mx; ++j) {
+                const bool doit = small && j < cnt[k];
+                emit_pair<PASSES>(pairKeys, pairVals, s_hist, o + j, capacity, (uint32_t)(ty0[k] + (int)ty) * rc.tilesX + (uint32_t)(tx0[k] + (int)tx), i, doit);
+                if (++tx == (uint32_t)tw[k]) { tx = 0; ++ty; }
             }
         }
         __syncthreads();
@@ -183,16 +217,17 @@ __global__ __launch_bounds__(kBinThreads) void bin_emit_kernel(const gsm::ViewDa
             const uint32_t qi = s_qi[e], qr = s_qrect[e], qw = s_qdim[e], qc = s_qcnt[e];
             const unsigned long long qo = s_qoff[e];
             const uint32_t qx0 = qr & 0xffffu, qy0 = qr >> 16;
-            for (uint32_t j = tid; j < qc; j += kBinThreads) {
+            for (uint32_t j0 = 0; j0 < qc; j0 += kBinThreads) {      // all threads iterate together (ballots inside emit_pair)
+                const uint32_t j = j0 + tid;
                 const uint32_t ty = j / qw, tx = j - ty * qw;
-                emit_pair(pairKeys, pairVals, s_hist, qo + j, capacity, (qy0 + ty) * rc.tilesX + (qx0 + tx), qi);
+                emit_pair<PASSES>(pairKeys, pairVals, s_hist, qo + j, capacity, (qy0 + ty) * rc.tilesX + (qx0 + tx), qi, j < qc);
             }
         }
         __syncthreads();
     }
 
     // ---- flush the pair-sort digit histograms, count visible splats ----------------------------------------------
-    for (int j = tid; j < 3 * 256; j += kBinThreads) {
+    for (int j = tid; j < PASSES * 256; j += kBinThreads) {
         const uint32_t c = s_hist[j];
         if (c) atomicAdd(&pairHist[j], c);
     }
@@ -222,12 +257,24 @@ __device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t total) {
     return (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + k;
 }
 
+typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+typedef float f2v __attribute__((ext_vector_type(2)));
+// RTNE to fp16 and back for two values at once: v_cvt_pk_f16_f32 + two v_cvt_f32_f16 (one with SDWA word select)
+__device__ __forceinline__ void round16x2(float& a, float& b) {
+    const f2v v = {a, b};
+    const f2v r = __builtin_convertvector(__builtin_convertvector(v, h2v), f2v);
+    a = r.x; b = r.y;
+}
+
 template <int MODE>
 __global__ __launch_bounds__(256) void blend_kernel(const uint32_t* __restrict__ pairVals, const uint32_t* __restrict__ tileStart,
                                                     const uint32_t* __restrict__ tileEnd, const SplatRec* __restrict__ recs,
                                                     uint16_t* __restrict__ rt, RasterConsts rc) {
-    __shared__ float4 s_r0[256];
-    __shared__ float4 s_r1[256];
+    // per staged record: everything that does not depend on the pixel is computed ONCE here (by the staging thread),
+    // not once per wave: inverse-scaled axes, conservative half extents, unpacked colour
+    __shared__ float4 s_a[256];      // cx, cy, u1x, u1y      (u_k = axis_k / |axis_k|^2)
+    __shared__ float4 s_b[256];      // u2x, u2y, ex, ey      (half extents of the footprint's bounding box, pixels)
+    __shared__ float4 s_c[256];      // r, g, b, a
     __shared__ int s_done;
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -256,37 +303,39 @@ __global__ __launch_bounds__(256) void blend_kernel(const uint32_t* __restrict__
         if (s_done == 4) break;
         const uint32_t cnt = min(256u, end - bs);
         if ((uint32_t)tid < cnt) {
-            const uint32_t i = pairVals[bs + tid];
-            const float4* rp = (const float4*)(recs + i);
-            s_r0[tid] = rp[0];
-            s_r1[tid] = rp[1];
+            const uint32_t sidx = pairVals[bs + tid];
+            const float4* rp = (const float4*)(recs + sidx);
+            const float4 r0 = rp[0], r1 = rp[1];               // cx cy a1x a1y | a2x a2y c0 c1
+            const float inv1 = 1.0f / gsm::dot2f(r0.z, r0.w, r0.z, r0.w);
+            const float inv2 = 1.0f / gsm::dot2f(r1.x, r1.y, r1.x, r1.y);
+            const uint32_t c0 = gsm::f2u(r1.z), c1 = gsm::f2u(r1.w);
+            const float ca = gsm::f16tof32(c1);
+            // bounding box of  quad |q|<=2  INTERSECT  {exp(-|q|^2) a >= 1/255}  (same formula as PrepareSplat)
+            const float exr = 2.0f * (fabsf(r0.z) + fabsf(r1.x)), eyr = 2.0f * (fabsf(r0.w) + fabsf(r1.y));
+            const float rr = sqrtf(fmaxf(fmaf(__logf(255.0f * ca), 1.0001f, 1.0e-3f), 0.0f));
+            const float exe = rr * sqrtf(gsm::dot2f(r0.z, r1.x, r0.z, r1.x)), eye = rr * sqrtf(gsm::dot2f(r0.w, r1.y, r0.w, r1.y));
+            s_a[tid] = make_float4(r0.x, r0.y, r0.z * inv1, r0.w * inv1);
+            s_b[tid] = make_float4(r1.x * inv2, r1.y * inv2, fminf(exr, exe) + 0.02f, fminf(eyr, eye) + 0.02f);
+            s_c[tid] = make_float4(gsm::f16tof32(c0 >> 16), gsm::f16tof32(c0), gsm::f16tof32(c1 >> 16), ca);
         }
         __syncthreads();
         if (!waveDone) {
             for (uint32_t c = 0; c < cnt; c += 64u) {
                 const uint32_t j = c + lane;
                 const bool has = j < cnt;
-                float4 r0 = make_float4(0.f, 0.f, 1.f, 0.f), r1 = make_float4(0.f, 1.f, 0.f, 0.f);
-                if (has) { r0 = s_r0[j]; r1 = s_r1[j]; }
-                // per-record quantities, computed by the lane that holds the record
-                const float ex = 2.0f * (fabsf(r0.z) + fabsf(r1.x)) + 0.01f, ey = 2.0f * (fabsf(r0.w) + fabsf(r1.y)) + 0.01f;
-                const bool hit = has && (r0.x + ex >= qminx) && (r0.x - ex <= qmaxx) && (r0.y + ey >= qminy) && (r0.y - ey <= qmaxy);
-                const float inv1 = 1.0f / gsm::dot2f(r0.z, r0.w, r0.z, r0.w);
-                const float inv2 = 1.0f / gsm::dot2f(r1.x, r1.y, r1.x, r1.y);
-                const uint32_t c0 = gsm::f2u(r1.z), c1 = gsm::f2u(r1.w);
-                const float colr = gsm::f16tof32(c0 >> 16), colg = gsm::f16tof32(c0), colb = gsm::f16tof32(c1 >> 16), cola = gsm::f16tof32(c1);
+                float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra, rcol = ra;
+                if (has) { ra = s_a[j]; rb = s_b[j]; rcol = s_c[j]; }
+                const bool hit = has && (ra.x + rb.z >= qminx) && (ra.x - rb.z <= qmaxx) && (ra.y + rb.w >= qminy) && (ra.y - rb.w <= qmaxy);
                 unsigned long long mask = __ballot(hit);
                 while (mask) {
                     const int b = __ffsll((long long)mask) - 1;
                     mask &= mask - 1ull;
-                    const float cx = rl(r0.x, b), cy = rl(r0.y, b);
-                    const float a1x = rl(r0.z, b), a1y = rl(r0.w, b);
-                    const float a2x = rl(r1.x, b), a2y = rl(r1.y, b);
-                    const float i1 = rl(inv1, b), i2 = rl(inv2, b);
-                    const float sr = rl(colr, b), sg = rl(colg, b), sb = rl(colb, b), sa = rl(cola, b);
+                    const float cx = rl(ra.x, b), cy = rl(ra.y, b), u1x = rl(ra.z, b), u1y = rl(ra.w, b);
+                    const float u2x = rl(rb.x, b), u2y = rl(rb.y, b);
+                    const float sr = rl(rcol.x, b), sg = rl(rcol.y, b), sb = rl(rcol.z, b), sa = rl(rcol.w, b);
                     const float dx = fx - cx, dy = fy - cy;
-                    const float q1 = fmaf(dy, a1y, dx * a1x) * i1;
-                    const float q2 = fmaf(dy, a2y, dx * a2x) * i2;
+                    const float q1 = fmaf(dy, u1y, dx * u1x);
+                    const float q2 = fmaf(dy, u2y, dx * u2x);
                     const float power = -fmaf(q2, q2, q1 * q1);
                     float alpha = __expf(power);
                     alpha = gsm::sat(alpha * sa);
@@ -295,10 +344,7 @@ __global__ __launch_bounds__(256) void blend_kernel(const uint32_t* __restrict__
                     if (live) {
                         const float t = 1.0f - A;
                         float nr = fmaf(sr * alpha, t, Cr), ng = fmaf(sg * alpha, t, Cg), nb = fmaf(sb * alpha, t, Cb), na = fmaf(alpha, t, A);
-                        if (MODE == 0) {
-                            nr = gsm::f16tof32(gsm::f32tof16(nr)); ng = gsm::f16tof32(gsm::f32tof16(ng));
-                            nb = gsm::f16tof32(gsm::f32tof16(nb)); na = gsm::f16tof32(gsm::f32tof16(na));
-                        }
+                        if (MODE == 0) { round16x2(nr, ng); round16x2(nb, na); }
                         Cr = nr; Cg = ng; Cb = nb; A = na;
                     }
                 }
@@ -377,7 +423,9 @@ int32_t ensure_arena(gs_renderer* r, uint32_t numTiles) {
 int32_t renderer_alloc_raster(gs_renderer* r) {
     gs_context* ctx = r->ctx;
     r->binParts = div_up(r->n, kBinPart);
-    GS_HIP(hipMalloc((void**)&r->recs, (size_t)r->n * sizeof(SplatRec)));
+    GS_HIP(hipMalloc((void**)&r->recs, (size_t)r->n * sizeof(SplatRec) + 64));
+    GS_HIP(hipMalloc((void**)&r->rects, (size_t)r->n * sizeof(uint2) + 64));
+    GS_HIP(hipMemsetAsync(r->rects, 0, (size_t)r->n * sizeof(uint2), ctx->stream));
     if (r->pairCapacity == 0) {
         unsigned long long cap = (unsigned long long)r->n * 8ull;
         if (cap < (1ull << 22)) cap = 1ull << 22;
@@ -395,12 +443,13 @@ int32_t renderer_alloc_raster(gs_renderer* r) {
 
 void renderer_free_raster(gs_renderer* r) {
     if (r->recs) (void)hipFree(r->recs);
+    if (r->rects) (void)hipFree(r->rects);
     if (r->pairKeys) (void)hipFree(r->pairKeys);
     if (r->pairVals) (void)hipFree(r->pairVals);
     sort_state_destroy(r->pairSort);
     if (r->frameArena) (void)hipFree(r->frameArena);
     if (r->hostBin) (void)hipHostFree(r->hostBin);
-    r->recs = nullptr; r->pairKeys = r->pairVals = nullptr; r->frameArena = nullptr; r->hostBin = nullptr;
+    r->recs = nullptr; r->rects = nullptr; r->pairKeys = r->pairVals = nullptr; r->frameArena = nullptr; r->hostBin = nullptr;
 }
 
 int32_t enqueue_draw(gs_renderer* r, const gs_frame_params* p, gs_target* rt) {
@@ -412,6 +461,9 @@ int32_t enqueue_draw(gs_renderer* r, const gs_frame_params* p, gs_target* rt) {
     rc.tilesX = div_up(rt->width, kTile); rc.tilesY = div_up(rt->height, kTile);
     const uint32_t numTiles = rc.tilesX * rc.tilesY;
     if (numTiles > (1u << 24)) return fail(GS_ERR_INVALID_ARGUMENT, "target too large (more than 2^24 tiles)");
+    // the per-splat footprints were computed by calc_view: it must have run with the same screen size and clip planes
+    if (!r->viewValid || r->viewW != rc.W || r->viewH != rc.H || r->viewNear != rc.nearClip || r->viewFar != rc.farClip)
+        return fail(GS_ERR_INVALID_ARGUMENT, "gs_renderer_draw: call gs_renderer_calc_view with the same screen size / clip planes first");
     GS_TRY(ensure_arena(r, numTiles));
     r->lastTilesX = rc.tilesX; r->lastTilesY = rc.tilesY;
 
@@ -424,10 +476,11 @@ int32_t enqueue_draw(gs_renderer* r, const gs_frame_params* p, gs_target* rt) {
 
     GS_HIP(hipMemsetAsync(r->frameArena, 0, r->frameArenaBytes, st));
     prof_record(r, 3);
-    hipLaunchKernelGGL(bin_emit_kernel, dim3(r->binParts), dim3(kBinThreads), 0, st, r->view, r->order, r->n, rc, r->recs, r->pairKeys,
+    const int passes = numTiles <= 256 ? 1 : (numTiles <= 65536 ? 2 : 3);
+    auto binKernel = passes == 1 ? bin_emit_kernel<1> : (passes == 2 ? bin_emit_kernel<2> : bin_emit_kernel<3>);
+    hipLaunchKernelGGL(binKernel, dim3(r->binParts), dim3(kBinThreads), 0, st, r->rects, r->order, r->n, rc, r->pairKeys,
                        r->pairVals, cap, binCtl, binStatus, pairCtl->hist);
     prof_record(r, 4);
-    const int passes = numTiles <= 256 ? 1 : (numTiles <= 65536 ? 2 : 3);
     GS_TRY(enqueue_sort_passes(ctx, r->pairSort, pairCtl, r->pairKeys, r->pairVals, cap, &binCtl->pairCountClamped, passes));
     hipLaunchKernelGGL(tile_ranges_kernel, dim3(max(1u, min(div_up(cap, 256), (uint32_t)ctx->cuCount * 8u))), dim3(256), 0, st, r->pairKeys,
                        &binCtl->pairCountClamped, tileStart, tileEnd, numTiles);

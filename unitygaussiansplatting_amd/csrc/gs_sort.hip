@@ -22,10 +22,16 @@ namespace gs {
 namespace {
 
 constexpr int RADIX = 256;
-constexpr int THREADS = kSortThreads;
+#ifndef GS_SORT_THREADS
+#define GS_SORT_THREADS 512
+#endif
+#ifndef GS_SORT_KPT
+#define GS_SORT_KPT 16
+#endif
+constexpr int THREADS = GS_SORT_THREADS;
 constexpr int WAVES = THREADS / 64;
-constexpr int KPT = kSortKPT;
-constexpr int PART = kSortPart;
+constexpr int KPT = GS_SORT_KPT;
+constexpr int PART = THREADS * KPT;
 constexpr uint32_t SPIN_LIMIT = 1u << 24;
 
 constexpr unsigned long long FLAG_AGG = 1ull, FLAG_INCL = 2ull;
@@ -39,6 +45,11 @@ __device__ __forceinline__ unsigned long long ld_status(const unsigned long long
 __device__ __forceinline__ void st_status(unsigned long long* p, unsigned long long v) {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+
+// 32-bit element index on a wave-uniform base pointer: lets the compiler use the SGPR-base + 32-bit-VGPR-offset
+// addressing form instead of a 64-bit address per access (arrays are < 4 GB: counts are capped at 2^30)
+__device__ __forceinline__ uint32_t ldg32(const uint32_t* base, uint32_t idx) { return *(const uint32_t*)((const char*)base + (size_t)(idx << 2)); }
+__device__ __forceinline__ void stg32(uint32_t* base, uint32_t idx, uint32_t v) { *(uint32_t*)((char*)base + (size_t)(idx << 2)) = v; }
 
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane) {
 #pragma unroll
@@ -121,8 +132,14 @@ __global__ __launch_bounds__(1024) void scan_hist_kernel(uint32_t* hist, int pas
     if (live) hist[t] = base + incl - v;
 }
 
-// One Onesweep pass: reads (keysIn, valsIn), writes (keysOut, valsOut) stably partitioned by digit (key>>shift)&255.
-__global__ __launch_bounds__(THREADS) void onesweep_kernel(const uint32_t* __restrict__ keysIn, const uint32_t* __restrict__ valsIn,
+// One Onesweep pass: reads (keysIn, valsIn), writes (keysOut, valsOut) stably partitioned by digit (key>>shift)&mask.
+// Register diet (the kernel is latency-bound, so resident waves matter): payloads are loaded only after the keys
+// have left the registers for LDS, local positions overwrite the ranks, and the digit of each output slot is kept
+// packed 4 per register instead of a 32-bit global index per slot.
+#ifndef GS_SORT_MINWAVES
+#define GS_SORT_MINWAVES 1
+#endif
+__global__ __launch_bounds__(THREADS, GS_SORT_MINWAVES) void onesweep_kernel(const uint32_t* __restrict__ keysIn, const uint32_t* __restrict__ valsIn,
                                                            uint32_t* __restrict__ keysOut, uint32_t* __restrict__ valsOut,
                                                            const uint32_t* __restrict__ histExcl, unsigned long long* status,
                                                            uint32_t* ticket, uint32_t* error, uint32_t nImm, const uint32_t* nPtr,
@@ -142,8 +159,7 @@ __global__ __launch_bounds__(THREADS) void onesweep_kernel(const uint32_t* __res
     for (;;) {
         __syncthreads();                                    // previous partition's LDS reads are finished
         if (tid == 0) s_part = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-        for (int k = 0; k < WAVES; ++k) s_hist[k * RADIX + tid] = 0;
+        for (int k = tid; k < WAVES * RADIX; k += THREADS) s_hist[k] = 0;
         __syncthreads();
         const uint32_t part = s_part;
         if (part >= numParts) break;
@@ -152,21 +168,24 @@ __global__ __launch_bounds__(THREADS) void onesweep_kernel(const uint32_t* __res
         const uint32_t valid = min((uint32_t)PART, n - partBase);
         const uint32_t waveBase = partBase + (uint32_t)w * (64u * KPT);
 
-        // ---- load: wave-striped, item (w,k,lane) has global index waveBase + k*64 + lane --------------
-        uint32_t key[KPT], val[KPT];
+        // ---- load keys: wave-striped, item (w,k,lane) has global index waveBase + k*64 + lane ----------
+        // full partitions (all but the last) take the unconditional path: wave-uniform base + lane*4 + immediate
+        uint32_t key[KPT];
+        const bool full = valid == (uint32_t)PART;
+        if (full) {
+            const uint32_t* kp = keysIn + waveBase;
 #pragma unroll
-        for (int k = 0; k < KPT; ++k) {
-            const uint32_t gi = waveBase + (uint32_t)k * 64u + lane;
-            key[k] = (gi < n) ? keysIn[gi] : 0xffffffffu;     // tail dummies sort last and are never written
-        }
+            for (int k = 0; k < KPT; ++k) key[k] = ldg32(kp + k * 64, (uint32_t)lane);
+        } else {
 #pragma unroll
-        for (int k = 0; k < KPT; ++k) {
-            const uint32_t gi = waveBase + (uint32_t)k * 64u + lane;
-            val[k] = (gi < n) ? valsIn[gi] : 0u;
+            for (int k = 0; k < KPT; ++k) {
+                const uint32_t gi = waveBase + (uint32_t)k * 64u + lane;
+                key[k] = (gi < n) ? ldg32(keysIn, gi) : 0xffffffffu; // tail dummies sort last and are never written
+            }
         }
 
         // ---- rank inside the wave: multi-split by 8 ballots, running per-wave LDS histogram ------------
-        uint32_t rank[KPT];
+        uint32_t pos[KPT];                                   // rank now, local position later
         uint32_t* wh = s_hist + w * RADIX;
 #pragma unroll
         for (int k = 0; k < KPT; ++k) {
@@ -184,73 +203,94 @@ __global__ __launch_bounds__(THREADS) void onesweep_kernel(const uint32_t* __res
             __builtin_amdgcn_wave_barrier();
             if (lower == 0) wh[d] = pre + cnt;
             __builtin_amdgcn_wave_barrier();
-            rank[k] = pre + lower;
+            pos[k] = pre + lower;
+            // Opaque to the optimiser: without it the digit and its LDS address are kept in registers per key for the
+            // scatter below (3 extra VGPRs x KPT, 150 VGPRs total = 3 waves/SIMD); recomputing them costs 2 VALU ops.
+            asm volatile("" : "+v"(key[k]));
         }
         __syncthreads();
 
         // ---- partition digit counts, wave-exclusive offsets, local exclusive scan over digits --------
-        uint32_t total = 0;
+        // (threads >= RADIX only help with loads/stores; digit `tid` is owned by thread tid < RADIX)
+        uint32_t total = 0, lbase = 0;
+        unsigned long long* myStatus = status + (size_t)part * RADIX + (tid & (RADIX - 1));
+        if (tid < RADIX) {
 #pragma unroll
-        for (int k = 0; k < WAVES; ++k) {
-            const uint32_t c = s_hist[k * RADIX + tid];
-            s_hist[k * RADIX + tid] = total;
-            total += c;
-        }
-        // publish this partition's digit count right away (decoupled look-back: successors need only this)
-        unsigned long long* myStatus = status + (size_t)part * RADIX + tid;
-        st_status(myStatus, pack_status(epoch, part == 0 ? FLAG_INCL : FLAG_AGG, total));
-
-        const uint32_t incl = wave_incl_scan(total, lane);
-        if (lane == 63) s_wtot[w] = incl;
-        __syncthreads();
-        uint32_t wbase = 0;
-#pragma unroll
-        for (int k = 0; k < WAVES; ++k) wbase += (k < w) ? s_wtot[k] : 0u;
-        const uint32_t lbase = wbase + incl - total;
-        s_lbase[tid] = lbase;
-
-        // ---- look back over earlier partitions for digit `tid` -----------------------------------------
-        uint32_t exclPrefix = 0;
-        if (part > 0) {
-            int q = (int)part - 1;
-            uint32_t spins = 0;
-            for (;;) {
-                const unsigned long long s = ld_status(status + (size_t)q * RADIX + tid);
-                const uint32_t e = (uint32_t)(s >> 34);
-                const uint32_t f = (uint32_t)(s >> 32) & 3u;
-                if (e == epoch && f != 0) {
-                    exclPrefix += (uint32_t)s;
-                    if (f == (uint32_t)FLAG_INCL) break;
-                    --q;                                   // partition 0 always publishes INCL, so q never drops below 0
-                    continue;
-                }
-                if (++spins > SPIN_LIMIT) { atomicOr(error, 1u); break; }
-                __builtin_amdgcn_s_sleep(2);
+            for (int k = 0; k < WAVES; ++k) {
+                const uint32_t c = s_hist[k * RADIX + tid];
+                s_hist[k * RADIX + tid] = total;
+                total += c;
             }
-            st_status(myStatus, pack_status(epoch, FLAG_INCL, exclPrefix + total));
+            // publish this partition's digit count right away (decoupled look-back: successors need only this)
+            st_status(myStatus, pack_status(epoch, part == 0 ? FLAG_INCL : FLAG_AGG, total));
+            const uint32_t incl = wave_incl_scan(total, lane);
+            if (lane == 63) s_wtot[w] = incl;
+            lbase = incl - total;
         }
-        s_gbase[tid] = histExcl[tid] + exclPrefix - lbase;
+        __syncthreads();
+        if (tid < RADIX) {
+            uint32_t wbase = 0;
+#pragma unroll
+            for (int k = 0; k < RADIX / 64; ++k) wbase += (k < w) ? s_wtot[k] : 0u;
+            lbase += wbase;
+            s_lbase[tid] = lbase;
+
+            // ---- look back over earlier partitions for digit `tid` -------------------------------------
+            uint32_t exclPrefix = 0;
+            if (part > 0) {
+                int q = (int)part - 1;
+                uint32_t spins = 0;
+                for (;;) {
+                    const unsigned long long s = ld_status(status + (size_t)q * RADIX + tid);
+                    const uint32_t e = (uint32_t)(s >> 34);
+                    const uint32_t f = (uint32_t)(s >> 32) & 3u;
+                    if (e == epoch && f != 0) {
+                        exclPrefix += (uint32_t)s;
+                        if (f == (uint32_t)FLAG_INCL) break;
+                        --q;                               // partition 0 always publishes INCL, so q never drops below 0
+                        continue;
+                    }
+                    if (++spins > SPIN_LIMIT) { atomicOr(error, 1u); break; }
+                    __builtin_amdgcn_s_sleep(2);
+                }
+                st_status(myStatus, pack_status(epoch, FLAG_INCL, exclPrefix + total));
+            }
+            s_gbase[tid] = histExcl[tid] + exclPrefix - lbase;
+        }
         __syncthreads();
 
         // ---- scatter keys through LDS so that global writes are runs of equal digits -------------------
-        uint32_t pos[KPT];
 #pragma unroll
         for (int k = 0; k < KPT; ++k) {
             const uint32_t d = (key[k] >> shift) & digitMask;
-            pos[k] = s_lbase[d] + wh[d] + rank[k];
+            pos[k] = s_lbase[d] + wh[d] + pos[k];
             s_buf[pos[k]] = key[k];
         }
+        // payloads: issued now (the key registers are dead), consumed after the key write-out
+        uint32_t val[KPT];
+        if (full) {
+            const uint32_t* vp = valsIn + waveBase;
+#pragma unroll
+            for (int k = 0; k < KPT; ++k) val[k] = ldg32(vp + k * 64, (uint32_t)lane);
+        } else {
+#pragma unroll
+            for (int k = 0; k < KPT; ++k) {
+                const uint32_t gi = waveBase + (uint32_t)k * 64u + lane;
+                val[k] = (gi < n) ? ldg32(valsIn, gi) : 0u;
+            }
+        }
         __syncthreads();
-        uint32_t gidx[KPT];
+        uint32_t dpack[(KPT + 3) / 4];
+#pragma unroll
+        for (int k = 0; k < (KPT + 3) / 4; ++k) dpack[k] = 0;
 #pragma unroll
         for (int k = 0; k < KPT; ++k) {
             const uint32_t j = (uint32_t)tid + (uint32_t)k * THREADS;
-            gidx[k] = 0xffffffffu;
             if (j < valid) {
                 const uint32_t kk = s_buf[j];
-                const uint32_t gi = s_gbase[(kk >> shift) & digitMask] + j;
-                keysOut[gi] = kk;
-                gidx[k] = gi;
+                const uint32_t d = (kk >> shift) & digitMask;
+                stg32(keysOut, s_gbase[d] + j, kk);
+                dpack[k >> 2] |= d << (8 * (k & 3));
             }
         }
         __syncthreads();
@@ -260,7 +300,7 @@ __global__ __launch_bounds__(THREADS) void onesweep_kernel(const uint32_t* __res
 #pragma unroll
         for (int k = 0; k < KPT; ++k) {
             const uint32_t j = (uint32_t)tid + (uint32_t)k * THREADS;
-            if (j < valid) valsOut[gidx[k]] = s_buf[j];
+            if (j < valid) stg32(valsOut, s_gbase[(dpack[k >> 2] >> (8 * (k & 3))) & 255u] + j, s_buf[j]);
         }
     }
 }
@@ -324,7 +364,7 @@ int32_t enqueue_sort_passes(gs_context* ctx, SortState& st, SortControl* control
     if (nUpper == 0) return GS_OK;
     hipLaunchKernelGGL(scan_hist_kernel, dim3(1), dim3(1024), 0, ctx->stream, control->hist, passes);
     const uint32_t parts = div_up(nUpper, PART);
-    const uint32_t grid = max(1u, min(parts, (uint32_t)ctx->cuCount * 4u));
+    const uint32_t grid = max(1u, min(parts, (uint32_t)ctx->cuCount * (uint32_t)(2048 / THREADS)));
     uint32_t *ks = keys, *vs = vals, *kd = st.altKeys, *vd = st.altVals;
     for (int p = 0; p < passes; ++p) {
         uint32_t epoch = (++st.epoch) & 0x3fffffffu;

@@ -8,6 +8,7 @@ thin layer over [DllImport("gsplat_hip")] (unitygaussiansplatting_amd/dotnet/Gau
 """
 from __future__ import annotations
 
+import atexit
 import ctypes as C
 import weakref
 from typing import List, Optional, Tuple
@@ -25,6 +26,20 @@ def _fptr(a: np.ndarray):
     return a.ctypes.data_as(C.POINTER(C.c_float))
 
 
+# Contexts still alive at interpreter exit are disposed (children first) BEFORE the HIP runtime's own static
+# destructors run; a late __del__ calling into a torn-down runtime aborts the process.
+_live_contexts = weakref.WeakSet()
+
+
+@atexit.register
+def _dispose_all_contexts():
+    for ctx in list(_live_contexts):
+        try:
+            ctx.Dispose()
+        except Exception:
+            pass
+
+
 class GpuContext:
     """One GPU + one HIP stream (the analogue of Unity's graphics device + render thread)."""
 
@@ -33,6 +48,7 @@ class GpuContext:
         check(_lib.lib().gs_context_create(device, C.c_void_p(stream) if stream else None, C.byref(self._h)), "gs_context_create")
         self.device = device
         self._children = weakref.WeakSet()      # targets / sorters / renderers: disposed before the context is
+        _live_contexts.add(self)
 
     def _adopt(self, child) -> None:
         self._children.add(child)
