@@ -32,7 +32,7 @@ constexpr int kSortThreads = 256;
 constexpr int kSortKPT = 16;              // keys per thread
 constexpr int kSortPart = kSortThreads * kSortKPT;   // 4096 keys per partition
 constexpr int kBinThreads = 256;
-constexpr int kBinItems = 4;              // sorted positions per thread
+constexpr int kBinItems = 16;             // sorted positions per thread
 constexpr int kBinPart = kBinThreads * kBinItems;
 constexpr int kEvPerFrame = 10;           // hipEvents per profiled frame
 
@@ -64,13 +64,17 @@ struct SortControl {
     uint32_t pad[3];
 };
 
+// The two words every workgroup hits with an atomic (ticket, visible) sit in their own 128-B lines: same-address
+// atomics serialise in one L2 channel (~11 ns each), so they must not also queue behind each other.
 struct BinControl {
     unsigned long long pairCount; // P: total pairs this frame (may exceed capacity => overflow)
-    uint32_t ticket;
-    uint32_t visible;
     uint32_t pairCountClamped;    // min(P, capacity), what the pair sort / ranges / blend see
     uint32_t error;
-    uint32_t pad[2];
+    uint32_t pad0[28];
+    uint32_t ticket;
+    uint32_t pad1[31];
+    uint32_t visible;
+    uint32_t pad2[31];
 };
 
 } // namespace gs

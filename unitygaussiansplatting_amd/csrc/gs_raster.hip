@@ -30,7 +30,6 @@ struct RasterConsts {
 
 constexpr unsigned long long BFLAG_AGG = 1ull << 62, BFLAG_INCL = 2ull << 62, BVAL_MASK = (1ull << 62) - 1ull;
 constexpr uint32_t BIN_SPIN_LIMIT = 1u << 24;
-constexpr int BIG_SPLAT = 32;      // splats covering more tiles than this are emitted cooperatively
 
 // broadcast lane `b` (wave-uniform) of x to every lane through v_readlane_b32: the result is a scalar operand
 __device__ __forceinline__ float rl(float x, int b) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), b)); }
@@ -62,44 +61,34 @@ __device__ __forceinline__ void hist_add_aggregated(uint32_t* h, uint32_t d, boo
     if (active) atomicAdd(&h[d], 1u);                      // many distinct values left: plain per-lane adds
 }
 
-template <int PASSES>
-__device__ __forceinline__ void emit_pair(uint32_t* __restrict__ pairKeys, uint32_t* __restrict__ pairVals, uint32_t* s_hist,
-                                          unsigned long long off, uint32_t capacity, uint32_t tile, uint32_t i, bool doit) {
-    const bool w = doit && off < (unsigned long long)capacity;
-#ifndef GS_EXP_NOSTORE
-    if (w) {
-        pairKeys[off] = tile;
-        pairVals[off] = i;
-    }
-#endif
-#ifndef GS_EXP_NOHIST
-    if (w) atomicAdd(&s_hist[tile & 255u], 1u);            // low digit: tiles of different splats, mostly distinct bins
-#ifdef GS_EXP_PLAINHIST
-    if (w && PASSES >= 2) atomicAdd(&s_hist[256u + ((tile >> 8) & 255u)], 1u);
-    if (w && PASSES >= 3) atomicAdd(&s_hist[512u + ((tile >> 16) & 255u)], 1u);
-#else
-    if (PASSES >= 2) hist_add_aggregated(s_hist + 256, (tile >> 8) & 255u, w);
-    if (PASSES >= 3) hist_add_aggregated(s_hist + 512, (tile >> 16) & 255u, w);
-#endif
-#endif
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += (uint32_t)__shfl_xor((int)v, o, 64);
+    return v;
 }
 
+// Binning: one workgroup per partition of kBinPart consecutive SORTED positions (front to back), handed out by ticket.
+// Wave w owns positions [w*1024, (w+1)*1024) of the partition, item (k, lane) = position k*64 + lane, so every load of
+// order[] is a coalesced 256-B row.  Pair offsets = exclusive scan of the per-position tile counts in position order:
+// inside the wave by DPP scans, across waves through LDS, across partitions by a single-pass chained scan whose
+// look-back is done 64 predecessors at a time by wave 0.  Emission is output-centric: the wave's pairs of 256 positions
+// are produced 64 consecutive output slots at a time, each lane finding its source position by a binary search over
+// the 256 exclusive offsets in LDS -- global stores of pairs are therefore fully coalesced whatever the footprints
+// are (a splat covering the whole screen is just a long run), and no lane idles behind a neighbour's big splat.
 template <int PASSES>
 __global__ __launch_bounds__(kBinThreads) void bin_emit_kernel(const uint2* __restrict__ rects, const uint32_t* __restrict__ order,
-                                                                uint32_t n, RasterConsts rc,
+                                                                uint32_t n, uint32_t tilesX,
                                                                 uint32_t* __restrict__ pairKeys, uint32_t* __restrict__ pairVals,
                                                                 uint32_t capacity, BinControl* ctl, unsigned long long* binStatus,
                                                                 uint32_t* pairHist) {
+    constexpr int SUB = 4;                                   // k's per emission batch: 256 positions per wave
     __shared__ uint32_t s_hist[3 * 256];
-    __shared__ uint32_t s_wtot[4];
+    __shared__ uint32_t s_wtot[4], s_wvis[4];
     __shared__ uint32_t s_part;
     __shared__ unsigned long long s_base;
-    __shared__ uint32_t s_qn;
-    __shared__ uint32_t s_qi[kBinThreads];
-    __shared__ uint32_t s_qrect[kBinThreads];       // tx0 | ty0 << 16
-    __shared__ uint32_t s_qdim[kBinThreads];        // tiles wide | count << 8 ... (count kept separately)
-    __shared__ uint32_t s_qcnt[kBinThreads];
-    __shared__ unsigned long long s_qoff[kBinThreads];
+    __shared__ uint32_t s_off[4][SUB * 64];
+    __shared__ uint32_t s_sid[4][SUB * 64];
+    __shared__ uint2 s_rect[4][SUB * 64];
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     if (tid == 0) s_part = __hip_atomic_fetch_add(&ctl->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -108,135 +97,131 @@ __global__ __launch_bounds__(kBinThreads) void bin_emit_kernel(const uint2* __re
     const uint32_t part = s_part;
     const uint32_t numParts = (n + kBinPart - 1) / kBinPart;
     if (part >= numParts) return;
-    const uint32_t base = part * (uint32_t)kBinPart;
+    const uint32_t waveBase = part * (uint32_t)kBinPart + (uint32_t)w * (64u * kBinItems);
 
     // ---- per sorted position: gather the splat's tile rectangle (8 B, written by calc_view) ----------------------
-    int tx0[kBinItems], ty0[kBinItems], tw[kBinItems];
-    uint32_t cnt[kBinItems], sid[kBinItems];
-    uint32_t visible = 0;
-    {
-        uint32_t sidx[kBinItems];
-#pragma unroll
-        for (int k = 0; k < kBinItems; ++k) {
-            const uint32_t i = base + (uint32_t)k * kBinThreads + tid;
-            sidx[k] = (i < n) ? order[i] : 0xffffffffu;
-        }
-#pragma unroll
-        for (int k = 0; k < kBinItems; ++k) {
-            uint2 rc2 = make_uint2(0u, 0u);
-            if (sidx[k] != 0xffffffffu) rc2 = rects[sidx[k]];
-            sid[k] = sidx[k];
-            tx0[k] = (int)(rc2.x & 0xffffu); ty0[k] = (int)(rc2.x >> 16);
-            tw[k] = (int)(rc2.y & 0xffffu);
-            cnt[k] = (rc2.y & 0xffffu) * (rc2.y >> 16);
-            visible += cnt[k] ? 1u : 0u;
-        }
-    }
-
-    // ---- block-wide exclusive scan of the pair counts in i order (round k, then thread) -----------------------
-    uint32_t off[kBinItems];
-    uint32_t running = 0;
+    uint32_t sid[kBinItems];
+    uint2 rc[kBinItems];
 #pragma unroll
     for (int k = 0; k < kBinItems; ++k) {
-        const uint32_t incl = wave_incl_scan_u32(cnt[k], lane);
-        if (lane == 63) s_wtot[w] = incl;
-        __syncthreads();
-        uint32_t wbase = 0, tot = 0;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { const uint32_t t = s_wtot[j]; wbase += (j < w) ? t : 0u; tot += t; }
-        off[k] = running + wbase + incl - cnt[k];
-        running += tot;
-        __syncthreads();
+        const uint32_t i = waveBase + (uint32_t)k * 64u + (uint32_t)lane;
+        sid[k] = (i < n) ? order[i] : 0xffffffffu;
     }
-    const uint32_t blockTotal = running;
+    uint32_t mySum = 0, myVis = 0;
+#pragma unroll
+    for (int k = 0; k < kBinItems; ++k) {
+        rc[k] = make_uint2(0u, 0u);
+        if (sid[k] != 0xffffffffu) rc[k] = rects[sid[k]];
+        const uint32_t c = (rc[k].y & 0xffffu) * (rc[k].y >> 16);
+        mySum += c;
+        myVis += c ? 1u : 0u;
+    }
+    const uint32_t waveTotal = wave_sum_u32(mySum);
+    const uint32_t waveVis = wave_sum_u32(myVis);
+    if (lane == 0) { s_wtot[w] = waveTotal; s_wvis[w] = waveVis; }
+    __syncthreads();
+    uint32_t wbase = 0, blockTotal = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const uint32_t t = s_wtot[j]; wbase += (j < w) ? t : 0u; blockTotal += t; }
 
-    // ---- chained scan across partitions (one lane looks back) ---------------------------------------------------
-    if (tid == 0) {
+    // ---- chained scan across partitions: wave 0 publishes the aggregate, then looks back 64 partitions at a time ----
+    if (w == 0) {
         unsigned long long* my = binStatus + part;
-        __hip_atomic_store(my, (part == 0 ? BFLAG_INCL : BFLAG_AGG) | (unsigned long long)blockTotal, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0) {
+            __hip_atomic_store(my, (part == 0 ? BFLAG_INCL : BFLAG_AGG) | (unsigned long long)blockTotal, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t vis = s_wvis[0] + s_wvis[1] + s_wvis[2] + s_wvis[3];
+            if (vis) atomicAdd(&ctl->visible, vis);
+        }
         unsigned long long excl = 0;
-#ifdef GS_EXP_NOLOOKBACK
-        if (false) {
-#else
         if (part > 0) {
-#endif
             int q = (int)part - 1;
             uint32_t spins = 0;
             for (;;) {
-                const unsigned long long s = __hip_atomic_load(binStatus + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (s & (BFLAG_AGG | BFLAG_INCL)) {
-                    excl += s & BVAL_MASK;
-                    if (s & BFLAG_INCL) break;
-                    --q;
+                const int idx = q - lane;
+                unsigned long long s = BFLAG_INCL;                    // before partition 0: inclusive prefix 0
+                if (idx >= 0) s = __hip_atomic_load(binStatus + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned long long incl = __ballot((s & BFLAG_INCL) != 0);
+                const unsigned long long notReady = __ballot((s & (BFLAG_AGG | BFLAG_INCL)) == 0);
+                const int lim = incl ? (__ffsll((long long)incl) - 1) : 63;       // nearest inclusive prefix in the window
+                const unsigned long long need = lim == 63 ? ~0ull : ((2ull << lim) - 1ull);
+                if (notReady & need) {
+                    if (++spins > BIN_SPIN_LIMIT) { if (lane == 0) atomicOr(&ctl->error, 2u); break; }
+                    __builtin_amdgcn_s_sleep(1);
                     continue;
                 }
-                if (++spins > BIN_SPIN_LIMIT) { atomicOr(&ctl->error, 2u); break; }
-                __builtin_amdgcn_s_sleep(2);
+                unsigned long long v = (lane <= lim) ? (s & BVAL_MASK) : 0ull;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+                excl += v;
+                if (incl) break;
+                q -= 64;
             }
-            __hip_atomic_store(my, BFLAG_INCL | (excl + blockTotal), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane == 0) __hip_atomic_store(my, BFLAG_INCL | (excl + blockTotal), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        s_base = excl;
-        if (part == numParts - 1) {
-            const unsigned long long total = excl + blockTotal;
-            ctl->pairCount = total;
-            ctl->pairCountClamped = (uint32_t)(total < (unsigned long long)capacity ? total : (unsigned long long)capacity);
-            if (total > (unsigned long long)capacity) atomicOr(&ctl->error, 1u);
+        if (lane == 0) {
+            s_base = excl;
+            if (part == numParts - 1) {
+                const unsigned long long total = excl + blockTotal;
+                ctl->pairCount = total;
+                ctl->pairCountClamped = (uint32_t)(total < (unsigned long long)capacity ? total : (unsigned long long)capacity);
+                if (total > (unsigned long long)capacity) atomicOr(&ctl->error, 1u);
+            }
         }
     }
     __syncthreads();
-    const unsigned long long blockBase = s_base;
+    const unsigned long long gbase = s_base + wbase;             // global offset of this wave's first pair
 
-    // ---- emit (tile, i) pairs: small footprints by their own lane, big ones by the whole workgroup -------------
+    // ---- emit (tile, splat) pairs, 256 positions of this wave at a time (no workgroup barriers below) -------------
+    uint32_t* offs = s_off[w];
+    uint32_t* sids = s_sid[w];
+    uint2* rcts = s_rect[w];
+    uint32_t run = 0;                                            // wave-local exclusive offset, wave-uniform
 #pragma unroll
-    for (int k = 0; k < kBinItems; ++k) {
-        const uint32_t i = sid[k];                 // pair payload = splat index: the blend kernel reads rec[splat]
-        if (tid == 0) s_qn = 0;
-        __syncthreads();
-        {
-            const bool small = cnt[k] > 0 && cnt[k] <= (uint32_t)BIG_SPLAT;
-            const unsigned long long o = blockBase + off[k];
-            if (cnt[k] > (uint32_t)BIG_SPLAT) {
-                const uint32_t slot = atomicAdd(&s_qn, 1u);
-                s_qi[slot] = i; s_qrect[slot] = (uint32_t)tx0[k] | ((uint32_t)ty0[k] << 16);
-                s_qdim[slot] = (uint32_t)tw[k]; s_qcnt[slot] = cnt[k]; s_qoff[slot] = o;
-            }
-            // every lane of the wave walks j = 0 .. (largest small count in the wave) together
-            uint32_t mx = small ? cnt[k] : 0u;
+    for (int sb = 0; sb < kBinItems / SUB; ++sb) {
+        const uint32_t subStart = run;
 #pragma unroll
-            for (int sh = 32; sh > 0; sh >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, sh, 64));
-            uint32_t tx = 0, ty = 0;
-            for (uint32_t j = 0; j < mx; ++j) {
-                const bool doit = small && j < cnt[k];
-                emit_pair<PASSES>(pairKeys, pairVals, s_hist, o + j, capacity, (uint32_t)(ty0[k] + (int)ty) * rc.tilesX + (uint32_t)(tx0[k] + (int)tx), i, doit);
-                if (++tx == (uint32_t)tw[k]) { tx = 0; ++ty; }
-            }
+        for (int kk = 0; kk < SUB; ++kk) {
+            const int k = sb * SUB + kk;
+            const uint32_t c = (rc[k].y & 0xffffu) * (rc[k].y >> 16);
+            const uint32_t incl = wave_incl_scan_u32(c, lane);
+            offs[kk * 64 + lane] = run + incl - c;
+            sids[kk * 64 + lane] = sid[k];
+            rcts[kk * 64 + lane] = rc[k];
+            run += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
         }
-        __syncthreads();
-        const uint32_t qn = s_qn;
-        for (uint32_t e = 0; e < qn; ++e) {
-            const uint32_t qi = s_qi[e], qr = s_qrect[e], qw = s_qdim[e], qc = s_qcnt[e];
-            const unsigned long long qo = s_qoff[e];
-            const uint32_t qx0 = qr & 0xffffu, qy0 = qr >> 16;
-            for (uint32_t j0 = 0; j0 < qc; j0 += kBinThreads) {      // all threads iterate together (ballots inside emit_pair)
-                const uint32_t j = j0 + tid;
-                const uint32_t ty = j / qw, tx = j - ty * qw;
-                emit_pair<PASSES>(pairKeys, pairVals, s_hist, qo + j, capacity, (qy0 + ty) * rc.tilesX + (qx0 + tx), qi, j < qc);
+        __builtin_amdgcn_wave_barrier();
+        for (uint32_t j0 = subStart; j0 < run; j0 += 64u) {       // wave-uniform trip count
+            const uint32_t j = j0 + (uint32_t)lane;
+            const bool act = j < run;
+            uint32_t e = 0;                                      // largest e with offs[e] <= j: the position that owns slot j
+#pragma unroll
+            for (uint32_t step = (SUB * 64) / 2; step > 0; step >>= 1)
+                if (offs[e + step] <= j) e += step;
+            const uint32_t o = j - offs[e];
+            const uint2 r = rcts[e];
+            const uint32_t s = sids[e];
+            const uint32_t tw = max(r.y & 0xffffu, 1u);
+            const uint32_t ty = o / tw, tx = o - ty * tw;
+            const uint32_t tile = ((r.x >> 16) + ty) * tilesX + (r.x & 0xffffu) + tx;
+            const unsigned long long gi = gbase + (unsigned long long)j;
+            const bool wr = act && gi < (unsigned long long)capacity;
+            if (wr) {
+                pairKeys[gi] = tile;
+                pairVals[gi] = s;                                // payload = splat index: the blend kernel reads rec[splat]
+                atomicAdd(&s_hist[tile & 255u], 1u);             // neighbouring slots are neighbouring tiles: distinct bins
             }
+            if (PASSES >= 2) hist_add_aggregated(s_hist + 256, (tile >> 8) & 255u, wr);
+            if (PASSES >= 3) hist_add_aggregated(s_hist + 512, (tile >> 16) & 255u, wr);
         }
-        __syncthreads();
+        __builtin_amdgcn_wave_barrier();
     }
 
-    // ---- flush the pair-sort digit histograms, count visible splats ----------------------------------------------
+    // ---- flush the pair-sort digit histograms ----------------------------------------------------------------------
+    __syncthreads();
     for (int j = tid; j < PASSES * 256; j += kBinThreads) {
         const uint32_t c = s_hist[j];
         if (c) atomicAdd(&pairHist[j], c);
     }
-    const unsigned long long vb = __ballot(visible != 0);
-    (void)vb;
-    uint32_t vsum = visible;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) vsum += __shfl_down(vsum, o, 64);
-    if (lane == 0 && vsum) atomicAdd(&ctl->visible, vsum);
 }
 
 // tile -> [start, end) in the tile-sorted pair array
@@ -478,7 +463,7 @@ int32_t enqueue_draw(gs_renderer* r, const gs_frame_params* p, gs_target* rt) {
     prof_record(r, 3);
     const int passes = numTiles <= 256 ? 1 : (numTiles <= 65536 ? 2 : 3);
     auto binKernel = passes == 1 ? bin_emit_kernel<1> : (passes == 2 ? bin_emit_kernel<2> : bin_emit_kernel<3>);
-    hipLaunchKernelGGL(binKernel, dim3(r->binParts), dim3(kBinThreads), 0, st, r->rects, r->order, r->n, rc, r->pairKeys,
+    hipLaunchKernelGGL(binKernel, dim3(r->binParts), dim3(kBinThreads), 0, st, r->rects, r->order, r->n, rc.tilesX, r->pairKeys,
                        r->pairVals, cap, binCtl, binStatus, pairCtl->hist);
     prof_record(r, 4);
     GS_TRY(enqueue_sort_passes(ctx, r->pairSort, pairCtl, r->pairKeys, r->pairVals, cap, &binCtl->pairCountClamped, passes));
