@@ -96,6 +96,32 @@ inline float f16tof32(uint32_t h) {
 }
 inline float round_f16(float f) { return f16tof32(f32tof16(f)); }
 
+// One blend of the render-target unit into an RGBA16F target (RenderGaussianSplats.shader:10-12, "Blend OneMinusDstAlpha
+// One"): dst' = RTNE_f16(src * t + dst) with the sum of products evaluated EXACTLY and rounded ONCE to the storage
+// format.  (The fragment's src = rgb*alpha and t = 1 - dst.a are fp32 values.)  src*t is exact in double (24 x 24 bits),
+// fma() makes the double result correctly rounded at 53 bits, and 53 bits are so much wider than the 11 of a half that
+// the second rounding below can only differ from a single rounding when the 53-bit result is an exact fp16 tie that
+// the infinitely precise value misses by < 2^-40 relative -- it does not occur for these operand widths.
+inline uint16_t f64tof16(double d) {
+    uint64_t u; std::memcpy(&u, &d, 8);
+    const uint16_t sign = (uint16_t)((u >> 48) & 0x8000u);
+    const int ebits = (int)((u >> 52) & 0x7ffu);
+    const uint64_t mant = u & ((1ull << 52) - 1ull);
+    if (ebits == 0x7ff) return (uint16_t)(sign | (mant ? 0x7e00u : 0x7c00u));
+    if (ebits == 0) return sign;                                          // 0 or a double subnormal: far below half range
+    const int e = ebits - 1023;
+    if (e > 15) return (uint16_t)(sign | 0x7c00u);
+    const uint64_t sig = mant | (1ull << 52);                             // 53-bit significand, value = sig * 2^(e-52)
+    const int shift = 42 + (e < -14 ? (-14 - e) : 0);                     // keep 11 bits (normal) or fewer (subnormal)
+    if (shift >= 64) return sign;
+    uint64_t q = sig >> shift;
+    const uint64_t rem = sig & ((1ull << shift) - 1ull), half = 1ull << (shift - 1);
+    if (rem > half || (rem == half && (q & 1ull))) q++;
+    const uint32_t h = (e < -14) ? (uint32_t)q : (uint32_t)(((uint32_t)(e + 14) << 10) + q);
+    return (uint16_t)(sign | (h >= 0x7c00u ? 0x7c00u : h));
+}
+inline float blend_f16(float src, float t, float dst) { return f16tof32(f64tof16(std::fma((double)src, (double)t, (double)dst))); }
+
 // ---------------------------------------------------------------------------------------------
 // asset view
 // ---------------------------------------------------------------------------------------------
@@ -496,6 +522,8 @@ void gso_set_num_threads(int32_t n) {
 // half conversion exposed for the f16 known-answer tests
 uint16_t gso_f32tof16(float f) { return f32tof16(f); }
 float gso_f16tof32(uint16_t h) { return f16tof32(h); }
+uint16_t gso_f64tof16(double d) { return f64tof16(d); }
+float gso_blend_f16(float src, float t, float dst) { return blend_f16(src, t, dst); }
 
 // SplatUtilities.compute:59-67 CSSetIndices
 void gso_set_indices(uint32_t* order, uint32_t n) { for (uint32_t i = 0; i < n; ++i) order[i] = i; }
@@ -620,12 +648,12 @@ int32_t gso_draw(const void* view_in, const uint32_t* order, uint32_t n, const g
                     alpha = saturatef(alpha * p.a);
                     if (alpha < 1.0f / 255.0f) continue;                        // discard
                     const float t = 1.0f - d[3];                                 // OneMinusDstAlpha
-                    float nr = fmaf(p.r * alpha, t, d[0]);
-                    float ng = fmaf(p.g * alpha, t, d[1]);
-                    float nb = fmaf(p.b * alpha, t, d[2]);
-                    float na = fmaf(alpha, t, d[3]);
-                    if (mode == 0) { nr = round_f16(nr); ng = round_f16(ng); nb = round_f16(nb); na = round_f16(na); }
-                    d[0] = nr; d[1] = ng; d[2] = nb; d[3] = na;
+                    const float sr = p.r * alpha, sg = p.g * alpha, sb = p.b * alpha;   // fragment output (fp32): rgb*alpha, alpha
+                    if (mode == 0) {        // exact: one RTNE to the fp16 storage format per blend
+                        d[0] = blend_f16(sr, t, d[0]); d[1] = blend_f16(sg, t, d[1]); d[2] = blend_f16(sb, t, d[2]); d[3] = blend_f16(alpha, t, d[3]);
+                    } else {                // fast: fp32 accumulation, rounded once at the end of the draw
+                        d[0] = fmaf(sr, t, d[0]); d[1] = fmaf(sg, t, d[1]); d[2] = fmaf(sb, t, d[2]); d[3] = fmaf(alpha, t, d[3]);
+                    }
                 }
             }
         }

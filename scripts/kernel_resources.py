@@ -4,7 +4,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 os.makedirs("/tmp/isa", exist_ok=True)
 files = sys.argv[1:] or ["gs_sort", "gs_view", "gs_raster"]
 for f in files:
-    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fno-gpu-rdc",
+    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize", "-fno-gpu-rdc",
            "-save-temps", "-c", "-Rpass-analysis=kernel-resource-usage", os.path.join(ROOT, "unitygaussiansplatting_amd", "csrc", f + ".hip"),
            "-o", f"/tmp/isa/{f}.o"] + [a for a in os.environ.get("EXTRA", "").split() if a]
     out = subprocess.run(cmd, cwd="/tmp/isa", capture_output=True, text=True).stderr

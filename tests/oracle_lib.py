@@ -32,6 +32,10 @@ def lib():
         _lib.gso_f16tof32.argtypes = [C.c_uint16]
         _lib.gso_f32tof16.restype = C.c_uint16
         _lib.gso_f32tof16.argtypes = [C.c_float]
+        _lib.gso_f64tof16.restype = C.c_uint16
+        _lib.gso_f64tof16.argtypes = [C.c_double]
+        _lib.gso_blend_f16.restype = C.c_float
+        _lib.gso_blend_f16.argtypes = [C.c_float, C.c_float, C.c_float]
         _lib.gso_num_threads.restype = C.c_int32
     return _lib
 

@@ -224,3 +224,48 @@ def test_resolve_formula():
     assert np.allclose(o32[0, 1, :3], want, atol=1e-6) and np.isclose(o32[0, 1, 3], 1.0)
     assert np.allclose(o32[0, 2, :3], g(np.array([0.5, 0.25, 1.0])), atol=1e-6)
     assert o8[0, 2, 2] == 255
+
+
+def test_f64tof16_is_correctly_rounded():
+    """f64tof16 (used by the exact-mode blend) == numpy's double -> half RTNE conversion: every half value, every
+    midpoint between neighbouring halves (ties to even), values just beside the midpoints, random doubles."""
+    L = O.lib()
+    h = np.arange(0, 0x7c00, dtype=np.uint16).view(np.float16).astype(np.float64)           # all finite non-negative halves
+    mids = (h[:-1] + h[1:]) / 2
+    xs = np.concatenate([h, mids, np.nextafter(mids, np.inf), np.nextafter(mids, -np.inf), [65504.0, 65519.999, 65520.0, 65536.0, 1e-9, 2.0 ** -25, np.nextafter(2.0 ** -25, 1.0), 0.0],
+                         np.random.default_rng(3).uniform(-2.0, 2.0, 20000), np.random.default_rng(4).normal(0, 1e-5, 20000)])
+    xs = np.concatenate([xs, -xs])
+    with np.errstate(over="ignore"):
+        want = xs.astype(np.float16).view(np.uint16)
+    got = np.array([L.gso_f64tof16(float(x)) for x in xs], np.uint16)
+    assert np.array_equal(got, want)
+
+
+def test_blend_f16_is_a_single_rounding_of_the_exact_fma():
+    """RenderGaussianSplats.shader:10-12 into RGBA16F, exact mode: dst' = RTNE_f16(src*t + dst), one rounding.  Checked
+    against exact rational arithmetic; includes cases where rounding to fp32 first (double rounding) gives the OTHER half."""
+    from fractions import Fraction
+    L = O.lib()
+    rng = np.random.default_rng(5)
+    n = 4000
+    src = rng.uniform(0, 1, n).astype(np.float32)
+    t = rng.uniform(0, 1, n).astype(np.float32)
+    dst = rng.uniform(0, 1, n).astype(np.float16).astype(np.float32)
+    halves = np.arange(0, 0x7c00, dtype=np.uint16).view(np.float16)
+    hf = [Fraction(float(x)) for x in halves]
+    import bisect
+    double_rounding_differs = 0
+    for k in range(n):
+        exact = Fraction(float(src[k])) * Fraction(float(t[k])) + Fraction(float(dst[k]))
+        i = bisect.bisect_left(hf, exact)
+        lo, hi = hf[i - 1], hf[i]
+        if exact - lo < hi - exact: want = halves[i - 1]
+        elif exact - lo > hi - exact: want = halves[i]
+        else: want = halves[i - 1] if ((i - 1) & 1) == 0 else halves[i]
+        got = L.gso_blend_f16(float(src[k]), float(t[k]), float(dst[k]))
+        assert np.float16(got) == want and float(np.float16(got)) == got, (k, src[k], t[k], dst[k])
+        two_step = np.float32(np.float64(src[k]) * np.float64(t[k]) + np.float64(dst[k])).astype(np.float16)   # fp32 first, then fp16
+        double_rounding_differs += int(two_step != want)
+    # a hand-made double-rounding case: exact = 1 + 2^-11 + 2^-30 (just above the tie) -> fp32 rounds it onto the tie -> even (1.0)
+    s, tt, d = np.float32(2.0 ** -11 + 2.0 ** -30), np.float32(1.0), np.float32(1.0)
+    assert L.gso_blend_f16(float(s), float(tt), float(d)) == float(np.float16(1.0) + np.float16(2.0 ** -10))

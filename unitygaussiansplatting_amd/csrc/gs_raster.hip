@@ -242,24 +242,106 @@ __device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t total) {
     return (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + k;
 }
 
-typedef _Float16 h2v __attribute__((ext_vector_type(2)));
-typedef float f2v __attribute__((ext_vector_type(2)));
-// RTNE to fp16 and back for two values at once: v_cvt_pk_f16_f32 + two v_cvt_f32_f16 (one with SDWA word select)
-__device__ __forceinline__ void round16x2(float& a, float& b) {
-    const f2v v = {a, b};
-    const f2v r = __builtin_convertvector(__builtin_convertvector(v, h2v), f2v);
-    a = r.x; b = r.y;
+// gfx950 mixed-precision FMA (v_fma_mix*): fp32 fma whose sources may be fp16 halves of a register and whose result
+// is either fp32 or RTNE-rounded into one fp16 half of the destination (the other half is preserved).  LLVM selects the
+// same instructions for  (half)fmaf(a, b, (float)h)  (so their semantics are fp32-fma-then-round), but only when its
+// SLP vectoriser has not packed the maths first; the helpers below pin them.
+__device__ __forceinline__ float mix_mul_lo(uint32_t h, float x) {      // (float)lo16(h) * x
+    float d;
+    asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel_hi:[1,0,0]" : "=v"(d) : "v"(h), "v"(x));
+    return d;
+}
+__device__ __forceinline__ float mix_mul_hi(uint32_t h, float x) {      // (float)hi16(h) * x
+    float d;
+    asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(h), "v"(x));
+    return d;
+}
+// x is the result of v_exp_f32: a transcendental's result needs one wait state before a non-transcendental VALU op
+// reads it (gfx940+ "trans forwarding" hazard).  hipcc pads its own instructions but not the inside of an asm string.
+__device__ __forceinline__ float mix_mul_lo_sat_after_trans(uint32_t h, float x) {  // saturate((float)lo16(h) * x)
+    float d;
+    asm("s_nop 0\n\tv_fma_mix_f32 %0, %1, %2, 0 op_sel_hi:[1,0,0] clamp" : "=v"(d) : "v"(h), "v"(x));
+    return d;
+}
+__device__ __forceinline__ float mix_one_minus_hi(uint32_t h) {         // 1 - (float)hi16(h)
+    float d;
+    asm("v_fma_mix_f32 %0, %1, -1.0, 1.0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(h));
+    return d;
+}
+// rg = { lo: f16(fma(pr, t, lo16(rg))), hi: f16(fma(pg, t, hi16(rg))) },  ba likewise with (pb, pa).  In place: each half
+// reads only itself.  A VALU op that writes HALF a register (op_sel destination) needs one wait state before a VALU op
+// reads that register (gfx940+ "dst_sel forwarding" hazard): the two registers are interleaved so that each mixhi is
+// one instruction away from the mixlo of its own register, no s_nop needed.
+__device__ __forceinline__ void mix_blend4(uint32_t& rg, uint32_t& ba, float pr, float pg, float pb, float pa, float t) {
+    asm("v_fma_mixlo_f16 %0, %2, %6, %0 op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixlo_f16 %1, %4, %6, %1 op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %0, %3, %6, %0 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %1, %5, %6, %1 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+        : "+v"(rg), "+v"(ba) : "v"(pr), "v"(pg), "v"(pb), "v"(pa), "v"(t));
 }
 
+// Accumulator of one pixel.  EXACT mode keeps the four channels as the two packed fp16 dwords the RGBA16F render
+// target holds between two blends of the reference's ROP (r | g << 16, b | a << 16).  Each blend is
+// f16(fma_f32(src, 1 - A, dst)): the product rgb*alpha is rounded to fp32 first (the fragment shader's output), the fma
+// and the RTNE to fp16 are one v_fma_mixlo/hi_f16.  FAST mode accumulates in fp32 and rounds once at the end.
+// Splat colour comes packed as in SplatViewData: c0 = f16 r << 16 | f16 g, c1 = f16 b << 16 | f16 a.
+__device__ __forceinline__ float half_lo(uint32_t u) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(u & 0xffffu)); }
+__device__ __forceinline__ float half_hi(uint32_t u) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(u >> 16)); }
+template <int MODE> struct PixelAcc;
+template <> struct PixelAcc<0> {
+    uint32_t rg, ba;
+    __device__ __forceinline__ void load(uint2 d) { rg = d.x; ba = d.y; }
+    __device__ __forceinline__ void blend(uint32_t c0, uint32_t c1, float alpha) {
+#ifdef GS_BLEND_PLAIN      // A/B reference: the same arithmetic written in plain C++ (compiler-selected instructions)
+        const float t = 1.0f - half_hi(ba);
+        const uint32_t nr = gsm::f32tof16(fmaf(half_hi(c0) * alpha, t, half_lo(rg))), ng = gsm::f32tof16(fmaf(half_lo(c0) * alpha, t, half_hi(rg)));
+        const uint32_t nb = gsm::f32tof16(fmaf(half_hi(c1) * alpha, t, half_lo(ba))), na = gsm::f32tof16(fmaf(alpha, t, half_hi(ba)));
+        rg = nr | (ng << 16); ba = nb | (na << 16);
+#else
+        const float t = mix_one_minus_hi(ba);
+        mix_blend4(rg, ba, mix_mul_hi(c0, alpha), mix_mul_lo(c0, alpha), mix_mul_hi(c1, alpha), alpha, t);
+#endif
+    }
+    __device__ __forceinline__ bool finished() const { return (ba >> 16) == 0x3c00u; }      // A == 1.0: further blends add exactly 0
+    __device__ __forceinline__ bool saturated() const { return false; }
+    __device__ __forceinline__ uint2 pack() const { return make_uint2(rg, ba); }
+};
+template <> struct PixelAcc<1> {
+    float r, g, b, a;
+    __device__ __forceinline__ void load(uint2 d) {
+        r = gsm::f16tof32(d.x); g = gsm::f16tof32(d.x >> 16); b = gsm::f16tof32(d.y); a = gsm::f16tof32(d.y >> 16);
+    }
+    __device__ __forceinline__ void blend(uint32_t c0, uint32_t c1, float alpha) {
+        const float t = 1.0f - a;
+        r = fmaf(mix_mul_hi(c0, alpha), t, r); g = fmaf(mix_mul_lo(c0, alpha), t, g); b = fmaf(mix_mul_hi(c1, alpha), t, b);
+        a = fmaf(alpha, t, a);
+    }
+    __device__ __forceinline__ bool finished() const { return (1.0f - a) < (1.0f / 4096.0f); }
+    __device__ __forceinline__ bool saturated() const { return (1.0f - a) < (1.0f / 4096.0f); }
+    __device__ __forceinline__ uint2 pack() const {
+        uint2 o;
+        o.x = gsm::f32tof16(r) | (gsm::f32tof16(g) << 16);
+        o.y = gsm::f32tof16(b) | (gsm::f32tof16(a) << 16);
+        return o;
+    }
+};
+
+typedef uint32_t u4v __attribute__((ext_vector_type(4)));
+
+// One workgroup per 16x16 tile, wave w owns the 8x8 quadrant (w&1, w>>1), one pixel per lane.  The tile's depth-ordered
+// list is streamed 256 pairs at a time: thread t gathers rec[pairVals[bs + t]] and stages, in LDS, everything that does
+// not depend on the pixel (inverse-scaled axes u_k = axis_k/|axis_k|^2, bounding half extents).  Each wave then
+//   (1) tests 64 staged records at once against its quadrant (lane j <-> record j, one ballot), and
+//   (2) walks the survivors in order, reading the record with WAVE-UNIFORM LDS loads (two ds_read_b128 per record:
+//       they issue on the LDS pipe, not the VALU, and the next record is requested before the current one is
+//       evaluated), so the per-(quadrant, splat) VALU cost is the fragment maths alone.
 template <int MODE>
 __global__ __launch_bounds__(256) void blend_kernel(const uint32_t* __restrict__ pairVals, const uint32_t* __restrict__ tileStart,
                                                     const uint32_t* __restrict__ tileEnd, const SplatRec* __restrict__ recs,
                                                     uint16_t* __restrict__ rt, RasterConsts rc) {
-    // per staged record: everything that does not depend on the pixel is computed ONCE here (by the staging thread),
-    // not once per wave: inverse-scaled axes, conservative half extents, unpacked colour
     __shared__ float4 s_a[256];      // cx, cy, u1x, u1y      (u_k = axis_k / |axis_k|^2)
-    __shared__ float4 s_b[256];      // u2x, u2y, ex, ey      (half extents of the footprint's bounding box, pixels)
-    __shared__ float4 s_c[256];      // r, g, b, a
+    __shared__ uint4 s_b[256];       // u2x, u2y (float bits), f16 r << 16 | f16 g, f16 b << 16 | f16 a
+    __shared__ float2 s_e[256];      // half extents of the footprint's bounding box, pixels
     __shared__ int s_done;
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -274,12 +356,9 @@ __global__ __launch_bounds__(256) void blend_kernel(const uint32_t* __restrict__
     const float fx = (float)px + 0.5f, fy = (float)py + 0.5f;
     const float qminx = (float)qx0 + 0.5f, qmaxx = (float)qx0 + 7.5f, qminy = (float)qy0 + 0.5f, qmaxy = (float)qy0 + 7.5f;
 
-    float Cr = 0.f, Cg = 0.f, Cb = 0.f, A = 0.f;
+    PixelAcc<MODE> acc;
     uint2* dst = (uint2*)(rt + ((size_t)py * rc.width + (size_t)px) * 4);
-    if (inside) {
-        const uint2 d = *dst;
-        Cr = gsm::f16tof32(d.x); Cg = gsm::f16tof32(d.x >> 16); Cb = gsm::f16tof32(d.y); A = gsm::f16tof32(d.y >> 16);
-    }
+    acc.load(inside ? *dst : make_uint2(0u, 0u));
     if (tid == 0) s_done = 0;
     bool waveDone = false;
 
@@ -293,48 +372,46 @@ __global__ __launch_bounds__(256) void blend_kernel(const uint32_t* __restrict__
             const float4 r0 = rp[0], r1 = rp[1];               // cx cy a1x a1y | a2x a2y c0 c1
             const float inv1 = 1.0f / gsm::dot2f(r0.z, r0.w, r0.z, r0.w);
             const float inv2 = 1.0f / gsm::dot2f(r1.x, r1.y, r1.x, r1.y);
-            const uint32_t c0 = gsm::f2u(r1.z), c1 = gsm::f2u(r1.w);
-            const float ca = gsm::f16tof32(c1);
+            const float ca = gsm::f16tof32(gsm::f2u(r1.w));
             // bounding box of  quad |q|<=2  INTERSECT  {exp(-|q|^2) a >= 1/255}  (same formula as PrepareSplat)
             const float exr = 2.0f * (fabsf(r0.z) + fabsf(r1.x)), eyr = 2.0f * (fabsf(r0.w) + fabsf(r1.y));
             const float rr = sqrtf(fmaxf(fmaf(__logf(255.0f * ca), 1.0001f, 1.0e-3f), 0.0f));
             const float exe = rr * sqrtf(gsm::dot2f(r0.z, r1.x, r0.z, r1.x)), eye = rr * sqrtf(gsm::dot2f(r0.w, r1.y, r0.w, r1.y));
             s_a[tid] = make_float4(r0.x, r0.y, r0.z * inv1, r0.w * inv1);
-            s_b[tid] = make_float4(r1.x * inv2, r1.y * inv2, fminf(exr, exe) + 0.02f, fminf(eyr, eye) + 0.02f);
-            s_c[tid] = make_float4(gsm::f16tof32(c0 >> 16), gsm::f16tof32(c0), gsm::f16tof32(c1 >> 16), ca);
+            s_b[tid] = make_uint4(gsm::f2u(r1.x * inv2), gsm::f2u(r1.y * inv2), gsm::f2u(r1.z), gsm::f2u(r1.w));
+            s_e[tid] = make_float2(fminf(exr, exe) + 0.02f, fminf(eyr, eye) + 0.02f);
         }
         __syncthreads();
         if (!waveDone) {
             for (uint32_t c = 0; c < cnt; c += 64u) {
                 const uint32_t j = c + lane;
-                const bool has = j < cnt;
-                float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra, rcol = ra;
-                if (has) { ra = s_a[j]; rb = s_b[j]; rcol = s_c[j]; }
-                const bool hit = has && (ra.x + rb.z >= qminx) && (ra.x - rb.z <= qmaxx) && (ra.y + rb.w >= qminy) && (ra.y - rb.w <= qmaxy);
+                bool hit = false;
+                if (j < cnt) {
+                    const float4 ra = s_a[j];
+                    const float2 re = s_e[j];
+                    hit = (ra.x + re.x >= qminx) && (ra.x - re.x <= qmaxx) && (ra.y + re.y >= qminy) && (ra.y - re.y <= qmaxy);
+                }
                 unsigned long long mask = __ballot(hit);
                 while (mask) {
                     const int b = __ffsll((long long)mask) - 1;
                     mask &= mask - 1ull;
-                    const float cx = rl(ra.x, b), cy = rl(ra.y, b), u1x = rl(ra.z, b), u1y = rl(ra.w, b);
-                    const float u2x = rl(rb.x, b), u2y = rl(rb.y, b);
-                    const float sr = rl(rcol.x, b), sg = rl(rcol.y, b), sb = rl(rcol.z, b), sa = rl(rcol.w, b);
-                    const float dx = fx - cx, dy = fy - cy;
-                    const float q1 = fmaf(dy, u1y, dx * u1x);
-                    const float q2 = fmaf(dy, u2y, dx * u2x);
+                    const float4 A4 = s_a[c + b];                      // wave-uniform address: LDS broadcast
+                    u4v B4 = *(const u4v*)&s_b[c + b];
+                    asm volatile("" : "+v"(B4));                       // keep it ONE ds_read_b128 (no piece sunk into the branch)
+                    const float dx = fx - A4.x, dy = fy - A4.y;
+                    const float q1 = fmaf(dy, A4.w, dx * A4.z);
+                    const float q2 = fmaf(dy, gsm::u2f(B4.y), dx * gsm::u2f(B4.x));
                     const float power = -fmaf(q2, q2, q1 * q1);
-                    float alpha = __expf(power);
-                    alpha = gsm::sat(alpha * sa);
-                    bool live = (fabsf(q1) <= 2.0f) && (fabsf(q2) <= 2.0f) && (alpha >= 1.0f / 255.0f);
-                    if (MODE == 1) live = live && !((1.0f - A) < (1.0f / 4096.0f));
-                    if (live) {
-                        const float t = 1.0f - A;
-                        float nr = fmaf(sr * alpha, t, Cr), ng = fmaf(sg * alpha, t, Cg), nb = fmaf(sb * alpha, t, Cb), na = fmaf(alpha, t, A);
-                        if (MODE == 0) { round16x2(nr, ng); round16x2(nb, na); }
-                        Cr = nr; Cg = ng; Cb = nb; A = na;
-                    }
+                    #ifdef GS_BLEND_PLAIN
+                    const float alpha = gsm::sat(__expf(power) * half_lo(B4.w));
+#else
+                    const float alpha = mix_mul_lo_sat_after_trans(B4.w, __expf(power));
+#endif
+                    bool live = ((int)(fabsf(q1) <= 2.0f) & (int)(fabsf(q2) <= 2.0f) & (int)(alpha >= 1.0f / 255.0f)) != 0;
+                    if (MODE == 1) live = live && !acc.saturated();
+                    if (live) acc.blend(B4.z, B4.w, alpha);
                 }
-                const bool pixDone = !inside || (MODE == 0 ? (A == 1.0f) : ((1.0f - A) < (1.0f / 4096.0f)));
-                if (__all(pixDone)) {
+                if (__all(!inside || acc.finished())) {
                     waveDone = true;
                     if (lane == 0) atomicAdd(&s_done, 1);
                     break;
@@ -342,12 +419,7 @@ __global__ __launch_bounds__(256) void blend_kernel(const uint32_t* __restrict__
             }
         }
     }
-    if (inside) {
-        uint2 o;
-        o.x = gsm::f32tof16(Cr) | (gsm::f32tof16(Cg) << 16);
-        o.y = gsm::f32tof16(Cb) | (gsm::f32tof16(A) << 16);
-        *dst = o;
-    }
+    if (inside) *dst = acc.pack();
 }
 
 // GaussianComposite.shader:25-39 + "Blend SrcAlpha OneMinusSrcAlpha" over a constant background
