@@ -25,6 +25,7 @@ ctx = GpuContext(0)
 r = GaussianSplatRenderer(ctx, asset)
 r.OnEnable()
 r.blendMode = mode
+r.m_SHOrder = int(os.environ.get("GS_SH_ORDER", "3"))
 rt = RenderTarget(ctx, cfg.width, cfg.height)
 cam_at = lambda f: camera.Camera(position=scenes.orbit_eye(cfg.eye_radius, cfg.eye_elev_deg, 0.25 * f), pixelWidth=cfg.width,
                                  pixelHeight=cfg.height, fieldOfView=cfg.fov_y)
@@ -50,5 +51,5 @@ wall = (time.perf_counter() - t0) / frames * 1e3
 st = r.FrameStats()
 t = r.StageTimes()
 out = {k: round(getattr(t, k), 4) for k, _ in t._fields_ if k.endswith("_ms") and k != "resolve_ms"}
-out.update(wall_ms=round(wall, 4), P=int(st.tile_pairs), lib=os.path.basename(os.environ.get("GSPLAT_LIB", "default")), mode=mode, cfg=key)
+out.update(wall_ms=round(wall, 4), P=int(st.tile_pairs), lib=os.path.basename(os.environ.get("GSPLAT_LIB", "default")), mode=mode, cfg=key, sh=r.m_SHOrder)
 print(json.dumps(out), flush=True)

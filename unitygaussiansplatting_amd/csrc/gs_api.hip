@@ -251,7 +251,7 @@ int32_t gs_renderer_calc_view(gs_renderer* r, const gs_frame_params* p) {
     if (!r || !p) return fail(GS_ERR_INVALID_ARGUMENT, "null argument");
     GS_TRY(bind_device(r->ctx));
     rec_ev(r, 7);
-    GS_TRY(enqueue_calc_view(r->ctx, r->asset->view, p, r->view, r->recs, r->rects));
+    GS_TRY(enqueue_calc_view(r->ctx, r->asset->view, p, r->view, r->recs, r->rects, r->visMask));
     r->viewW = p->screen_w; r->viewH = p->screen_h; r->viewNear = p->near_clip; r->viewFar = p->far_clip; r->viewValid = true;
     rec_ev(r, 8);
     return GS_OK;

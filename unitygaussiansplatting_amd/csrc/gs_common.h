@@ -124,6 +124,7 @@ struct gs_renderer {
     // compositor buffers
     gs::SplatRec* recs = nullptr;           // N x 32 B, indexed by splat (written by calc_view)
     uint2* rects = nullptr;                 // N x 8 B: x = tx0 | ty0 << 16, y = tiles wide | tiles high << 16 (0 = culled)
+    unsigned long long* visMask = nullptr;  // ceil(N/64) x 8 B: bit s = splat s reaches at least one tile (written by calc_view)
     float viewW = 0.f, viewH = 0.f, viewNear = 0.f, viewFar = 0.f;   // what the last calc_view was run with
     bool viewValid = false;
     uint32_t* pairKeys = nullptr;           // tile ids
@@ -168,7 +169,7 @@ int32_t enqueue_sort_passes(gs_context* ctx, SortState& st, SortControl* control
 int32_t enqueue_set_indices(gs_context* ctx, uint32_t* order, uint32_t n);
 // view (gs_view.hip)
 int32_t enqueue_calc_view(gs_context* ctx, const gsm::AssetView& a, const gs_frame_params* p, gsm::ViewData* out, SplatRec* recs,
-                          uint2* rects);
+                          uint2* rects, unsigned long long* visMask);
 void flatten_params(const gs_frame_params* p, gsm::FrameConsts& c);
 // raster (gs_raster.hip)
 int32_t renderer_alloc_raster(gs_renderer* r);

@@ -235,10 +235,19 @@ GS_HD uint32_t shStrideOf(uint32_t shFormat) { return shFormat == 0 ? 192u : (sh
 
 #define GS_SH_C1 0.4886025f
 
+// Where the raw (still chunk-normalised) SH coefficients of a splat come from: straight from the asset blob here; the
+// view kernel substitutes a reader of its LDS-staged copy (gs_view.hip).  begin() receives the record's address.
+struct SHFromBlob {
+    const uint8_t* sp; uint32_t fmt;
+    GS_HD void begin(const uint8_t* p, uint32_t f) { sp = p; fmt = f; }
+    GS_HD V3 load(int k) const { return LoadSH(sp, fmt, k); }
+};
+
 // CSCalcViewData for one splat (SplatUtilities.compute:189-252), cutouts/deleted bits absent.
 // SH coefficients are consumed in order sh1..sh15 by three fmaf chains (degree 1, 2, 3), so they are decoded
 // one at a time instead of being held in 45 registers.
-GS_HD ViewData CalcViewData(const AssetView& a, const FrameConsts& P, uint32_t idx) {
+template <class SHSource>
+GS_HD ViewData CalcViewDataT(const AssetView& a, const FrameConsts& P, uint32_t idx, SHSource& shsrc) {
     ViewData view;
     view.pos[0] = view.pos[1] = view.pos[2] = view.pos[3] = 0.0f;
     view.axis1[0] = view.axis1[1] = view.axis2[0] = view.axis2[1] = 0.0f;
@@ -365,9 +374,9 @@ GS_HD ViewData CalcViewData(const AssetView& a, const FrameConsts& P, uint32_t i
     if (P.shOrder >= 1) {
         uint32_t shIndex = idx;
         if (a.shFmt > 3) shIndex = LoadUShort(a.other, otherAddr + otherStride - 2);
-        const uint8_t* sp = a.sh + (uint64_t)shIndex * shStrideOf(a.shFmt);
+        shsrc.begin(a.sh + (uint64_t)shIndex * shStrideOf(a.shFmt), a.shFmt);
         auto SHK = [&](int k) -> V3 {
-            V3 s = LoadSH(sp, a.shFmt, k);
+            V3 s = shsrc.load(k);
             if (shLerp) { s.x = lerpf(shMin.x, shMax.x, s.x); s.y = lerpf(shMin.y, shMax.y, s.y); s.z = lerpf(shMin.z, shMax.z, s.z); }
             return s;
         };
@@ -417,6 +426,11 @@ GS_HD ViewData CalcViewData(const AssetView& a, const FrameConsts& P, uint32_t i
     view.color[0] = (f32tof16(r) << 16) | f32tof16(g);
     view.color[1] = (f32tof16(b) << 16) | f32tof16(al);
     return view;
+}
+
+GS_HD ViewData CalcViewData(const AssetView& a, const FrameConsts& P, uint32_t idx) {
+    SHFromBlob src;
+    return CalcViewDataT(a, P, idx, src);
 }
 
 // ---- compositor set-up: which splats are drawn, where, and which 16x16 tiles they can touch -----------

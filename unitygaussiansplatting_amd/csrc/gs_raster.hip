@@ -76,8 +76,8 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
 // the 256 exclusive offsets in LDS -- global stores of pairs are therefore fully coalesced whatever the footprints
 // are (a splat covering the whole screen is just a long run), and no lane idles behind a neighbour's big splat.
 template <int PASSES>
-__global__ __launch_bounds__(kBinThreads) void bin_emit_kernel(const uint2* __restrict__ rects, const uint32_t* __restrict__ order,
-                                                                uint32_t n, uint32_t tilesX,
+__global__ __launch_bounds__(kBinThreads) void bin_emit_kernel(const uint2* __restrict__ rects, const uint32_t* __restrict__ visMask32,
+                                                                const uint32_t* __restrict__ order, uint32_t n, uint32_t tilesX,
                                                                 uint32_t* __restrict__ pairKeys, uint32_t* __restrict__ pairVals,
                                                                 uint32_t capacity, BinControl* ctl, unsigned long long* binStatus,
                                                                 uint32_t* pairHist) {
@@ -107,11 +107,16 @@ __global__ __launch_bounds__(kBinThreads) void bin_emit_kernel(const uint2* __re
         const uint32_t i = waveBase + (uint32_t)k * 64u + (uint32_t)lane;
         sid[k] = (i < n) ? order[i] : 0xffffffffu;
     }
+    // 1 bit per splat first (a 0.8 MB array for 6.1 M splats: it stays in L2), so that only the splats that reach a tile
+    // pay for the random 8-byte gather of their rectangle from the N x 8 B array
+    uint32_t visw[kBinItems];
+#pragma unroll
+    for (int k = 0; k < kBinItems; ++k) visw[k] = (sid[k] != 0xffffffffu) ? visMask32[sid[k] >> 5] : 0u;
     uint32_t mySum = 0, myVis = 0;
 #pragma unroll
     for (int k = 0; k < kBinItems; ++k) {
         rc[k] = make_uint2(0u, 0u);
-        if (sid[k] != 0xffffffffu) rc[k] = rects[sid[k]];
+        if ((visw[k] >> (sid[k] & 31u)) & 1u) rc[k] = rects[sid[k]];
         const uint32_t c = (rc[k].y & 0xffffu) * (rc[k].y >> 16);
         mySum += c;
         myVis += c ? 1u : 0u;
@@ -483,6 +488,8 @@ int32_t renderer_alloc_raster(gs_renderer* r) {
     GS_HIP(hipMalloc((void**)&r->recs, (size_t)r->n * sizeof(SplatRec) + 64));
     GS_HIP(hipMalloc((void**)&r->rects, (size_t)r->n * sizeof(uint2) + 64));
     GS_HIP(hipMemsetAsync(r->rects, 0, (size_t)r->n * sizeof(uint2), ctx->stream));
+    GS_HIP(hipMalloc((void**)&r->visMask, ((size_t)r->n + 63) / 64 * 8 + 64));
+    GS_HIP(hipMemsetAsync(r->visMask, 0, ((size_t)r->n + 63) / 64 * 8, ctx->stream));
     if (r->pairCapacity == 0) {
         unsigned long long cap = (unsigned long long)r->n * 8ull;
         if (cap < (1ull << 22)) cap = 1ull << 22;
@@ -501,12 +508,13 @@ int32_t renderer_alloc_raster(gs_renderer* r) {
 void renderer_free_raster(gs_renderer* r) {
     if (r->recs) (void)hipFree(r->recs);
     if (r->rects) (void)hipFree(r->rects);
+    if (r->visMask) (void)hipFree(r->visMask);
     if (r->pairKeys) (void)hipFree(r->pairKeys);
     if (r->pairVals) (void)hipFree(r->pairVals);
     sort_state_destroy(r->pairSort);
     if (r->frameArena) (void)hipFree(r->frameArena);
     if (r->hostBin) (void)hipHostFree(r->hostBin);
-    r->recs = nullptr; r->rects = nullptr; r->pairKeys = r->pairVals = nullptr; r->frameArena = nullptr; r->hostBin = nullptr;
+    r->recs = nullptr; r->rects = nullptr; r->visMask = nullptr; r->pairKeys = r->pairVals = nullptr; r->frameArena = nullptr; r->hostBin = nullptr;
 }
 
 int32_t enqueue_draw(gs_renderer* r, const gs_frame_params* p, gs_target* rt) {
@@ -535,7 +543,7 @@ int32_t enqueue_draw(gs_renderer* r, const gs_frame_params* p, gs_target* rt) {
     prof_record(r, 3);
     const int passes = numTiles <= 256 ? 1 : (numTiles <= 65536 ? 2 : 3);
     auto binKernel = passes == 1 ? bin_emit_kernel<1> : (passes == 2 ? bin_emit_kernel<2> : bin_emit_kernel<3>);
-    hipLaunchKernelGGL(binKernel, dim3(r->binParts), dim3(kBinThreads), 0, st, r->rects, r->order, r->n, rc.tilesX, r->pairKeys,
+    hipLaunchKernelGGL(binKernel, dim3(r->binParts), dim3(kBinThreads), 0, st, r->rects, (const uint32_t*)r->visMask, r->order, r->n, rc.tilesX, r->pairKeys,
                        r->pairVals, cap, binCtl, binStatus, pairCtl->hist);
     prof_record(r, 4);
     GS_TRY(enqueue_sort_passes(ctx, r->pairSort, pairCtl, r->pairKeys, r->pairVals, cap, &binCtl->pairCountClamped, passes));

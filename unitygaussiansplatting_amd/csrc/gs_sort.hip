@@ -78,20 +78,39 @@ __global__ __launch_bounds__(1024) void set_indices_kernel(uint32_t* order, uint
 }
 
 // CSCalcDistances fused with the 4 digit histograms of the Onesweep sort.
+// The kernel is a dependent chain  order[i] -> pos[order[i]] (random 4..12-B gather) -> key  per splat, i.e. pure memory
+// latency: each thread carries GS_DIST_ILP independent chains (all index loads first, then all gathers), and the grid is
+// sized for full occupancy, so that enough gathers are in flight to cover the ~2 us round trip of a miss.
+#ifndef GS_DIST_ILP
+#define GS_DIST_ILP 4
+#endif
 __global__ __launch_bounds__(256) void calc_distances_kernel(gsm::AssetView a, const uint32_t* __restrict__ order,
                                                              float m20, float m21, float m22, float m23,
                                                              uint32_t* __restrict__ keys, uint32_t* __restrict__ hist, uint32_t n) {
     __shared__ uint32_t s_h[4 * RADIX];
     for (int j = threadIdx.x; j < 4 * RADIX; j += 256) s_h[j] = 0;
     __syncthreads();
-    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
-        const uint32_t origIdx = order[i];
-        const uint32_t key = gsm::SortKey(a, origIdx, m20, m21, m22, m23);
-        keys[i] = key;
-        lds_hist_add(s_h, key & 255u);
-        lds_hist_add(s_h + RADIX, (key >> 8) & 255u);
-        lds_hist_add(s_h + 2 * RADIX, (key >> 16) & 255u);
-        lds_hist_add(s_h + 3 * RADIX, key >> 24);
+    constexpr uint32_t ILP = GS_DIST_ILP;
+    const uint32_t stride = gridDim.x * 256u * ILP;
+    for (uint32_t base = blockIdx.x * 256u * ILP + threadIdx.x; base < n; base += stride) {   // wave-uniform trip count except the tail
+        uint32_t oi[ILP];
+#pragma unroll
+        for (uint32_t k = 0; k < ILP; ++k) {
+            const uint32_t i = base + k * 256u;
+            oi[k] = (i < n) ? order[i] : 0xffffffffu;
+        }
+        uint32_t key[ILP];
+#pragma unroll
+        for (uint32_t k = 0; k < ILP; ++k) key[k] = (oi[k] != 0xffffffffu) ? gsm::SortKey(a, oi[k], m20, m21, m22, m23) : 0u;
+#pragma unroll
+        for (uint32_t k = 0; k < ILP; ++k) {
+            if (oi[k] == 0xffffffffu) continue;
+            keys[base + k * 256u] = key[k];
+            lds_hist_add(s_h, key[k] & 255u);
+            lds_hist_add(s_h + RADIX, (key[k] >> 8) & 255u);
+            lds_hist_add(s_h + 2 * RADIX, (key[k] >> 16) & 255u);
+            lds_hist_add(s_h + 3 * RADIX, key[k] >> 24);
+        }
     }
     __syncthreads();
     for (int j = threadIdx.x; j < 4 * RADIX; j += 256) {
@@ -237,7 +256,11 @@ __global__ __launch_bounds__(THREADS, GS_SORT_MINWAVES) void onesweep_kernel(con
 
             // ---- look back over earlier partitions for digit `tid` -------------------------------------
             uint32_t exclPrefix = 0;
+#ifdef GS_EXP_SORT_NOLOOKBACK      // timing experiment only (wrong output): what the look-back chain costs
+            if (false) {
+#else
             if (part > 0) {
+#endif
                 int q = (int)part - 1;
                 uint32_t spins = 0;
                 for (;;) {
@@ -342,7 +365,7 @@ int32_t enqueue_set_indices(gs_context* ctx, uint32_t* order, uint32_t n) {
 int32_t enqueue_calc_distances(gs_context* ctx, const gsm::AssetView& a, const uint32_t* order, const float* m, uint32_t* keys,
                                SortControl* control, uint32_t n) {
     GS_HIP(hipMemsetAsync(control, 0, sizeof(SortControl), ctx->stream));
-    const uint32_t grid = min(div_up(n, 256), (uint32_t)ctx->cuCount * 4u);
+    const uint32_t grid = max(1u, min(div_up(n, 256u * GS_DIST_ILP), (uint32_t)ctx->cuCount * 8u));
     hipLaunchKernelGGL(calc_distances_kernel, dim3(grid), dim3(256), 0, ctx->stream, a, order, m[8], m[9], m[10], m[11], keys,
                        control->hist, n);
     GS_HIP(hipGetLastError());

@@ -16,25 +16,112 @@ namespace gs {
 
 namespace {
 
+// Reader of one splat's SH record staged in LDS as dwords (record stride padded to an odd dword count: conflict-free).
+// k is a compile-time constant wherever it is called from, so every index below folds to an immediate LDS offset.
+template <int FMT> struct SHFromLds {
+    const uint32_t* rec;
+    __device__ __forceinline__ void begin(const uint8_t*, uint32_t) {}
+    __device__ __forceinline__ uint32_t half_at(int h) const { return (rec[h >> 1] >> ((h & 1) * 16)) & 0xffffu; }
+    __device__ __forceinline__ gsm::V3 load(int k) const {
+        if (FMT == 0) return { gsm::u2f(rec[(k - 1) * 3]), gsm::u2f(rec[(k - 1) * 3 + 1]), gsm::u2f(rec[(k - 1) * 3 + 2]) };
+        if (FMT == 2) return gsm::Dec_11_10_11(rec[k - 1]);
+        if (FMT == 3) return gsm::Dec_5_6_5(half_at(k - 1));
+        return { gsm::f16tof32(half_at((k - 1) * 3)), gsm::f16tof32(half_at((k - 1) * 3 + 1)), gsm::f16tof32(half_at((k - 1) * 3 + 2)) };
+    }
+};
+
+constexpr int sh_rec_dwords(int fmt) { return fmt == 0 ? 48 : (fmt == 1 ? 24 : (fmt == 2 ? 15 : 8)); }
+constexpr int cmax(int a, int b) { return a > b ? a : b; }
+
+// SHMODE 0..3: per-splat SH records of SHFormat Float32 / Float16 / Norm11 / Norm6, staged through LDS;
+// SHMODE 4: SH read straight from the blob (Cluster* tables are gathered by a per-splat index, nothing to stage).
+//
+// SH is two thirds of the bytes this kernel reads (32 of 48.25 B per splat at Medium, 192 of 236 at VeryHigh), laid out
+// as one record per splat.  Read record-per-lane it is 15 narrow loads at a 32..192-byte lane stride, each touching 16-64
+// cache lines for 4 bytes apiece and relying on L1 to keep ~2-12 KB per wave alive in between.  Instead the workgroup
+// copies its 256 contiguous records (8-48 KB) with lane-contiguous 16-byte loads issued FIRST (they are in flight while
+// the positions are projected), parks them in LDS and decodes from there.
+template <int SHMODE>
 __global__ __launch_bounds__(256) void calc_view_kernel(gsm::AssetView a, gsm::FrameConsts P, gsm::ViewData* __restrict__ out,
-                                                        SplatRec* __restrict__ recs, uint2* __restrict__ rects) {
-    __shared__ uint4 s_stage[256 * 10 / 4];
-    uint32_t* s_out = (uint32_t*)s_stage;
+                                                        SplatRec* __restrict__ recs, uint2* __restrict__ rects,
+                                                        unsigned long long* __restrict__ visMask) {
+    constexpr int REC = sh_rec_dwords(SHMODE < 4 ? SHMODE : 3);       // dwords per record
+    constexpr int STRIDE = REC | 1;                                    // odd LDS stride
+    constexpr int SH_DW = SHMODE < 4 ? 256 * STRIDE : 0;
+    constexpr int NVEC = (REC * 256 / 4 + 255) / 256;                  // 16-byte vectors per thread
+    __shared__ uint4 s_stage[cmax(SH_DW, 256 * 10) / 4 + 1];
+    uint32_t* s_dw = (uint32_t*)s_stage;
     const uint32_t base = blockIdx.x * 256u;
     const uint32_t idx = base + threadIdx.x;
     const uint32_t cnt = min(256u, a.n - base);
+
+    // ---- issue the SH copy: cnt*REC dwords from a 16-byte aligned address (256*REC*4 bytes per workgroup)
+    uint4 shv[SHMODE < 4 ? NVEC : 1];
+    const uint32_t totalDw = cnt * (uint32_t)REC, totalVec = totalDw >> 2;
+    const uint32_t* shSrc = (const uint32_t*)(a.sh + (size_t)base * (REC * 4));
+    uint32_t shTail = 0;
+    if (SHMODE < 4) {
+#pragma unroll
+        for (int it = 0; it < NVEC; ++it) {
+            const uint32_t j = (uint32_t)it * 256u + threadIdx.x;
+            shv[it] = make_uint4(0u, 0u, 0u, 0u);
+            if (j < totalVec) shv[it] = ((const uint4*)shSrc)[j];
+        }
+        if ((totalDw & 3u) && threadIdx.x < (totalDw & 3u)) shTail = shSrc[(totalVec << 2) + threadIdx.x];
+    }
+    // ---- park it in LDS (record r, dword o  ->  r*STRIDE + o)
+    if (SHMODE < 4) {
+#pragma unroll
+        for (int it = 0; it < NVEC; ++it) {
+            const uint32_t j = (uint32_t)it * 256u + threadIdx.x;
+            if (j < totalVec) {
+                const uint32_t d = j << 2;
+                const uint32_t v[4] = { shv[it].x, shv[it].y, shv[it].z, shv[it].w };
+                if (REC % 4 == 0) {
+                    const uint32_t r = d / (uint32_t)REC, o = d - r * (uint32_t)REC;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) s_dw[r * STRIDE + o + c] = v[c];
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) { const uint32_t dd = d + c, r = dd / (uint32_t)REC; s_dw[r * STRIDE + (dd - r * (uint32_t)REC)] = v[c]; }
+                }
+            }
+        }
+        if ((totalDw & 3u) && threadIdx.x < (totalDw & 3u)) { const uint32_t dd = (totalVec << 2) + threadIdx.x, r = dd / (uint32_t)REC; s_dw[r * STRIDE + (dd - r * (uint32_t)REC)] = shTail; }
+        __syncthreads();
+    }
+
     gsm::ViewData v;
     gsm::SplatFootprint fp;
     uint2 rect = make_uint2(0u, 0u);
+    bool visible = false;
     if (idx < a.n) {
-        v = gsm::CalcViewData(a, P, idx);
+        if (SHMODE < 4) {
+            SHFromLds<SHMODE < 4 ? SHMODE : 3> src;
+            src.rec = s_dw + threadIdx.x * STRIDE;
+            v = gsm::CalcViewDataT(a, P, idx, src);
+        } else {
+            gsm::SHFromBlob src;
+            v = gsm::CalcViewDataT(a, P, idx, src);
+        }
         const bool ok = gsm::PrepareSplat(v, P.screenW, P.screenH, P.nearClip, P.farClip, fp);
         if (ok && fp.tx0 <= fp.tx1) {
             rect.x = (uint32_t)fp.tx0 | ((uint32_t)fp.ty0 << 16);
             rect.y = (uint32_t)(fp.tx1 - fp.tx0 + 1) | ((uint32_t)(fp.ty1 - fp.ty0 + 1) << 16);
+            visible = true;
         }
         rects[idx] = rect;
-        uint32_t* o = s_out + threadIdx.x * 10;
+        if (visible) {      // the blend kernel only ever reads records of splats that reach a tile
+            uint4* rp = (uint4*)(recs + idx);
+            rp[0] = make_uint4(gsm::f2u(fp.cx), gsm::f2u(fp.cy), gsm::f2u(v.axis1[0]), gsm::f2u(v.axis1[1]));
+            rp[1] = make_uint4(gsm::f2u(v.axis2[0]), gsm::f2u(v.axis2[1]), v.color[0], v.color[1]);
+        }
+    }
+    const unsigned long long vb = __ballot(visible);
+    if ((threadIdx.x & 63u) == 0u && (idx < a.n)) visMask[idx >> 6] = vb;          // 1 bit per splat: the binning pass tests it first
+    if (SHMODE < 4) __syncthreads();                                                 // every thread is done with the SH records
+    if (idx < a.n) {
+        uint32_t* o = s_dw + threadIdx.x * 10;
         o[0] = gsm::f2u(v.pos[0]); o[1] = gsm::f2u(v.pos[1]); o[2] = gsm::f2u(v.pos[2]); o[3] = gsm::f2u(v.pos[3]);
         o[4] = gsm::f2u(v.axis1[0]); o[5] = gsm::f2u(v.axis1[1]); o[6] = gsm::f2u(v.axis2[0]); o[7] = gsm::f2u(v.axis2[1]);
         o[8] = v.color[0]; o[9] = v.color[1];
@@ -45,19 +132,7 @@ __global__ __launch_bounds__(256) void calc_view_kernel(gsm::AssetView a, gsm::F
         uint32_t* g = (uint32_t*)(out + base);             // base*40 B is 16-B aligned (256*40 = 10240)
         const uint32_t vec = dwords / 4u;
         for (uint32_t j = threadIdx.x; j < vec; j += 256u) ((uint4*)g)[j] = s_stage[j];
-        for (uint32_t j = vec * 4u + threadIdx.x; j < dwords; j += 256u) g[j] = s_out[j];
-    }
-    __syncthreads();
-    if (idx < a.n) {
-        uint32_t* o = s_out + threadIdx.x * 8;
-        o[0] = gsm::f2u(fp.cx); o[1] = gsm::f2u(fp.cy);
-        o[2] = gsm::f2u(v.axis1[0]); o[3] = gsm::f2u(v.axis1[1]); o[4] = gsm::f2u(v.axis2[0]); o[5] = gsm::f2u(v.axis2[1]);
-        o[6] = v.color[0]; o[7] = v.color[1];
-    }
-    __syncthreads();
-    {
-        uint4* g = (uint4*)(recs + base);
-        for (uint32_t j = threadIdx.x; j < cnt * 2u; j += 256u) g[j] = s_stage[j];
+        for (uint32_t j = vec * 4u + threadIdx.x; j < dwords; j += 256u) g[j] = s_dw[j];
     }
 }
 
@@ -76,11 +151,20 @@ void flatten_params(const gs_frame_params* p, gsm::FrameConsts& c) {
 }
 
 int32_t enqueue_calc_view(gs_context* ctx, const gsm::AssetView& a, const gs_frame_params* p, gsm::ViewData* out, SplatRec* recs,
-                          uint2* rects) {
+                          uint2* rects, unsigned long long* visMask) {
     gsm::FrameConsts c;
     flatten_params(p, c);
     const uint32_t grid = (a.n + 255u) / 256u;
-    hipLaunchKernelGGL(calc_view_kernel, dim3(grid), dim3(256), 0, ctx->stream, a, c, out, recs, rects);
+    // per-splat SH records are staged through LDS (needs the blob 16-byte aligned, which hipMalloc and torch guarantee);
+    // Cluster* tables, an unaligned borrowed blob, or SH switched off read straight from the blob
+    int mode = (a.shFmt <= 3 && (((uintptr_t)a.sh) & 15u) == 0 && p->sh_order >= 1) ? (int)a.shFmt : 4;
+    switch (mode) {
+        case 0: hipLaunchKernelGGL(calc_view_kernel<0>, dim3(grid), dim3(256), 0, ctx->stream, a, c, out, recs, rects, visMask); break;
+        case 1: hipLaunchKernelGGL(calc_view_kernel<1>, dim3(grid), dim3(256), 0, ctx->stream, a, c, out, recs, rects, visMask); break;
+        case 2: hipLaunchKernelGGL(calc_view_kernel<2>, dim3(grid), dim3(256), 0, ctx->stream, a, c, out, recs, rects, visMask); break;
+        case 3: hipLaunchKernelGGL(calc_view_kernel<3>, dim3(grid), dim3(256), 0, ctx->stream, a, c, out, recs, rects, visMask); break;
+        default: hipLaunchKernelGGL(calc_view_kernel<4>, dim3(grid), dim3(256), 0, ctx->stream, a, c, out, recs, rects, visMask); break;
+    }
     GS_HIP(hipGetLastError());
     return GS_OK;
 }
