@@ -47,18 +47,19 @@ def parse():
     return ap.parse_args()
 
 
-def stage_bytes(n, P, W, H, asset, passes_pair):
-    """ALGORITHMIC bytes per launch of each stage (DESIGN.md "measurement")."""
+def stage_bytes(n, P, vis, W, H, asset, passes_pair):
+    """ALGORITHMIC bytes per launch of each stage (DESIGN.md "measurement"): the compulsory
+    traffic of the algorithm as shipped, every buffer counted once per pass over it."""
     from unitygaussiansplatting_amd.asset import GetVectorSize, GetOtherSizeNoSHIndex, GetColorSize
     b_pos = GetVectorSize(asset.posFormat)
     sh_item = {0: 192, 1: 96, 2: 60, 3: 32}.get(int(asset.shFormat), 96)
     chunk = 64.0 / 256.0 if asset.chunkCount else 0.0
     b_asset = b_pos + GetOtherSizeNoSHIndex(asset.scaleFormat) + GetColorSize(asset.colorFormat) + sh_item + chunk
     return {
-        "calc_distances": n * (4 + b_pos + chunk + 4),           # prev order + gathered pos + key out
+        "calc_distances": n * (4 + b_pos + chunk + 4),           # prev order in, gathered pos, key out
         "sort": n * 16 * 4,                                      # 4 Onesweep passes x (key+payload read + write); histogram is fused into calc_distances
-        "calc_view": n * (b_asset + 40),                         # asset record in, 40-byte view record out
-        "bin": n * (4 + 40 + 32) + P * 8,                        # order + view gather + 32-byte record out, (tile,i) pairs out
+        "calc_view": n * (b_asset + 40 + 8 + 0.125) + vis * 32,  # asset record in; 40-B view, 8-B tile rect, 1 visibility bit out; 32-B blend record per visible splat
+        "bin": n * (4 + 0.125) + vis * 8 + P * 8,                # order + visibility bit per position, rect per visible splat, (tile, splat) pairs out
         "pair_sort": P * 16 * passes_pair + P * 4,               # Onesweep passes over the pairs + tile-range scan of the keys
         "blend": P * (4 + 32) + W * H * 16,                      # pair index + record per pair, RT read + write
         "resolve": W * H * (8 + 16 + 4),                         # RGBA16F in, float RGBA + RGBA8 out
@@ -196,26 +197,44 @@ def main():
             rt.ResolveAsync((0.0, 0.0, 0.0, 1.0))
         ctx.Synchronize()
         resolve_ms = (time.perf_counter() - t_r) / 20 * 1e3
-        sb = stage_bytes(n, P, W, H, r.m_Asset, passes_pair)
+        vis = int(st.visible_splats)
+        sb = stage_bytes(n, P, vis, W, H, r.m_Asset, passes_pair)
         times = {"calc_distances": stage.calc_distances_ms, "sort": stage.sort_ms, "calc_view": stage.calc_view_ms,
                  "bin": stage.bin_ms, "pair_sort": stage.pair_sort_ms, "blend": stage.blend_ms, "resolve": resolve_ms}
         stages = {}
         for k, ms in times.items():
             gbs = sb[k] / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
             stages[k] = {"ms": round(ms, 4), "alg_MB": round(sb[k] / 1e6, 2), "GBps": round(gbs, 1), "hbm_frac": round(gbs / HBM_PEAK_GBS, 4)}
-        dom = max((k for k in times if k != "resolve"), key=lambda k: times[k])
-        kernel_of = {"calc_distances": "calc_distances_kernel", "sort": "onesweep_kernel (x4)", "calc_view": "calc_view_kernel",
-                     "bin": "bin_emit_kernel", "pair_sort": "onesweep_kernel (pairs)", "blend": "blend_kernel"}
-        dom_launches = 4 if dom == "sort" else (passes_pair if dom == "pair_sort" else 1)
-        dom_ms = times[dom] / dom_launches
-        dom_bytes = (sb[dom] - (P * 4 if dom == "pair_sort" else 0)) / dom_launches
+        # The dominant kernel = the one with the largest total time per frame in the rocprofv3 --stats summary.  The six
+        # Onesweep launches of a frame (4 depth-sort passes + the pair-sort passes) are one kernel; it is timed on its own
+        # by hipEvents recorded around exactly those launches on the context's stream (gs_stage_times.onesweep_*).
+        launches = {"onesweep_kernel": 4 + int(stage.onesweep_pair_launches), "blend_kernel": 1, "calc_view_kernel": 1, "bin_emit_kernel": 1,
+                    "calc_distances_kernel": 1}
+        ktime = {"onesweep_kernel": stage.onesweep_depth_ms + stage.onesweep_pairs_ms, "blend_kernel": stage.blend_ms,
+                 "calc_view_kernel": stage.calc_view_ms, "bin_emit_kernel": stage.bin_ms, "calc_distances_kernel": stage.calc_distances_ms}
+        kbytes = {"onesweep_kernel": n * 16 * 4 + P * 16 * passes_pair, "blend_kernel": sb["blend"], "calc_view_kernel": sb["calc_view"],
+                  "bin_emit_kernel": sb["bin"], "calc_distances_kernel": sb["calc_distances"]}
+        dom = max(ktime, key=lambda k: ktime[k])
+        dom_ms = ktime[dom] / launches[dom]
+        dom_bytes = kbytes[dom] / launches[dom]
         achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         frame_bytes = sum(sb.values())
-        roofline = {"bound": "hbm", "kernel": kernel_of[dom], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")     # PMC bytes per launch, written by scripts/pmc_traffic.py from rocprofv3 --pmc passes
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                if tj.get("config") == args.config and dom in tj.get("kernels", {}):
+                    traffic = tj["kernels"][dom]["hbm_bytes_per_launch"]
+            except Exception:
+                traffic = None
+        roofline = {"bound": "hbm", "kernel": dom, "launches_per_frame": launches[dom], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "alg_bytes_per_launch": int(dom_bytes), "avg_launch_ms": round(dom_ms, 4), "frames_averaged": int(stage.frames),
+                    "kernel_ms_per_frame": {k: round(v, 4) for k, v in ktime.items()},
                     "whole_frame": {"alg_MB": round(frame_bytes / 1e6, 1), "GBps": round(frame_bytes / (ms_per_step * 1e-3) / 1e9, 1),
-                                    "hbm_frac": round(frame_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}}
+                                    "hbm_frac": round(frame_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+                    "note": "blend_kernel is VALU-bound (exp + per-blend fp16 rounding), not HBM-bound: its hbm_frac in `stages` is not a quality measure"}
 
         cpu = None
         parity = None

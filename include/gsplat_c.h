@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define GS_ABI_VERSION 1
+#define GS_ABI_VERSION 2
 
 typedef enum gs_error {
     GS_OK = 0,
@@ -112,6 +112,11 @@ typedef struct gs_stage_times {
     float resolve_ms;          /* GaussianComposite.shader */
     float total_ms;
     uint32_t frames;           /* number of frames the averages cover */
+    /* the Onesweep launches alone (the kernel with the largest time share): sort_ms / pair_sort_ms minus the
+     * histogram-scan, copy-back and tile-range kernels that share those stages */
+    float onesweep_depth_ms;   /* sum of the 4 depth-sort launches of one frame */
+    float onesweep_pairs_ms;   /* sum of the pair-sort launches of one frame */
+    uint32_t onesweep_pair_launches;   /* 1..3, by tile count */
 } gs_stage_times;
 
 int32_t gs_abi_version(void);

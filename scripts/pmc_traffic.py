@@ -1,0 +1,77 @@
+"""Turns the rocprofv3 outputs of scripts/profile_round.sh (gpurun_out/prof/) into the files kept under profiles/:
+  profiles/<tag>_rocprof_kernel_stats_<cfg>.txt   per-kernel time summary (--kernel-trace --stats)
+  profiles/hbm_traffic.json                       HBM bytes per launch per kernel from the FETCH_SIZE / WRITE_SIZE PMC passes,
+                                                  corrected with factors calibrated on known-byte-count kernels in the same session
+Usage: python scripts/pmc_traffic.py <tag> [config]"""
+import csv, glob, json, os, re, sys
+from collections import defaultdict
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+P = os.path.join(ROOT, "gpurun_out", "prof")
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+config = sys.argv[2] if len(sys.argv) > 2 else "C2"
+
+def short(name):
+    name = name.replace("(anonymous namespace)::", "").replace("void ", "")
+    return re.sub(r"\(.*", "", name).replace("gs::", "")
+
+def counters(d):
+    out = defaultdict(list)
+    for f in glob.glob(os.path.join(P, d, "*", "*_counter_collection.csv")):
+        for r in csv.DictReader(open(f)):
+            out[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
+    return out
+
+# ---- calibration: every calib_* kernel moves exactly 1 GiB (scripts/probes/pmc_calib.hip); counters are in KiB
+GIB_KIB = float(1 << 20)
+cf, cw = counters("calib_FETCH_SIZE"), counters("calib_WRITE_SIZE")
+cal = {}
+for k in ("calib_read_b32", "calib_read_b128"):
+    if k in cf: cal[k] = {"FETCH_SIZE_KiB": sum(cf[k]) / len(cf[k]), "true_over_counter": GIB_KIB / (sum(cf[k]) / len(cf[k]))}
+for k in ("calib_write_b32", "calib_write_b128", "calib_scatter_runs32"):
+    if k in cw: cal[k] = {"WRITE_SIZE_KiB": sum(cw[k]) / len(cw[k]), "true_over_counter": GIB_KIB / (sum(cw[k]) / len(cw[k]))}
+    if k in cf: cal[k]["FETCH_SIZE_KiB_of_a_pure_write"] = sum(cf[k]) / len(cf[k])
+# which calibration applies to which kernel's dominant access width
+READ_CAL = {"onesweep_kernel": "calib_read_b32", "calc_distances_kernel": "calib_read_b32", "bin_emit_kernel": "calib_read_b32",
+            "tile_ranges_kernel": "calib_read_b32", "calc_view_kernel": "calib_read_b128", "blend_kernel": "calib_read_b128", "resolve_kernel": "calib_read_b128"}
+WRITE_CAL = {"onesweep_kernel": "calib_scatter_runs32", "calc_distances_kernel": "calib_write_b32", "bin_emit_kernel": "calib_write_b32",
+             "calc_view_kernel": "calib_write_b128", "blend_kernel": "calib_write_b128", "resolve_kernel": "calib_write_b128"}
+bf, bw = counters("pmc_FETCH_SIZE"), counters("pmc_WRITE_SIZE")
+kernels = {}
+for k in sorted(set(bf) | set(bw)):
+    base = re.sub(r"<.*", "", k)
+    if not (base.endswith("_kernel")): continue
+    rf = cal.get(READ_CAL.get(base, "calib_read_b128"), {}).get("true_over_counter", 2.0)
+    wf = cal.get(WRITE_CAL.get(base, "calib_write_b128"), {}).get("true_over_counter", 1.0)
+    f_kib = sum(bf.get(k, [0])) / max(1, len(bf.get(k, [0])))
+    w_kib = sum(bw.get(k, [0])) / max(1, len(bw.get(k, [0])))
+    kernels[base] = {"launches_sampled": len(bf.get(k, [])), "FETCH_SIZE_KiB_per_launch": round(f_kib, 1), "WRITE_SIZE_KiB_per_launch": round(w_kib, 1),
+                     "read_factor": round(rf, 3), "write_factor": round(wf, 3),
+                     "hbm_bytes_per_launch": int((f_kib * rf + w_kib * wf) * 1024)}
+os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
+json.dump({"config": config, "source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on `bench.py --steps 20 --warmup 5`, {tag}",
+           "units": "counters are KiB; true bytes = counter * factor * 1024, factors calibrated on 1-GiB kernels of the same access width in the same session",
+           "calibration": cal, "kernels": kernels}, open(os.path.join(ROOT, "profiles", "hbm_traffic.json"), "w"), indent=1)
+
+# ---- kernel time summary
+rows = []
+for f in glob.glob(os.path.join(P, "stats", "*", "*_kernel_stats.csv")):
+    rows += list(csv.DictReader(open(f)))
+trace = defaultdict(lambda: [0, 0, 0, 0])
+for f in glob.glob(os.path.join(P, "stats", "*", "*_kernel_trace.csv")):
+    for r in csv.DictReader(open(f)):
+        t = trace[short(r["Kernel_Name"])]
+        t[0] = max(t[0], int(r.get("VGPR_Count", 0) or 0)); t[1] = max(t[1], int(r.get("SGPR_Count", 0) or 0)); t[2] = max(t[2], int(r.get("LDS_Block_Size", 0) or 0))
+        t[3] = max(t[3], int(r.get("Grid_Size", 0) or r.get("Grid_Size_X", 0) or 0))
+outp = os.path.join(ROOT, "profiles", f"{tag}_rocprof_kernel_stats_{config.lower()}.txt")
+with open(outp, "w") as o:
+    o.write(f"# rocprofv3 --kernel-trace --stats -- python bench.py --steps 20 --warmup 5 --cpu-baseline off   ({config}, {tag})\n")
+    o.write(f"{'kernel':34s} {'calls':>6s} {'total_us':>11s} {'avg_us':>9s} {'min_us':>9s} {'max_us':>9s} {'pct':>6s} {'vgpr':>5s} {'sgpr':>5s} {'lds':>6s} {'grid':>9s}\n")
+    for r in sorted(rows, key=lambda r: -float(r["TotalDurationNs"])):
+        n = short(r["Name"]); t = trace.get(n, [0, 0, 0, 0])
+        o.write(f"{n[:34]:34s} {int(r['Calls']):6d} {float(r['TotalDurationNs'])/1e3:11.1f} {float(r['AverageNs'])/1e3:9.2f} {float(r['MinNs'])/1e3:9.2f} {float(r['MaxNs'])/1e3:9.2f} {float(r['Percentage']):6.2f} {t[0]:5d} {t[1]:5d} {t[2]:6d} {t[3]:9d}\n")
+    o.write("\n# HBM traffic per launch from the PMC passes (profiles/hbm_traffic.json)\n")
+    for k, v in kernels.items():
+        o.write(f"{k:34s} fetch {v['FETCH_SIZE_KiB_per_launch']:>11.1f} KiB x{v['read_factor']:<5}  write {v['WRITE_SIZE_KiB_per_launch']:>11.1f} KiB x{v['write_factor']:<5} -> {v['hbm_bytes_per_launch']/1e6:9.1f} MB\n")
+    o.write("\n# calibration (1 GiB each)\n")
+    for k, v in cal.items(): o.write(f"{k:26s} {v}\n")
+print(open(outp).read())

@@ -242,7 +242,7 @@ int32_t gs_renderer_sort(gs_renderer* r, const float m[16]) {
     rec_ev(r, 0);
     GS_TRY(enqueue_calc_distances(r->ctx, r->asset->view, r->order, m, r->distances, r->depthControl, r->n));
     rec_ev(r, 1);
-    GS_TRY(enqueue_sort_passes(r->ctx, r->depthSort, r->depthControl, r->distances, r->order, r->n, nullptr, 4));
+    GS_TRY(enqueue_sort_passes(r->ctx, r->depthSort, r->depthControl, r->distances, r->order, r->n, nullptr, 4, 255u, r, 10));
     rec_ev(r, 2);
     return GS_OK;
 }
@@ -403,6 +403,9 @@ int32_t gs_renderer_stage_times(gs_renderer* r, gs_stage_times* out) {
     out->pair_sort_ms = avg(4, 5);
     out->blend_ms = avg(5, 6);
     out->resolve_ms = 0.f;
+    out->onesweep_depth_ms = avg(10, 11);
+    out->onesweep_pairs_ms = avg(12, 13);
+    out->onesweep_pair_launches = r->lastPairPasses;
     out->total_ms = out->calc_distances_ms + out->sort_ms + out->calc_view_ms + out->bin_ms + out->pair_sort_ms + out->blend_ms;
     out->frames = (uint32_t)(r->profCompleted < r->profCapacity ? r->profCompleted : r->profCapacity);
     r->profCur = 0; r->profCompleted = 0;

@@ -34,7 +34,7 @@ constexpr int kSortPart = kSortThreads * kSortKPT;   // 4096 keys per partition
 constexpr int kBinThreads = 256;
 constexpr int kBinItems = 16;             // sorted positions per thread
 constexpr int kBinPart = kBinThreads * kBinItems;
-constexpr int kEvPerFrame = 10;           // hipEvents per profiled frame
+constexpr int kEvPerFrame = 14;           // hipEvents per profiled frame
 
 // 32-byte per-splat record consumed by the blend kernel (written by calc_view, splat-index order)
 struct alignas(16) SplatRec {
@@ -146,7 +146,7 @@ struct gs_renderer {
     // host copy of last frame's control (pinned), read lazily
     gs::BinControl* hostBin = nullptr;
     gs::SortControl* hostSortErr = nullptr;
-    uint32_t lastTilesX = 0, lastTilesY = 0;
+    uint32_t lastTilesX = 0, lastTilesY = 0, lastPairPasses = 0;
     bool frameInFlight = false;
     float resolveMs = 0.f;
 };
@@ -164,8 +164,10 @@ int32_t enqueue_histogram(gs_context* ctx, const uint32_t* keys, uint32_t n, con
                           SortControl* control);
 // scan + `passes` Onesweep passes.  Histograms must already be in control->hist.  Result ends in (keys, vals) when
 // passes is even, otherwise it is copied back.
+// profR/evFirst: optional hipEvent slots (evFirst = just before the first Onesweep launch, evFirst + 1 = after the last)
 int32_t enqueue_sort_passes(gs_context* ctx, SortState& st, SortControl* control, uint32_t* keys, uint32_t* vals,
-                            uint32_t nUpper, const uint32_t* nPtr, int passes, uint32_t lastMask = 255u);
+                            uint32_t nUpper, const uint32_t* nPtr, int passes, uint32_t lastMask = 255u,
+                            gs_renderer* profR = nullptr, int evFirst = -1);
 int32_t enqueue_set_indices(gs_context* ctx, uint32_t* order, uint32_t n);
 // view (gs_view.hip)
 int32_t enqueue_calc_view(gs_context* ctx, const gsm::AssetView& a, const gs_frame_params* p, gsm::ViewData* out, SplatRec* recs,

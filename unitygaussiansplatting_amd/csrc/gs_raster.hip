@@ -546,7 +546,8 @@ int32_t enqueue_draw(gs_renderer* r, const gs_frame_params* p, gs_target* rt) {
     hipLaunchKernelGGL(binKernel, dim3(r->binParts), dim3(kBinThreads), 0, st, r->rects, (const uint32_t*)r->visMask, r->order, r->n, rc.tilesX, r->pairKeys,
                        r->pairVals, cap, binCtl, binStatus, pairCtl->hist);
     prof_record(r, 4);
-    GS_TRY(enqueue_sort_passes(ctx, r->pairSort, pairCtl, r->pairKeys, r->pairVals, cap, &binCtl->pairCountClamped, passes));
+    GS_TRY(enqueue_sort_passes(ctx, r->pairSort, pairCtl, r->pairKeys, r->pairVals, cap, &binCtl->pairCountClamped, passes, 255u, r, 12));
+    r->lastPairPasses = (uint32_t)passes;
     hipLaunchKernelGGL(tile_ranges_kernel, dim3(max(1u, min(div_up(cap, 256), (uint32_t)ctx->cuCount * 8u))), dim3(256), 0, st, r->pairKeys,
                        &binCtl->pairCountClamped, tileStart, tileEnd, numTiles);
     prof_record(r, 5);

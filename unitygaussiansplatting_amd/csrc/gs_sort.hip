@@ -91,8 +91,18 @@ __global__ __launch_bounds__(256) void calc_distances_kernel(gsm::AssetView a, c
     for (int j = threadIdx.x; j < 4 * RADIX; j += 256) s_h[j] = 0;
     __syncthreads();
     constexpr uint32_t ILP = GS_DIST_ILP;
-    const uint32_t stride = gridDim.x * 256u * ILP;
-    for (uint32_t base = blockIdx.x * 256u * ILP + threadIdx.x; base < n; base += stride) {   // wave-uniform trip count except the tail
+    constexpr uint32_t TILE = 256u * ILP;
+    // XCD-aware traversal.  Workgroup b runs on XCD b % 8 (MI355X_MICROARCH.md), each XCD has its own 4 MB L2, and the
+    // gather pos[order[i]] fetches a whole 64-byte sector (16 Norm11 positions) per splat.  The asset is in Morton order,
+    // so the 16 splats of a sector are spatial neighbours and therefore close in DEPTH ORDER too: if one XCD walks a
+    // contiguous eighth of the sorted positions front to back, the other 15 accesses of a sector arrive at the same L2
+    // while the sector is still resident, instead of 16 fetches spread over 8 L2s.
+    const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3, slots = gridDim.x >> 3;     // gridDim.x is a multiple of 8
+    const uint32_t tilesTotal = (n + TILE - 1u) / TILE;
+    const uint32_t tilesPerXcd = (tilesTotal + 7u) / 8u;
+    const uint32_t tileEnd = min(tilesTotal, (xcd + 1u) * tilesPerXcd);
+    for (uint32_t tile = xcd * tilesPerXcd + slot; tile < tileEnd; tile += slots) {
+        const uint32_t base = tile * TILE + threadIdx.x;
         uint32_t oi[ILP];
 #pragma unroll
         for (uint32_t k = 0; k < ILP; ++k) {
@@ -101,11 +111,23 @@ __global__ __launch_bounds__(256) void calc_distances_kernel(gsm::AssetView a, c
         }
         uint32_t key[ILP];
 #pragma unroll
-        for (uint32_t k = 0; k < ILP; ++k) key[k] = (oi[k] != 0xffffffffu) ? gsm::SortKey(a, oi[k], m20, m21, m22, m23) : 0u;
+        for (uint32_t k = 0; k < ILP; ++k) {
+#if defined(GS_EXP_DIST_NOGATHER)          // timing experiments only (wrong keys)
+            key[k] = oi[k] * 2654435761u;
+#elif defined(GS_EXP_DIST_NOCHUNK)
+            { const gsm::V3 pp = gsm::LoadVec(a.pos, (uint64_t)(oi[k] == 0xffffffffu ? 0u : oi[k]) * gsm::vecStride(a.posFmt), a.posFmt);
+              key[k] = gsm::FloatToSortableUint(fmaf(m22, pp.z, fmaf(m21, pp.y, fmaf(m20, pp.x, m23)))); }
+#else
+            key[k] = (oi[k] != 0xffffffffu) ? gsm::SortKey(a, oi[k], m20, m21, m22, m23) : 0u;
+#endif
+        }
 #pragma unroll
         for (uint32_t k = 0; k < ILP; ++k) {
             if (oi[k] == 0xffffffffu) continue;
             keys[base + k * 256u] = key[k];
+#ifdef GS_EXP_DIST_NOHIST
+            continue;
+#endif
             lds_hist_add(s_h, key[k] & 255u);
             lds_hist_add(s_h + RADIX, (key[k] >> 8) & 255u);
             lds_hist_add(s_h + 2 * RADIX, (key[k] >> 16) & 255u);
@@ -365,7 +387,10 @@ int32_t enqueue_set_indices(gs_context* ctx, uint32_t* order, uint32_t n) {
 int32_t enqueue_calc_distances(gs_context* ctx, const gsm::AssetView& a, const uint32_t* order, const float* m, uint32_t* keys,
                                SortControl* control, uint32_t n) {
     GS_HIP(hipMemsetAsync(control, 0, sizeof(SortControl), ctx->stream));
-    const uint32_t grid = max(1u, min(div_up(n, 256u * GS_DIST_ILP), (uint32_t)ctx->cuCount * 8u));
+#ifndef GS_DIST_BLOCKS_PER_CU
+#define GS_DIST_BLOCKS_PER_CU 2      // a narrow window of sorted positions per XCD keeps the gathered sectors in its L2 (measured: 2 beats 4 and 8)
+#endif
+    const uint32_t grid = (max(1u, min(div_up(n, 256u * GS_DIST_ILP), (uint32_t)ctx->cuCount * GS_DIST_BLOCKS_PER_CU)) + 7u) & ~7u;
     hipLaunchKernelGGL(calc_distances_kernel, dim3(grid), dim3(256), 0, ctx->stream, a, order, m[8], m[9], m[10], m[11], keys,
                        control->hist, n);
     GS_HIP(hipGetLastError());
@@ -381,7 +406,7 @@ int32_t enqueue_histogram(gs_context* ctx, const uint32_t* keys, uint32_t n, con
 }
 
 int32_t enqueue_sort_passes(gs_context* ctx, SortState& st, SortControl* control, uint32_t* keys, uint32_t* vals, uint32_t nUpper,
-                            const uint32_t* nPtr, int passes, uint32_t lastMask) {
+                            const uint32_t* nPtr, int passes, uint32_t lastMask, gs_renderer* profR, int evFirst) {
     if (passes < 1 || passes > 4) return fail(GS_ERR_INVALID_ARGUMENT, "sort passes");
     if (nUpper > st.maxCount) return fail(GS_ERR_INVALID_ARGUMENT, "sort count exceeds sorter capacity");
     if (nUpper == 0) return GS_OK;
@@ -389,6 +414,7 @@ int32_t enqueue_sort_passes(gs_context* ctx, SortState& st, SortControl* control
     const uint32_t parts = div_up(nUpper, PART);
     const uint32_t grid = max(1u, min(parts, (uint32_t)ctx->cuCount * (uint32_t)(2048 / THREADS)));
     uint32_t *ks = keys, *vs = vals, *kd = st.altKeys, *vd = st.altVals;
+    if (profR && evFirst >= 0) prof_record(profR, evFirst);
     for (int p = 0; p < passes; ++p) {
         uint32_t epoch = (++st.epoch) & 0x3fffffffu;
         if (epoch == 0) {   // 30-bit epoch wrapped: wipe the status array (it may hold every old epoch), restart at 1
@@ -400,6 +426,7 @@ int32_t enqueue_sort_passes(gs_context* ctx, SortState& st, SortControl* control
         uint32_t* t = ks; ks = kd; kd = t;
         t = vs; vs = vd; vd = t;
     }
+    if (profR && evFirst >= 0) prof_record(profR, evFirst + 1);
     if (ks != keys) {
         hipLaunchKernelGGL(copy_pairs_kernel, dim3(max(1u, min(div_up(nUpper, 256), (uint32_t)ctx->cuCount * 8u))), dim3(256), 0,
                            ctx->stream, ks, vs, keys, vals, nUpper, nPtr);
