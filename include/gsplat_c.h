@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define GS_ABI_VERSION 2
+#define GS_ABI_VERSION 3
 
 typedef enum gs_error {
     GS_OK = 0,
@@ -90,6 +90,15 @@ typedef struct gs_frame_params {
     uint32_t sh_only;                /* m_SHOnly */
     float near_clip, far_clip;       /* camera near/far: a splat whose centre depth (clip.w) is outside is clipped */
 } gs_frame_params;
+
+/* One element of _SplatCutouts (SplatUtilities.compute:91-100 GaussianCutoutShaderData, filled by
+ * GaussianCutout.GetShaderData, GaussianCutout.cs:24-40): `matrix` = cutout.worldToLocal * renderer.localToWorld
+ * (row-major like every matrix of this ABI), type_and_flags = type (0 ellipsoid, 1 box, 0xFF.. = null cutout, ignored)
+ * | 0x100 if inverted. */
+typedef struct gs_cutout {
+    float matrix[16];
+    uint32_t type_and_flags;
+} gs_cutout;
 
 typedef struct gs_frame_stats {
     uint64_t tile_pairs;        /* P: (16x16 tile, splat) overlaps emitted by the binning kernel this frame */
@@ -156,6 +165,14 @@ int32_t gs_renderer_calc_view(gs_renderer* r, const gs_frame_params* p);
 int32_t gs_renderer_draw(gs_renderer* r, const gs_frame_params* p, gs_target* rt);
 /* convenience: sort (if do_sort) + calc_view + clear + draw, one call */
 int32_t gs_renderer_render(gs_renderer* r, const float matrix_sort[16], const gs_frame_params* p, gs_target* rt, int32_t do_sort);
+/* UpdateCutoutsBuffer (GaussianSplatRenderer.cs:742-764) + _SplatCutoutsCount (:508): the cutouts CSCalcViewData tests
+ * every splat against (IsSplatCut, SplatUtilities.compute:164-187; a cut splat gets clip.w = 0).  Copied; count 0 /
+ * NULL removes them.  At most GS_MAX_CUTOUTS. */
+#define GS_MAX_CUTOUTS 64
+int32_t gs_renderer_set_cutouts(gs_renderer* r, const gs_cutout* cutouts, uint32_t count);
+/* m_GpuEditDeleted + _SplatBitsValid (GaussianSplatRenderer.cs:497,501; SplatUtilities.compute:204-214): one bit per
+ * splat, bit set = deleted (clip.w = 0).  `words` = ceil(N/32) host uint32s, copied; NULL => _SplatBitsValid = 0. */
+int32_t gs_renderer_set_deleted_bits(gs_renderer* r, const uint32_t* words, size_t word_count);
 /* 0 (default): "exact" -- accumulate in fp16 (RTNE after every blend, like the RGBA16F ROP).
  * 1: "fast" -- accumulate in fp32, stop a pixel when 1-A < 1/4096. */
 int32_t gs_renderer_set_blend_mode(gs_renderer* r, int32_t mode);

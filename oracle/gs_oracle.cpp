@@ -351,13 +351,37 @@ struct ViewData {           // GaussianSplatting.hlsl:610-615  (40 bytes)
 };
 static_assert(sizeof(ViewData) == 40, "SplatViewData is 40 B");
 
-// SplatUtilities.compute:189-252 CSCalcViewData for one splat (cutouts / deleted bits: count 0)
-ViewData CalcViewDataOne(const Asset& a, const gs_frame_params& P, uint32_t idx) {
+// SplatUtilities.compute:164-187 IsSplatCut over _SplatCutouts[0.._SplatCutoutsCount)
+bool IsSplatCut(const gs_cutout* cutouts, uint32_t count, f3 pos) {
+    bool finalCut = false;
+    for (uint32_t i = 0; i < count; ++i) {
+        const gs_cutout& cutData = cutouts[i];
+        const uint32_t type = cutData.type_and_flags & 0xFFu;
+        if (type == 0xFFu) continue;                                   // invalid/null cutout, ignore
+        const bool invert = (cutData.type_and_flags & 0xFF00u) != 0;
+        const f3 cutoutPos = { mul_row(cutData.matrix, 0, pos), mul_row(cutData.matrix, 1, pos), mul_row(cutData.matrix, 2, pos) };
+        if (type == 0u) { if (dot3(cutoutPos, cutoutPos) <= 1.0f) return invert; }                                          // ellipsoid
+        if (type == 1u) { if (fabsf(cutoutPos.x) <= 1.0f && fabsf(cutoutPos.y) <= 1.0f && fabsf(cutoutPos.z) <= 1.0f) return invert; }   // box
+        finalCut |= !invert;
+    }
+    return finalCut;
+}
+
+// SplatUtilities.compute:189-252 CSCalcViewData for one splat
+ViewData CalcViewDataOne(const Asset& a, const gs_frame_params& P, uint32_t idx, const gs_cutout* cutouts = nullptr, uint32_t cutoutCount = 0,
+                         const uint32_t* deletedBits = nullptr) {
     const SplatData splat = LoadSplatData(a, idx);
     ViewData view; std::memset(&view, 0, sizeof(view));
 
     const f3 centerWorldPos = { mul_row(P.matrix_object_to_world, 0, splat.pos), mul_row(P.matrix_object_to_world, 1, splat.pos), mul_row(P.matrix_object_to_world, 2, splat.pos) };
-    const float clip[4] = { mul_row(P.matrix_vp, 0, centerWorldPos), mul_row(P.matrix_vp, 1, centerWorldPos), mul_row(P.matrix_vp, 2, centerWorldPos), mul_row(P.matrix_vp, 3, centerWorldPos) };
+    float clip[4] = { mul_row(P.matrix_vp, 0, centerWorldPos), mul_row(P.matrix_vp, 1, centerWorldPos), mul_row(P.matrix_vp, 2, centerWorldPos), mul_row(P.matrix_vp, 3, centerWorldPos) };
+    // deleted? (:204-214, _SplatBitsValid = deletedBits != null)
+    if (deletedBits) {
+        const uint32_t wordIdx = idx / 32, bitIdx = idx & 31;
+        if (deletedBits[wordIdx] & (1u << bitIdx)) clip[3] = 0.0f;
+    }
+    // cutouts (:216-220)
+    if (IsSplatCut(cutouts, cutoutCount, splat.pos)) clip[3] = 0.0f;
     for (int k = 0; k < 4; ++k) view.pos[k] = clip[k];
     const bool behindCam = !(clip[3] > 0.0f);                     // centerClipPos.w <= 0 (NaN counts as behind)
     if (behindCam) return view;
@@ -583,13 +607,15 @@ void gso_decode_all(const gs_asset_desc* d, float* out /* n x 59 */) {
 }
 void gso_pixel_index(uint32_t idx, uint32_t* xy) { SplatIndexToPixelIndex(idx, xy[0], xy[1]); }
 
-// SplatUtilities.compute:189-252 CSCalcViewData over all splats
-void gso_calc_view(const gs_asset_desc* d, const gs_frame_params* P, void* view_out) {
+// SplatUtilities.compute:189-252 CSCalcViewData over all splats; deleted_bits may be null (_SplatBitsValid = 0)
+void gso_calc_view_ex(const gs_asset_desc* d, const gs_frame_params* P, const gs_cutout* cutouts, uint32_t cutout_count,
+                      const uint32_t* deleted_bits, void* view_out) {
     const Asset a = make_asset(d);
     ViewData* out = (ViewData*)view_out;
 #pragma omp parallel for schedule(static)
-    for (int64_t i = 0; i < (int64_t)a.n; ++i) out[i] = CalcViewDataOne(a, *P, (uint32_t)i);
+    for (int64_t i = 0; i < (int64_t)a.n; ++i) out[i] = CalcViewDataOne(a, *P, (uint32_t)i, cutouts, cutout_count, deleted_bits);
 }
+void gso_calc_view(const gs_asset_desc* d, const gs_frame_params* P, void* view_out) { gso_calc_view_ex(d, P, nullptr, 0, nullptr, view_out); }
 
 // The DrawProcedural of GaussianSplatRenderer.cs:156-166 with RenderGaussianSplats.shader, executed splat by
 // splat in order[] (instance order), "Blend OneMinusDstAlpha One" into an RGBA16F target (rt, W*H*4 halfs,

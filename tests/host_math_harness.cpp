@@ -22,11 +22,14 @@ static gsm::FrameConsts fl(const gs_frame_params* p) {
     return c;
 }
 extern "C" {
-void hm_calc_view(const gs_asset_desc* d, const gs_frame_params* p, void* out) {
+void hm_calc_view_ex(const gs_asset_desc* d, const gs_frame_params* p, const gs_cutout* cutouts, uint32_t cutoutCount,
+                     const uint32_t* deletedBits, void* out) {
     const gsm::AssetView a = mk(d); const gsm::FrameConsts c = fl(p);
+    gsm::EditView e; e.deletedBits = deletedBits; e.cutouts = (const uint32_t*)cutouts; e.cutoutCount = cutoutCount;
     gsm::ViewData* o = (gsm::ViewData*)out;
-    for (uint32_t i = 0; i < a.n; ++i) o[i] = gsm::CalcViewData(a, c, i);
+    for (uint32_t i = 0; i < a.n; ++i) o[i] = gsm::CalcViewData(a, c, e, i);
 }
+void hm_calc_view(const gs_asset_desc* d, const gs_frame_params* p, void* out) { hm_calc_view_ex(d, p, nullptr, 0, nullptr, out); }
 void hm_calc_distances(const gs_asset_desc* d, const uint32_t* order, const float* m, uint32_t* keys) {
     const gsm::AssetView a = mk(d);
     for (uint32_t i = 0; i < a.n; ++i) keys[i] = gsm::SortKey(a, order[i], m[8], m[9], m[10], m[11]);

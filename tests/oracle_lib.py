@@ -70,8 +70,11 @@ class Oracle:
         lib().gso_sort_pairs(_p(self.keys), _p(self.order), C.c_uint32(self.n), C.c_uint32(32))
         return self.order
 
-    def calc_view(self, params: gs_frame_params):
-        lib().gso_calc_view(C.byref(self.desc), C.byref(params), _p(self.view))
+    def calc_view(self, params: gs_frame_params, cutouts=None, cutout_count: int = 0, deleted_bits: np.ndarray | None = None):
+        """cutouts: a ctypes array of gs_cutout (cutout.shader_data_array); deleted_bits: ceil(n/32) uint32 words or None."""
+        db = np.ascontiguousarray(deleted_bits, np.uint32) if deleted_bits is not None else None
+        lib().gso_calc_view_ex(C.byref(self.desc), C.byref(params), cutouts if cutout_count else None, C.c_uint32(cutout_count),
+                               _p(db) if db is not None else None, _p(self.view))
         return self.view
 
     def draw(self, params: gs_frame_params, mode: int = 0, rt: np.ndarray | None = None):

@@ -41,6 +41,10 @@ class gs_frame_params(C.Structure):
     ]
 
 
+class gs_cutout(C.Structure):
+    _fields_ = [("matrix", C.c_float * 16), ("type_and_flags", C.c_uint32)]
+
+
 class gs_frame_stats(C.Structure):
     _fields_ = [("tile_pairs", C.c_uint64), ("pair_capacity", C.c_uint64), ("visible_splats", C.c_uint32),
                 ("tiles_x", C.c_uint32), ("tiles_y", C.c_uint32), ("sort_error", C.c_uint32)]

@@ -6,7 +6,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-from ._abi import gs_asset_desc, gs_frame_params, gs_frame_stats, gs_stage_times
+from ._abi import gs_asset_desc, gs_cutout, gs_frame_params, gs_frame_stats, gs_stage_times
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GSPLAT_LIB") or os.path.join(_HERE, "libgsplat_hip.so")   # GSPLAT_LIB: A/B a variant build
@@ -42,6 +42,8 @@ SIGNATURES = {
     "gs_renderer_calc_view": (C.c_int32, [_P, C.POINTER(gs_frame_params)]),
     "gs_renderer_draw": (C.c_int32, [_P, C.POINTER(gs_frame_params), _P]),
     "gs_renderer_render": (C.c_int32, [_P, C.POINTER(C.c_float), C.POINTER(gs_frame_params), _P, C.c_int32]),
+    "gs_renderer_set_cutouts": (C.c_int32, [_P, C.POINTER(gs_cutout), C.c_uint32]),
+    "gs_renderer_set_deleted_bits": (C.c_int32, [_P, _P, C.c_size_t]),
     "gs_renderer_set_blend_mode": (C.c_int32, [_P, C.c_int32]),
     "gs_renderer_set_profiling": (C.c_int32, [_P, C.c_int32]),
     "gs_renderer_reserve_pairs": (C.c_int32, [_P, C.c_uint64]),

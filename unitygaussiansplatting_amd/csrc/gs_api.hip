@@ -221,6 +221,10 @@ int32_t gs_renderer_destroy(gs_renderer* r) {
     if (r->distances) (void)hipFree(r->distances);
     if (r->order) (void)hipFree(r->order);
     if (r->depthControl) (void)hipFree(r->depthControl);
+    if (r->deletedBits) (void)hipFree(r->deletedBits);
+    if (r->cutouts) (void)hipFree(r->cutouts);
+    if (r->cutoutsHost) (void)hipHostFree(r->cutoutsHost);
+    if (r->cutoutsCopied) (void)hipEventDestroy(r->cutoutsCopied);
     sort_state_destroy(r->depthSort);
     renderer_free_raster(r);
     if (r->ev) { for (int k = 0; k < r->profCapacity * kEvPerFrame; ++k) (void)hipEventDestroy(r->ev[k]); delete[] r->ev; delete[] r->evValid; }
@@ -251,7 +255,9 @@ int32_t gs_renderer_calc_view(gs_renderer* r, const gs_frame_params* p) {
     if (!r || !p) return fail(GS_ERR_INVALID_ARGUMENT, "null argument");
     GS_TRY(bind_device(r->ctx));
     rec_ev(r, 7);
-    GS_TRY(enqueue_calc_view(r->ctx, r->asset->view, p, r->view, r->recs, r->rects, r->visMask));
+    gsm::EditView e;
+    e.deletedBits = r->deletedBits; e.cutouts = r->cutouts; e.cutoutCount = r->cutoutCount;
+    GS_TRY(enqueue_calc_view(r->ctx, r->asset->view, p, e, r->view, r->recs, r->rects, r->visMask));
     r->viewW = p->screen_w; r->viewH = p->screen_h; r->viewNear = p->near_clip; r->viewFar = p->far_clip; r->viewValid = true;
     rec_ev(r, 8);
     return GS_OK;
@@ -283,6 +289,51 @@ int32_t gs_renderer_render(gs_renderer* r, const float m[16], const gs_frame_par
     GS_TRY(gs_renderer_calc_view(r, p));
     GS_TRY(gs_target_clear(rt));
     return gs_renderer_draw(r, p, rt);
+}
+
+int32_t gs_renderer_set_cutouts(gs_renderer* r, const gs_cutout* cutouts, uint32_t count) {
+    if (!r || (count && !cutouts)) return fail(GS_ERR_INVALID_ARGUMENT, "null argument");
+    if (count > GS_MAX_CUTOUTS) return fail(GS_ERR_INVALID_ARGUMENT, "more than GS_MAX_CUTOUTS cutouts");
+    static_assert(sizeof(gs_cutout) == 17 * 4, "gs_cutout is 17 dwords");
+    GS_TRY(bind_device(r->ctx));
+    if (count) {
+        if (!r->cutouts) {
+            GS_HIP(hipMalloc((void**)&r->cutouts, (size_t)GS_MAX_CUTOUTS * sizeof(gs_cutout)));
+            GS_HIP(hipHostMalloc((void**)&r->cutoutsHost, (size_t)GS_MAX_CUTOUTS * sizeof(gs_cutout), hipHostMallocDefault));
+            GS_HIP(hipEventCreateWithFlags(&r->cutoutsCopied, hipEventDisableTiming));
+            r->cutoutsHostCount = 0;
+        }
+        // the C# re-uploads the buffer every CalcViewData (UpdateCutoutsBuffer); here an unchanged set costs nothing.
+        // A changed set goes through a pinned shadow copy, so the caller's memory is only read during this call and the
+        // copy is stream-ordered after the calc_view launches that still read the previous set.
+        const size_t bytes = (size_t)count * sizeof(gs_cutout);
+        if (count != r->cutoutsHostCount || memcmp(r->cutoutsHost, cutouts, bytes) != 0) {
+            if (r->cutoutsCopyPending) GS_HIP(hipEventSynchronize(r->cutoutsCopied));      // the shadow is still being read
+            memcpy(r->cutoutsHost, cutouts, bytes);
+            r->cutoutsHostCount = count;
+            GS_HIP(hipMemcpyAsync(r->cutouts, r->cutoutsHost, bytes, hipMemcpyHostToDevice, r->ctx->stream));
+            GS_HIP(hipEventRecord(r->cutoutsCopied, r->ctx->stream));
+            r->cutoutsCopyPending = true;
+        }
+    }
+    r->cutoutCount = count;
+    return GS_OK;
+}
+
+int32_t gs_renderer_set_deleted_bits(gs_renderer* r, const uint32_t* words, size_t word_count) {
+    if (!r) return fail(GS_ERR_INVALID_ARGUMENT, "renderer is null");
+    GS_TRY(bind_device(r->ctx));
+    const size_t need = ((size_t)r->n + 31) / 32;
+    if (!words) {                                           // _SplatBitsValid = 0
+        if (r->deletedBits) { GS_HIP(hipStreamSynchronize(r->ctx->stream)); (void)hipFree(r->deletedBits); r->deletedBits = nullptr; }
+        return GS_OK;
+    }
+    if (word_count != need) return fail(GS_ERR_INVALID_ARGUMENT, "deleted bits: word_count must be ceil(splat_count / 32)");
+    if (!r->deletedBits) GS_HIP(hipMalloc((void**)&r->deletedBits, need * 4));
+    // an edit-time operation (EditDeleteSelected): stream-ordered copy, then block so `words` is only read during the call
+    GS_HIP(hipMemcpyAsync(r->deletedBits, words, need * 4, hipMemcpyHostToDevice, r->ctx->stream));
+    GS_HIP(hipStreamSynchronize(r->ctx->stream));
+    return GS_OK;
 }
 
 int32_t gs_renderer_set_blend_mode(gs_renderer* r, int32_t mode) {

@@ -125,6 +125,14 @@ struct gs_renderer {
     gs::SplatRec* recs = nullptr;           // N x 32 B, indexed by splat (written by calc_view)
     uint2* rects = nullptr;                 // N x 8 B: x = tx0 | ty0 << 16, y = tiles wide | tiles high << 16 (0 = culled)
     unsigned long long* visMask = nullptr;  // ceil(N/64) x 8 B: bit s = splat s reaches at least one tile (written by calc_view)
+    // edit state read by calc_view (m_GpuEditDeleted / m_GpuEditCutouts, GaussianSplatRenderer.cs:266,269)
+    uint32_t* deletedBits = nullptr;        // ceil(N/32) words, or null (_SplatBitsValid = 0)
+    uint32_t* cutouts = nullptr;            // GS_MAX_CUTOUTS x 17 dwords
+    uint32_t cutoutCount = 0;
+    uint8_t* cutoutsHost = nullptr;         // pinned shadow of the last uploaded set
+    uint32_t cutoutsHostCount = 0;
+    hipEvent_t cutoutsCopied = nullptr;
+    bool cutoutsCopyPending = false;
     float viewW = 0.f, viewH = 0.f, viewNear = 0.f, viewFar = 0.f;   // what the last calc_view was run with
     bool viewValid = false;
     uint32_t* pairKeys = nullptr;           // tile ids
@@ -170,8 +178,8 @@ int32_t enqueue_sort_passes(gs_context* ctx, SortState& st, SortControl* control
                             gs_renderer* profR = nullptr, int evFirst = -1);
 int32_t enqueue_set_indices(gs_context* ctx, uint32_t* order, uint32_t n);
 // view (gs_view.hip)
-int32_t enqueue_calc_view(gs_context* ctx, const gsm::AssetView& a, const gs_frame_params* p, gsm::ViewData* out, SplatRec* recs,
-                          uint2* rects, unsigned long long* visMask);
+int32_t enqueue_calc_view(gs_context* ctx, const gsm::AssetView& a, const gs_frame_params* p, const gsm::EditView& e, gsm::ViewData* out,
+                          SplatRec* recs, uint2* rects, unsigned long long* visMask);
 void flatten_params(const gs_frame_params* p, gsm::FrameConsts& c);
 // raster (gs_raster.hip)
 int32_t renderer_alloc_raster(gs_renderer* r);

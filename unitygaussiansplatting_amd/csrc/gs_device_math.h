@@ -46,6 +46,13 @@ struct FrameConsts {            // gs_frame_params flattened for kernel argument
     float nearClip, farClip;
 };
 
+// Edit state CSCalcViewData consults (SplatUtilities.compute:91-105): _SplatDeletedBits / _SplatBitsValid and _SplatCutouts
+struct EditView {
+    const uint32_t* deletedBits;    // ceil(n/32) words, or null (_SplatBitsValid = 0)
+    const uint32_t* cutouts;        // cutoutCount x 17 dwords: float4x4 (rows of 4) + typeAndFlags
+    uint32_t cutoutCount;
+};
+
 struct ViewData { float pos[4]; float axis1[2]; float axis2[2]; uint32_t color[2]; };   // 40 B SplatViewData
 
 // ---- bit casts / half ---------------------------------------------------------------------------
@@ -243,11 +250,31 @@ struct SHFromBlob {
     GS_HD V3 load(int k) const { return LoadSH(sp, fmt, k); }
 };
 
-// CSCalcViewData for one splat (SplatUtilities.compute:189-252), cutouts/deleted bits absent.
+// IsSplatCut (SplatUtilities.compute:164-187); pos is the object-space position
+GS_HD bool IsSplatCut(const EditView& e, float px, float py, float pz) {
+    bool finalCut = false;
+    for (uint32_t i = 0; i < e.cutoutCount; ++i) {
+        const uint32_t* c = e.cutouts + i * 17u;                   // wave-uniform address: scalar loads
+        const uint32_t tf = c[16];
+        const uint32_t type = tf & 0xFFu;
+        if (type == 0xFFu) continue;                               // invalid/null cutout, ignore
+        const bool invert = (tf & 0xFF00u) != 0;
+        float m[12];
+#pragma unroll
+        for (int k = 0; k < 12; ++k) m[k] = u2f(c[k]);
+        const float cx = mrow(m, 0, px, py, pz), cy = mrow(m, 1, px, py, pz), cz = mrow(m, 2, px, py, pz);
+        if (type == 0u) { if (dot3f(cx, cy, cz, cx, cy, cz) <= 1.0f) return invert; }
+        if (type == 1u) { if (fabsf(cx) <= 1.0f && fabsf(cy) <= 1.0f && fabsf(cz) <= 1.0f) return invert; }
+        finalCut = finalCut || !invert;
+    }
+    return finalCut;
+}
+
+// CSCalcViewData for one splat (SplatUtilities.compute:189-252).
 // SH coefficients are consumed in order sh1..sh15 by three fmaf chains (degree 1, 2, 3), so they are decoded
 // one at a time instead of being held in 45 registers.
 template <class SHSource>
-GS_HD ViewData CalcViewDataT(const AssetView& a, const FrameConsts& P, uint32_t idx, SHSource& shsrc) {
+GS_HD ViewData CalcViewDataT(const AssetView& a, const FrameConsts& P, const EditView& E, uint32_t idx, SHSource& shsrc) {
     ViewData view;
     view.pos[0] = view.pos[1] = view.pos[2] = view.pos[3] = 0.0f;
     view.axis1[0] = view.axis1[1] = view.axis2[0] = view.axis2[1] = 0.0f;
@@ -269,6 +296,9 @@ GS_HD ViewData CalcViewDataT(const AssetView& a, const FrameConsts& P, uint32_t 
     view.pos[1] = mrow(P.vp, 1, wx, wy, wz);
     view.pos[2] = mrow(P.vp, 2, wx, wy, wz);
     view.pos[3] = mrow(P.vp, 3, wx, wy, wz);
+    // deleted? (:204-214) / cutouts (:216-220): centerClipPos.w = 0, the rest of the clip position is kept
+    if (E.deletedBits && ((E.deletedBits[idx >> 5] >> (idx & 31u)) & 1u)) view.pos[3] = 0.0f;
+    if (E.cutoutCount && IsSplatCut(E, pos.x, pos.y, pos.z)) view.pos[3] = 0.0f;
     if (!(view.pos[3] > 0.0f)) return view;                       // behindCam
 
     // ---- rotation / scale
@@ -428,9 +458,9 @@ GS_HD ViewData CalcViewDataT(const AssetView& a, const FrameConsts& P, uint32_t 
     return view;
 }
 
-GS_HD ViewData CalcViewData(const AssetView& a, const FrameConsts& P, uint32_t idx) {
+GS_HD ViewData CalcViewData(const AssetView& a, const FrameConsts& P, const EditView& E, uint32_t idx) {
     SHFromBlob src;
-    return CalcViewDataT(a, P, idx, src);
+    return CalcViewDataT(a, P, E, idx, src);
 }
 
 // ---- compositor set-up: which splats are drawn, where, and which 16x16 tiles they can touch -----------

@@ -42,7 +42,7 @@ constexpr int cmax(int a, int b) { return a > b ? a : b; }
 // copies its 256 contiguous records (8-48 KB) with lane-contiguous 16-byte loads issued FIRST (they are in flight while
 // the positions are projected), parks them in LDS and decodes from there.
 template <int SHMODE>
-__global__ __launch_bounds__(256) void calc_view_kernel(gsm::AssetView a, gsm::FrameConsts P, gsm::ViewData* __restrict__ out,
+__global__ __launch_bounds__(256) void calc_view_kernel(gsm::AssetView a, gsm::FrameConsts P, gsm::EditView E, gsm::ViewData* __restrict__ out,
                                                         SplatRec* __restrict__ recs, uint2* __restrict__ rects,
                                                         unsigned long long* __restrict__ visMask) {
     constexpr int REC = sh_rec_dwords(SHMODE < 4 ? SHMODE : 3);       // dwords per record
@@ -99,10 +99,10 @@ __global__ __launch_bounds__(256) void calc_view_kernel(gsm::AssetView a, gsm::F
         if (SHMODE < 4) {
             SHFromLds<SHMODE < 4 ? SHMODE : 3> src;
             src.rec = s_dw + threadIdx.x * STRIDE;
-            v = gsm::CalcViewDataT(a, P, idx, src);
+            v = gsm::CalcViewDataT(a, P, E, idx, src);
         } else {
             gsm::SHFromBlob src;
-            v = gsm::CalcViewDataT(a, P, idx, src);
+            v = gsm::CalcViewDataT(a, P, E, idx, src);
         }
         const bool ok = gsm::PrepareSplat(v, P.screenW, P.screenH, P.nearClip, P.farClip, fp);
         if (ok && fp.tx0 <= fp.tx1) {
@@ -150,8 +150,8 @@ void flatten_params(const gs_frame_params* p, gsm::FrameConsts& c) {
     c.nearClip = p->near_clip; c.farClip = p->far_clip;
 }
 
-int32_t enqueue_calc_view(gs_context* ctx, const gsm::AssetView& a, const gs_frame_params* p, gsm::ViewData* out, SplatRec* recs,
-                          uint2* rects, unsigned long long* visMask) {
+int32_t enqueue_calc_view(gs_context* ctx, const gsm::AssetView& a, const gs_frame_params* p, const gsm::EditView& e, gsm::ViewData* out,
+                          SplatRec* recs, uint2* rects, unsigned long long* visMask) {
     gsm::FrameConsts c;
     flatten_params(p, c);
     const uint32_t grid = (a.n + 255u) / 256u;
@@ -159,11 +159,11 @@ int32_t enqueue_calc_view(gs_context* ctx, const gsm::AssetView& a, const gs_fra
     // Cluster* tables, an unaligned borrowed blob, or SH switched off read straight from the blob
     int mode = (a.shFmt <= 3 && (((uintptr_t)a.sh) & 15u) == 0 && p->sh_order >= 1) ? (int)a.shFmt : 4;
     switch (mode) {
-        case 0: hipLaunchKernelGGL(calc_view_kernel<0>, dim3(grid), dim3(256), 0, ctx->stream, a, c, out, recs, rects, visMask); break;
-        case 1: hipLaunchKernelGGL(calc_view_kernel<1>, dim3(grid), dim3(256), 0, ctx->stream, a, c, out, recs, rects, visMask); break;
-        case 2: hipLaunchKernelGGL(calc_view_kernel<2>, dim3(grid), dim3(256), 0, ctx->stream, a, c, out, recs, rects, visMask); break;
-        case 3: hipLaunchKernelGGL(calc_view_kernel<3>, dim3(grid), dim3(256), 0, ctx->stream, a, c, out, recs, rects, visMask); break;
-        default: hipLaunchKernelGGL(calc_view_kernel<4>, dim3(grid), dim3(256), 0, ctx->stream, a, c, out, recs, rects, visMask); break;
+        case 0: hipLaunchKernelGGL(calc_view_kernel<0>, dim3(grid), dim3(256), 0, ctx->stream, a, c, e, out, recs, rects, visMask); break;
+        case 1: hipLaunchKernelGGL(calc_view_kernel<1>, dim3(grid), dim3(256), 0, ctx->stream, a, c, e, out, recs, rects, visMask); break;
+        case 2: hipLaunchKernelGGL(calc_view_kernel<2>, dim3(grid), dim3(256), 0, ctx->stream, a, c, e, out, recs, rects, visMask); break;
+        case 3: hipLaunchKernelGGL(calc_view_kernel<3>, dim3(grid), dim3(256), 0, ctx->stream, a, c, e, out, recs, rects, visMask); break;
+        default: hipLaunchKernelGGL(calc_view_kernel<4>, dim3(grid), dim3(256), 0, ctx->stream, a, c, e, out, recs, rects, visMask); break;
     }
     GS_HIP(hipGetLastError());
     return GS_OK;

@@ -70,6 +70,11 @@ namespace GaussianSplatting.Runtime
         [DllImport(Lib)] public static extern int gs_renderer_calc_view(IntPtr renderer, ref FrameParams p);
         [DllImport(Lib)] public static extern int gs_renderer_draw(IntPtr renderer, ref FrameParams p, IntPtr target);
         [DllImport(Lib)] public static extern int gs_renderer_render(IntPtr renderer, float[] matrixSort16, ref FrameParams p, IntPtr target, int doSort);
+        // GaussianCutout.ShaderData (GaussianCutout.cs:19-23), matrix transposed to this ABI's row-major convention
+        [StructLayout(LayoutKind.Sequential)]
+        public unsafe struct Cutout { public fixed float matrix[16]; public uint typeAndFlags; }
+        [DllImport(Lib)] public static extern int gs_renderer_set_cutouts(IntPtr renderer, Cutout[] cutouts, uint count);
+        [DllImport(Lib)] public static extern int gs_renderer_set_deleted_bits(IntPtr renderer, uint[] words, UIntPtr wordCount);
         [DllImport(Lib)] public static extern int gs_renderer_set_blend_mode(IntPtr renderer, int mode);
         [DllImport(Lib)] public static extern int gs_renderer_set_profiling(IntPtr renderer, int frames);
         [DllImport(Lib)] public static extern int gs_renderer_reserve_pairs(IntPtr renderer, ulong pairCapacity);

@@ -20,6 +20,7 @@ from ._abi import (GS_ERR_PAIR_OVERFLOW, VIEW_DTYPE, gs_frame_params, gs_frame_s
 from ._lib import GsError, check
 from .asset import GaussianSplatAsset, kCurrentVersion
 from .camera import Camera, Transform, frame_params, sort_matrix
+from .cutout import GaussianCutout, shader_data_array
 
 
 def _fptr(a: np.ndarray):
@@ -167,6 +168,7 @@ class GaussianSplatRenderer:
         self.m_SHOrder = 3
         self.m_SHOnly = False
         self.m_SortNthFrame = 1
+        self.m_Cutouts: Optional[List[Optional[GaussianCutout]]] = None      # :244
         self.m_FrameCounter = 0
         self.blendMode = 0            # 0 exact (fp16 ROP rounding), 1 fast (fp32 accumulate)
         self._asset_h = C.c_void_p()
@@ -259,7 +261,21 @@ class GaussianSplatRenderer:
         m = np.ascontiguousarray(sort_matrix(cam, matrix), np.float32).reshape(16)
         check(_lib.lib().gs_renderer_sort(self._r_h, _fptr(m)), "gs_renderer_sort")
 
+    def UpdateCutoutsBuffer(self) -> None:          # :742-764 (+ _SplatCutoutsCount, :508)
+        arr, n = shader_data_array(self.m_Cutouts, self.transform.localToWorldMatrix)
+        check(_lib.lib().gs_renderer_set_cutouts(self._r_h, arr, n), "gs_renderer_set_cutouts")
+
+    def SetDeletedBits(self, bits: Optional[np.ndarray]) -> None:
+        """The m_GpuEditDeleted buffer (:269,779): one bit per splat, ceil(N/32) uint32 words; None = no edit buffers
+        (_SplatBitsValid = 0).  The editing tools that fill it in the reference (EditDeleteSelected ...) are out of scope."""
+        if bits is None:
+            check(_lib.lib().gs_renderer_set_deleted_bits(self._r_h, None, 0), "gs_renderer_set_deleted_bits")
+            return
+        w = np.ascontiguousarray(bits, np.uint32)
+        check(_lib.lib().gs_renderer_set_deleted_bits(self._r_h, w.ctypes.data, len(w)), "gs_renderer_set_deleted_bits")
+
     def CalcViewData(self, cam: Camera) -> None:    # :579-610
+        self.UpdateCutoutsBuffer()                  # SetAssetDataOnCS, :507
         p = self.FrameParams(cam)
         check(_lib.lib().gs_renderer_calc_view(self._r_h, C.byref(p)), "gs_renderer_calc_view")
 
