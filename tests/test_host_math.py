@@ -77,8 +77,86 @@ def test_footprints_match_oracle_prepare(hm):
     orc.draw(P)
     out = np.zeros((a.splatCount, 5), np.int32)
     cxy = np.zeros((a.splatCount, 2), np.float32)
-    hm.hm_prepare(v.ctypes.data_as(C.c_void_p), C.c_uint32(a.splatCount), C.byref(P), out.ctypes.data_as(C.c_void_p), cxy.ctypes.data_as(C.c_void_p))
+    tiles = np.zeros(a.splatCount, np.uint32)
+    hm.hm_prepare_ex(v.ctypes.data_as(C.c_void_p), C.c_uint32(a.splatCount), C.byref(P), out.ctypes.data_as(C.c_void_p), cxy.ctypes.data_as(C.c_void_p),
+                     tiles.ctypes.data_as(C.c_void_p))
     w = np.maximum(out[:, 1] - out[:, 0] + 1, 0).astype(np.int64)
     h = np.maximum(out[:, 3] - out[:, 2] + 1, 0).astype(np.int64)
-    assert int((w * h).sum()) == orc.tile_pairs
-    assert int(((w * h) > 0).sum()) == orc.visible
+    assert int(tiles.sum()) == orc.tile_pairs
+    assert int((tiles > 0).sum()) == orc.visible
+    assert (tiles <= w * h).all() and 0.6 < tiles.sum() / (w * h).sum() < 0.98          # the per-tile mask does drop tiles
+
+
+def _live_pixels(v, P, i):
+    """Pixel-exact liveness of splat i (the fragment test of the blend kernel / oracle), fp32, over its quad bounding box."""
+    f = np.float32
+    W, H = int(P.screen_w), int(P.screen_h)
+    w = v["pos"][i, 3]
+    a1, a2 = v["axis1"][i], v["axis2"][i]
+    al = np.uint16(v["color"][i, 1] & 0xffff).view(np.float16).astype(f)
+    cx = f(f(f(0.5) * f(v["pos"][i, 0] * f(f(1) / w))) * f(W) + f(0.5 * W))
+    cy = f(f(f(-0.5) * f(v["pos"][i, 1] * f(f(1) / w))) * f(H) + f(0.5 * H))
+    u1 = a1 * f(f(1) / (a1 * a1).sum(dtype=f)); u2 = a2 * f(f(1) / (a2 * a2).sum(dtype=f))
+    ex = f(2) * (abs(a1[0]) + abs(a2[0])) + f(1); ey = f(2) * (abs(a1[1]) + abs(a2[1])) + f(1)
+    x0, x1 = max(int(np.floor(cx - ex)), 0), min(int(np.ceil(cx + ex)), W - 1)
+    y0, y1 = max(int(np.floor(cy - ey)), 0), min(int(np.ceil(cy + ey)), H - 1)
+    if x0 > x1 or y0 > y1:
+        return None
+    xs = (np.arange(x0, x1 + 1, dtype=f) + f(0.5))[None, :] - cx
+    ys = (np.arange(y0, y1 + 1, dtype=f) + f(0.5))[:, None] - cy
+    q1 = xs * u1[0] + ys * u1[1]; q2 = xs * u2[0] + ys * u2[1]
+    alpha = np.clip(np.exp(-(q1 * q1 + q2 * q2), dtype=f) * al, 0, 1)
+    live = (np.abs(q1) <= 2) & (np.abs(q2) <= 2) & (alpha >= f(1 / 255))
+    return x0, y0, live, (cx, cy, u1, u2, al)
+
+
+def test_block_culling_never_drops_a_live_fragment(hm):
+    """BlockMayTouch (tile mask of the binning, quadrant test of the blend kernel) is conservative w.r.t. the pixel-exact
+    fragment test, and the tile masks PrepareSplat stores contain every tile that owns a live pixel."""
+    hm.hm_block_may_touch.argtypes = [C.c_float] * 10
+    hm.hm_log_det.restype = C.c_float
+    hm.hm_log_det.argtypes = [C.c_float]
+    for x in [1.0, 1.0001, 1.5, 2.0, 2.7182817, 10.0, 255.0, 16575000.0, 0.999]:
+        assert abs(hm.hm_log_det(x) - np.log(np.float64(np.float32(x)))) < 2e-6
+    a = small_asset(20000, 7, "Medium")
+    cam = default_camera(W=333, H=217, az=12.0)
+    tr = camera.Transform()
+    orc = O.Oracle(a)
+    P = camera.frame_params(cam, tr)
+    v = orc.calc_view(P)
+    n = a.splatCount
+    out = np.zeros((n, 5), np.int32); cxy = np.zeros((n, 2), np.float32); tiles = np.zeros(n, np.uint32)
+    mask = np.zeros(n, np.uint32); masked = np.zeros(n, np.uint8)
+    vp = v.ctypes.data_as(C.c_void_p)
+    hm.hm_prepare_ex(vp, C.c_uint32(n), C.byref(P), out.ctypes.data_as(C.c_void_p), cxy.ctypes.data_as(C.c_void_p), tiles.ctypes.data_as(C.c_void_p))
+    hm.hm_footprint_masks(vp, C.c_uint32(n), C.byref(P), mask.ctypes.data_as(C.c_void_p), masked.ctypes.data_as(C.c_void_p))
+    checked_tiles = dropped_tiles = checked_quads = dropped_quads = 0
+    for i in np.flatnonzero(out[:, 4] == 1)[:4000]:
+        lp = _live_pixels(v, P, i)
+        if lp is None:
+            continue
+        x0, y0, live, (cx, cy, u1, u2, al) = lp
+        ys, xs = np.nonzero(live)
+        tx0, tx1, ty0, ty1 = out[i, :4]
+        if len(xs) == 0:
+            continue
+        assert tx0 <= tx1, "a splat with live pixels has an empty footprint"
+        tw = tx1 - tx0 + 1
+        live_tiles = set(zip(((xs + x0) >> 4).tolist(), ((ys + y0) >> 4).tolist()))
+        for (tx, ty) in live_tiles:
+            assert tx0 <= tx <= tx1 and ty0 <= ty <= ty1
+            if masked[i]:
+                assert (mask[i] >> ((ty - ty0) * tw + (tx - tx0))) & 1, f"splat {i}: live tile ({tx},{ty}) missing from the mask"
+        checked_tiles += (tx1 - tx0 + 1) * (ty1 - ty0 + 1)
+        dropped_tiles += (tx1 - tx0 + 1) * (ty1 - ty0 + 1) - int(tiles[i])
+        r2 = np.float32(np.float32(hm.hm_log_det(np.float32(255.0) * al)) * np.float32(1.0001) + np.float32(1e-3))
+        live_quads = set(zip(((xs + x0) >> 3).tolist(), ((ys + y0) >> 3).tolist()))
+        for qy in range((y0 >> 3), ((y0 + live.shape[0] - 1) >> 3) + 1):
+            for qx in range((x0 >> 3), ((x0 + live.shape[1] - 1) >> 3) + 1):
+                hit = hm.hm_block_may_touch(qx * 8 + 4.0, qy * 8 + 4.0, 3.5, cx, cy, u1[0], u1[1], u2[0], u2[1], r2)
+                checked_quads += 1
+                dropped_quads += 0 if hit else 1
+                if (qx, qy) in live_quads:
+                    assert hit, f"splat {i}: quadrant ({qx},{qy}) has a live pixel but was culled"
+    assert checked_tiles > 3000 and dropped_tiles > 0.05 * checked_tiles
+    assert checked_quads > 10000 and dropped_quads > 0.1 * checked_quads

@@ -2,6 +2,7 @@
 // Mirrors what GaussianSplatRenderer.cs / GpuSorting.cs do on Unity's main thread (buffer creation :373-445,
 // dispatch order :108-211,579-639, disposal :527-577); every kernel lives in gs_sort/gs_view/gs_raster.hip.
 #include <stdarg.h>
+#include <stdlib.h>
 
 #include <new>
 
@@ -26,10 +27,16 @@ int32_t fail_hip(hipError_t e, const char* what, const char* file, int line) {
     return e == hipErrorOutOfMemory ? GS_ERR_OUT_OF_MEMORY : GS_ERR_HIP;
 }
 
-void prof_record(gs_renderer* r, int k) {
+void prof_record(gs_renderer* r, int k, hipStream_t st) {
     if (!r->profiling || !r->ev) return;
     const int idx = r->profCur * kEvPerFrame + k;
-    if (hipEventRecord(r->ev[idx], r->ctx->stream) == hipSuccess) r->evValid[idx] = 1;
+    if (hipEventRecord(r->ev[idx], st ? st : r->ctx->stream) == hipSuccess) r->evValid[idx] = 1;
+}
+int32_t join_sort(gs_renderer* r) {
+    if (!r->sortPending) return GS_OK;
+    GS_HIP(hipStreamWaitEvent(r->ctx->stream, r->evSortDone, 0));
+    r->sortPending = false;
+    return GS_OK;
 }
 void prof_end_frame(gs_renderer* r) {
     if (!r->profiling || !r->ev) return;
@@ -85,6 +92,9 @@ int32_t gs_context_create(int32_t device, void* hip_stream, gs_context** out) {
         if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return fail(GS_ERR_HIP, "hipStreamCreate"); }
         ctx->ownStream = true;
     }
+    if (hipStreamCreateWithFlags(&ctx->aux, hipStreamNonBlocking) != hipSuccess) { gs_context_destroy(ctx); return fail(GS_ERR_HIP, "hipStreamCreate (aux)"); }
+    const char* ov = getenv("GSPLAT_OVERLAP");                  // A/B switch for measurements; default on
+    ctx->overlap = !(ov && ov[0] == '0');
     *out = ctx;
     return GS_OK;
 }
@@ -92,8 +102,9 @@ int32_t gs_context_create(int32_t device, void* hip_stream, gs_context** out) {
 int32_t gs_context_destroy(gs_context* ctx) {
     if (!ctx) return GS_OK;
     (void)hipSetDevice(ctx->device);
-    (void)hipStreamSynchronize(ctx->stream);
-    if (ctx->ownStream) (void)hipStreamDestroy(ctx->stream);
+    if (ctx->aux) { (void)hipStreamSynchronize(ctx->aux); (void)hipStreamDestroy(ctx->aux); }
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->ownStream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return GS_OK;
 }
@@ -101,7 +112,16 @@ int32_t gs_context_destroy(gs_context* ctx) {
 int32_t gs_context_synchronize(gs_context* ctx) {
     if (!ctx) return fail(GS_ERR_INVALID_ARGUMENT, "ctx is null");
     GS_TRY(bind_device(ctx));
+    GS_HIP(hipStreamSynchronize(ctx->aux));
     GS_HIP(hipStreamSynchronize(ctx->stream));
+    return GS_OK;
+}
+
+int32_t gs_context_set_overlap(gs_context* ctx, int32_t enabled) {
+    if (!ctx) return fail(GS_ERR_INVALID_ARGUMENT, "ctx is null");
+    GS_TRY(bind_device(ctx));
+    GS_HIP(hipStreamSynchronize(ctx->aux));
+    ctx->overlap = enabled != 0;
     return GS_OK;
 }
 
@@ -204,6 +224,8 @@ int32_t gs_renderer_create(gs_context* ctx, gs_asset* asset, gs_renderer** out) 
     chk(hipMalloc((void**)&r->distances, (size_t)(r->n + 16) * 4), "alloc distances");
     chk(hipMalloc((void**)&r->order, (size_t)(r->n + 16) * 4), "alloc order");
     chk(hipMalloc((void**)&r->depthControl, sizeof(SortControl)), "alloc sort control");
+    chk(hipEventCreateWithFlags(&r->evFork, hipEventDisableTiming), "create event");
+    chk(hipEventCreateWithFlags(&r->evSortDone, hipEventDisableTiming), "create event");
     if (rc == GS_OK) rc = sort_state_create(ctx, r->depthSort, r->n);
     if (rc == GS_OK) rc = renderer_alloc_raster(r);
     if (rc == GS_OK) rc = enqueue_set_indices(ctx, r->order, r->n);
@@ -216,7 +238,10 @@ int32_t gs_renderer_create(gs_context* ctx, gs_asset* asset, gs_renderer** out) 
 int32_t gs_renderer_destroy(gs_renderer* r) {
     if (!r) return GS_OK;
     (void)hipSetDevice(r->ctx->device);
+    (void)hipStreamSynchronize(r->ctx->aux);
     (void)hipStreamSynchronize(r->ctx->stream);
+    if (r->evFork) (void)hipEventDestroy(r->evFork);
+    if (r->evSortDone) (void)hipEventDestroy(r->evSortDone);
     if (r->view) (void)hipFree(r->view);
     if (r->distances) (void)hipFree(r->distances);
     if (r->order) (void)hipFree(r->order);
@@ -235,6 +260,7 @@ int32_t gs_renderer_destroy(gs_renderer* r) {
 int32_t gs_renderer_reset_order(gs_renderer* r) {
     if (!r) return fail(GS_ERR_INVALID_ARGUMENT, "renderer is null");
     GS_TRY(bind_device(r->ctx));
+    GS_TRY(join_sort(r));
     return enqueue_set_indices(r->ctx, r->order, r->n);
 }
 
@@ -242,12 +268,26 @@ static void rec_ev(gs_renderer* r, int k) { gs::prof_record(r, k); }
 
 int32_t gs_renderer_sort(gs_renderer* r, const float m[16]) {
     if (!r || !m) return fail(GS_ERR_INVALID_ARGUMENT, "null argument");
-    GS_TRY(bind_device(r->ctx));
-    rec_ev(r, 0);
-    GS_TRY(enqueue_calc_distances(r->ctx, r->asset->view, r->order, m, r->distances, r->depthControl, r->n));
-    rec_ev(r, 1);
-    GS_TRY(enqueue_sort_passes(r->ctx, r->depthSort, r->depthControl, r->distances, r->order, r->n, nullptr, 4, 255u, r, 10));
-    rec_ev(r, 2);
+    gs_context* ctx = r->ctx;
+    GS_TRY(bind_device(ctx));
+    // SortPoints and CalcViewData are independent (the C# merely records them one after the other, :120-126): with
+    // overlap on, the sort is forked onto the context's second queue here and joined by the first consumer of order[]
+    // (gs_renderer_draw, or any readback), so it runs concurrently with gs_renderer_calc_view.
+    hipStream_t st = ctx->stream;
+    if (ctx->overlap) {
+        GS_HIP(hipEventRecord(r->evFork, ctx->stream));          // after everything that still reads order[] / distances[]
+        GS_HIP(hipStreamWaitEvent(ctx->aux, r->evFork, 0));
+        st = ctx->aux;
+    } else GS_TRY(join_sort(r));
+    gs::prof_record(r, 0, st);
+    GS_TRY(enqueue_calc_distances(ctx, st, r->asset->view, r->order, m, r->distances, r->depthControl, r->n));
+    gs::prof_record(r, 1, st);
+    GS_TRY(enqueue_sort_passes(ctx, st, r->depthSort, r->depthControl, r->distances, r->order, r->n, nullptr, 4, 255u, r, 10));
+    gs::prof_record(r, 2, st);
+    if (ctx->overlap) {
+        GS_HIP(hipEventRecord(r->evSortDone, ctx->aux));
+        r->sortPending = true;
+    }
     return GS_OK;
 }
 
@@ -387,15 +427,18 @@ static int32_t download(gs_context* ctx, void* dst, const void* src, size_t byte
 
 int32_t gs_renderer_download_order(gs_renderer* r, uint32_t* out, size_t count) {
     if (!r || !out || count > r->n) return fail(GS_ERR_INVALID_ARGUMENT, "bad argument");
+    GS_TRY(join_sort(r));
     return download(r->ctx, out, r->order, count * 4);
 }
 int32_t gs_renderer_download_distances(gs_renderer* r, uint32_t* out, size_t count) {
     if (!r || !out || count > r->n) return fail(GS_ERR_INVALID_ARGUMENT, "bad argument");
+    GS_TRY(join_sort(r));
     return download(r->ctx, out, r->distances, count * 4);
 }
 int32_t gs_renderer_upload_order(gs_renderer* r, const uint32_t* in, size_t count) {
     if (!r || !in || count != r->n) return fail(GS_ERR_INVALID_ARGUMENT, "bad argument");
     GS_TRY(bind_device(r->ctx));
+    GS_TRY(join_sort(r));
     GS_HIP(hipMemcpyAsync(r->order, in, count * 4, hipMemcpyHostToDevice, r->ctx->stream));
     GS_HIP(hipStreamSynchronize(r->ctx->stream));
     return GS_OK;
@@ -408,6 +451,7 @@ int32_t gs_renderer_download_view(gs_renderer* r, void* out, size_t bytes) {
 int32_t gs_renderer_frame_stats(gs_renderer* r, gs_frame_stats* out) {
     if (!r || !out) return fail(GS_ERR_INVALID_ARGUMENT, "null argument");
     GS_TRY(bind_device(r->ctx));
+    GS_TRY(join_sort(r));
     GS_HIP(hipStreamSynchronize(r->ctx->stream));
     uint32_t depthErr = 0;
     GS_HIP(hipMemcpy(&depthErr, &r->depthControl->error, 4, hipMemcpyDeviceToHost));
@@ -435,6 +479,7 @@ int32_t gs_renderer_stage_times(gs_renderer* r, gs_stage_times* out) {
     memset(out, 0, sizeof(*out));
     if (!r->ev) return fail(GS_ERR_INVALID_ARGUMENT, "profiling was never enabled");
     GS_TRY(bind_device(r->ctx));
+    GS_HIP(hipStreamSynchronize(r->ctx->aux));
     GS_HIP(hipStreamSynchronize(r->ctx->stream));
     // average every stage over the completed slots of the ring (the slot in progress is included if it holds events)
     const int slots = r->profCompleted < r->profCapacity ? r->profCompleted + 1 : r->profCapacity;
@@ -556,8 +601,8 @@ int32_t gs_sorter_dispatch(gs_sorter* s, void* keys_dev, void* values_dev, uint3
     const int passes = (int)((key_bits + 7) / 8);
     const uint32_t lastBits = key_bits - 8u * (uint32_t)(passes - 1);
     const uint32_t lastMask = (1u << lastBits) - 1u;
-    GS_TRY(enqueue_histogram(s->ctx, (const uint32_t*)keys_dev, count, nullptr, passes, lastMask, s->control));
-    return enqueue_sort_passes(s->ctx, s->st, s->control, (uint32_t*)keys_dev, (uint32_t*)values_dev, count, nullptr, passes, lastMask);
+    GS_TRY(enqueue_histogram(s->ctx, s->ctx->stream, (const uint32_t*)keys_dev, count, nullptr, passes, lastMask, s->control));
+    return enqueue_sort_passes(s->ctx, s->ctx->stream, s->st, s->control, (uint32_t*)keys_dev, (uint32_t*)values_dev, count, nullptr, passes, lastMask);
 }
 
 int32_t gs_sorter_sort_host(gs_sorter* s, uint32_t* keys, uint32_t* values, uint32_t count, uint32_t key_bits) {

@@ -83,6 +83,10 @@ struct gs_context {
     int device = 0;
     hipStream_t stream = nullptr;
     bool ownStream = false;
+    // second in-order queue: the depth sort of a frame (SortPoints) has no data dependence on CalcViewData, so it runs
+    // here, forked from / joined to `stream` with events, and the two latency-bound kernels share the GPU
+    hipStream_t aux = nullptr;
+    bool overlap = true;
     int cuCount = 0;
     hipDeviceProp_t props;
 };
@@ -123,7 +127,7 @@ struct gs_renderer {
     gs::SortControl* depthControl = nullptr;
     // compositor buffers
     gs::SplatRec* recs = nullptr;           // N x 32 B, indexed by splat (written by calc_view)
-    uint2* rects = nullptr;                 // N x 8 B: x = tx0 | ty0 << 16, y = tiles wide | tiles high << 16 (0 = culled)
+    uint2* rects = nullptr;                 // N x 8 B: x = tx0 | ty0 << 16, y = tiles wide / high (+ tile mask), see rect_count() (0 = culled)
     unsigned long long* visMask = nullptr;  // ceil(N/64) x 8 B: bit s = splat s reaches at least one tile (written by calc_view)
     // edit state read by calc_view (m_GpuEditDeleted / m_GpuEditCutouts, GaussianSplatRenderer.cs:266,269)
     uint32_t* deletedBits = nullptr;        // ceil(N/32) words, or null (_SplatBitsValid = 0)
@@ -154,26 +158,29 @@ struct gs_renderer {
     // host copy of last frame's control (pinned), read lazily
     gs::BinControl* hostBin = nullptr;
     gs::SortControl* hostSortErr = nullptr;
+    hipEvent_t evFork = nullptr, evSortDone = nullptr;   // main -> aux fork, aux -> main join (timing disabled)
+    bool sortPending = false;               // a sort on ctx->aux has not been joined into ctx->stream yet
     uint32_t lastTilesX = 0, lastTilesY = 0, lastPairPasses = 0;
     bool frameInFlight = false;
     float resolveMs = 0.f;
 };
 
 namespace gs {
-void prof_record(gs_renderer* r, int k);   // gs_api.hip: record event k of the current profiling slot
+void prof_record(gs_renderer* r, int k, hipStream_t st = nullptr);   // gs_api.hip: record event k of the current profiling slot (on st, default ctx->stream)
+int32_t join_sort(gs_renderer* r);          // make ctx->stream wait for a sort still running on ctx->aux
 void prof_end_frame(gs_renderer* r);
 // sort entry points (gs_sort.hip)
 int32_t sort_state_create(gs_context* ctx, SortState& st, uint32_t maxCount);
 void sort_state_destroy(SortState& st);
 // CSCalcDistances + fused 4x256 histogram
-int32_t enqueue_calc_distances(gs_context* ctx, const gsm::AssetView& a, const uint32_t* order, const float* matSort,
+int32_t enqueue_calc_distances(gs_context* ctx, hipStream_t st, const gsm::AssetView& a, const uint32_t* order, const float* matSort,
                                uint32_t* keys, SortControl* control, uint32_t n);
-int32_t enqueue_histogram(gs_context* ctx, const uint32_t* keys, uint32_t n, const uint32_t* nPtr, int passes, uint32_t lastMask,
+int32_t enqueue_histogram(gs_context* ctx, hipStream_t st, const uint32_t* keys, uint32_t n, const uint32_t* nPtr, int passes, uint32_t lastMask,
                           SortControl* control);
 // scan + `passes` Onesweep passes.  Histograms must already be in control->hist.  Result ends in (keys, vals) when
 // passes is even, otherwise it is copied back.
 // profR/evFirst: optional hipEvent slots (evFirst = just before the first Onesweep launch, evFirst + 1 = after the last)
-int32_t enqueue_sort_passes(gs_context* ctx, SortState& st, SortControl* control, uint32_t* keys, uint32_t* vals,
+int32_t enqueue_sort_passes(gs_context* ctx, hipStream_t stream, SortState& st, SortControl* control, uint32_t* keys, uint32_t* vals,
                             uint32_t nUpper, const uint32_t* nPtr, int passes, uint32_t lastMask = 255u,
                             gs_renderer* profR = nullptr, int evFirst = -1);
 int32_t enqueue_set_indices(gs_context* ctx, uint32_t* order, uint32_t n);

@@ -475,13 +475,55 @@ GS_HD void PixRange(float c, float e, float size, int& lo, int& hi) {
     lo = (int)flo; hi = (int)fhi;
 }
 
+// ln(x) for a positive normal x from fp32 operations only (bit manipulation, one division, explicit fmaf): the same bits
+// on the host and on the device, unlike logf().  |error| < 1e-6 (atanh series of the mantissa reduced to [0.707, 1.414)).
+GS_HD float LogDet(float x) {
+    const uint32_t u = f2u(x);
+    float e = (float)((int)(u >> 23) - 127);
+    float m = u2f((u & 0x7fffffu) | 0x3f800000u);
+    if (m > 1.41421356f) { m *= 0.5f; e += 1.0f; }
+    const float t = (m - 1.0f) / (m + 1.0f);
+    const float t2 = t * t;
+    const float p = fmaf(t2, fmaf(t2, fmaf(t2, 1.0f / 7.0f, 0.2f), 1.0f / 3.0f), 1.0f);
+    return fmaf(e, 0.69314718f, (2.0f * t) * p);
+}
+
+// Can the splat put a live fragment on a pixel centre of the square block of pixel centres [bc - half, bc + half]^2 ?
+// A fragment is live iff |q1| <= 2, |q2| <= 2 and exp(-(q1^2+q2^2)) a >= 1/255, q_k = u_k . (p - c)  (frag, :79-106).
+// q_k is linear in p, so min |q_k| over the block is closed form (separating-axis test along u_1 and u_2); the block is
+// rejected when even those minima violate one of the three conditions.  Conservative: never rejects a live fragment
+// (r2 carries the slack for the fp32 rounding of this test and of the kernel's exp).
+GS_HD bool BlockMayTouch(float bcx, float bcy, float half, float cx, float cy, float u1x, float u1y, float u2x, float u2y, float r2) {
+    const float dx = bcx - cx, dy = bcy - cy;
+    const float d1 = fabsf(fmaf(dy, u1y, dx * u1x)) - half * (fabsf(u1x) + fabsf(u1y));
+    const float d2 = fabsf(fmaf(dy, u2y, dx * u2x)) - half * (fabsf(u2x) + fabsf(u2y));
+    const float m1 = fmaxf(d1, 0.0f), m2 = fmaxf(d2, 0.0f);
+    return (m1 <= 2.001f) && (m2 <= 2.001f) && (fmaf(m2, m2, m1 * m1) <= r2);
+}
+
+constexpr int kMaskTiles = 16;  // footprints of at most this many tiles carry a per-tile bit mask
+
 struct SplatFootprint {
     float cx, cy;               // centre in pixels, y down
     int tx0, tx1, ty0, ty1;     // inclusive tile rect (tx0 > tx1: nothing to draw)
+    uint32_t mask;              // rects of 2..kMaskTiles tiles: bit (ty - ty0) * w + (tx - tx0) = the tile can receive a fragment
+    bool masked;
 };
 
+GS_HD uint32_t FootprintTileCount(const SplatFootprint& fp) {
+    if (fp.tx0 > fp.tx1) return 0u;
+    if (fp.masked) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        return (uint32_t)__popc(fp.mask);
+#else
+        return (uint32_t)__builtin_popcount(fp.mask);
+#endif
+    }
+    return (uint32_t)(fp.tx1 - fp.tx0 + 1) * (uint32_t)(fp.ty1 - fp.ty0 + 1);
+}
+
 GS_HD bool PrepareSplat(const ViewData& v, float W, float H, float nearClip, float farClip, SplatFootprint& fp) {
-    fp.tx0 = 1; fp.tx1 = 0; fp.ty0 = 1; fp.ty1 = 0; fp.cx = 0.0f; fp.cy = 0.0f;
+    fp.tx0 = 1; fp.tx1 = 0; fp.ty0 = 1; fp.ty1 = 0; fp.cx = 0.0f; fp.cy = 0.0f; fp.mask = 0u; fp.masked = false;
     const float w = v.pos[3];
     if (!(w > 0.0f)) return false;
     if (!(w >= nearClip && w <= farClip)) return false;
@@ -501,13 +543,26 @@ GS_HD bool PrepareSplat(const ViewData& v, float W, float H, float nearClip, flo
     PixRange(fp.cx, exr + slack, W, x0, x1);
     PixRange(fp.cy, eyr + slack, H, y0, y1);
     if (x0 > x1 || y0 > y1) return false;
-    const float r2 = fmaf(logf(255.0f * a), 1.0001f, 1.0e-4f);
+    const float r2 = fmaf(LogDet(255.0f * a), 1.0001f, 1.0e-3f);
     const float rr = sqrtf(fmaxf(r2, 0.0f));
     const float exe = rr * sqrtf(dot2f(a1x, a2x, a1x, a2x)), eye = rr * sqrtf(dot2f(a1y, a2y, a1y, a2y));
     PixRange(fp.cx, fminf(exr, exe) + slack, W, x0, x1);
     PixRange(fp.cy, fminf(eyr, eye) + slack, H, y0, y1);
     if (x0 > x1 || y0 > y1) return true;         // drawn by the reference, but every fragment is below 1/255
     fp.tx0 = x0 >> 4; fp.tx1 = x1 >> 4; fp.ty0 = y0 >> 4; fp.ty1 = y1 >> 4;
+    // small footprints (the bulk): drop the tiles of the rectangle that the oriented footprint cannot reach
+    const int tw = fp.tx1 - fp.tx0 + 1, th = fp.ty1 - fp.ty0 + 1;
+    if (tw * th >= 2 && tw * th <= kMaskTiles) {
+        const float u1x = a1x * inv1, u1y = a1y * inv1, u2x = a2x * inv2, u2y = a2y * inv2;
+        uint32_t m = 0u;
+        for (int ty = 0; ty < th; ++ty)
+            for (int tx = 0; tx < tw; ++tx) {
+                const float bcx = (float)((fp.tx0 + tx) * 16 + 8), bcy = (float)((fp.ty0 + ty) * 16 + 8);
+                if (BlockMayTouch(bcx, bcy, 7.5f, fp.cx, fp.cy, u1x, u1y, u2x, u2y, r2)) m |= 1u << (ty * tw + tx);
+            }
+        fp.mask = m; fp.masked = true;
+        if (m == 0u) { fp.tx0 = 1; fp.tx1 = 0; fp.ty0 = 1; fp.ty1 = 0; fp.masked = false; }
+    }
     return true;
 }
 

@@ -61,6 +61,22 @@ __device__ __forceinline__ void hist_add_aggregated(uint32_t* h, uint32_t d, boo
     if (active) atomicAdd(&h[d], 1u);                      // many distinct values left: plain per-lane adds
 }
 
+// rect.y as written by calc_view: bit 15 set => masked footprint: tiles wide (5 bits) | tiles high << 5 | 1 << 15 | mask << 16,
+// else tiles wide (15 bits) | tiles high << 16.  0 = culled.
+__device__ __forceinline__ uint32_t rect_count(uint32_t y) {
+    return (y & 0x8000u) ? (uint32_t)__popc(y >> 16) : (y & 0x7fffu) * (y >> 16);
+}
+__device__ __forceinline__ uint32_t nth_set_bit16(uint32_t m, uint32_t o) {      // position of the o-th (0-based) set bit of m
+    uint32_t pos = 0, c = (uint32_t)__popc(m & 0xffu);
+    if (o >= c) { o -= c; pos = 8; m >>= 8; }
+    c = (uint32_t)__popc(m & 0xfu);
+    if (o >= c) { o -= c; pos += 4; m >>= 4; }
+    c = (uint32_t)__popc(m & 3u);
+    if (o >= c) { o -= c; pos += 2; m >>= 2; }
+    if (o >= (m & 1u)) pos += 1;
+    return pos;
+}
+
 __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += (uint32_t)__shfl_xor((int)v, o, 64);
@@ -117,7 +133,7 @@ __global__ __launch_bounds__(kBinThreads) void bin_emit_kernel(const uint2* __re
     for (int k = 0; k < kBinItems; ++k) {
         rc[k] = make_uint2(0u, 0u);
         if ((visw[k] >> (sid[k] & 31u)) & 1u) rc[k] = rects[sid[k]];
-        const uint32_t c = (rc[k].y & 0xffffu) * (rc[k].y >> 16);
+        const uint32_t c = rect_count(rc[k].y);
         mySum += c;
         myVis += c ? 1u : 0u;
     }
@@ -187,7 +203,7 @@ __global__ __launch_bounds__(kBinThreads) void bin_emit_kernel(const uint2* __re
 #pragma unroll
         for (int kk = 0; kk < SUB; ++kk) {
             const int k = sb * SUB + kk;
-            const uint32_t c = (rc[k].y & 0xffffu) * (rc[k].y >> 16);
+            const uint32_t c = rect_count(rc[k].y);
             const uint32_t incl = wave_incl_scan_u32(c, lane);
             offs[kk * 64 + lane] = run + incl - c;
             sids[kk * 64 + lane] = sid[k];
@@ -202,10 +218,12 @@ __global__ __launch_bounds__(kBinThreads) void bin_emit_kernel(const uint2* __re
 #pragma unroll
             for (uint32_t step = (SUB * 64) / 2; step > 0; step >>= 1)
                 if (offs[e + step] <= j) e += step;
-            const uint32_t o = j - offs[e];
+            uint32_t o = j - offs[e];
             const uint2 r = rcts[e];
             const uint32_t s = sids[e];
-            const uint32_t tw = max(r.y & 0xffffu, 1u);
+            const bool masked = (r.y & 0x8000u) != 0;
+            const uint32_t tw = max(masked ? (r.y & 31u) : (r.y & 0x7fffu), 1u);
+            if (masked) o = nth_set_bit16(r.y >> 16, o);          // o-th tile of the footprint -> its index in the rectangle
             const uint32_t ty = o / tw, tx = o - ty * tw;
             const uint32_t tile = ((r.x >> 16) + ty) * tilesX + (r.x & 0xffffu) + tx;
             const unsigned long long gi = gbase + (unsigned long long)j;
@@ -346,7 +364,7 @@ __global__ __launch_bounds__(256) void blend_kernel(const uint32_t* __restrict__
                                                     uint16_t* __restrict__ rt, RasterConsts rc) {
     __shared__ float4 s_a[256];      // cx, cy, u1x, u1y      (u_k = axis_k / |axis_k|^2)
     __shared__ uint4 s_b[256];       // u2x, u2y (float bits), f16 r << 16 | f16 g, f16 b << 16 | f16 a
-    __shared__ float2 s_e[256];      // half extents of the footprint's bounding box, pixels
+    __shared__ float4 s_e[256];      // half extents of the footprint's bounding box, pixels; r^2 = ln(255 a) with slack
     __shared__ int s_done;
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -380,11 +398,12 @@ __global__ __launch_bounds__(256) void blend_kernel(const uint32_t* __restrict__
             const float ca = gsm::f16tof32(gsm::f2u(r1.w));
             // bounding box of  quad |q|<=2  INTERSECT  {exp(-|q|^2) a >= 1/255}  (same formula as PrepareSplat)
             const float exr = 2.0f * (fabsf(r0.z) + fabsf(r1.x)), eyr = 2.0f * (fabsf(r0.w) + fabsf(r1.y));
-            const float rr = sqrtf(fmaxf(fmaf(__logf(255.0f * ca), 1.0001f, 1.0e-3f), 0.0f));
+            const float r2 = fmaf(gsm::LogDet(255.0f * ca), 1.0001f, 1.0e-3f);
+            const float rr = sqrtf(fmaxf(r2, 0.0f));
             const float exe = rr * sqrtf(gsm::dot2f(r0.z, r1.x, r0.z, r1.x)), eye = rr * sqrtf(gsm::dot2f(r0.w, r1.y, r0.w, r1.y));
             s_a[tid] = make_float4(r0.x, r0.y, r0.z * inv1, r0.w * inv1);
             s_b[tid] = make_uint4(gsm::f2u(r1.x * inv2), gsm::f2u(r1.y * inv2), gsm::f2u(r1.z), gsm::f2u(r1.w));
-            s_e[tid] = make_float2(fminf(exr, exe) + 0.02f, fminf(eyr, eye) + 0.02f);
+            s_e[tid] = make_float4(fminf(exr, exe) + 0.02f, fminf(eyr, eye) + 0.02f, r2, 0.0f);
         }
         __syncthreads();
         if (!waveDone) {
@@ -393,8 +412,13 @@ __global__ __launch_bounds__(256) void blend_kernel(const uint32_t* __restrict__
                 bool hit = false;
                 if (j < cnt) {
                     const float4 ra = s_a[j];
-                    const float2 re = s_e[j];
+                    const float4 re = s_e[j];
                     hit = (ra.x + re.x >= qminx) && (ra.x - re.x <= qmaxx) && (ra.y + re.y >= qminy) && (ra.y - re.y <= qmaxy);
+#ifndef GS_EXP_BLEND_NOSAT
+                    // oriented test: 30 % of the bounding-box survivors cannot put a live fragment on this 8x8 quadrant
+                    const uint4 rb = s_b[j];
+                    hit = hit && gsm::BlockMayTouch((float)qx0 + 4.0f, (float)qy0 + 4.0f, 3.5f, ra.x, ra.y, ra.z, ra.w, gsm::u2f(rb.x), gsm::u2f(rb.y), re.z);
+#endif
                 }
                 unsigned long long mask = __ballot(hit);
                 while (mask) {
@@ -530,6 +554,7 @@ int32_t enqueue_draw(gs_renderer* r, const gs_frame_params* p, gs_target* rt) {
     if (!r->viewValid || r->viewW != rc.W || r->viewH != rc.H || r->viewNear != rc.nearClip || r->viewFar != rc.farClip)
         return fail(GS_ERR_INVALID_ARGUMENT, "gs_renderer_draw: call gs_renderer_calc_view with the same screen size / clip planes first");
     GS_TRY(ensure_arena(r, numTiles));
+    GS_TRY(join_sort(r));                                       // bin_emit reads order[]
     r->lastTilesX = rc.tilesX; r->lastTilesY = rc.tilesY;
 
     BinControl* binCtl = (BinControl*)r->frameArena;
@@ -546,7 +571,7 @@ int32_t enqueue_draw(gs_renderer* r, const gs_frame_params* p, gs_target* rt) {
     hipLaunchKernelGGL(binKernel, dim3(r->binParts), dim3(kBinThreads), 0, st, r->rects, (const uint32_t*)r->visMask, r->order, r->n, rc.tilesX, r->pairKeys,
                        r->pairVals, cap, binCtl, binStatus, pairCtl->hist);
     prof_record(r, 4);
-    GS_TRY(enqueue_sort_passes(ctx, r->pairSort, pairCtl, r->pairKeys, r->pairVals, cap, &binCtl->pairCountClamped, passes, 255u, r, 12));
+    GS_TRY(enqueue_sort_passes(ctx, st, r->pairSort, pairCtl, r->pairKeys, r->pairVals, cap, &binCtl->pairCountClamped, passes, 255u, r, 12));
     r->lastPairPasses = (uint32_t)passes;
     hipLaunchKernelGGL(tile_ranges_kernel, dim3(max(1u, min(div_up(cap, 256), (uint32_t)ctx->cuCount * 8u))), dim3(256), 0, st, r->pairKeys,
                        &binCtl->pairCountClamped, tileStart, tileEnd, numTiles);

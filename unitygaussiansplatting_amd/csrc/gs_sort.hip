@@ -384,52 +384,52 @@ int32_t enqueue_set_indices(gs_context* ctx, uint32_t* order, uint32_t n) {
     return GS_OK;
 }
 
-int32_t enqueue_calc_distances(gs_context* ctx, const gsm::AssetView& a, const uint32_t* order, const float* m, uint32_t* keys,
+int32_t enqueue_calc_distances(gs_context* ctx, hipStream_t stream, const gsm::AssetView& a, const uint32_t* order, const float* m, uint32_t* keys,
                                SortControl* control, uint32_t n) {
-    GS_HIP(hipMemsetAsync(control, 0, sizeof(SortControl), ctx->stream));
+    GS_HIP(hipMemsetAsync(control, 0, sizeof(SortControl), stream));
 #ifndef GS_DIST_BLOCKS_PER_CU
 #define GS_DIST_BLOCKS_PER_CU 2      // a narrow window of sorted positions per XCD keeps the gathered sectors in its L2 (measured: 2 beats 4 and 8)
 #endif
     const uint32_t grid = (max(1u, min(div_up(n, 256u * GS_DIST_ILP), (uint32_t)ctx->cuCount * GS_DIST_BLOCKS_PER_CU)) + 7u) & ~7u;
-    hipLaunchKernelGGL(calc_distances_kernel, dim3(grid), dim3(256), 0, ctx->stream, a, order, m[8], m[9], m[10], m[11], keys,
+    hipLaunchKernelGGL(calc_distances_kernel, dim3(grid), dim3(256), 0, stream, a, order, m[8], m[9], m[10], m[11], keys,
                        control->hist, n);
     GS_HIP(hipGetLastError());
     return GS_OK;
 }
 
-int32_t enqueue_histogram(gs_context* ctx, const uint32_t* keys, uint32_t n, const uint32_t* nPtr, int passes, uint32_t lastMask, SortControl* control) {
-    GS_HIP(hipMemsetAsync(control, 0, sizeof(SortControl), ctx->stream));
+int32_t enqueue_histogram(gs_context* ctx, hipStream_t stream, const uint32_t* keys, uint32_t n, const uint32_t* nPtr, int passes, uint32_t lastMask, SortControl* control) {
+    GS_HIP(hipMemsetAsync(control, 0, sizeof(SortControl), stream));
     const uint32_t grid = max(1u, min(div_up(n, 256), (uint32_t)ctx->cuCount * 4u));
-    hipLaunchKernelGGL(histogram_kernel, dim3(grid), dim3(256), 0, ctx->stream, keys, n, nPtr, passes, lastMask, control->hist);
+    hipLaunchKernelGGL(histogram_kernel, dim3(grid), dim3(256), 0, stream, keys, n, nPtr, passes, lastMask, control->hist);
     GS_HIP(hipGetLastError());
     return GS_OK;
 }
 
-int32_t enqueue_sort_passes(gs_context* ctx, SortState& st, SortControl* control, uint32_t* keys, uint32_t* vals, uint32_t nUpper,
+int32_t enqueue_sort_passes(gs_context* ctx, hipStream_t stream, SortState& st, SortControl* control, uint32_t* keys, uint32_t* vals, uint32_t nUpper,
                             const uint32_t* nPtr, int passes, uint32_t lastMask, gs_renderer* profR, int evFirst) {
     if (passes < 1 || passes > 4) return fail(GS_ERR_INVALID_ARGUMENT, "sort passes");
     if (nUpper > st.maxCount) return fail(GS_ERR_INVALID_ARGUMENT, "sort count exceeds sorter capacity");
     if (nUpper == 0) return GS_OK;
-    hipLaunchKernelGGL(scan_hist_kernel, dim3(1), dim3(1024), 0, ctx->stream, control->hist, passes);
+    hipLaunchKernelGGL(scan_hist_kernel, dim3(1), dim3(1024), 0, stream, control->hist, passes);
     const uint32_t parts = div_up(nUpper, PART);
     const uint32_t grid = max(1u, min(parts, (uint32_t)ctx->cuCount * (uint32_t)(2048 / THREADS)));
     uint32_t *ks = keys, *vs = vals, *kd = st.altKeys, *vd = st.altVals;
-    if (profR && evFirst >= 0) prof_record(profR, evFirst);
+    if (profR && evFirst >= 0) prof_record(profR, evFirst, stream);
     for (int p = 0; p < passes; ++p) {
         uint32_t epoch = (++st.epoch) & 0x3fffffffu;
         if (epoch == 0) {   // 30-bit epoch wrapped: wipe the status array (it may hold every old epoch), restart at 1
-            GS_HIP(hipMemsetAsync(st.status, 0, (size_t)st.maxParts * RADIX * 8, ctx->stream));
+            GS_HIP(hipMemsetAsync(st.status, 0, (size_t)st.maxParts * RADIX * 8, stream));
             st.epoch = epoch = 1;
         }
-        hipLaunchKernelGGL(onesweep_kernel, dim3(grid), dim3(THREADS), 0, ctx->stream, ks, vs, kd, vd, control->hist + RADIX * p,
+        hipLaunchKernelGGL(onesweep_kernel, dim3(grid), dim3(THREADS), 0, stream, ks, vs, kd, vd, control->hist + RADIX * p,
                            st.status, &control->tickets[p], &control->error, nUpper, nPtr, (uint32_t)(8 * p), epoch, p == passes - 1 ? lastMask : 255u);
         uint32_t* t = ks; ks = kd; kd = t;
         t = vs; vs = vd; vd = t;
     }
-    if (profR && evFirst >= 0) prof_record(profR, evFirst + 1);
+    if (profR && evFirst >= 0) prof_record(profR, evFirst + 1, stream);
     if (ks != keys) {
         hipLaunchKernelGGL(copy_pairs_kernel, dim3(max(1u, min(div_up(nUpper, 256), (uint32_t)ctx->cuCount * 8u))), dim3(256), 0,
-                           ctx->stream, ks, vs, keys, vals, nUpper, nPtr);
+                           stream, ks, vs, keys, vals, nUpper, nPtr);
     }
     GS_HIP(hipGetLastError());
     return GS_OK;

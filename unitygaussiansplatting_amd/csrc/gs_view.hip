@@ -7,7 +7,7 @@
 // global stores are whole, coalesced uint4s:
 //   view[s]  40 B  the reference's SplatViewData (m_GpuView; parity surface)
 //   rec[s]   32 B  centre in pixels + the two axes + rgba16f: what the blend kernel reads per (tile, splat) pair
-//   rect[s]   8 B  inclusive 16x16-tile rectangle of the splat's footprint, or 0 if it is culled
+//   rect[s]   8 B  inclusive 16x16-tile rectangle of the splat's footprint (+ a per-tile bit mask when it spans <= 16 tiles), or 0 if culled
 // Writing rec/rect here (where everything is in registers) means the binning kernel only gathers 8 B per sorted
 // position instead of the 40-B view record, and never writes records itself.
 #include "gs_common.h"
@@ -106,8 +106,9 @@ __global__ __launch_bounds__(256) void calc_view_kernel(gsm::AssetView a, gsm::F
         }
         const bool ok = gsm::PrepareSplat(v, P.screenW, P.screenH, P.nearClip, P.farClip, fp);
         if (ok && fp.tx0 <= fp.tx1) {
+            const uint32_t tw = (uint32_t)(fp.tx1 - fp.tx0 + 1), th = (uint32_t)(fp.ty1 - fp.ty0 + 1);
             rect.x = (uint32_t)fp.tx0 | ((uint32_t)fp.ty0 << 16);
-            rect.y = (uint32_t)(fp.tx1 - fp.tx0 + 1) | ((uint32_t)(fp.ty1 - fp.ty0 + 1) << 16);
+            rect.y = fp.masked ? (tw | (th << 5) | 0x8000u | (fp.mask << 16)) : (tw | (th << 16));     // decoded by bin_emit (rect_count)
             visible = true;
         }
         rects[idx] = rect;

@@ -57,6 +57,10 @@ class GpuContext:
     def Synchronize(self) -> None:
         check(_lib.lib().gs_context_synchronize(self._h), "gs_context_synchronize")
 
+    def SetOverlap(self, enabled: bool) -> None:
+        """Run SortPoints concurrently with CalcViewData on the context's second queue (default on)."""
+        check(_lib.lib().gs_context_set_overlap(self._h, int(bool(enabled))), "gs_context_set_overlap")
+
     def DeviceInfo(self) -> Tuple[str, int, int]:
         name = C.create_string_buffer(256)
         cus = C.c_int32()
