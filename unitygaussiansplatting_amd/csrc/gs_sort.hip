@@ -177,6 +177,9 @@ __global__ __launch_bounds__(1024) void scan_hist_kernel(uint32_t* hist, int pas
 // Register diet (the kernel is latency-bound, so resident waves matter): payloads are loaded only after the keys
 // have left the registers for LDS, local positions overwrite the ranks, and the digit of each output slot is kept
 // packed 4 per register instead of a 32-bit global index per slot.
+#ifndef GS_SORT_LOOKBACK_BATCH
+#define GS_SORT_LOOKBACK_BATCH 8
+#endif
 #ifndef GS_SORT_MINWAVES
 #define GS_SORT_MINWAVES 1
 #endif
@@ -276,31 +279,6 @@ __global__ __launch_bounds__(THREADS, GS_SORT_MINWAVES) void onesweep_kernel(con
             lbase += wbase;
             s_lbase[tid] = lbase;
 
-            // ---- look back over earlier partitions for digit `tid` -------------------------------------
-            uint32_t exclPrefix = 0;
-#ifdef GS_EXP_SORT_NOLOOKBACK      // timing experiment only (wrong output): what the look-back chain costs
-            if (false) {
-#else
-            if (part > 0) {
-#endif
-                int q = (int)part - 1;
-                uint32_t spins = 0;
-                for (;;) {
-                    const unsigned long long s = ld_status(status + (size_t)q * RADIX + tid);
-                    const uint32_t e = (uint32_t)(s >> 34);
-                    const uint32_t f = (uint32_t)(s >> 32) & 3u;
-                    if (e == epoch && f != 0) {
-                        exclPrefix += (uint32_t)s;
-                        if (f == (uint32_t)FLAG_INCL) break;
-                        --q;                               // partition 0 always publishes INCL, so q never drops below 0
-                        continue;
-                    }
-                    if (++spins > SPIN_LIMIT) { atomicOr(error, 1u); break; }
-                    __builtin_amdgcn_s_sleep(2);
-                }
-                st_status(myStatus, pack_status(epoch, FLAG_INCL, exclPrefix + total));
-            }
-            s_gbase[tid] = histExcl[tid] + exclPrefix - lbase;
         }
         __syncthreads();
 
@@ -323,6 +301,51 @@ __global__ __launch_bounds__(THREADS, GS_SORT_MINWAVES) void onesweep_kernel(con
                 const uint32_t gi = waveBase + (uint32_t)k * 64u + lane;
                 val[k] = (gi < n) ? ldg32(valsIn, gi) : 0u;
             }
+        }
+        // ---- look back over earlier partitions for digit `tid` (keys are parked in LDS by now, so the batch of
+        //      status words below replaces the key registers instead of adding to them) ------------------------
+        if (tid < RADIX) {
+            uint32_t exclPrefix = 0;
+#ifdef GS_EXP_SORT_NOLOOKBACK      // timing experiment only (wrong output): what the look-back chain costs
+            if (false) {
+#else
+            if (part > 0) {
+#endif
+                // Every partition of a pass is resident at once (persistent grid), so the nearest INCLUSIVE predecessor can
+                // be hundreds of partitions back and a one-word-at-a-time walk is a chain of that many L2 round trips.
+                // LB independent loads are issued per round and consumed in order: the chain is LB times shorter.
+                constexpr int LB = GS_SORT_LOOKBACK_BATCH;
+                int q = (int)part - 1;
+                uint32_t spins = 0;
+                bool done = false;
+                while (!done) {
+                    unsigned long long sv[LB];
+#pragma unroll
+                    for (int b = 0; b < LB; ++b) {
+                        const int qi = q - b;
+                        sv[b] = qi >= 0 ? ld_status(status + (size_t)qi * RADIX + tid) : 0ull;   // partition 0 is INCLUSIVE: never consumed past it
+                    }
+                    int consumed = 0;
+#pragma unroll
+                    for (int b = 0; b < LB; ++b) {
+                        if (done || consumed != b) continue;                         // stop at the first word that is not ready
+                        const uint32_t e = (uint32_t)(sv[b] >> 34);
+                        const uint32_t f = (uint32_t)(sv[b] >> 32) & 3u;
+                        if (e == epoch && f != 0) {
+                            exclPrefix += (uint32_t)sv[b];
+                            consumed = b + 1;
+                            if (f == (uint32_t)FLAG_INCL) done = true;
+                        }
+                    }
+                    q -= consumed;
+                    if (!done && consumed == 0) {
+                        if (++spins > SPIN_LIMIT) { atomicOr(error, 1u); break; }
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                }
+                st_status(myStatus, pack_status(epoch, FLAG_INCL, exclPrefix + total));
+            }
+            s_gbase[tid] = histExcl[tid] + exclPrefix - lbase;
         }
         __syncthreads();
         uint32_t dpack[(KPT + 3) / 4];
