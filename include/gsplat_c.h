@@ -12,7 +12,7 @@
  * Conventions
  *  - every function returns int32: 0 = GS_OK, < 0 = gs_error.  Nothing throws, nothing calls back.
  *  - handles are opaque.  One gs_context = one GPU + one HIP stream.  All work of a context is enqueued
- *    on that stream in call order (like one Unity CommandBuffer; see gs_context_set_overlap for the one exception,
+ *    on that stream in call order (like one Unity CommandBuffer; see gs_context_set_overlap for the one opt-in exception,
  *    which is not observable through this API); calls on one context are NOT thread
  *    safe (Unity records on its single render thread); different contexts are independent.
  *  - host pointers passed in are only read during the call (data is copied); the caller keeps ownership.
@@ -139,10 +139,11 @@ const char* gs_last_error_string(void);          /* thread-local detail of the l
 int32_t gs_context_create(int32_t device, void* hip_stream, gs_context** out);
 int32_t gs_context_destroy(gs_context* ctx);
 int32_t gs_context_synchronize(gs_context* ctx);
-/* The depth sort of a frame does not depend on CalcViewData.  With overlap on (the default) gs_renderer_sort is enqueued
- * on a second in-order queue owned by the context, forked from the context's stream and joined to it by the first
- * consumer of the order (gs_renderer_draw or a readback), so sort and view data run concurrently on the GPU.  Results are
- * identical either way; 0 serialises everything on the one stream.  Blocks until the second queue is idle. */
+/* The depth sort of a frame does not depend on CalcViewData.  With overlap on, gs_renderer_sort is enqueued on a second
+ * in-order queue owned by the context, forked from the context's stream and joined to it by the first consumer of the
+ * order (gs_renderer_draw or a readback), so sort and view data run concurrently on the GPU.  Results are identical
+ * either way.  Default OFF: on MI355X the two stages compete for the memory system and the frame is not shorter
+ * (DESIGN.md).  Blocks until the second queue is idle. */
 int32_t gs_context_set_overlap(gs_context* ctx, int32_t enabled);
 int32_t gs_context_device_info(gs_context* ctx, char* name_out, size_t name_cap, int32_t* cu_count, uint64_t* hbm_bytes);
 

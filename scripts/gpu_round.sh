@@ -11,15 +11,13 @@ tests)
 variants)
   : > $O/variants.log
   timeout 300 python scripts/bench_stages.py C2 30 2>&1 | tail -1 | tee -a $O/variants.log
-  GSPLAT_OVERLAP=0 timeout 200 python scripts/bench_stages.py C2 30 2>&1 | tail -1 | sed 's/"lib": "default"/"lib": "default-nooverlap"/' | tee -a $O/variants.log
+  GSPLAT_OVERLAP=1 timeout 200 python scripts/bench_stages.py C2 30 2>&1 | tail -1 | sed 's/"lib": "default"/"lib": "default-overlap"/' | tee -a $O/variants.log
   for v in unitygaussiansplatting_amd/variants/*.so; do
     GSPLAT_LIB=$PWD/$v timeout 200 python scripts/bench_stages.py C2 30 2>&1 | tail -1 | tee -a $O/variants.log
-    GSPLAT_OVERLAP=0 GSPLAT_LIB=$PWD/$v timeout 200 python scripts/bench_stages.py C2 30 2>&1 | tail -1 | sed 's/\.so"/.so-nooverlap"/' | tee -a $O/variants.log
   done;;
 prof)
   (cd /tmp && export TMPDIR=/tmp && rm -rf $O/prof && mkdir -p $O/prof && R=$GRAFT_REPO_ROOT && \
-   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof/stats -- python $R/bench.py --steps 20 --warmup 5 --cpu-baseline off > $O/prof/bench_stats.json 2> $O/prof/bench_stats.err; \
-   GSPLAT_OVERLAP=0 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof/stats_nooverlap -- python $R/bench.py --steps 20 --warmup 5 --cpu-baseline off > $O/prof/bench_stats_nooverlap.json 2> $O/prof/bench_stats_nooverlap.err)
+   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof/stats -- python $R/bench.py --steps 20 --warmup 5 --cpu-baseline off > $O/prof/bench_stats.json 2> $O/prof/bench_stats.err)
   find $O/prof -name "*kernel_stats.csv" | head; tail -c 600 $O/prof/bench_stats.json;;
 bench)
   timeout 900 python bench.py > $O/bench.json 2> $O/bench.err; tail -c 3000 $O/bench.json;;

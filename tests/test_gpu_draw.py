@@ -167,3 +167,32 @@ def test_determinism_run_twice(gpu_ctx):
     x = render_both(gpu_ctx, a, cam)
     y = render_both(gpu_ctx, a, cam)
     assert np.array_equal(x["img"], y["img"]) and np.array_equal(x["o8"], y["o8"])
+
+
+def test_overlapped_sort_queue_gives_identical_frames(gpu_ctx):
+    """gs_context_set_overlap(1): SortPoints runs on the context's second queue concurrently with CalcViewData and is joined
+    by the draw / by any readback.  Orders, keys and frames must equal the serial ones bit for bit, over several frames
+    (stateful previous order), including a readback issued while the sort is still un-joined."""
+    a = small_asset(120_000, 5, "Medium")
+    frames = {}
+    for overlap in (False, True):
+        gpu_ctx.SetOverlap(overlap)
+        r = GaussianSplatRenderer(gpu_ctx, a)
+        r.OnEnable()
+        rt = RenderTarget(gpu_ctx, 640, 360)
+        out = []
+        for f in range(4):
+            cam = default_camera(W=640, H=360, az=30.0 + 25.0 * f)
+            r.SortPoints(cam)
+            if f == 2:
+                out.append(r.DownloadOrder().copy())          # readback before the join point
+            r.CalcViewData(cam)
+            rt.Clear()
+            r.Draw(cam, rt)
+            out += [rt.Download().copy(), r.DownloadOrder().copy(), r.DownloadDistances().copy(), r.FrameStats().tile_pairs]
+        frames[overlap] = out
+        r.OnDisable()
+        rt.Dispose()
+    gpu_ctx.SetOverlap(False)
+    for x, y in zip(frames[False], frames[True]):
+        assert np.array_equal(x, y)

@@ -56,3 +56,33 @@ def test_full_size_sort_view_and_draw_properties(gpu_ctx, c2):
     assert (O.f16_to_f32(rt.Download())[..., 3] >= f[..., 3]).all()
     assert 0 < st.visible_splats < n and st.tile_pairs >= st.visible_splats
     r.OnDisable()
+
+
+def test_garden_like_veryhigh_1080p_properties(gpu_ctx):
+    """C3's shape at a quarter of its size: VeryHigh (all-fp32, no chunk buffer) asset, 1920x1080, fov 47 -- the fp32 SH
+    staging path of calc_view and the compositor at 8160 tiles, checked against
+    the oracle for keys/order/view and through properties for the frame."""
+    cfg = scenes.CONFIGS["C3"]
+    n = 1_458_696
+    a = creator.CreateAssetFromSplats(scenes.make_config_splats(cfg, n), cfg.quality, name="C3q")
+    assert a.chunkData is None or len(a.chunkData) == 0
+    r = GaussianSplatRenderer(gpu_ctx, a)
+    r.OnEnable()
+    orc = O.Oracle(a)
+    rt = RenderTarget(gpu_ctx, cfg.width, cfg.height)
+    prev_pairs = None
+    for az in (0.0, 137.0):                                           # second frame: sort through a non-identity previous order
+        cam = camera.Camera(position=scenes.orbit_eye(cfg.eye_radius, cfg.eye_elev_deg, az), pixelWidth=cfg.width, pixelHeight=cfg.height,
+                            fieldOfView=cfg.fov_y)
+        r.SortPoints(cam)
+        r.CalcViewData(cam)
+        rt.Clear(); r.Draw(cam, rt)
+        orc.sort(camera.sort_matrix(cam, r.transform.localToWorldMatrix))
+        assert np.array_equal(r.DownloadOrder(), orc.order) and np.array_equal(r.DownloadDistances(), orc.keys)
+        assert np.array_equal(r.DownloadView().view(np.uint32), orc.calc_view(r.FrameParams(cam)).view(np.uint32))
+        st = r.FrameStats()
+        f = O.f16_to_f32(rt.Download())
+        assert np.isfinite(f).all() and 0.0 <= f[..., 3].min() and f[..., 3].max() <= 1.0 and f[..., 3].mean() > 0.01
+        assert 0 < st.visible_splats < n and st.tile_pairs >= st.visible_splats and st.tile_pairs != prev_pairs
+        prev_pairs = st.tile_pairs
+    r.OnDisable()

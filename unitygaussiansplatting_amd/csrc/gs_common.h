@@ -86,7 +86,7 @@ struct gs_context {
     // second in-order queue: the depth sort of a frame (SortPoints) has no data dependence on CalcViewData, so it runs
     // here, forked from / joined to `stream` with events, and the two latency-bound kernels share the GPU
     hipStream_t aux = nullptr;
-    bool overlap = true;
+    bool overlap = false;
     int cuCount = 0;
     hipDeviceProp_t props;
 };

@@ -297,8 +297,10 @@ GS_HD ViewData CalcViewDataT(const AssetView& a, const FrameConsts& P, const Edi
     view.pos[2] = mrow(P.vp, 2, wx, wy, wz);
     view.pos[3] = mrow(P.vp, 3, wx, wy, wz);
     // deleted? (:204-214) / cutouts (:216-220): centerClipPos.w = 0, the rest of the clip position is kept
+#ifndef GS_EXP_NO_EDIT              // timing experiment only
     if (E.deletedBits && ((E.deletedBits[idx >> 5] >> (idx & 31u)) & 1u)) view.pos[3] = 0.0f;
     if (E.cutoutCount && IsSplatCut(E, pos.x, pos.y, pos.z)) view.pos[3] = 0.0f;
+#endif
     if (!(view.pos[3] > 0.0f)) return view;                       // behindCam
 
     // ---- rotation / scale
@@ -552,7 +554,11 @@ GS_HD bool PrepareSplat(const ViewData& v, float W, float H, float nearClip, flo
     fp.tx0 = x0 >> 4; fp.tx1 = x1 >> 4; fp.ty0 = y0 >> 4; fp.ty1 = y1 >> 4;
     // small footprints (the bulk): drop the tiles of the rectangle that the oriented footprint cannot reach
     const int tw = fp.tx1 - fp.tx0 + 1, th = fp.ty1 - fp.ty0 + 1;
+#ifdef GS_EXP_NO_TILE_MASK          // timing experiment only
+    if (false) {
+#else
     if (tw * th >= 2 && tw * th <= kMaskTiles) {
+#endif
         const float u1x = a1x * inv1, u1y = a1y * inv1, u2x = a2x * inv2, u2y = a2y * inv2;
         uint32_t m = 0u;
         for (int ty = 0; ty < th; ++ty)

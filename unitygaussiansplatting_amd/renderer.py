@@ -58,7 +58,7 @@ class GpuContext:
         check(_lib.lib().gs_context_synchronize(self._h), "gs_context_synchronize")
 
     def SetOverlap(self, enabled: bool) -> None:
-        """Run SortPoints concurrently with CalcViewData on the context's second queue (default on)."""
+        """Run SortPoints concurrently with CalcViewData on the context's second queue (default off: no gain on MI355X)."""
         check(_lib.lib().gs_context_set_overlap(self._h, int(bool(enabled))), "gs_context_set_overlap")
 
     def DeviceInfo(self) -> Tuple[str, int, int]:
