@@ -58,7 +58,9 @@ def stage_bytes(n, P, vis, W, H, asset, passes_pair):
     return {
         "calc_distances": n * (4 + b_pos + chunk + 4),           # prev order in, gathered pos, key out
         "sort": n * 16 * 4,                                      # 4 Onesweep passes x (key+payload read + write); histogram is fused into calc_distances
-        "calc_view": n * (b_asset + 40 + 8 + 0.125) + vis * 32,  # asset record in; 40-B view, 8-B tile rect, 1 visibility bit out; 32-B blend record per visible splat
+        # pos/rot/scale/colour/chunk of every splat in, 8-B tile rect + 1 visibility bit out; the SH record is read and the
+        # 32-B blend record written only for splats that reach the screen (the 40-B m_GpuView record is materialised on demand)
+        "calc_view": n * (b_asset - sh_item + 8 + 0.125) + vis * (sh_item + 32),
         "bin": n * (4 + 0.125) + vis * 8 + P * 8,                # order + visibility bit per position, rect per visible splat, (tile, splat) pairs out
         "pair_sort": P * 16 * passes_pair + P * 4,               # Onesweep passes over the pairs + tile-range scan of the keys
         "blend": P * (4 + 32) + W * H * 16,                      # pair index + record per pair, RT read + write

@@ -165,8 +165,14 @@ int32_t gs_renderer_reset_order(gs_renderer* r);
  * (= worldToCameraMatrix with m20,m21,m22 negated, times localToWorld -- the host builds it exactly as
  * the C# does), then GpuSorting.Dispatch on (distances, order). */
 int32_t gs_renderer_sort(gs_renderer* r, const float matrix_sort[16]);
-/* CalcViewData (GaussianSplatRenderer.cs:579-610): CSCalcViewData into the N x 40 B view buffer */
+/* CalcViewData (GaussianSplatRenderer.cs:579-610): CSCalcViewData.  The reference's output, the N x 40 B m_GpuView
+ * buffer, is only read by its own vertex shader; here the compositor reads compact per-splat records instead, so by
+ * default the kernel evaluates colour (SH) only for the splats that reach the screen and does not write m_GpuView.
+ * gs_renderer_download_view materialises it on demand (re-running the frame's launch as the reference's full kernel), so
+ * what that function returns is the reference's buffer either way. */
 int32_t gs_renderer_calc_view(gs_renderer* r, const gs_frame_params* p);
+/* 1: run the full CSCalcViewData every frame (all colours, m_GpuView written), exactly like the reference; 0 (default): on demand */
+int32_t gs_renderer_set_view_buffer_mode(gs_renderer* r, int32_t every_frame);
 /* the DrawProcedural of SortAndRenderSplats (GaussianSplatRenderer.cs:156-166): blends all splats in
  * order[] front-to-back into `rt` (RGBA16F, premultiplied; "Blend OneMinusDstAlpha One"). rt is NOT cleared. */
 int32_t gs_renderer_draw(gs_renderer* r, const gs_frame_params* p, gs_target* rt);

@@ -470,7 +470,6 @@ struct Prepared {
     float r, g, b, a;       // colour as the vertex shader unpacks it (f16 -> f32)
     int x0, x1, y0, y1;     // pixel rect of the quad's bounding box, clamped to the screen (x0>x1 => nothing)
     int tx0, tx1, ty0, ty1; // 16x16 tile rect of the *tight* footprint used by the shipped binning kernel
-    uint32_t tiles;         // tiles of that rect the shipped binning emits (rects of 2..16 tiles drop unreachable tiles)
     bool valid;
 };
 
@@ -486,16 +485,6 @@ inline float log_det(float x) {
     const float t2 = t * t;
     const float p = fmaf(t2, fmaf(t2, fmaf(t2, 1.0f / 7.0f, 0.2f), 1.0f / 3.0f), 1.0f);
     return fmaf(e, 0.69314718f, (2.0f * t) * p);
-}
-
-// min |q_k| over the block of pixel centres [bc - half, bc + half]^2 is closed form (q_k linear in the pixel): the block
-// cannot receive a live fragment if those minima already break |q_k| <= 2 or q_1^2 + q_2^2 <= ln(255 a).
-inline bool block_may_touch(float bcx, float bcy, float half, const Prepared& p, float r2) {
-    const float dx = bcx - p.cx, dy = bcy - p.cy;
-    const float d1 = fabsf(fmaf(dy, p.u1y, dx * p.u1x)) - half * (fabsf(p.u1x) + fabsf(p.u1y));
-    const float d2 = fabsf(fmaf(dy, p.u2y, dx * p.u2x)) - half * (fabsf(p.u2x) + fabsf(p.u2y));
-    const float m1 = fmaxf(d1, 0.0f), m2 = fmaxf(d2, 0.0f);
-    return (m1 <= 2.001f) && (m2 <= 2.001f) && (fmaf(m2, m2, m1 * m1) <= r2);
 }
 
 inline bool finitef(float v) { return std::isfinite(v); }
@@ -543,16 +532,6 @@ Prepared prepare(const ViewData& v, const gs_frame_params& P) {
     pix_range(p.cy, fminf(eyr, eye) + slack, H, by0, by1);
     if (bx0 <= bx1 && by0 <= by1) {
         p.tx0 = bx0 >> 4; p.tx1 = bx1 >> 4; p.ty0 = by0 >> 4; p.ty1 = by1 >> 4;
-        const int tw = p.tx1 - p.tx0 + 1, th = p.ty1 - p.ty0 + 1;
-        p.tiles = (uint32_t)(tw * th);
-        if (tw * th >= 2 && tw * th <= 16) {
-            uint32_t cnt = 0;
-            for (int ty = p.ty0; ty <= p.ty1; ++ty)
-                for (int tx = p.tx0; tx <= p.tx1; ++tx)
-                    if (block_may_touch((float)(tx * 16 + 8), (float)(ty * 16 + 8), 7.5f, p, r2)) cnt++;
-            p.tiles = cnt;
-            if (cnt == 0) { p.tx0 = 1; p.tx1 = 0; }
-        }
     }
     p.valid = true;
     return p;
@@ -670,7 +649,7 @@ int32_t gso_draw(const void* view_in, const uint32_t* order, uint32_t n, const g
     for (int64_t i = 0; i < (int64_t)n; ++i) {
         prep[i] = prepare(view[order[i]], *P);
         if (prep[i].valid && prep[i].tx0 <= prep[i].tx1) {
-            pairs += (uint64_t)prep[i].tiles;
+            pairs += (uint64_t)(prep[i].tx1 - prep[i].tx0 + 1) * (uint64_t)(prep[i].ty1 - prep[i].ty0 + 1);
             visible++;
         }
     }

@@ -1,0 +1,20 @@
+"""Per-kernel means of the SQ counters collected by scripts/pmc_sq.sh (gpurun_out/pmc_sq/p*/)."""
+import csv, glob, os, re, sys
+from collections import defaultdict
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+P = os.path.join(ROOT, "gpurun_out", "pmc_sq")
+def short(n): return re.sub(r"\(.*", "", n.replace("(anonymous namespace)::", "").replace("void ", "")).replace("gs::", "")
+acc = defaultdict(lambda: defaultdict(list))
+for f in glob.glob(os.path.join(P, "p*", "*", "*_counter_collection.csv")):
+    for r in csv.DictReader(open(f)):
+        acc[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+names = sorted({c for k in acc.values() for c in k})
+for k, cs in sorted(acc.items()):
+    if not k.endswith("_kernel") and "<" not in k: continue
+    m = {c: sum(v) / len(v) for c, v in cs.items()}
+    print(f"== {k}  (n={len(next(iter(cs.values())))})")
+    wc = m.get("SQ_WAVE_CYCLES", 0)
+    for c in names:
+        if c in m:
+            extra = f"  ({100 * m[c] / wc:5.1f} % of wave cycles)" if wc and c in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS", "SQ_ACTIVE_INST_VMEM", "SQ_WAIT_INST_LDS") else ""
+            print(f"   {c:24s} {m[c]:16.0f}{extra}")

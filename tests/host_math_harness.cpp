@@ -44,7 +44,7 @@ void hm_prepare_ex(const void* view, uint32_t n, const gs_frame_params* p, int32
         const bool ok = gsm::PrepareSplat(v[i], p->screen_w, p->screen_h, p->near_clip, p->far_clip, fp);
         out[i * 5 + 0] = fp.tx0; out[i * 5 + 1] = fp.tx1; out[i * 5 + 2] = fp.ty0; out[i * 5 + 3] = fp.ty1; out[i * 5 + 4] = ok;
         cxy[i * 2] = fp.cx; cxy[i * 2 + 1] = fp.cy;
-        if (tiles) tiles[i] = ok ? gsm::FootprintTileCount(fp) : 0u;
+        if (tiles) tiles[i] = (ok && fp.tx0 <= fp.tx1) ? (uint32_t)((fp.tx1 - fp.tx0 + 1) * (fp.ty1 - fp.ty0 + 1)) : 0u;
     }
 }
 // the culling predicate shared by the binning (16x16 tiles, half = 7.5) and the blend kernel (8x8 quadrants, half = 3.5)
@@ -52,15 +52,6 @@ int32_t hm_block_may_touch(float bcx, float bcy, float half, float cx, float cy,
     return gsm::BlockMayTouch(bcx, bcy, half, cx, cy, u1x, u1y, u2x, u2y, r2) ? 1 : 0;
 }
 float hm_log_det(float x) { return gsm::LogDet(x); }
-// per splat: the footprint's tile mask (bit (ty-ty0)*w + (tx-tx0)) and whether the footprint is masked at all
-void hm_footprint_masks(const void* view, uint32_t n, const gs_frame_params* p, uint32_t* mask, uint8_t* masked) {
-    const gsm::ViewData* v = (const gsm::ViewData*)view;
-    for (uint32_t i = 0; i < n; ++i) {
-        gsm::SplatFootprint fp;
-        gsm::PrepareSplat(v[i], p->screen_w, p->screen_h, p->near_clip, p->far_clip, fp);
-        mask[i] = fp.mask; masked[i] = fp.masked ? 1 : 0;
-    }
-}
 uint32_t hm_f32tof16(float f) { return gsm::f32tof16(f); }
 float hm_f16tof32(uint32_t h) { return gsm::f16tof32(h); }
 }

@@ -84,7 +84,7 @@ def test_footprints_match_oracle_prepare(hm):
     h = np.maximum(out[:, 3] - out[:, 2] + 1, 0).astype(np.int64)
     assert int(tiles.sum()) == orc.tile_pairs
     assert int((tiles > 0).sum()) == orc.visible
-    assert (tiles <= w * h).all() and 0.6 < tiles.sum() / (w * h).sum() < 0.98          # the per-tile mask does drop tiles
+    assert (tiles == w * h).all()
 
 
 def _live_pixels(v, P, i):
@@ -111,8 +111,8 @@ def _live_pixels(v, P, i):
 
 
 def test_block_culling_never_drops_a_live_fragment(hm):
-    """BlockMayTouch (tile mask of the binning, quadrant test of the blend kernel) is conservative w.r.t. the pixel-exact
-    fragment test, and the tile masks PrepareSplat stores contain every tile that owns a live pixel."""
+    """BlockMayTouch (the 8x8-quadrant test of the blend kernel's ballot; also checked at 16x16) is conservative w.r.t. the
+    pixel-exact fragment test, and PrepareSplat's tile rectangle contains every tile that owns a live pixel."""
     hm.hm_block_may_touch.argtypes = [C.c_float] * 10
     hm.hm_log_det.restype = C.c_float
     hm.hm_log_det.argtypes = [C.c_float]
@@ -126,10 +126,8 @@ def test_block_culling_never_drops_a_live_fragment(hm):
     v = orc.calc_view(P)
     n = a.splatCount
     out = np.zeros((n, 5), np.int32); cxy = np.zeros((n, 2), np.float32); tiles = np.zeros(n, np.uint32)
-    mask = np.zeros(n, np.uint32); masked = np.zeros(n, np.uint8)
     vp = v.ctypes.data_as(C.c_void_p)
     hm.hm_prepare_ex(vp, C.c_uint32(n), C.byref(P), out.ctypes.data_as(C.c_void_p), cxy.ctypes.data_as(C.c_void_p), tiles.ctypes.data_as(C.c_void_p))
-    hm.hm_footprint_masks(vp, C.c_uint32(n), C.byref(P), mask.ctypes.data_as(C.c_void_p), masked.ctypes.data_as(C.c_void_p))
     checked_tiles = dropped_tiles = checked_quads = dropped_quads = 0
     for i in np.flatnonzero(out[:, 4] == 1)[:4000]:
         lp = _live_pixels(v, P, i)
@@ -141,15 +139,17 @@ def test_block_culling_never_drops_a_live_fragment(hm):
         if len(xs) == 0:
             continue
         assert tx0 <= tx1, "a splat with live pixels has an empty footprint"
-        tw = tx1 - tx0 + 1
+        r2 = np.float32(np.float32(hm.hm_log_det(np.float32(255.0) * al)) * np.float32(1.0001) + np.float32(1e-3))
         live_tiles = set(zip(((xs + x0) >> 4).tolist(), ((ys + y0) >> 4).tolist()))
         for (tx, ty) in live_tiles:
             assert tx0 <= tx <= tx1 and ty0 <= ty <= ty1
-            if masked[i]:
-                assert (mask[i] >> ((ty - ty0) * tw + (tx - tx0))) & 1, f"splat {i}: live tile ({tx},{ty}) missing from the mask"
-        checked_tiles += (tx1 - tx0 + 1) * (ty1 - ty0 + 1)
-        dropped_tiles += (tx1 - tx0 + 1) * (ty1 - ty0 + 1) - int(tiles[i])
-        r2 = np.float32(np.float32(hm.hm_log_det(np.float32(255.0) * al)) * np.float32(1.0001) + np.float32(1e-3))
+        for ty in range(ty0, ty1 + 1):
+            for tx in range(tx0, tx1 + 1):
+                hit = hm.hm_block_may_touch(tx * 16 + 8.0, ty * 16 + 8.0, 7.5, cx, cy, u1[0], u1[1], u2[0], u2[1], r2)
+                checked_tiles += 1
+                dropped_tiles += 0 if hit else 1
+                if (tx, ty) in live_tiles:
+                    assert hit, f"splat {i}: tile ({tx},{ty}) has a live pixel but fails the block test"
         live_quads = set(zip(((xs + x0) >> 3).tolist(), ((ys + y0) >> 3).tolist()))
         for qy in range((y0 >> 3), ((y0 + live.shape[0] - 1) >> 3) + 1):
             for qx in range((x0 >> 3), ((x0 + live.shape[1] - 1) >> 3) + 1):

@@ -45,6 +45,7 @@ SIGNATURES = {
     "gs_renderer_render": (C.c_int32, [_P, C.POINTER(C.c_float), C.POINTER(gs_frame_params), _P, C.c_int32]),
     "gs_renderer_set_cutouts": (C.c_int32, [_P, C.POINTER(gs_cutout), C.c_uint32]),
     "gs_renderer_set_deleted_bits": (C.c_int32, [_P, _P, C.c_size_t]),
+    "gs_renderer_set_view_buffer_mode": (C.c_int32, [_P, C.c_int32]),
     "gs_renderer_set_blend_mode": (C.c_int32, [_P, C.c_int32]),
     "gs_renderer_set_profiling": (C.c_int32, [_P, C.c_int32]),
     "gs_renderer_reserve_pairs": (C.c_int32, [_P, C.c_uint64]),

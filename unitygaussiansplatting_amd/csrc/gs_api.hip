@@ -300,7 +300,9 @@ int32_t gs_renderer_calc_view(gs_renderer* r, const gs_frame_params* p) {
     rec_ev(r, 7);
     gsm::EditView e;
     e.deletedBits = r->deletedBits; e.cutouts = r->cutouts; e.cutoutCount = r->cutoutCount;
-    GS_TRY(enqueue_calc_view(r->ctx, r->asset->view, p, e, r->view, r->recs, r->rects, r->visMask));
+    GS_TRY(enqueue_calc_view(r->ctx, r->asset->view, p, e, r->view, r->recs, r->rects, r->visMask, r->alwaysWriteView));
+    r->viewMaterialised = r->alwaysWriteView;
+    r->lastParams = *p;
     r->viewW = p->screen_w; r->viewH = p->screen_h; r->viewNear = p->near_clip; r->viewFar = p->far_clip; r->viewValid = true;
     rec_ev(r, 8);
     return GS_OK;
@@ -379,6 +381,12 @@ int32_t gs_renderer_set_deleted_bits(gs_renderer* r, const uint32_t* words, size
     return GS_OK;
 }
 
+int32_t gs_renderer_set_view_buffer_mode(gs_renderer* r, int32_t every_frame) {
+    if (!r) return fail(GS_ERR_INVALID_ARGUMENT, "renderer is null");
+    r->alwaysWriteView = every_frame != 0;
+    return GS_OK;
+}
+
 int32_t gs_renderer_set_blend_mode(gs_renderer* r, int32_t mode) {
     if (!r || (mode != 0 && mode != 1)) return fail(GS_ERR_INVALID_ARGUMENT, "blend mode must be 0 or 1");
     r->blendMode = mode;
@@ -448,6 +456,15 @@ int32_t gs_renderer_upload_order(gs_renderer* r, const uint32_t* in, size_t coun
 }
 int32_t gs_renderer_download_view(gs_renderer* r, void* out, size_t bytes) {
     if (!r || !out || bytes > (size_t)r->n * sizeof(gsm::ViewData)) return fail(GS_ERR_INVALID_ARGUMENT, "bad argument");
+    if (r->viewValid && !r->viewMaterialised) {
+        // m_GpuView is materialised on demand: the per-frame launch skips it (nothing in this renderer reads it); re-run the
+        // frame's launch as the reference's full kernel.  rec/rect/visibility are rewritten with identical values.
+        GS_TRY(bind_device(r->ctx));
+        gsm::EditView e;
+        e.deletedBits = r->deletedBits; e.cutouts = r->cutouts; e.cutoutCount = r->cutoutCount;
+        GS_TRY(enqueue_calc_view(r->ctx, r->asset->view, &r->lastParams, e, r->view, r->recs, r->rects, r->visMask, true));
+        r->viewMaterialised = true;
+    }
     return download(r->ctx, out, r->view, bytes);
 }
 

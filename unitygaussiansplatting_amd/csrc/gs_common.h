@@ -127,7 +127,7 @@ struct gs_renderer {
     gs::SortControl* depthControl = nullptr;
     // compositor buffers
     gs::SplatRec* recs = nullptr;           // N x 32 B, indexed by splat (written by calc_view)
-    uint2* rects = nullptr;                 // N x 8 B: x = tx0 | ty0 << 16, y = tiles wide / high (+ tile mask), see rect_count() (0 = culled)
+    uint2* rects = nullptr;                 // N x 8 B: x = tx0 | ty0 << 16, y = tiles wide | tiles high << 16 (0 = culled)
     unsigned long long* visMask = nullptr;  // ceil(N/64) x 8 B: bit s = splat s reaches at least one tile (written by calc_view)
     // edit state read by calc_view (m_GpuEditDeleted / m_GpuEditCutouts, GaussianSplatRenderer.cs:266,269)
     uint32_t* deletedBits = nullptr;        // ceil(N/32) words, or null (_SplatBitsValid = 0)
@@ -139,6 +139,9 @@ struct gs_renderer {
     bool cutoutsCopyPending = false;
     float viewW = 0.f, viewH = 0.f, viewNear = 0.f, viewFar = 0.f;   // what the last calc_view was run with
     bool viewValid = false;
+    bool viewMaterialised = false;          // the N x 40 B view buffer holds the last calc_view's records (written on demand)
+    bool alwaysWriteView = false;           // gs_renderer_set_view_buffer_mode(1): write it every frame like the reference
+    gs_frame_params lastParams;             // of the last gs_renderer_calc_view (for the on-demand FULL launch)
     uint32_t* pairKeys = nullptr;           // tile ids
     uint32_t* pairVals = nullptr;           // sorted positions
     gs::SortState pairSort;
@@ -186,7 +189,7 @@ int32_t enqueue_sort_passes(gs_context* ctx, hipStream_t stream, SortState& st, 
 int32_t enqueue_set_indices(gs_context* ctx, uint32_t* order, uint32_t n);
 // view (gs_view.hip)
 int32_t enqueue_calc_view(gs_context* ctx, const gsm::AssetView& a, const gs_frame_params* p, const gsm::EditView& e, gsm::ViewData* out,
-                          SplatRec* recs, uint2* rects, unsigned long long* visMask);
+                          SplatRec* recs, uint2* rects, unsigned long long* visMask, bool full);
 void flatten_params(const gs_frame_params* p, gsm::FrameConsts& c);
 // raster (gs_raster.hip)
 int32_t renderer_alloc_raster(gs_renderer* r);

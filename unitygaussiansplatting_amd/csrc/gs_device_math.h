@@ -270,15 +270,28 @@ GS_HD bool IsSplatCut(const EditView& e, float px, float py, float pz) {
     return finalCut;
 }
 
-// CSCalcViewData for one splat (SplatUtilities.compute:189-252).
-// SH coefficients are consumed in order sh1..sh15 by three fmaf chains (degree 1, 2, 3), so they are decoded
-// one at a time instead of being held in 45 registers.
-template <class SHSource>
-GS_HD ViewData CalcViewDataT(const AssetView& a, const FrameConsts& P, const EditView& E, uint32_t idx, SHSource& shsrc) {
-    ViewData view;
+// CSCalcViewData for one splat (SplatUtilities.compute:189-252), in two halves so that a caller which only needs the
+// splats that reach the screen can stop after the geometry:
+//   CalcViewGeom   LoadSplatData minus SH, clip position, deleted bit / cutouts, 3D -> 2D covariance, axes, opacity
+//   CalcViewColor  view direction, ShadeSH, colour packing
+// CalcViewDataT = both, i.e. the reference's kernel; the arithmetic is the same whichever way it is called.
+struct ViewPartial {
+    ViewData view;              // pos, axis1/2 final after CalcViewGeom; color[1] low half = f16 opacity
+    V4 col;                     // de-normalised colour (col.w = opacity before _SplatOpacityScale)
+    V3 shMin, shMax;
+    float wx, wy, wz;           // centerWorldPos
+    uint64_t otherEnd;          // byte address one past the splat's `other` record (the u16 SH index sits just before it)
+    bool shLerp;
+    bool front;                 // clip.w > 0 after deletion / cutouts: the rest of the record is meaningful
+};
+
+GS_HD void CalcViewGeom(const AssetView& a, const FrameConsts& P, const EditView& E, uint32_t idx, ViewPartial& vp) {
+    ViewData& view = vp.view;
     view.pos[0] = view.pos[1] = view.pos[2] = view.pos[3] = 0.0f;
     view.axis1[0] = view.axis1[1] = view.axis2[0] = view.axis2[1] = 0.0f;
     view.color[0] = view.color[1] = 0u;
+    vp.front = false; vp.shLerp = false; vp.otherEnd = 0u;
+    vp.shMin = { 0, 0, 0 }; vp.shMax = { 0, 0, 0 }; vp.col = { 0, 0, 0, 0 };
 
     // ---- LoadSplatData: position first (needed for the early out)
     V3 pos = LoadVec(a.pos, (uint64_t)idx * vecStride(a.posFmt), a.posFmt);
@@ -292,6 +305,7 @@ GS_HD ViewData CalcViewDataT(const AssetView& a, const FrameConsts& P, const Edi
         pos.z = lerpf(u2f(ck.w[8]), u2f(ck.w[9]), pos.z);
     }
     const float wx = mrow(P.o2w, 0, pos.x, pos.y, pos.z), wy = mrow(P.o2w, 1, pos.x, pos.y, pos.z), wz = mrow(P.o2w, 2, pos.x, pos.y, pos.z);
+    vp.wx = wx; vp.wy = wy; vp.wz = wz;
     view.pos[0] = mrow(P.vp, 0, wx, wy, wz);
     view.pos[1] = mrow(P.vp, 1, wx, wy, wz);
     view.pos[2] = mrow(P.vp, 2, wx, wy, wz);
@@ -301,12 +315,14 @@ GS_HD ViewData CalcViewDataT(const AssetView& a, const FrameConsts& P, const Edi
     if (E.deletedBits && ((E.deletedBits[idx >> 5] >> (idx & 31u)) & 1u)) view.pos[3] = 0.0f;
     if (E.cutoutCount && IsSplatCut(E, pos.x, pos.y, pos.z)) view.pos[3] = 0.0f;
 #endif
-    if (!(view.pos[3] > 0.0f)) return view;                       // behindCam
+    if (!(view.pos[3] > 0.0f)) return;                            // behindCam
+    vp.front = true;
 
     // ---- rotation / scale
     uint32_t otherStride = 4 + vecStride(a.scaleFmt);
     if (a.shFmt > 3) otherStride += 2;
     const uint64_t otherAddr = (uint64_t)idx * otherStride;
+    vp.otherEnd = otherAddr + otherStride;
     const V4 q = DecodeRotation(LoadUInt(a.other, otherAddr));
     V3 scale = LoadVec(a.other, otherAddr + 4, a.scaleFmt);
 
@@ -326,8 +342,6 @@ GS_HD ViewData CalcViewDataT(const AssetView& a, const FrameConsts& P, const Edi
         col = { (float)(e & 255) * GS_R255, (float)((e >> 8) & 255) * GS_R255, (float)((e >> 16) & 255) * GS_R255, (float)(e >> 24) * GS_R255 };
     }
 
-    V3 shMin = { 0, 0, 0 }, shMax = { 0, 0, 0 };
-    bool shLerp = false;
     if (chunked) {
         scale.x = lerpf(f16tof32(ck.w[10]), f16tof32(ck.w[10] >> 16), scale.x);
         scale.y = lerpf(f16tof32(ck.w[11]), f16tof32(ck.w[11] >> 16), scale.y);
@@ -340,10 +354,11 @@ GS_HD ViewData CalcViewDataT(const AssetView& a, const FrameConsts& P, const Edi
         col.z = lerpf(f16tof32(ck.w[2]), f16tof32(ck.w[2] >> 16), col.z);
         col.w = lerpf(f16tof32(ck.w[3]), f16tof32(ck.w[3] >> 16), col.w);
         col.w = InvSquareCentered01(col.w);
-        shMin = { f16tof32(ck.w[13]), f16tof32(ck.w[14]), f16tof32(ck.w[15]) };
-        shMax = { f16tof32(ck.w[13] >> 16), f16tof32(ck.w[14] >> 16), f16tof32(ck.w[15] >> 16) };
-        shLerp = a.shFmt > 0 && a.shFmt <= 3;
+        vp.shMin = { f16tof32(ck.w[13]), f16tof32(ck.w[14]), f16tof32(ck.w[15]) };
+        vp.shMax = { f16tof32(ck.w[13] >> 16), f16tof32(ck.w[14] >> 16), f16tof32(ck.w[15] >> 16) };
+        vp.shLerp = a.shFmt > 0 && a.shFmt <= 3;
     }
+    vp.col = col;
 
     // ---- CalcMatrixFromRotationScale + CalcCovariance3D
     const float x = q.x, y = q.y, z = q.z, w = q.w;
@@ -394,6 +409,20 @@ GS_HD ViewData CalcViewDataT(const AssetView& a, const FrameConsts& P, const Edi
     view.axis1[0] = s1 * dvx; view.axis1[1] = s1 * dvy;
     view.axis2[0] = s2 * dvy; view.axis2[1] = s2 * (-dvx);
 
+    // ---- opacity (the colour's alpha half; rgb is added by CalcViewColor)
+    const float al = fminf(col.w * P.opacityScale, 65000.0f);
+    view.color[1] = f32tof16(al);
+}
+
+// SH coefficients are consumed in order sh1..sh15 by three fmaf chains (degree 1, 2, 3), so they are decoded
+// one at a time instead of being held in 45 registers.
+template <class SHSource>
+GS_HD void CalcViewColor(const AssetView& a, const FrameConsts& P, uint32_t idx, ViewPartial& vp, SHSource& shsrc) {
+    ViewData& view = vp.view;
+    const V4 col = vp.col;
+    const V3 shMin = vp.shMin, shMax = vp.shMax;
+    const bool shLerp = vp.shLerp;
+    const float wx = vp.wx, wy = vp.wy, wz = vp.wz;
     // ---- view direction in object space, SH basis
     const float dwx = P.camx - wx, dwy = P.camy - wy, dwz = P.camz - wz;
     float ox = mrow3(P.w2o, 0, dwx, dwy, dwz), oy = mrow3(P.w2o, 1, dwx, dwy, dwz), oz = mrow3(P.w2o, 2, dwx, dwy, dwz);
@@ -405,7 +434,7 @@ GS_HD ViewData CalcViewDataT(const AssetView& a, const FrameConsts& P, const Edi
     float r = onlySH ? 0.5f : col.x, g = onlySH ? 0.5f : col.y, b = onlySH ? 0.5f : col.z;
     if (P.shOrder >= 1) {
         uint32_t shIndex = idx;
-        if (a.shFmt > 3) shIndex = LoadUShort(a.other, otherAddr + otherStride - 2);
+        if (a.shFmt > 3) shIndex = LoadUShort(a.other, vp.otherEnd - 2);
         shsrc.begin(a.sh + (uint64_t)shIndex * shStrideOf(a.shFmt), a.shFmt);
         auto SHK = [&](int k) -> V3 {
             V3 s = shsrc.load(k);
@@ -454,10 +483,16 @@ GS_HD ViewData CalcViewDataT(const AssetView& a, const FrameConsts& P, const Edi
         }
     }
     r = fmaxf(r, 0.0f); g = fmaxf(g, 0.0f); b = fmaxf(b, 0.0f);
-    const float al = fminf(col.w * P.opacityScale, 65000.0f);
     view.color[0] = (f32tof16(r) << 16) | f32tof16(g);
-    view.color[1] = (f32tof16(b) << 16) | f32tof16(al);
-    return view;
+    view.color[1] = (f32tof16(b) << 16) | (view.color[1] & 0xffffu);
+}
+
+template <class SHSource>
+GS_HD ViewData CalcViewDataT(const AssetView& a, const FrameConsts& P, const EditView& E, uint32_t idx, SHSource& shsrc) {
+    ViewPartial vp;
+    CalcViewGeom(a, P, E, idx, vp);
+    if (vp.front) CalcViewColor(a, P, idx, vp, shsrc);
+    return vp.view;
 }
 
 GS_HD ViewData CalcViewData(const AssetView& a, const FrameConsts& P, const EditView& E, uint32_t idx) {
@@ -503,29 +538,13 @@ GS_HD bool BlockMayTouch(float bcx, float bcy, float half, float cx, float cy, f
     return (m1 <= 2.001f) && (m2 <= 2.001f) && (fmaf(m2, m2, m1 * m1) <= r2);
 }
 
-constexpr int kMaskTiles = 16;  // footprints of at most this many tiles carry a per-tile bit mask
-
 struct SplatFootprint {
     float cx, cy;               // centre in pixels, y down
     int tx0, tx1, ty0, ty1;     // inclusive tile rect (tx0 > tx1: nothing to draw)
-    uint32_t mask;              // rects of 2..kMaskTiles tiles: bit (ty - ty0) * w + (tx - tx0) = the tile can receive a fragment
-    bool masked;
 };
 
-GS_HD uint32_t FootprintTileCount(const SplatFootprint& fp) {
-    if (fp.tx0 > fp.tx1) return 0u;
-    if (fp.masked) {
-#if defined(__HIP_DEVICE_COMPILE__)
-        return (uint32_t)__popc(fp.mask);
-#else
-        return (uint32_t)__builtin_popcount(fp.mask);
-#endif
-    }
-    return (uint32_t)(fp.tx1 - fp.tx0 + 1) * (uint32_t)(fp.ty1 - fp.ty0 + 1);
-}
-
 GS_HD bool PrepareSplat(const ViewData& v, float W, float H, float nearClip, float farClip, SplatFootprint& fp) {
-    fp.tx0 = 1; fp.tx1 = 0; fp.ty0 = 1; fp.ty1 = 0; fp.cx = 0.0f; fp.cy = 0.0f; fp.mask = 0u; fp.masked = false;
+    fp.tx0 = 1; fp.tx1 = 0; fp.ty0 = 1; fp.ty1 = 0; fp.cx = 0.0f; fp.cy = 0.0f;
     const float w = v.pos[3];
     if (!(w > 0.0f)) return false;
     if (!(w >= nearClip && w <= farClip)) return false;
@@ -552,23 +571,6 @@ GS_HD bool PrepareSplat(const ViewData& v, float W, float H, float nearClip, flo
     PixRange(fp.cy, fminf(eyr, eye) + slack, H, y0, y1);
     if (x0 > x1 || y0 > y1) return true;         // drawn by the reference, but every fragment is below 1/255
     fp.tx0 = x0 >> 4; fp.tx1 = x1 >> 4; fp.ty0 = y0 >> 4; fp.ty1 = y1 >> 4;
-    // small footprints (the bulk): drop the tiles of the rectangle that the oriented footprint cannot reach
-    const int tw = fp.tx1 - fp.tx0 + 1, th = fp.ty1 - fp.ty0 + 1;
-#ifdef GS_EXP_NO_TILE_MASK          // timing experiment only
-    if (false) {
-#else
-    if (tw * th >= 2 && tw * th <= kMaskTiles) {
-#endif
-        const float u1x = a1x * inv1, u1y = a1y * inv1, u2x = a2x * inv2, u2y = a2y * inv2;
-        uint32_t m = 0u;
-        for (int ty = 0; ty < th; ++ty)
-            for (int tx = 0; tx < tw; ++tx) {
-                const float bcx = (float)((fp.tx0 + tx) * 16 + 8), bcy = (float)((fp.ty0 + ty) * 16 + 8);
-                if (BlockMayTouch(bcx, bcy, 7.5f, fp.cx, fp.cy, u1x, u1y, u2x, u2y, r2)) m |= 1u << (ty * tw + tx);
-            }
-        fp.mask = m; fp.masked = true;
-        if (m == 0u) { fp.tx0 = 1; fp.tx1 = 0; fp.ty0 = 1; fp.ty1 = 0; fp.masked = false; }
-    }
     return true;
 }
 

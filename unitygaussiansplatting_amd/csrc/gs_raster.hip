@@ -61,22 +61,6 @@ __device__ __forceinline__ void hist_add_aggregated(uint32_t* h, uint32_t d, boo
     if (active) atomicAdd(&h[d], 1u);                      // many distinct values left: plain per-lane adds
 }
 
-// rect.y as written by calc_view: bit 15 set => masked footprint: tiles wide (5 bits) | tiles high << 5 | 1 << 15 | mask << 16,
-// else tiles wide (15 bits) | tiles high << 16.  0 = culled.
-__device__ __forceinline__ uint32_t rect_count(uint32_t y) {
-    return (y & 0x8000u) ? (uint32_t)__popc(y >> 16) : (y & 0x7fffu) * (y >> 16);
-}
-__device__ __forceinline__ uint32_t nth_set_bit16(uint32_t m, uint32_t o) {      // position of the o-th (0-based) set bit of m
-    uint32_t pos = 0, c = (uint32_t)__popc(m & 0xffu);
-    if (o >= c) { o -= c; pos = 8; m >>= 8; }
-    c = (uint32_t)__popc(m & 0xfu);
-    if (o >= c) { o -= c; pos += 4; m >>= 4; }
-    c = (uint32_t)__popc(m & 3u);
-    if (o >= c) { o -= c; pos += 2; m >>= 2; }
-    if (o >= (m & 1u)) pos += 1;
-    return pos;
-}
-
 __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += (uint32_t)__shfl_xor((int)v, o, 64);
@@ -133,7 +117,7 @@ __global__ __launch_bounds__(kBinThreads) void bin_emit_kernel(const uint2* __re
     for (int k = 0; k < kBinItems; ++k) {
         rc[k] = make_uint2(0u, 0u);
         if ((visw[k] >> (sid[k] & 31u)) & 1u) rc[k] = rects[sid[k]];
-        const uint32_t c = rect_count(rc[k].y);
+        const uint32_t c = (rc[k].y & 0xffffu) * (rc[k].y >> 16);
         mySum += c;
         myVis += c ? 1u : 0u;
     }
@@ -203,7 +187,7 @@ __global__ __launch_bounds__(kBinThreads) void bin_emit_kernel(const uint2* __re
 #pragma unroll
         for (int kk = 0; kk < SUB; ++kk) {
             const int k = sb * SUB + kk;
-            const uint32_t c = rect_count(rc[k].y);
+            const uint32_t c = (rc[k].y & 0xffffu) * (rc[k].y >> 16);
             const uint32_t incl = wave_incl_scan_u32(c, lane);
             offs[kk * 64 + lane] = run + incl - c;
             sids[kk * 64 + lane] = sid[k];
@@ -218,12 +202,10 @@ __global__ __launch_bounds__(kBinThreads) void bin_emit_kernel(const uint2* __re
 #pragma unroll
             for (uint32_t step = (SUB * 64) / 2; step > 0; step >>= 1)
                 if (offs[e + step] <= j) e += step;
-            uint32_t o = j - offs[e];
+            const uint32_t o = j - offs[e];
             const uint2 r = rcts[e];
             const uint32_t s = sids[e];
-            const bool masked = (r.y & 0x8000u) != 0;
-            const uint32_t tw = max(masked ? (r.y & 31u) : (r.y & 0x7fffu), 1u);
-            if (masked) o = nth_set_bit16(r.y >> 16, o);          // o-th tile of the footprint -> its index in the rectangle
+            const uint32_t tw = max(r.y & 0xffffu, 1u);
             const uint32_t ty = o / tw, tx = o - ty * tw;
             const uint32_t tile = ((r.x >> 16) + ty) * tilesX + (r.x & 0xffffu) + tx;
             const unsigned long long gi = gbase + (unsigned long long)j;

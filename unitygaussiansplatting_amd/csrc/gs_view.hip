@@ -7,7 +7,7 @@
 // global stores are whole, coalesced uint4s:
 //   view[s]  40 B  the reference's SplatViewData (m_GpuView; parity surface)
 //   rec[s]   32 B  centre in pixels + the two axes + rgba16f: what the blend kernel reads per (tile, splat) pair
-//   rect[s]   8 B  inclusive 16x16-tile rectangle of the splat's footprint (+ a per-tile bit mask when it spans <= 16 tiles), or 0 if culled
+//   rect[s]   8 B  inclusive 16x16-tile rectangle of the splat's footprint, or 0 if it is culled
 // Writing rec/rect here (where everything is in registers) means the binning kernel only gathers 8 B per sorted
 // position instead of the 40-B view record, and never writes records itself.
 #include "gs_common.h"
@@ -39,9 +39,15 @@ constexpr int cmax(int a, int b) { return a > b ? a : b; }
 // SH is two thirds of the bytes this kernel reads (32 of 48.25 B per splat at Medium, 192 of 236 at VeryHigh), laid out
 // as one record per splat.  Read record-per-lane it is 15 narrow loads at a 32..192-byte lane stride, each touching 16-64
 // cache lines for 4 bytes apiece and relying on L1 to keep ~2-12 KB per wave alive in between.  Instead the workgroup
-// copies its 256 contiguous records (8-48 KB) with lane-contiguous 16-byte loads issued FIRST (they are in flight while
-// the positions are projected), parks them in LDS and decodes from there.
-template <int SHMODE>
+// copies its 256 contiguous records (8-48 KB) with lane-contiguous 16-byte loads, parks them in LDS and decodes from there.
+//
+// FULL = true is the reference's kernel: every splat in front of the camera gets its colour and the N x 40 B view buffer
+// (m_GpuView) is written.  Nothing in this renderer reads that buffer -- the compositor consumes rec/rect -- so the
+// per-frame launch is FULL = false: geometry for every splat, then SH + colour ONLY for the splats whose footprint
+// reaches a tile (a third of the scene for C2; culling is spatially coherent and the asset is in Morton order, so whole
+// waves and whole workgroups drop out), and no view write.  gs_renderer_download_view re-runs the frame's launch with
+// FULL = true on demand, so the parity surface is unchanged.  VALU-bound either way (~1200 instructions per splat FULL).
+template <int SHMODE, bool FULL>
 __global__ __launch_bounds__(256) void calc_view_kernel(gsm::AssetView a, gsm::FrameConsts P, gsm::EditView E, gsm::ViewData* __restrict__ out,
                                                         SplatRec* __restrict__ recs, uint2* __restrict__ rects,
                                                         unsigned long long* __restrict__ visMask) {
@@ -49,18 +55,19 @@ __global__ __launch_bounds__(256) void calc_view_kernel(gsm::AssetView a, gsm::F
     constexpr int STRIDE = REC | 1;                                    // odd LDS stride
     constexpr int SH_DW = SHMODE < 4 ? 256 * STRIDE : 0;
     constexpr int NVEC = (REC * 256 / 4 + 255) / 256;                  // 16-byte vectors per thread
-    __shared__ uint4 s_stage[cmax(SH_DW, 256 * 10) / 4 + 1];
+    __shared__ uint4 s_stage[cmax(SH_DW, FULL ? 256 * 10 : 4) / 4 + 1];
+    __shared__ int s_any;
     uint32_t* s_dw = (uint32_t*)s_stage;
     const uint32_t base = blockIdx.x * 256u;
     const uint32_t idx = base + threadIdx.x;
     const uint32_t cnt = min(256u, a.n - base);
-
-    // ---- issue the SH copy: cnt*REC dwords from a 16-byte aligned address (256*REC*4 bytes per workgroup)
-    uint4 shv[SHMODE < 4 ? NVEC : 1];
     const uint32_t totalDw = cnt * (uint32_t)REC, totalVec = totalDw >> 2;
     const uint32_t* shSrc = (const uint32_t*)(a.sh + (size_t)base * (REC * 4));
+
+    // copy cnt*REC dwords from a 16-byte aligned address (256*REC*4 bytes per workgroup) into LDS: record r, dword o -> r*STRIDE + o
+    uint4 shv[SHMODE < 4 ? NVEC : 1];
     uint32_t shTail = 0;
-    if (SHMODE < 4) {
+    auto sh_issue = [&]() {
 #pragma unroll
         for (int it = 0; it < NVEC; ++it) {
             const uint32_t j = (uint32_t)it * 256u + threadIdx.x;
@@ -68,9 +75,8 @@ __global__ __launch_bounds__(256) void calc_view_kernel(gsm::AssetView a, gsm::F
             if (j < totalVec) shv[it] = ((const uint4*)shSrc)[j];
         }
         if ((totalDw & 3u) && threadIdx.x < (totalDw & 3u)) shTail = shSrc[(totalVec << 2) + threadIdx.x];
-    }
-    // ---- park it in LDS (record r, dword o  ->  r*STRIDE + o)
-    if (SHMODE < 4) {
+    };
+    auto sh_park = [&]() {
 #pragma unroll
         for (int it = 0; it < NVEC; ++it) {
             const uint32_t j = (uint32_t)it * 256u + threadIdx.x;
@@ -88,40 +94,68 @@ __global__ __launch_bounds__(256) void calc_view_kernel(gsm::AssetView a, gsm::F
             }
         }
         if ((totalDw & 3u) && threadIdx.x < (totalDw & 3u)) { const uint32_t dd = (totalVec << 2) + threadIdx.x, r = dd / (uint32_t)REC; s_dw[r * STRIDE + (dd - r * (uint32_t)REC)] = shTail; }
-        __syncthreads();
-    }
-
-    gsm::ViewData v;
-    gsm::SplatFootprint fp;
-    uint2 rect = make_uint2(0u, 0u);
-    bool visible = false;
-    if (idx < a.n) {
+    };
+    auto shade = [&](gsm::ViewPartial& vp) {
         if (SHMODE < 4) {
             SHFromLds<SHMODE < 4 ? SHMODE : 3> src;
             src.rec = s_dw + threadIdx.x * STRIDE;
-            v = gsm::CalcViewDataT(a, P, E, idx, src);
+            gsm::CalcViewColor(a, P, idx, vp, src);
         } else {
             gsm::SHFromBlob src;
-            v = gsm::CalcViewDataT(a, P, E, idx, src);
+            gsm::CalcViewColor(a, P, idx, vp, src);
         }
-        const bool ok = gsm::PrepareSplat(v, P.screenW, P.screenH, P.nearClip, P.farClip, fp);
-        if (ok && fp.tx0 <= fp.tx1) {
-            const uint32_t tw = (uint32_t)(fp.tx1 - fp.tx0 + 1), th = (uint32_t)(fp.ty1 - fp.ty0 + 1);
+    };
+
+    gsm::ViewPartial vp;
+    gsm::SplatFootprint fp;
+    uint2 rect = make_uint2(0u, 0u);
+    bool visible = false;
+    const bool shStaged = SHMODE < 4;
+
+    if (FULL) {
+        // the loads are in flight while the positions are projected
+        if (shStaged) { sh_issue(); sh_park(); __syncthreads(); }
+        if (idx < a.n) {
+            gsm::CalcViewGeom(a, P, E, idx, vp);
+            if (vp.front) shade(vp);
+            const bool ok = gsm::PrepareSplat(vp.view, P.screenW, P.screenH, P.nearClip, P.farClip, fp);
+            visible = ok && fp.tx0 <= fp.tx1;
+        }
+    } else {
+        if (threadIdx.x == 0) s_any = 0;
+        if (idx < a.n) {
+            gsm::CalcViewGeom(a, P, E, idx, vp);
+            const bool ok = vp.front && gsm::PrepareSplat(vp.view, P.screenW, P.screenH, P.nearClip, P.farClip, fp);
+            visible = ok && fp.tx0 <= fp.tx1;
+        }
+        __syncthreads();
+        if (__any(visible) && (threadIdx.x & 63u) == 0u) s_any = 1;          // benign race: every writer stores 1
+        __syncthreads();
+        if (s_any) {                                                          // workgroup-uniform
+            if (shStaged) { sh_issue(); sh_park(); __syncthreads(); }
+            if (visible) shade(vp);
+        }
+    }
+
+    if (idx < a.n) {
+        if (visible) {
             rect.x = (uint32_t)fp.tx0 | ((uint32_t)fp.ty0 << 16);
-            rect.y = fp.masked ? (tw | (th << 5) | 0x8000u | (fp.mask << 16)) : (tw | (th << 16));     // decoded by bin_emit (rect_count)
-            visible = true;
+            rect.y = (uint32_t)(fp.tx1 - fp.tx0 + 1) | ((uint32_t)(fp.ty1 - fp.ty0 + 1) << 16);
+            // the blend kernel only ever reads records of splats that reach a tile
+            uint4* rp = (uint4*)(recs + idx);
+            rp[0] = make_uint4(gsm::f2u(fp.cx), gsm::f2u(fp.cy), gsm::f2u(vp.view.axis1[0]), gsm::f2u(vp.view.axis1[1]));
+            rp[1] = make_uint4(gsm::f2u(vp.view.axis2[0]), gsm::f2u(vp.view.axis2[1]), vp.view.color[0], vp.view.color[1]);
         }
         rects[idx] = rect;
-        if (visible) {      // the blend kernel only ever reads records of splats that reach a tile
-            uint4* rp = (uint4*)(recs + idx);
-            rp[0] = make_uint4(gsm::f2u(fp.cx), gsm::f2u(fp.cy), gsm::f2u(v.axis1[0]), gsm::f2u(v.axis1[1]));
-            rp[1] = make_uint4(gsm::f2u(v.axis2[0]), gsm::f2u(v.axis2[1]), v.color[0], v.color[1]);
-        }
     }
     const unsigned long long vb = __ballot(visible);
     if ((threadIdx.x & 63u) == 0u && (idx < a.n)) visMask[idx >> 6] = vb;          // 1 bit per splat: the binning pass tests it first
-    if (SHMODE < 4) __syncthreads();                                                 // every thread is done with the SH records
+    if (!FULL) return;
+
+    // ---- FULL: the 40-byte records, staged through LDS so that the global stores are whole uint4s
+    if (shStaged) __syncthreads();                                                   // every thread is done with the SH records
     if (idx < a.n) {
+        const gsm::ViewData& v = vp.view;
         uint32_t* o = s_dw + threadIdx.x * 10;
         o[0] = gsm::f2u(v.pos[0]); o[1] = gsm::f2u(v.pos[1]); o[2] = gsm::f2u(v.pos[2]); o[3] = gsm::f2u(v.pos[3]);
         o[4] = gsm::f2u(v.axis1[0]); o[5] = gsm::f2u(v.axis1[1]); o[6] = gsm::f2u(v.axis2[0]); o[7] = gsm::f2u(v.axis2[1]);
@@ -151,21 +185,29 @@ void flatten_params(const gs_frame_params* p, gsm::FrameConsts& c) {
     c.nearClip = p->near_clip; c.farClip = p->far_clip;
 }
 
+template <bool FULL>
+static void launch_calc_view(int mode, uint32_t grid, hipStream_t st, const gsm::AssetView& a, const gsm::FrameConsts& c, const gsm::EditView& e,
+                             gsm::ViewData* out, SplatRec* recs, uint2* rects, unsigned long long* visMask) {
+    switch (mode) {
+        case 0: hipLaunchKernelGGL((calc_view_kernel<0, FULL>), dim3(grid), dim3(256), 0, st, a, c, e, out, recs, rects, visMask); break;
+        case 1: hipLaunchKernelGGL((calc_view_kernel<1, FULL>), dim3(grid), dim3(256), 0, st, a, c, e, out, recs, rects, visMask); break;
+        case 2: hipLaunchKernelGGL((calc_view_kernel<2, FULL>), dim3(grid), dim3(256), 0, st, a, c, e, out, recs, rects, visMask); break;
+        case 3: hipLaunchKernelGGL((calc_view_kernel<3, FULL>), dim3(grid), dim3(256), 0, st, a, c, e, out, recs, rects, visMask); break;
+        default: hipLaunchKernelGGL((calc_view_kernel<4, FULL>), dim3(grid), dim3(256), 0, st, a, c, e, out, recs, rects, visMask); break;
+    }
+}
+
+// full = true: also evaluate the colour of every splat in front of the camera and write the N x 40 B view buffer
 int32_t enqueue_calc_view(gs_context* ctx, const gsm::AssetView& a, const gs_frame_params* p, const gsm::EditView& e, gsm::ViewData* out,
-                          SplatRec* recs, uint2* rects, unsigned long long* visMask) {
+                          SplatRec* recs, uint2* rects, unsigned long long* visMask, bool full) {
     gsm::FrameConsts c;
     flatten_params(p, c);
     const uint32_t grid = (a.n + 255u) / 256u;
     // per-splat SH records are staged through LDS (needs the blob 16-byte aligned, which hipMalloc and torch guarantee);
     // Cluster* tables, an unaligned borrowed blob, or SH switched off read straight from the blob
-    int mode = (a.shFmt <= 3 && (((uintptr_t)a.sh) & 15u) == 0 && p->sh_order >= 1) ? (int)a.shFmt : 4;
-    switch (mode) {
-        case 0: hipLaunchKernelGGL(calc_view_kernel<0>, dim3(grid), dim3(256), 0, ctx->stream, a, c, e, out, recs, rects, visMask); break;
-        case 1: hipLaunchKernelGGL(calc_view_kernel<1>, dim3(grid), dim3(256), 0, ctx->stream, a, c, e, out, recs, rects, visMask); break;
-        case 2: hipLaunchKernelGGL(calc_view_kernel<2>, dim3(grid), dim3(256), 0, ctx->stream, a, c, e, out, recs, rects, visMask); break;
-        case 3: hipLaunchKernelGGL(calc_view_kernel<3>, dim3(grid), dim3(256), 0, ctx->stream, a, c, e, out, recs, rects, visMask); break;
-        default: hipLaunchKernelGGL(calc_view_kernel<4>, dim3(grid), dim3(256), 0, ctx->stream, a, c, e, out, recs, rects, visMask); break;
-    }
+    const int mode = (a.shFmt <= 3 && (((uintptr_t)a.sh) & 15u) == 0 && p->sh_order >= 1) ? (int)a.shFmt : 4;
+    if (full) launch_calc_view<true>(mode, grid, ctx->stream, a, c, e, out, recs, rects, visMask);
+    else launch_calc_view<false>(mode, grid, ctx->stream, a, c, e, out, recs, rects, visMask);
     GS_HIP(hipGetLastError());
     return GS_OK;
 }

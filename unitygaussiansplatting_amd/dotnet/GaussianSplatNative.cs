@@ -76,6 +76,7 @@ namespace GaussianSplatting.Runtime
         public unsafe struct Cutout { public fixed float matrix[16]; public uint typeAndFlags; }
         [DllImport(Lib)] public static extern int gs_renderer_set_cutouts(IntPtr renderer, Cutout[] cutouts, uint count);
         [DllImport(Lib)] public static extern int gs_renderer_set_deleted_bits(IntPtr renderer, uint[] words, UIntPtr wordCount);
+        [DllImport(Lib)] public static extern int gs_renderer_set_view_buffer_mode(IntPtr renderer, int everyFrame);
         [DllImport(Lib)] public static extern int gs_renderer_set_blend_mode(IntPtr renderer, int mode);
         [DllImport(Lib)] public static extern int gs_renderer_set_profiling(IntPtr renderer, int frames);
         [DllImport(Lib)] public static extern int gs_renderer_reserve_pairs(IntPtr renderer, ulong pairCapacity);

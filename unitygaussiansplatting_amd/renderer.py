@@ -289,6 +289,11 @@ class GaussianSplatRenderer:
         check(_lib.lib().gs_renderer_draw(self._r_h, C.byref(p), rt._h), "gs_renderer_draw")
 
     # -- parity / measurement hooks ---------------------------------------------------------------------------
+    def SetViewBufferMode(self, every_frame: bool) -> None:
+        """True: run the reference's full CSCalcViewData every frame (m_GpuView written); False (default): colours only for
+        splats that reach the screen, m_GpuView materialised by DownloadView on demand."""
+        check(_lib.lib().gs_renderer_set_view_buffer_mode(self._r_h, int(bool(every_frame))), "gs_renderer_set_view_buffer_mode")
+
     def SetProfiling(self, frames: int) -> None:
         """frames = 0 off; > 0: ring of per-frame hipEvent sets, averaged by StageTimes()."""
         check(_lib.lib().gs_renderer_set_profiling(self._r_h, int(frames)), "gs_renderer_set_profiling")
