@@ -51,6 +51,8 @@ struct SortState {
     uint32_t* altKeys = nullptr;
     uint32_t* altVals = nullptr;
     unsigned long long* status = nullptr;   // maxParts x 256 words {epoch:30 | flag:2 | value:32}
+    unsigned long long* groupAgg = nullptr; // 4 passes x maxGroups x 256 words {members:24 | sum:40}, zeroed per sort
+    uint32_t maxGroups = 0;
     uint32_t maxCount = 0;
     uint32_t maxParts = 0;
     uint32_t epoch = 0;                     // last epoch used on `status` (30 bits, never 0)
@@ -59,7 +61,7 @@ struct SortState {
 // small per-sort control block (zeroed by one memset before each sort)
 struct SortControl {
     uint32_t hist[4 * 256];       // digit histograms, then exclusive offsets
-    uint32_t tickets[4];          // partition tickets, one per pass
+    uint32_t tickets[4][16 * 32]; // partition tickets: per pass, 16 counters (ticket classes) in separate 128-B lines
     uint32_t error;               // != 0: bounded spin expired
     uint32_t pad[3];
 };

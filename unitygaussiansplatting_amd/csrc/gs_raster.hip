@@ -75,8 +75,11 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
 // are produced 64 consecutive output slots at a time, each lane finding its source position by a binary search over
 // the 256 exclusive offsets in LDS -- global stores of pairs are therefore fully coalesced whatever the footprints
 // are (a splat covering the whole screen is just a long run), and no lane idles behind a neighbour's big splat.
+#ifndef GS_BIN_MINWAVES
+#define GS_BIN_MINWAVES 1
+#endif
 template <int PASSES>
-__global__ __launch_bounds__(kBinThreads) void bin_emit_kernel(const uint2* __restrict__ rects, const uint32_t* __restrict__ visMask32,
+__global__ __launch_bounds__(kBinThreads, GS_BIN_MINWAVES) void bin_emit_kernel(const uint2* __restrict__ rects, const uint32_t* __restrict__ visMask32,
                                                                 const uint32_t* __restrict__ order, uint32_t n, uint32_t tilesX,
                                                                 uint32_t* __restrict__ pairKeys, uint32_t* __restrict__ pairVals,
                                                                 uint32_t capacity, BinControl* ctl, unsigned long long* binStatus,

@@ -33,6 +33,8 @@ constexpr int WAVES = THREADS / 64;
 constexpr int KPT = GS_SORT_KPT;
 constexpr int PART = THREADS * KPT;
 constexpr uint32_t SPIN_LIMIT = 1u << 24;
+constexpr uint32_t TICKET_CLASSES = 16;        // partition-ticket counters per pass (one 128-B line each)
+constexpr int GROUP = 32;                     // partitions per look-back group (~sqrt of the partition count of a 6 M key sort)
 
 constexpr unsigned long long FLAG_AGG = 1ull, FLAG_INCL = 2ull;
 
@@ -177,16 +179,22 @@ __global__ __launch_bounds__(1024) void scan_hist_kernel(uint32_t* hist, int pas
 // Register diet (the kernel is latency-bound, so resident waves matter): payloads are loaded only after the keys
 // have left the registers for LDS, local positions overwrite the ranks, and the digit of each output slot is kept
 // packed 4 per register instead of a 32-bit global index per slot.
+#ifdef GS_EXP_SORT_TIMELINE       // experiment build: per-partition phase timestamps (100 MHz wall clock) of the LAST launch
+__device__ unsigned long long g_timeline[16384 * 16];
+#define GS_TL(k) do { if (threadIdx.x == 0 && part < 16384u) g_timeline[part * 16u + (k)] = wall_clock64(); } while (0)
+#else
+#define GS_TL(k) do { } while (0)
+#endif
 #ifndef GS_SORT_LOOKBACK_BATCH
 #define GS_SORT_LOOKBACK_BATCH 8
 #endif
 #ifndef GS_SORT_MINWAVES
-#define GS_SORT_MINWAVES 1
+#define GS_SORT_MINWAVES 6      // <= 80 VGPRs: three 512-thread workgroups per CU (a handful of loop-invariant values spill to scratch)
 #endif
 __global__ __launch_bounds__(THREADS, GS_SORT_MINWAVES) void onesweep_kernel(const uint32_t* __restrict__ keysIn, const uint32_t* __restrict__ valsIn,
                                                            uint32_t* __restrict__ keysOut, uint32_t* __restrict__ valsOut,
                                                            const uint32_t* __restrict__ histExcl, unsigned long long* status,
-                                                           uint32_t* ticket, uint32_t* error, uint32_t nImm, const uint32_t* nPtr,
+                                                           unsigned long long* groupAgg, uint32_t* ticket, uint32_t* error, uint32_t nImm, const uint32_t* nPtr,
                                                            uint32_t shift, uint32_t epoch, uint32_t digitMask) {
     __shared__ uint32_t s_hist[WAVES * RADIX];   // per-wave digit counts -> wave-exclusive offsets
     __shared__ uint32_t s_lbase[RADIX];          // exclusive digit offsets inside the partition
@@ -201,11 +209,27 @@ __global__ __launch_bounds__(THREADS, GS_SORT_MINWAVES) void onesweep_kernel(con
 
     for (;;) {
         __syncthreads();                                    // previous partition's LDS reads are finished
-        if (tid == 0) s_part = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef GS_EXP_SORT_TIMELINE
+        const unsigned long long tl0 = wall_clock64();
+#endif
+        // Partition tickets.  One counter would serialise every workgroup of the grid on a single L2 channel (~12 ns per
+        // same-address atomic: the 768th workgroup starts 9 us late in a 35 us pass), so there are TICKET_CLASSES counters
+        // in separate 128-B lines; workgroup b draws from counter b % TICKET_CLASSES and ticket t of class c is partition
+        // t * TICKET_CLASSES + c.  The grid is persistent and every class has resident workgroups, so the lowest partition
+        // that is not finished has either been drawn or will be drawn by a workgroup of its class that is free to do so:
+        // a workgroup still only waits on partitions that are running or will run without needing a new slot.
+        if (tid == 0) {
+            const uint32_t cls = blockIdx.x % TICKET_CLASSES;
+            s_part = __hip_atomic_fetch_add(ticket + cls * 32u, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * TICKET_CLASSES + cls;
+        }
         for (int k = tid; k < WAVES * RADIX; k += THREADS) s_hist[k] = 0;
         __syncthreads();
         const uint32_t part = s_part;
         if (part >= numParts) break;
+#ifdef GS_EXP_SORT_TIMELINE
+        if (tid == 0 && part < 16384u) g_timeline[part * 16u + 0] = tl0;
+#endif
+        GS_TL(1);                                           // ticket taken, histogram cleared
 
         const uint32_t partBase = part * (uint32_t)PART;
         const uint32_t valid = min((uint32_t)PART, n - partBase);
@@ -227,6 +251,13 @@ __global__ __launch_bounds__(THREADS, GS_SORT_MINWAVES) void onesweep_kernel(con
             }
         }
 
+#ifdef GS_EXP_SORT_TIMELINE
+        { uint32_t x = 0;
+#pragma unroll
+          for (int k = 0; k < KPT; ++k) x |= key[k];
+          asm volatile("" :: "v"(x)); }                     // wait for the key loads before the timestamp
+#endif
+        GS_TL(2);                                           // keys arrived
         // ---- rank inside the wave: multi-split by 8 ballots, running per-wave LDS histogram ------------
         uint32_t pos[KPT];                                   // rank now, local position later
         uint32_t* wh = s_hist + w * RADIX;
@@ -256,6 +287,7 @@ __global__ __launch_bounds__(THREADS, GS_SORT_MINWAVES) void onesweep_kernel(con
             asm volatile("" : "+v"(key[k]));
         }
         __syncthreads();
+        GS_TL(3);                                           // ranked
 
         // ---- partition digit counts, wave-exclusive offsets, local exclusive scan over digits --------
         // (threads >= RADIX only help with loads/stores; digit `tid` is owned by thread tid < RADIX)
@@ -270,6 +302,10 @@ __global__ __launch_bounds__(THREADS, GS_SORT_MINWAVES) void onesweep_kernel(con
             }
             // publish this partition's digit count right away (decoupled look-back: successors need only this)
             st_status(myStatus, pack_status(epoch, part == 0 ? FLAG_INCL : FLAG_AGG, total));
+            // ... and add it to the aggregate of this partition's group of GROUP consecutive partitions: one 64-bit word per
+            // (group, digit) = members published << 40 | sum of their counts, so a reader sees a consistent pair
+            __hip_atomic_fetch_add(groupAgg + (size_t)(part / GROUP) * RADIX + tid, (1ull << 40) | (unsigned long long)total, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
             const uint32_t incl = wave_incl_scan(total, lane);
             if (lane == 63) s_wtot[w] = incl;
             lbase = incl - total;
@@ -305,28 +341,39 @@ __global__ __launch_bounds__(THREADS, GS_SORT_MINWAVES) void onesweep_kernel(con
                 val[k] = (gi < n) ? ldg32(valsIn, gi) : 0u;
             }
         }
+        GS_TL(4);                                           // keys scattered to LDS, payload loads issued
         // ---- look back over earlier partitions for digit `tid` (keys are parked in LDS by now, so the batch of
         //      status words below replaces the key registers instead of adding to them) ------------------------
         if (tid < RADIX) {
             uint32_t exclPrefix = 0;
-#ifdef GS_EXP_SORT_NOLOOKBACK      // timing experiment only (wrong output): what the look-back chain costs
-            if (false) {
-#else
-            if (part > 0) {
-#endif
-                // Every partition of a pass is resident at once (persistent grid), so the nearest INCLUSIVE predecessor can
-                // be hundreds of partitions back and a one-word-at-a-time walk is a chain of that many L2 round trips.
-                // LB independent loads are issued per round and consumed in order: the chain is LB times shorter.
+            // A digit this partition does not hold needs no base (s_gbase[d] is never read) and its INCLUSIVE word is never
+            // required by anyone (successors pass over the AGGREGATE 0 / use the group aggregates), so its look-back is
+            // skipped: in the passes over the high key bytes almost every digit is empty almost everywhere.
+            if (part > 0 && total > 0) {
+                // Every partition of a pass is resident at once (persistent grid) and all of them finish ranking at about the
+                // same time, so a plain decoupled look-back degenerates into a serial chain of INCLUSIVE hand-offs sweeping
+                // over the partitions (measured: 23 us of a 39 us pass for 749 partitions).  Two levels remove the chain:
+                //   1. walk the earlier partitions of the own group (< GROUP words, AGGREGATE or INCLUSIVE),
+                //   2. then whole groups: the group's last partition if it is already INCLUSIVE, else the group aggregate
+                //      once all GROUP members have added to it -- which depends on ranking only, not on anyone's look-back.
+                // LB words are requested per round and consumed in order.
                 constexpr int LB = GS_SORT_LOOKBACK_BATCH;
+                const int grp = (int)(part / GROUP), grpStart = grp * GROUP;
                 int q = (int)part - 1;
                 uint32_t spins = 0;
                 bool done = false;
-                while (!done) {
+#ifdef GS_EXP_SORT_TIMELINE
+                uint32_t tlRounds = 0;
+#endif
+                while (!done && q >= grpStart) {                                   // ---- level 1: own group
+#ifdef GS_EXP_SORT_TIMELINE
+                    ++tlRounds;
+#endif
                     unsigned long long sv[LB];
 #pragma unroll
                     for (int b = 0; b < LB; ++b) {
                         const int qi = q - b;
-                        sv[b] = qi >= 0 ? ld_status(status + (size_t)qi * RADIX + tid) : 0ull;   // partition 0 is INCLUSIVE: never consumed past it
+                        sv[b] = qi >= grpStart ? ld_status(status + (size_t)qi * RADIX + tid) : 0ull;
                     }
                     int consumed = 0;
 #pragma unroll
@@ -342,15 +389,54 @@ __global__ __launch_bounds__(THREADS, GS_SORT_MINWAVES) void onesweep_kernel(con
                     }
                     q -= consumed;
                     if (!done && consumed == 0) {
-                        if (++spins > SPIN_LIMIT) { atomicOr(error, 1u); break; }
+                        if (++spins > SPIN_LIMIT) { atomicOr(error, 1u); done = true; }
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                }
+                int j = grp - 1;
+                while (!done && j >= 0) {                                          // ---- level 2: whole groups (all of them full)
+#ifdef GS_EXP_SORT_TIMELINE
+                    ++tlRounds;
+#endif
+                    constexpr int GB = LB / 2 > 0 ? LB / 2 : 1;
+                    unsigned long long last[GB], agg[GB];
+#pragma unroll
+                    for (int b = 0; b < GB; ++b) {
+                        const int jj = j - b;
+                        last[b] = jj >= 0 ? ld_status(status + ((size_t)(jj + 1) * GROUP - 1) * RADIX + tid) : 0ull;
+                        agg[b] = jj >= 0 ? __hip_atomic_load(groupAgg + (size_t)jj * RADIX + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+                    }
+                    int consumed = 0;
+#pragma unroll
+                    for (int b = 0; b < GB; ++b) {
+                        if (done || consumed != b || j - b < 0) continue;
+                        const uint32_t e = (uint32_t)(last[b] >> 34);
+                        const uint32_t f = (uint32_t)(last[b] >> 32) & 3u;
+                        if (e == epoch && f == (uint32_t)FLAG_INCL) {              // everything up to the end of group j-b
+                            exclPrefix += (uint32_t)last[b];
+                            consumed = b + 1;
+                            done = true;
+                        } else if ((uint32_t)(agg[b] >> 40) == (uint32_t)GROUP) {  // all members of group j-b have ranked
+                            exclPrefix += (uint32_t)agg[b];
+                            consumed = b + 1;
+                        }
+                    }
+                    j -= consumed;
+                    if (!done && consumed == 0) {
+                        if (++spins > SPIN_LIMIT) { atomicOr(error, 1u); done = true; }
                         __builtin_amdgcn_s_sleep(1);
                     }
                 }
                 st_status(myStatus, pack_status(epoch, FLAG_INCL, exclPrefix + total));
+#ifdef GS_EXP_SORT_TIMELINE
+                if (tid == 0 && part < 16384u) { g_timeline[part * 16u + 10] = tlRounds; g_timeline[part * 16u + 11] = (unsigned long long)((int)part - 1 - q) + (unsigned long long)(grp - 1 - j) * 1000ull; g_timeline[part * 16u + 12] = spins; }
+#endif
             }
             s_gbase[tid] = histExcl[tid] + exclPrefix - lbase;
         }
+        GS_TL(5);                                           // look-back done (thread 0 = digit 0)
         __syncthreads();
+        GS_TL(6);                                           // everyone's look-back done
         uint32_t dpack[(KPT + 3) / 4];
 #pragma unroll
         for (int k = 0; k < (KPT + 3) / 4; ++k) dpack[k] = 0;
@@ -365,14 +451,17 @@ __global__ __launch_bounds__(THREADS, GS_SORT_MINWAVES) void onesweep_kernel(con
             }
         }
         __syncthreads();
+        GS_TL(7);                                           // keys written out
 #pragma unroll
         for (int k = 0; k < KPT; ++k) s_buf[pos[k]] = val[k];
         __syncthreads();
+        GS_TL(8);                                           // payloads in LDS
 #pragma unroll
         for (int k = 0; k < KPT; ++k) {
             const uint32_t j = (uint32_t)tid + (uint32_t)k * THREADS;
             if (j < valid) stg32(valsOut, s_gbase[(dpack[k >> 2] >> (8 * (k & 3))) & 255u] + j, s_buf[j]);
         }
+        GS_TL(9);                                           // payload stores issued
     }
 }
 
@@ -386,6 +475,13 @@ inline uint32_t div_up(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
 
 } // namespace
 
+#ifdef GS_EXP_SORT_TIMELINE
+extern "C" int32_t gs_debug_read_sort_timeline(void* out, size_t bytes) {
+    (void)hipDeviceSynchronize();
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_timeline), bytes) == hipSuccess ? 0 : -2;
+}
+#endif
+
 int32_t sort_state_create(gs_context* ctx, SortState& st, uint32_t maxCount) {
     (void)ctx;
     st.maxCount = maxCount;
@@ -394,6 +490,8 @@ int32_t sort_state_create(gs_context* ctx, SortState& st, uint32_t maxCount) {
     GS_HIP(hipMalloc((void**)&st.altVals, (size_t)(maxCount + 16) * 4));
     GS_HIP(hipMalloc((void**)&st.status, (size_t)st.maxParts * RADIX * 8));
     GS_HIP(hipMemsetAsync(st.status, 0, (size_t)st.maxParts * RADIX * 8, ctx->stream));
+    st.maxGroups = div_up(st.maxParts, (uint32_t)GROUP);
+    GS_HIP(hipMalloc((void**)&st.groupAgg, (size_t)4 * st.maxGroups * RADIX * 8));
     return GS_OK;
 }
 
@@ -401,6 +499,7 @@ void sort_state_destroy(SortState& st) {
     if (st.altKeys) (void)hipFree(st.altKeys);
     if (st.altVals) (void)hipFree(st.altVals);
     if (st.status) (void)hipFree(st.status);
+    if (st.groupAgg) (void)hipFree(st.groupAgg);
     st = SortState();
 }
 
@@ -438,8 +537,13 @@ int32_t enqueue_sort_passes(gs_context* ctx, hipStream_t stream, SortState& st, 
     if (nUpper == 0) return GS_OK;
     hipLaunchKernelGGL(scan_hist_kernel, dim3(1), dim3(1024), 0, stream, control->hist, passes);
     const uint32_t parts = div_up(nUpper, PART);
-    const uint32_t grid = max(1u, min(parts, (uint32_t)ctx->cuCount * (uint32_t)(2048 / THREADS)));
+    // persistent grid: no more workgroups than are resident at once (3 per CU at <= 80 VGPRs / 43 KB LDS), a multiple of
+    // the ticket classes so that every class is served
+    const uint32_t capacity = max(((uint32_t)ctx->cuCount * 3u / TICKET_CLASSES) * TICKET_CLASSES, TICKET_CLASSES);
+    const uint32_t grid = min(div_up(parts, TICKET_CLASSES) * TICKET_CLASSES, capacity);
     uint32_t *ks = keys, *vs = vals, *kd = st.altKeys, *vd = st.altVals;
+    const uint32_t groups = div_up(parts, (uint32_t)GROUP);
+    GS_HIP(hipMemsetAsync(st.groupAgg, 0, (size_t)passes * groups * RADIX * 8, stream));     // group aggregates accumulate: zeroed per sort
     if (profR && evFirst >= 0) prof_record(profR, evFirst, stream);
     for (int p = 0; p < passes; ++p) {
         uint32_t epoch = (++st.epoch) & 0x3fffffffu;
@@ -448,7 +552,7 @@ int32_t enqueue_sort_passes(gs_context* ctx, hipStream_t stream, SortState& st, 
             st.epoch = epoch = 1;
         }
         hipLaunchKernelGGL(onesweep_kernel, dim3(grid), dim3(THREADS), 0, stream, ks, vs, kd, vd, control->hist + RADIX * p,
-                           st.status, &control->tickets[p], &control->error, nUpper, nPtr, (uint32_t)(8 * p), epoch, p == passes - 1 ? lastMask : 255u);
+                           st.status, st.groupAgg + (size_t)p * groups * RADIX, control->tickets[p], &control->error, nUpper, nPtr, (uint32_t)(8 * p), epoch, p == passes - 1 ? lastMask : 255u);
         uint32_t* t = ks; ks = kd; kd = t;
         t = vs; vs = vd; vd = t;
     }
