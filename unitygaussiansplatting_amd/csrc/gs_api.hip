@@ -283,7 +283,7 @@ int32_t gs_renderer_sort(gs_renderer* r, const float m[16]) {
         st = ctx->aux;
     } else GS_TRY(join_sort(r));
     gs::prof_record(r, 0, st);
-    GS_TRY(enqueue_calc_distances(ctx, st, r->asset->view, r->order, m, r->distances, r->depthControl, r->n));
+    GS_TRY(enqueue_calc_distances(ctx, st, r->asset->view, r->order, m, r->distances, r->depthControl, r->n, r->depthSort));
     gs::prof_record(r, 1, st);
     GS_TRY(enqueue_sort_passes(ctx, st, r->depthSort, r->depthControl, r->distances, r->order, r->n, nullptr, 4, 255u, r, 10));
     gs::prof_record(r, 2, st);
@@ -621,7 +621,7 @@ int32_t gs_sorter_dispatch(gs_sorter* s, void* keys_dev, void* values_dev, uint3
     const int passes = (int)((key_bits + 7) / 8);
     const uint32_t lastBits = key_bits - 8u * (uint32_t)(passes - 1);
     const uint32_t lastMask = (1u << lastBits) - 1u;
-    GS_TRY(enqueue_histogram(s->ctx, s->ctx->stream, (const uint32_t*)keys_dev, count, nullptr, passes, lastMask, s->control));
+    GS_TRY(enqueue_histogram(s->ctx, s->ctx->stream, (const uint32_t*)keys_dev, count, nullptr, passes, lastMask, s->control, s->st));
     return enqueue_sort_passes(s->ctx, s->ctx->stream, s->st, s->control, (uint32_t*)keys_dev, (uint32_t*)values_dev, count, nullptr, passes, lastMask);
 }
 

@@ -179,10 +179,11 @@ int32_t sort_state_create(gs_context* ctx, SortState& st, uint32_t maxCount);
 void sort_state_destroy(SortState& st);
 // CSCalcDistances + fused 4x256 histogram
 int32_t enqueue_calc_distances(gs_context* ctx, hipStream_t st, const gsm::AssetView& a, const uint32_t* order, const float* matSort,
-                               uint32_t* keys, SortControl* control, uint32_t n);
+                               uint32_t* keys, SortControl* control, uint32_t n, SortState& sort);
+uint32_t sort_group_words(uint32_t nUpper, int passes);   // 8-byte words of SortState::groupAgg a sort of nUpper keys uses (to be zeroed before the passes)
 int32_t enqueue_histogram(gs_context* ctx, hipStream_t st, const uint32_t* keys, uint32_t n, const uint32_t* nPtr, int passes, uint32_t lastMask,
-                          SortControl* control);
-// scan + `passes` Onesweep passes.  Histograms must already be in control->hist.  Result ends in (keys, vals) when
+                          SortControl* control, SortState& sort);
+// `passes` Onesweep passes.  The raw digit histograms must already be in control->hist and sort.groupAgg zeroed.  Result ends in (keys, vals) when
 // passes is even, otherwise it is copied back.
 // profR/evFirst: optional hipEvent slots (evFirst = just before the first Onesweep launch, evFirst + 1 = after the last)
 int32_t enqueue_sort_passes(gs_context* ctx, hipStream_t stream, SortState& st, SortControl* control, uint32_t* keys, uint32_t* vals,

@@ -83,7 +83,7 @@ __global__ __launch_bounds__(kBinThreads, GS_BIN_MINWAVES) void bin_emit_kernel(
                                                                 const uint32_t* __restrict__ order, uint32_t n, uint32_t tilesX,
                                                                 uint32_t* __restrict__ pairKeys, uint32_t* __restrict__ pairVals,
                                                                 uint32_t capacity, BinControl* ctl, unsigned long long* binStatus,
-                                                                uint32_t* pairHist) {
+                                                                uint32_t* pairHist, unsigned long long* __restrict__ groupAgg, uint32_t groupAggWords) {
     constexpr int SUB = 4;                                   // k's per emission batch: 256 positions per wave
     __shared__ uint32_t s_hist[3 * 256];
     __shared__ uint32_t s_wtot[4], s_wvis[4];
@@ -96,6 +96,7 @@ __global__ __launch_bounds__(kBinThreads, GS_BIN_MINWAVES) void bin_emit_kernel(
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     if (tid == 0) s_part = __hip_atomic_fetch_add(&ctl->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     for (int j = tid; j < 3 * 256; j += kBinThreads) s_hist[j] = 0;
+    for (uint32_t j = blockIdx.x * (uint32_t)kBinThreads + (uint32_t)tid; j < groupAggWords; j += gridDim.x * (uint32_t)kBinThreads) groupAgg[j] = 0ull;   // for the pair sort's look-back
     __syncthreads();
     const uint32_t part = s_part;
     const uint32_t numParts = (n + kBinPart - 1) / kBinPart;
@@ -554,7 +555,7 @@ int32_t enqueue_draw(gs_renderer* r, const gs_frame_params* p, gs_target* rt) {
     const int passes = numTiles <= 256 ? 1 : (numTiles <= 65536 ? 2 : 3);
     auto binKernel = passes == 1 ? bin_emit_kernel<1> : (passes == 2 ? bin_emit_kernel<2> : bin_emit_kernel<3>);
     hipLaunchKernelGGL(binKernel, dim3(r->binParts), dim3(kBinThreads), 0, st, r->rects, (const uint32_t*)r->visMask, r->order, r->n, rc.tilesX, r->pairKeys,
-                       r->pairVals, cap, binCtl, binStatus, pairCtl->hist);
+                       r->pairVals, cap, binCtl, binStatus, pairCtl->hist, r->pairSort.groupAgg, sort_group_words(cap, passes));
     prof_record(r, 4);
     GS_TRY(enqueue_sort_passes(ctx, st, r->pairSort, pairCtl, r->pairKeys, r->pairVals, cap, &binCtl->pairCountClamped, passes, 255u, r, 12));
     r->lastPairPasses = (uint32_t)passes;

@@ -88,9 +88,11 @@ __global__ __launch_bounds__(1024) void set_indices_kernel(uint32_t* order, uint
 #endif
 __global__ __launch_bounds__(256) void calc_distances_kernel(gsm::AssetView a, const uint32_t* __restrict__ order,
                                                              float m20, float m21, float m22, float m23,
-                                                             uint32_t* __restrict__ keys, uint32_t* __restrict__ hist, uint32_t n) {
+                                                             uint32_t* __restrict__ keys, uint32_t* __restrict__ hist, uint32_t n,
+                                                             unsigned long long* __restrict__ groupAgg, uint32_t groupAggWords) {
     __shared__ uint32_t s_h[4 * RADIX];
     for (int j = threadIdx.x; j < 4 * RADIX; j += 256) s_h[j] = 0;
+    for (uint32_t j = blockIdx.x * 256u + threadIdx.x; j < groupAggWords; j += gridDim.x * 256u) groupAgg[j] = 0ull;   // the sort passes accumulate into it
     __syncthreads();
     constexpr uint32_t ILP = GS_DIST_ILP;
     constexpr uint32_t TILE = 256u * ILP;
@@ -145,9 +147,11 @@ __global__ __launch_bounds__(256) void calc_distances_kernel(gsm::AssetView a, c
 
 // stand-alone histogram (gs_sorter path): `passes` digit histograms of keys[0..n)
 __global__ __launch_bounds__(256) void histogram_kernel(const uint32_t* __restrict__ keys, uint32_t nImm, const uint32_t* nPtr,
-                                                        int passes, uint32_t lastMask, uint32_t* __restrict__ hist) {
+                                                        int passes, uint32_t lastMask, uint32_t* __restrict__ hist,
+                                                        unsigned long long* __restrict__ groupAgg, uint32_t groupAggWords) {
     __shared__ uint32_t s_h[4 * RADIX];
     for (int j = threadIdx.x; j < 4 * RADIX; j += 256) s_h[j] = 0;
+    for (uint32_t j = blockIdx.x * 256u + threadIdx.x; j < groupAggWords; j += gridDim.x * 256u) groupAgg[j] = 0ull;
     __syncthreads();
     const uint32_t n = nPtr ? min(*nPtr, nImm) : nImm;
     for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
@@ -159,20 +163,6 @@ __global__ __launch_bounds__(256) void histogram_kernel(const uint32_t* __restri
         const uint32_t c = s_h[j];
         if (c) atomicAdd(&hist[j], c);
     }
-}
-
-// in-place exclusive scan of each 256-bin histogram (one 256-thread group per pass)
-__global__ __launch_bounds__(1024) void scan_hist_kernel(uint32_t* hist, int passes) {
-    __shared__ uint32_t s_w[16];
-    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-    const bool live = (t >> 8) < passes;
-    const uint32_t v = live ? hist[t] : 0u;
-    const uint32_t incl = wave_incl_scan(v, lane);
-    if (lane == 63) s_w[w] = incl;
-    __syncthreads();
-    uint32_t base = 0;
-    for (int k = (w & ~3); k < w; ++k) base += s_w[k];
-    if (live) hist[t] = base + incl - v;
 }
 
 // One Onesweep pass: reads (keysIn, valsIn), writes (keysOut, valsOut) stably partitioned by digit (key>>shift)&mask.
@@ -193,7 +183,7 @@ __device__ unsigned long long g_timeline[16384 * 16];
 #endif
 __global__ __launch_bounds__(THREADS, GS_SORT_MINWAVES) void onesweep_kernel(const uint32_t* __restrict__ keysIn, const uint32_t* __restrict__ valsIn,
                                                            uint32_t* __restrict__ keysOut, uint32_t* __restrict__ valsOut,
-                                                           const uint32_t* __restrict__ histExcl, unsigned long long* status,
+                                                           const uint32_t* __restrict__ hist, unsigned long long* status,
                                                            unsigned long long* groupAgg, uint32_t* ticket, uint32_t* error, uint32_t nImm, const uint32_t* nPtr,
                                                            uint32_t shift, uint32_t epoch, uint32_t digitMask) {
     __shared__ uint32_t s_hist[WAVES * RADIX];   // per-wave digit counts -> wave-exclusive offsets
@@ -201,11 +191,25 @@ __global__ __launch_bounds__(THREADS, GS_SORT_MINWAVES) void onesweep_kernel(con
     __shared__ uint32_t s_gbase[RADIX];          // global index of local slot j with digit d = s_gbase[d] + j
     __shared__ uint32_t s_buf[PART];
     __shared__ uint32_t s_wtot[WAVES];
+    __shared__ uint32_t s_htot[RADIX / 64];
     __shared__ uint32_t s_part;
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const uint32_t n = nPtr ? min(*nPtr, nImm) : nImm;
     const uint32_t numParts = (n + PART - 1) / PART;
+
+    // global exclusive digit offsets = exclusive scan of this pass's 256-bin histogram (raw counts, accumulated by the key
+    // generation / histogram kernel): every workgroup scans it for itself instead of a separate 1-workgroup launch
+    uint32_t histExcl = 0;
+    if (tid < RADIX) {
+        const uint32_t c = hist[tid];
+        const uint32_t incl = wave_incl_scan(c, lane);
+        if (lane == 63) s_htot[w] = incl;
+        histExcl = incl - c;
+    }
+    __syncthreads();
+    if (tid < RADIX)
+        for (int k = 0; k < w; ++k) histExcl += s_htot[k];
 
     for (;;) {
         __syncthreads();                                    // previous partition's LDS reads are finished
@@ -432,7 +436,7 @@ __global__ __launch_bounds__(THREADS, GS_SORT_MINWAVES) void onesweep_kernel(con
                 if (tid == 0 && part < 16384u) { g_timeline[part * 16u + 10] = tlRounds; g_timeline[part * 16u + 11] = (unsigned long long)((int)part - 1 - q) + (unsigned long long)(grp - 1 - j) * 1000ull; g_timeline[part * 16u + 12] = spins; }
 #endif
             }
-            s_gbase[tid] = histExcl[tid] + exclPrefix - lbase;
+            s_gbase[tid] = histExcl + exclPrefix - lbase;
         }
         GS_TL(5);                                           // look-back done (thread 0 = digit 0)
         __syncthreads();
@@ -509,23 +513,26 @@ int32_t enqueue_set_indices(gs_context* ctx, uint32_t* order, uint32_t n) {
     return GS_OK;
 }
 
+uint32_t sort_group_words(uint32_t nUpper, int passes) { return (uint32_t)passes * div_up(div_up(max(nUpper, 1u), PART), (uint32_t)GROUP) * RADIX; }
+
 int32_t enqueue_calc_distances(gs_context* ctx, hipStream_t stream, const gsm::AssetView& a, const uint32_t* order, const float* m, uint32_t* keys,
-                               SortControl* control, uint32_t n) {
+                               SortControl* control, uint32_t n, SortState& st) {
     GS_HIP(hipMemsetAsync(control, 0, sizeof(SortControl), stream));
 #ifndef GS_DIST_BLOCKS_PER_CU
 #define GS_DIST_BLOCKS_PER_CU 2      // a narrow window of sorted positions per XCD keeps the gathered sectors in its L2 (measured: 2 beats 4 and 8)
 #endif
     const uint32_t grid = (max(1u, min(div_up(n, 256u * GS_DIST_ILP), (uint32_t)ctx->cuCount * GS_DIST_BLOCKS_PER_CU)) + 7u) & ~7u;
     hipLaunchKernelGGL(calc_distances_kernel, dim3(grid), dim3(256), 0, stream, a, order, m[8], m[9], m[10], m[11], keys,
-                       control->hist, n);
+                       control->hist, n, st.groupAgg, sort_group_words(n, 4));
     GS_HIP(hipGetLastError());
     return GS_OK;
 }
 
-int32_t enqueue_histogram(gs_context* ctx, hipStream_t stream, const uint32_t* keys, uint32_t n, const uint32_t* nPtr, int passes, uint32_t lastMask, SortControl* control) {
+int32_t enqueue_histogram(gs_context* ctx, hipStream_t stream, const uint32_t* keys, uint32_t n, const uint32_t* nPtr, int passes, uint32_t lastMask, SortControl* control,
+                          SortState& st) {
     GS_HIP(hipMemsetAsync(control, 0, sizeof(SortControl), stream));
     const uint32_t grid = max(1u, min(div_up(n, 256), (uint32_t)ctx->cuCount * 4u));
-    hipLaunchKernelGGL(histogram_kernel, dim3(grid), dim3(256), 0, stream, keys, n, nPtr, passes, lastMask, control->hist);
+    hipLaunchKernelGGL(histogram_kernel, dim3(grid), dim3(256), 0, stream, keys, n, nPtr, passes, lastMask, control->hist, st.groupAgg, sort_group_words(n, passes));
     GS_HIP(hipGetLastError());
     return GS_OK;
 }
@@ -535,7 +542,6 @@ int32_t enqueue_sort_passes(gs_context* ctx, hipStream_t stream, SortState& st, 
     if (passes < 1 || passes > 4) return fail(GS_ERR_INVALID_ARGUMENT, "sort passes");
     if (nUpper > st.maxCount) return fail(GS_ERR_INVALID_ARGUMENT, "sort count exceeds sorter capacity");
     if (nUpper == 0) return GS_OK;
-    hipLaunchKernelGGL(scan_hist_kernel, dim3(1), dim3(1024), 0, stream, control->hist, passes);
     const uint32_t parts = div_up(nUpper, PART);
     // persistent grid: no more workgroups than are resident at once (3 per CU at <= 80 VGPRs / 43 KB LDS), a multiple of
     // the ticket classes so that every class is served
@@ -543,7 +549,7 @@ int32_t enqueue_sort_passes(gs_context* ctx, hipStream_t stream, SortState& st, 
     const uint32_t grid = min(div_up(parts, TICKET_CLASSES) * TICKET_CLASSES, capacity);
     uint32_t *ks = keys, *vs = vals, *kd = st.altKeys, *vd = st.altVals;
     const uint32_t groups = div_up(parts, (uint32_t)GROUP);
-    GS_HIP(hipMemsetAsync(st.groupAgg, 0, (size_t)passes * groups * RADIX * 8, stream));     // group aggregates accumulate: zeroed per sort
+    // st.groupAgg[passes][groups][256] accumulates: it was zeroed by the kernel that produced the keys / their histograms
     if (profR && evFirst >= 0) prof_record(profR, evFirst, stream);
     for (int p = 0; p < passes; ++p) {
         uint32_t epoch = (++st.epoch) & 0x3fffffffu;
