@@ -22,6 +22,25 @@ def test_sorter_random_keys(gpu_ctx, n):
     s.Dispose()
 
 
+@pytest.mark.parametrize("n,pattern", [(25_000_019, "random"), (12_582_912, "sparse_digits"), (8192 * 32 * 3 + 1, "random")])
+def test_sorter_many_partitions_multi_round(gpu_ctx, n, pattern):
+    """More partitions than resident workgroups (3052 / 1536 of 8192 keys vs 768 slots): the persistent grid takes several
+    tickets per workgroup, the look-back crosses many 32-partition groups and uses INCLUSIVE anchors of finished rounds;
+    "sparse_digits" leaves most digits empty in most partitions (their look-back is skipped); the third size ends exactly
+    one key past a group boundary."""
+    rng = np.random.default_rng(n)
+    if pattern == "random":
+        keys = rng.integers(0, 2 ** 32, n, dtype=np.uint64).astype(np.uint32)
+    else:
+        keys = (rng.integers(0, 3, n).astype(np.uint32) << 24) | (rng.integers(0, 2, n).astype(np.uint32) << 9) | rng.integers(0, 5, n).astype(np.uint32)
+    vals = np.arange(n, dtype=np.uint32)
+    s = GpuSorting(gpu_ctx, n)
+    k, v = s.DispatchHost(keys, vals)
+    ko, vo = O.sort_pairs(keys, vals)
+    assert np.array_equal(k, ko) and np.array_equal(v, vo)
+    s.Dispose()
+
+
 @pytest.mark.parametrize("kind", ["all_equal", "two_values", "low_byte_only", "high_byte_only", "sorted", "reversed", "max_keys"])
 def test_sorter_ties_and_adversarial_patterns(gpu_ctx, kind):
     n = 300_001

@@ -34,6 +34,7 @@ constexpr int kSortPart = kSortThreads * kSortKPT;   // 4096 keys per partition
 constexpr int kBinThreads = 256;
 constexpr int kBinItems = 16;             // sorted positions per thread
 constexpr int kBinPart = kBinThreads * kBinItems;
+constexpr uint32_t kBinTicketClasses = 16;
 constexpr int kEvPerFrame = 14;           // hipEvents per profiled frame
 
 // 32-byte per-splat record consumed by the blend kernel (written by calc_view, splat-index order)
@@ -73,10 +74,9 @@ struct BinControl {
     uint32_t pairCountClamped;    // min(P, capacity), what the pair sort / ranges / blend see
     uint32_t error;
     uint32_t pad0[28];
-    uint32_t ticket;
-    uint32_t pad1[31];
     uint32_t visible;
-    uint32_t pad2[31];
+    uint32_t pad1[31];
+    uint32_t tickets[16 * 32];    // kBinTicketClasses partition-ticket counters, one per 128-B line
 };
 
 } // namespace gs

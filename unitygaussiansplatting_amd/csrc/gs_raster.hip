@@ -94,13 +94,22 @@ __global__ __launch_bounds__(kBinThreads, GS_BIN_MINWAVES) void bin_emit_kernel(
     __shared__ uint2 s_rect[4][SUB * 64];
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    if (tid == 0) s_part = __hip_atomic_fetch_add(&ctl->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     for (int j = tid; j < 3 * 256; j += kBinThreads) s_hist[j] = 0;
     for (uint32_t j = blockIdx.x * (uint32_t)kBinThreads + (uint32_t)tid; j < groupAggWords; j += gridDim.x * (uint32_t)kBinThreads) groupAgg[j] = 0ull;   // for the pair sort's look-back
+    const uint32_t numParts = (n + kBinPart - 1) / kBinPart;
+    uint32_t visAcc = 0;                                         // thread 0: visible splats of this workgroup's partitions
+    // Persistent grid, partitions drawn from kBinTicketClasses counters in separate 128-B lines (one counter would
+    // serialise ~1500 same-address atomics, 12 ns each, at the start of the kernel): ticket t of class c = partition
+    // t * classes + c; see the same scheme in gs_sort.hip for why a workgroup still only waits on running partitions.
+    for (;;) {
+    __syncthreads();                                             // s_part / s_wtot / s_base of the previous partition are no longer read
+    if (tid == 0) {
+        const uint32_t cls = blockIdx.x % kBinTicketClasses;
+        s_part = __hip_atomic_fetch_add(&ctl->tickets[cls * 32u], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * kBinTicketClasses + cls;
+    }
     __syncthreads();
     const uint32_t part = s_part;
-    const uint32_t numParts = (n + kBinPart - 1) / kBinPart;
-    if (part >= numParts) return;
+    if (part >= numParts) break;
     const uint32_t waveBase = part * (uint32_t)kBinPart + (uint32_t)w * (64u * kBinItems);
 
     // ---- per sorted position: gather the splat's tile rectangle (8 B, written by calc_view) ----------------------
@@ -138,8 +147,7 @@ __global__ __launch_bounds__(kBinThreads, GS_BIN_MINWAVES) void bin_emit_kernel(
         unsigned long long* my = binStatus + part;
         if (lane == 0) {
             __hip_atomic_store(my, (part == 0 ? BFLAG_INCL : BFLAG_AGG) | (unsigned long long)blockTotal, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const uint32_t vis = s_wvis[0] + s_wvis[1] + s_wvis[2] + s_wvis[3];
-            if (vis) atomicAdd(&ctl->visible, vis);
+            visAcc += s_wvis[0] + s_wvis[1] + s_wvis[2] + s_wvis[3];
         }
         unsigned long long excl = 0;
         if (part > 0) {
@@ -225,8 +233,10 @@ __global__ __launch_bounds__(kBinThreads, GS_BIN_MINWAVES) void bin_emit_kernel(
         __builtin_amdgcn_wave_barrier();
     }
 
-    // ---- flush the pair-sort digit histograms ----------------------------------------------------------------------
-    __syncthreads();
+    }   // next partition
+
+    // ---- flush the pair-sort digit histograms and the visible count ---------------------------------------------
+    if (tid == 0 && visAcc) atomicAdd(&ctl->visible, visAcc);
     for (int j = tid; j < PASSES * 256; j += kBinThreads) {
         const uint32_t c = s_hist[j];
         if (c) atomicAdd(&pairHist[j], c);
@@ -554,7 +564,13 @@ int32_t enqueue_draw(gs_renderer* r, const gs_frame_params* p, gs_target* rt) {
     prof_record(r, 3);
     const int passes = numTiles <= 256 ? 1 : (numTiles <= 65536 ? 2 : 3);
     auto binKernel = passes == 1 ? bin_emit_kernel<1> : (passes == 2 ? bin_emit_kernel<2> : bin_emit_kernel<3>);
-    hipLaunchKernelGGL(binKernel, dim3(r->binParts), dim3(kBinThreads), 0, st, r->rects, (const uint32_t*)r->visMask, r->order, r->n, rc.tilesX, r->pairKeys,
+    // persistent: as many workgroups as are resident at once (5 per CU at 92 VGPRs), a multiple of the ticket classes
+#ifndef GS_BIN_BLOCKS_PER_CU
+#define GS_BIN_BLOCKS_PER_CU 5
+#endif
+    const uint32_t binCap = max((uint32_t)ctx->cuCount * (uint32_t)GS_BIN_BLOCKS_PER_CU / kBinTicketClasses * kBinTicketClasses, kBinTicketClasses);
+    const uint32_t binGrid = min(div_up(r->binParts, kBinTicketClasses) * kBinTicketClasses, binCap);
+    hipLaunchKernelGGL(binKernel, dim3(binGrid), dim3(kBinThreads), 0, st, r->rects, (const uint32_t*)r->visMask, r->order, r->n, rc.tilesX, r->pairKeys,
                        r->pairVals, cap, binCtl, binStatus, pairCtl->hist, r->pairSort.groupAgg, sort_group_words(cap, passes));
     prof_record(r, 4);
     GS_TRY(enqueue_sort_passes(ctx, st, r->pairSort, pairCtl, r->pairKeys, r->pairVals, cap, &binCtl->pairCountClamped, passes, 255u, r, 12));
