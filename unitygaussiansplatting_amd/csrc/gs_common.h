@@ -148,11 +148,12 @@ struct gs_renderer {
     uint32_t* pairVals = nullptr;           // sorted positions
     gs::SortState pairSort;
     uint64_t pairCapacity = 0;
-    // per-frame zero arena: [BinControl | SortControl(pair) | binStatus | tileStart | tileEnd]
+    // per-frame zero arena: [BinControl | SortControl(pair) | binStatus | tileStart | tileEnd | tileOrder]
     uint8_t* frameArena = nullptr;
     size_t frameArenaBytes = 0;
-    size_t offBinStatus = 0, offTileStart = 0, offTileEnd = 0, offPairControl = 0;
+    size_t offBinStatus = 0, offTileStart = 0, offTileEnd = 0, offTileOrder = 0, offPairControl = 0;
     uint32_t arenaTiles = 0;                // tiles the arena was sized for
+    uint32_t* tileCost = nullptr;           // arenaTiles x u32: 256-record batches each tile walked in the previous draw (scheduling hint)
     uint32_t binParts = 0;
     int blendMode = 0;
     // profiling: a ring of per-frame hipEvent sets (slot advances at the end of gs_renderer_draw)

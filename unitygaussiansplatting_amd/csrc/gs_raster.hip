@@ -255,6 +255,50 @@ __global__ __launch_bounds__(256) void tile_ranges_kernel(const uint32_t* __rest
     }
 }
 
+// Longest lists first.  The blend launch has ~2 workgroups per slot (3750 tiles, 2048 slots at 8 per CU) and list lengths
+// spread over 0..10^4 pairs: dispatched in screen order, the second wave of workgroups starts at 55-105 us and the long
+// lists among them finish at 190 us while the machine-wide work is only 125 us (measured per-tile timeline, C2).  The
+// hardware hands out workgroups in blockIdx order as slots free up, so a permutation of the tiles by descending list
+// cost turns the launch into longest-processing-time-first list scheduling.  The cost of a tile is not its list length
+// (pixels saturate: only 30 % of the 256-record batches are ever walked) but the number of batches it walked in the
+// PREVIOUS frame, which the blend kernel leaves in tileCost[] (cameras move slowly); a tile without history counts by
+// length.  Counting sort into 256 buckets, one workgroup; the order inside a bucket is whatever the atomics give -- the
+// image does not depend on it.
+__device__ __forceinline__ uint32_t tile_bucket(uint32_t len, uint32_t lastCost) {   // 0 = most expensive ... 255 = empty
+    if (len == 0) return 255u;
+    const uint32_t pred = lastCost ? lastCost * 4u : min((len + 255u) >> 8, 12u);      // batches x 4; no history: a third of a long list at most
+    return 254u - min(pred, 254u);
+}
+__global__ __launch_bounds__(1024) void tile_order_kernel(const uint32_t* __restrict__ tileStart, const uint32_t* __restrict__ tileEnd,
+                                                          const uint32_t* __restrict__ tileCost, uint32_t numTiles, uint32_t* __restrict__ tileOrder) {
+    __shared__ uint32_t s_cnt[256], s_off[256], s_w[4];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    if (tid < 256) s_cnt[tid] = 0;
+    __syncthreads();
+    for (uint32_t t = tid; t < numTiles; t += 1024u) {
+        atomicAdd(&s_cnt[tile_bucket(tileEnd[t] - tileStart[t], tileCost[t])], 1u);
+    }
+    __syncthreads();
+    uint32_t v = 0, incl = 0;
+    if (tid < 256) {
+        v = s_cnt[tid];
+        incl = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t u = __shfl_up(incl, o, 64); if (lane >= o) incl += u; }
+        if (lane == 63) s_w[w] = incl;
+    }
+    __syncthreads();
+    if (tid < 256) {
+        uint32_t base = 0;
+        for (int k = 0; k < w; ++k) base += s_w[k];
+        s_off[tid] = base + incl - v;
+    }
+    __syncthreads();
+    for (uint32_t t = tid; t < numTiles; t += 1024u) {
+        tileOrder[atomicAdd(&s_off[tile_bucket(tileEnd[t] - tileStart[t], tileCost[t])], 1u)] = t;
+    }
+}
+
 // XCD-aware bijective block -> tile map: consecutive tiles (which share splat records) stay on one XCD's L2
 __device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t total) {
     const uint32_t q = total >> 3, r = total & 7u, xcd = b & 7u, k = b >> 3;
@@ -354,9 +398,13 @@ typedef uint32_t u4v __attribute__((ext_vector_type(4)));
 //   (2) walks the survivors in order, reading the record with WAVE-UNIFORM LDS loads (two ds_read_b128 per record:
 //       they issue on the LDS pipe, not the VALU, and the next record is requested before the current one is
 //       evaluated), so the per-(quadrant, splat) VALU cost is the fragment maths alone.
+#ifdef GS_EXP_BLEND_TIMELINE      // experiment build: per-tile start / end (100 MHz wall clock), list length, batches walked
+__device__ unsigned long long g_blend_tl[65536 * 8];
+#endif
 template <int MODE>
 __global__ __launch_bounds__(256) void blend_kernel(const uint32_t* __restrict__ pairVals, const uint32_t* __restrict__ tileStart,
-                                                    const uint32_t* __restrict__ tileEnd, const SplatRec* __restrict__ recs,
+                                                    const uint32_t* __restrict__ tileEnd, const uint32_t* __restrict__ tileOrder,
+                                                    uint32_t* __restrict__ tileCost, const SplatRec* __restrict__ recs,
                                                     uint16_t* __restrict__ rt, RasterConsts rc) {
     __shared__ float4 s_a[256];      // cx, cy, u1x, u1y      (u_k = axis_k / |axis_k|^2)
     __shared__ uint4 s_b[256];       // u2x, u2y (float bits), f16 r << 16 | f16 g, f16 b << 16 | f16 a
@@ -364,10 +412,21 @@ __global__ __launch_bounds__(256) void blend_kernel(const uint32_t* __restrict__
     __shared__ int s_done;
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+#ifdef GS_EXP_BLEND_SCREEN_ORDER
     const uint32_t tile = xcd_remap(blockIdx.x, rc.tilesX * rc.tilesY);
+#else
+    const uint32_t tile = tileOrder[blockIdx.x];
+#endif
     const uint32_t tx = tile % rc.tilesX, ty = tile / rc.tilesX;
     const uint32_t start = tileStart[tile], end = tileEnd[tile];
-    if (start >= end) return;                                  // nothing lands on this tile: target unchanged
+#ifdef GS_EXP_BLEND_TIMELINE
+    const unsigned long long tl0 = wall_clock64();
+    uint32_t tlBatches = 0, tlSurv = 0;
+    unsigned long long tlStage = 0, tlProc = 0, tlMark = tl0;
+    if (threadIdx.x == 0 && tile < 65536u) { g_blend_tl[tile * 8 + 0] = tl0; g_blend_tl[tile * 8 + 1] = tl0; g_blend_tl[tile * 8 + 2] = end - start; g_blend_tl[tile * 8 + 3] = 0; }
+#endif
+    if (start >= end) { if (threadIdx.x == 0) tileCost[tile] = 0; return; }    // nothing lands on this tile: target unchanged
+    uint32_t batchesWalked = 0;
 
     const int qx0 = (int)tx * 16 + (w & 1) * 8, qy0 = (int)ty * 16 + (w >> 1) * 8;
     const int px = qx0 + (lane & 7), py = qy0 + (lane >> 3);
@@ -381,14 +440,26 @@ __global__ __launch_bounds__(256) void blend_kernel(const uint32_t* __restrict__
     if (tid == 0) s_done = 0;
     bool waveDone = false;
 
+    // Two-deep software pipeline of the staging loads (pair -> splat index -> 32-byte record: two dependent global loads).
+    // While batch k is evaluated, the records of batch k+1 and the splat indices of batch k+2 are in flight.  Every load is
+    // unconditional (index clamped to the tile's last pair): a load inside a divergent branch makes the compiler wait for
+    // it at the end of the branch, which is exactly the latency this is meant to hide.
+    const uint32_t lastPair = end - 1u;
+    float4 r0, r1;
+    {
+        const float4* rp = (const float4*)(recs + pairVals[min(start + (uint32_t)tid, lastPair)]);
+        r0 = rp[0]; r1 = rp[1];                                   // cx cy a1x a1y | a2x a2y c0 c1
+    }
+    uint32_t sidxNext = pairVals[min(start + 256u + (uint32_t)tid, lastPair)];
     for (uint32_t bs = start; bs < end; bs += 256u) {
         __syncthreads();
         if (s_done == 4) break;
+        ++batchesWalked;
+#ifdef GS_EXP_BLEND_TIMELINE
+        ++tlBatches;
+#endif
         const uint32_t cnt = min(256u, end - bs);
         if ((uint32_t)tid < cnt) {
-            const uint32_t sidx = pairVals[bs + tid];
-            const float4* rp = (const float4*)(recs + sidx);
-            const float4 r0 = rp[0], r1 = rp[1];               // cx cy a1x a1y | a2x a2y c0 c1
             const float inv1 = 1.0f / gsm::dot2f(r0.z, r0.w, r0.z, r0.w);
             const float inv2 = 1.0f / gsm::dot2f(r1.x, r1.y, r1.x, r1.y);
             const float ca = gsm::f16tof32(gsm::f2u(r1.w));
@@ -401,7 +472,15 @@ __global__ __launch_bounds__(256) void blend_kernel(const uint32_t* __restrict__
             s_b[tid] = make_uint4(gsm::f2u(r1.x * inv2), gsm::f2u(r1.y * inv2), gsm::f2u(r1.z), gsm::f2u(r1.w));
             s_e[tid] = make_float4(fminf(exr, exe) + 0.02f, fminf(eyr, eye) + 0.02f, r2, 0.0f);
         }
+        {
+            const float4* rp = (const float4*)(recs + sidxNext);
+            r0 = rp[0]; r1 = rp[1];
+            sidxNext = pairVals[min(bs + 512u + (uint32_t)tid, lastPair)];
+        }
         __syncthreads();
+#ifdef GS_EXP_BLEND_TIMELINE
+        { const unsigned long long now = wall_clock64(); tlStage += now - tlMark; tlMark = now; }
+#endif
         if (!waveDone) {
             for (uint32_t c = 0; c < cnt; c += 64u) {
                 const uint32_t j = c + lane;
@@ -417,6 +496,9 @@ __global__ __launch_bounds__(256) void blend_kernel(const uint32_t* __restrict__
 #endif
                 }
                 unsigned long long mask = __ballot(hit);
+#ifdef GS_EXP_BLEND_TIMELINE
+                tlSurv += (uint32_t)__popcll(mask);
+#endif
                 while (mask) {
                     const int b = __ffsll((long long)mask) - 1;
                     mask &= mask - 1ull;
@@ -427,7 +509,7 @@ __global__ __launch_bounds__(256) void blend_kernel(const uint32_t* __restrict__
                     const float q1 = fmaf(dy, A4.w, dx * A4.z);
                     const float q2 = fmaf(dy, gsm::u2f(B4.y), dx * gsm::u2f(B4.x));
                     const float power = -fmaf(q2, q2, q1 * q1);
-                    #ifdef GS_BLEND_PLAIN
+#ifdef GS_BLEND_PLAIN
                     const float alpha = gsm::sat(__expf(power) * half_lo(B4.w));
 #else
                     const float alpha = mix_mul_lo_sat_after_trans(B4.w, __expf(power));
@@ -443,9 +525,23 @@ __global__ __launch_bounds__(256) void blend_kernel(const uint32_t* __restrict__
                 }
             }
         }
+#ifdef GS_EXP_BLEND_TIMELINE
+        { const unsigned long long now = wall_clock64(); tlProc += now - tlMark; tlMark = now; }
+#endif
     }
     if (inside) *dst = acc.pack();
+    if (threadIdx.x == 0) tileCost[tile] = batchesWalked;         // next frame's scheduling hint (tile_order_kernel)
+#ifdef GS_EXP_BLEND_TIMELINE
+    __syncthreads();
+    if (threadIdx.x == 0 && tile < 65536u) { g_blend_tl[tile * 8 + 1] = wall_clock64(); g_blend_tl[tile * 8 + 3] = tlBatches; g_blend_tl[tile * 8 + 4] = tlSurv; g_blend_tl[tile * 8 + 5] = tlStage; g_blend_tl[tile * 8 + 6] = tlProc; }
+#endif
 }
+#ifdef GS_EXP_BLEND_TIMELINE
+extern "C" int32_t gs_debug_read_blend_timeline(void* out, size_t bytes) {
+    (void)hipDeviceSynchronize();
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_blend_tl), bytes) == hipSuccess ? 0 : -2;
+}
+#endif
 
 // GaussianComposite.shader:25-39 + "Blend SrcAlpha OneMinusSrcAlpha" over a constant background
 __global__ __launch_bounds__(256) void resolve_kernel(const uint16_t* __restrict__ rt, uint32_t numPix, float bgr, float bgg, float bgb,
@@ -494,9 +590,14 @@ int32_t ensure_arena(gs_renderer* r, uint32_t numTiles) {
     r->offBinStatus = off;   off += align_up((size_t)r->binParts * 8, 256);
     r->offTileStart = off;   off += align_up((size_t)numTiles * 4, 256);
     r->offTileEnd = off;     off += align_up((size_t)numTiles * 4, 256);
+    r->offTileOrder = off;   off += align_up((size_t)numTiles * 4, 256);
     r->frameArenaBytes = off;
     r->arenaTiles = numTiles;
     GS_HIP(hipMalloc((void**)&r->frameArena, off));
+    if (r->tileCost) (void)hipFree(r->tileCost);
+    r->tileCost = nullptr;
+    GS_HIP(hipMalloc((void**)&r->tileCost, (size_t)numTiles * 4));                      // persists across frames (not part of the zeroed arena)
+    GS_HIP(hipMemsetAsync(r->tileCost, 0, (size_t)numTiles * 4, r->ctx->stream));
     return GS_OK;
 }
 
@@ -533,6 +634,8 @@ void renderer_free_raster(gs_renderer* r) {
     if (r->pairVals) (void)hipFree(r->pairVals);
     sort_state_destroy(r->pairSort);
     if (r->frameArena) (void)hipFree(r->frameArena);
+    if (r->tileCost) (void)hipFree(r->tileCost);
+    r->tileCost = nullptr;
     if (r->hostBin) (void)hipHostFree(r->hostBin);
     r->recs = nullptr; r->rects = nullptr; r->visMask = nullptr; r->pairKeys = r->pairVals = nullptr; r->frameArena = nullptr; r->hostBin = nullptr;
 }
@@ -558,15 +661,16 @@ int32_t enqueue_draw(gs_renderer* r, const gs_frame_params* p, gs_target* rt) {
     unsigned long long* binStatus = (unsigned long long*)(r->frameArena + r->offBinStatus);
     uint32_t* tileStart = (uint32_t*)(r->frameArena + r->offTileStart);
     uint32_t* tileEnd = (uint32_t*)(r->frameArena + r->offTileEnd);
+    uint32_t* tileOrder = (uint32_t*)(r->frameArena + r->offTileOrder);
     const uint32_t cap = (uint32_t)r->pairCapacity;
 
     GS_HIP(hipMemsetAsync(r->frameArena, 0, r->frameArenaBytes, st));
     prof_record(r, 3);
     const int passes = numTiles <= 256 ? 1 : (numTiles <= 65536 ? 2 : 3);
     auto binKernel = passes == 1 ? bin_emit_kernel<1> : (passes == 2 ? bin_emit_kernel<2> : bin_emit_kernel<3>);
-    // persistent: as many workgroups as are resident at once (5 per CU at 92 VGPRs), a multiple of the ticket classes
+    // persistent: as many workgroups as are resident at once, a multiple of the ticket classes
 #ifndef GS_BIN_BLOCKS_PER_CU
-#define GS_BIN_BLOCKS_PER_CU 5
+#define GS_BIN_BLOCKS_PER_CU 4      // 110 VGPRs: four 256-thread workgroups per CU
 #endif
     const uint32_t binCap = max((uint32_t)ctx->cuCount * (uint32_t)GS_BIN_BLOCKS_PER_CU / kBinTicketClasses * kBinTicketClasses, kBinTicketClasses);
     const uint32_t binGrid = min(div_up(r->binParts, kBinTicketClasses) * kBinTicketClasses, binCap);
@@ -577,11 +681,12 @@ int32_t enqueue_draw(gs_renderer* r, const gs_frame_params* p, gs_target* rt) {
     r->lastPairPasses = (uint32_t)passes;
     hipLaunchKernelGGL(tile_ranges_kernel, dim3(max(1u, min(div_up(cap, 256), (uint32_t)ctx->cuCount * 8u))), dim3(256), 0, st, r->pairKeys,
                        &binCtl->pairCountClamped, tileStart, tileEnd, numTiles);
+    hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, st, tileStart, tileEnd, r->tileCost, numTiles, tileOrder);
     prof_record(r, 5);
     if (r->blendMode == 0)
-        hipLaunchKernelGGL(blend_kernel<0>, dim3(numTiles), dim3(256), 0, st, r->pairVals, tileStart, tileEnd, r->recs, rt->rgba16f, rc);
+        hipLaunchKernelGGL(blend_kernel<0>, dim3(numTiles), dim3(256), 0, st, r->pairVals, tileStart, tileEnd, tileOrder, r->tileCost, r->recs, rt->rgba16f, rc);
     else
-        hipLaunchKernelGGL(blend_kernel<1>, dim3(numTiles), dim3(256), 0, st, r->pairVals, tileStart, tileEnd, r->recs, rt->rgba16f, rc);
+        hipLaunchKernelGGL(blend_kernel<1>, dim3(numTiles), dim3(256), 0, st, r->pairVals, tileStart, tileEnd, tileOrder, r->tileCost, r->recs, rt->rgba16f, rc);
     prof_record(r, 6);
     GS_HIP(hipGetLastError());
     GS_HIP(hipMemcpyAsync(r->hostBin, binCtl, sizeof(BinControl), hipMemcpyDeviceToHost, st));
