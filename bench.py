@@ -252,7 +252,8 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": cfg.label + (f" [splat count overridden to {n}]" if args.splats else ""),
                        "splats": n, "resolution": [W, H], "asset_MB": round(sum(b.numel() for b in blobs if b is not None) / 1e6, 1),
-                       "blend": args.blend, "sort_nth_frame": args.sort_nth_frame, "tile_pairs_P": P, "visible_splats": int(st.visible_splats),
+                       "blend": args.blend, "sort_nth_frame": args.sort_nth_frame, "view_buffer": "on demand (gs_renderer_download_view)",
+                       "sort_queue_overlap": os.environ.get("GSPLAT_OVERLAP", "0") == "1", "tile_pairs_P": P, "visible_splats": int(st.visible_splats),
                        "parallelism": f"view-parallel x{world} (one camera per GPU, asset broadcast once over RCCL)" if world > 1 else "single GPU",
                        "baseline_note": "vs_baseline = per-GPU Msplats/s / 901.8 (reference: 6.8 ms/frame on RTX 3080 Ti, real INRIA bicycle, BASELINE.md)"},
             "roofline": roofline, "stages": stages, "cpu_baseline": cpu, "parity_vs_oracle": parity,

@@ -1,5 +1,5 @@
 export PYTHONPATH=$PWD
 mkdir -p gpurun_out
-timeout 900 python -m pytest tests/test_gpu_draw.py tests/test_golden.py tests/test_cutouts.py -x -q -m gpu 2>&1 | tail -3
-GSPLAT_LIB=$PWD/unitygaussiansplatting_amd/variants/btl.so python scripts/blend_timeline.py C2 2>&1 | head -8
-bash scripts/gpu_round.sh variants 2>&1 | grep -v "btl.so" | cut -c1-400
+free -g | head -2
+(time timeout 600 python bench.py --config C3 --steps 30 --warmup 5 --cpu-baseline off) > gpurun_out/bench_c3.json 2> gpurun_out/bench_c3.err; tail -c 1500 gpurun_out/bench_c3.json; tail -3 gpurun_out/bench_c3.err
+(time timeout 900 python bench.py --config C4 --steps 20 --warmup 5 --cpu-baseline off) > gpurun_out/bench_c4.json 2> gpurun_out/bench_c4.err; tail -c 1500 gpurun_out/bench_c4.json; tail -3 gpurun_out/bench_c4.err
