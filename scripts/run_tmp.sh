@@ -1,6 +1,5 @@
 export PYTHONPATH=$PWD
 mkdir -p gpurun_out
-python scripts/bench_stages.py C2 100 2>&1 | tail -1 | cut -c1-400
-GS_NOPROF=1 python scripts/bench_stages.py C2 100 2>&1 | tail -1
+timeout 900 python -m pytest tests -x -q -m gpu 2>&1 | tail -3
 python scripts/bench_stages.py C2 100 2>&1 | tail -1 | cut -c1-400
 GS_NOPROF=1 python scripts/bench_stages.py C2 100 2>&1 | tail -1

@@ -226,7 +226,8 @@ int32_t gs_renderer_create(gs_context* ctx, gs_asset* asset, gs_renderer** out) 
     chk(hipMalloc((void**)&r->view, (size_t)r->n * sizeof(gsm::ViewData) + 64), "alloc view");
     chk(hipMalloc((void**)&r->distances, (size_t)(r->n + 16) * 4), "alloc distances");
     chk(hipMalloc((void**)&r->order, (size_t)(r->n + 16) * 4), "alloc order");
-    chk(hipMalloc((void**)&r->depthControl, sizeof(SortControl)), "alloc sort control");
+    chk(hipMalloc((void**)&r->depthControl, 2 * sizeof(SortControl)), "alloc sort control");
+    if (rc == GS_OK) chk(hipMemsetAsync(r->depthControl, 0, 2 * sizeof(SortControl), ctx->stream), "clear sort control");
     chk(hipEventCreateWithFlags(&r->evFork, hipEventDisableTiming), "create event");
     chk(hipEventCreateWithFlags(&r->evSortDone, hipEventDisableTiming), "create event");
     if (rc == GS_OK) rc = sort_state_create(ctx, r->depthSort, r->n);
@@ -283,9 +284,11 @@ int32_t gs_renderer_sort(gs_renderer* r, const float m[16]) {
         st = ctx->aux;
     } else GS_TRY(join_sort(r));
     gs::prof_record(r, 0, st);
-    GS_TRY(enqueue_calc_distances(ctx, st, r->asset->view, r->order, m, r->distances, r->depthControl, r->n, r->depthSort));
+    r->depthControlIdx ^= 1;
+    SortControl* control = r->depthControl + r->depthControlIdx;
+    GS_TRY(enqueue_calc_distances(ctx, st, r->asset->view, r->order, m, r->distances, control, r->depthControl + (r->depthControlIdx ^ 1), r->n, r->depthSort));
     gs::prof_record(r, 1, st);
-    GS_TRY(enqueue_sort_passes(ctx, st, r->depthSort, r->depthControl, r->distances, r->order, r->n, nullptr, 4, 255u, r, 10));
+    GS_TRY(enqueue_sort_passes(ctx, st, r->depthSort, control, r->distances, r->order, r->n, nullptr, 4, 255u, r, 10));
     gs::prof_record(r, 2, st);
     if (ctx->overlap) {
         GS_HIP(hipEventRecord(r->evSortDone, ctx->aux));
@@ -474,7 +477,7 @@ int32_t gs_renderer_frame_stats(gs_renderer* r, gs_frame_stats* out) {
     GS_TRY(join_sort(r));
     GS_HIP(hipStreamSynchronize(r->ctx->stream));
     uint32_t depthErr = 0;
-    GS_HIP(hipMemcpy(&depthErr, &r->depthControl->error, 4, hipMemcpyDeviceToHost));
+    GS_HIP(hipMemcpy(&depthErr, &r->depthControl[r->depthControlIdx].error, 4, hipMemcpyDeviceToHost));
     memset(out, 0, sizeof(*out));
     out->pair_capacity = r->pairCapacity;
     out->tiles_x = r->lastTilesX; out->tiles_y = r->lastTilesY;
@@ -557,19 +560,20 @@ int32_t gs_target_destroy(gs_target* t) {
 
 int32_t gs_target_clear(gs_target* t) {
     if (!t) return fail(GS_ERR_INVALID_ARGUMENT, "target is null");
-    GS_TRY(bind_device(t->ctx));
-    GS_HIP(hipMemsetAsync(t->rgba16f, 0, (size_t)t->width * t->height * 8, t->ctx->stream));
+    t->clearPending = true;                 // the next draw writes every pixel (blend kernel); anything else clears first
     return GS_OK;
 }
 
 int32_t gs_target_download(gs_target* t, void* out, size_t bytes) {
     if (!t || !out || bytes > (size_t)t->width * t->height * 8) return fail(GS_ERR_INVALID_ARGUMENT, "bad argument");
+    GS_TRY(flush_clear(t));
     return download(t->ctx, out, t->rgba16f, bytes);
 }
 
 int32_t gs_target_resolve(gs_target* t, const float bg[4], float* out32, uint8_t* out8) {
     if (!t || !bg) return fail(GS_ERR_INVALID_ARGUMENT, "null argument");
     GS_TRY(bind_device(t->ctx));
+    GS_TRY(flush_clear(t));
     GS_TRY(enqueue_resolve(t, bg));
     const size_t px = (size_t)t->width * t->height;
     if (out32) GS_HIP(hipMemcpyAsync(out32, t->resolved, px * 16, hipMemcpyDeviceToHost, t->ctx->stream));
@@ -580,6 +584,7 @@ int32_t gs_target_resolve(gs_target* t, const float bg[4], float* out32, uint8_t
 
 int32_t gs_target_device_ptr(gs_target* t, void** rgba16f_dev, void** resolved_dev) {
     if (!t) return fail(GS_ERR_INVALID_ARGUMENT, "target is null");
+    GS_TRY(flush_clear(t));                 // the caller is about to read the memory directly
     if (rgba16f_dev) *rgba16f_dev = t->rgba16f;
     if (resolved_dev) *resolved_dev = t->resolved;
     return GS_OK;

@@ -113,6 +113,8 @@ struct gs_target {
     gs_context* ctx = nullptr;
     uint32_t width = 0, height = 0;
     uint16_t* rgba16f = nullptr;            // W*H*4 halfs
+    bool clearPending = false;              // gs_target_clear was called and nothing has touched the target since: the next
+                                            // draw writes every pixel itself (no 8 B/px memset); any other reader clears first
     float* resolved = nullptr;              // W*H*4 floats, lazily allocated
     uint8_t* resolved8 = nullptr;
 };
@@ -126,7 +128,8 @@ struct gs_renderer {
     uint32_t* distances = nullptr;          // m_GpuSortDistances
     uint32_t* order = nullptr;              // m_GpuSortKeys (_OrderBuffer)
     gs::SortState depthSort;
-    gs::SortControl* depthControl = nullptr;
+    gs::SortControl* depthControl = nullptr;   // two blocks, used alternately: each sort zeroes the other one for the next
+    int depthControlIdx = 0;                   // the block the last / current sort uses
     // compositor buffers
     gs::SplatRec* recs = nullptr;           // N x 32 B, indexed by splat (written by calc_view)
     uint2* rects = nullptr;                 // N x 8 B: x = tx0 | ty0 << 16, y = tiles wide | tiles high << 16 (0 = culled)
@@ -149,8 +152,9 @@ struct gs_renderer {
     gs::SortState pairSort;
     uint64_t pairCapacity = 0;
     // per-frame zero arena: [BinControl | SortControl(pair) | binStatus | tileStart | tileEnd | tileOrder]
-    uint8_t* frameArena = nullptr;
-    size_t frameArenaBytes = 0;
+    uint8_t* frameArena = nullptr;          // two copies, used alternately: each draw zeroes the other one for the next
+    int arenaIdx = 0;
+    size_t frameArenaBytes = 0;             // of one copy
     size_t offBinStatus = 0, offTileStart = 0, offTileEnd = 0, offTileOrder = 0, offPairControl = 0;
     uint32_t arenaTiles = 0;                // tiles the arena was sized for
     uint32_t* tileCost = nullptr;           // arenaTiles x u32: 256-record batches each tile walked in the previous draw (scheduling hint)
@@ -180,7 +184,7 @@ int32_t sort_state_create(gs_context* ctx, SortState& st, uint32_t maxCount);
 void sort_state_destroy(SortState& st);
 // CSCalcDistances + fused 4x256 histogram
 int32_t enqueue_calc_distances(gs_context* ctx, hipStream_t st, const gsm::AssetView& a, const uint32_t* order, const float* matSort,
-                               uint32_t* keys, SortControl* control, uint32_t n, SortState& sort);
+                               uint32_t* keys, SortControl* control, SortControl* nextControl, uint32_t n, SortState& sort);
 uint32_t sort_group_words(uint32_t nUpper, int passes);   // 8-byte words of SortState::groupAgg a sort of nUpper keys uses (to be zeroed before the passes)
 int32_t enqueue_histogram(gs_context* ctx, hipStream_t st, const uint32_t* keys, uint32_t n, const uint32_t* nPtr, int passes, uint32_t lastMask,
                           SortControl* control, SortState& sort);
@@ -200,4 +204,5 @@ int32_t renderer_alloc_raster(gs_renderer* r);
 void renderer_free_raster(gs_renderer* r);
 int32_t enqueue_draw(gs_renderer* r, const gs_frame_params* p, gs_target* rt);
 int32_t enqueue_resolve(gs_target* t, const float bg[4]);
+int32_t flush_clear(gs_target* t);          // perform a pending gs_target_clear now
 } // namespace gs

@@ -83,7 +83,8 @@ __global__ __launch_bounds__(kBinThreads, GS_BIN_MINWAVES) void bin_emit_kernel(
                                                                 const uint32_t* __restrict__ order, uint32_t n, uint32_t tilesX,
                                                                 uint32_t* __restrict__ pairKeys, uint32_t* __restrict__ pairVals,
                                                                 uint32_t capacity, BinControl* ctl, unsigned long long* binStatus,
-                                                                uint32_t* pairHist, unsigned long long* __restrict__ groupAgg, uint32_t groupAggWords) {
+                                                                uint32_t* pairHist, unsigned long long* __restrict__ groupAgg, uint32_t groupAggWords,
+                                                                uint32_t* __restrict__ nextArena, uint32_t nextArenaWords) {
     constexpr int SUB = 4;                                   // k's per emission batch: 256 positions per wave
     __shared__ uint32_t s_hist[3 * 256];
     __shared__ uint32_t s_wtot[4], s_wvis[4];
@@ -96,6 +97,8 @@ __global__ __launch_bounds__(kBinThreads, GS_BIN_MINWAVES) void bin_emit_kernel(
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     for (int j = tid; j < 3 * 256; j += kBinThreads) s_hist[j] = 0;
     for (uint32_t j = blockIdx.x * (uint32_t)kBinThreads + (uint32_t)tid; j < groupAggWords; j += gridDim.x * (uint32_t)kBinThreads) groupAgg[j] = 0ull;   // for the pair sort's look-back
+    // the zero-initialised per-draw arena of the NEXT draw (the two copies alternate: no memset launch per draw)
+    for (uint32_t j = blockIdx.x * (uint32_t)kBinThreads + (uint32_t)tid; j < nextArenaWords; j += gridDim.x * (uint32_t)kBinThreads) nextArena[j] = 0u;
     const uint32_t numParts = (n + kBinPart - 1) / kBinPart;
     uint32_t visAcc = 0;                                         // thread 0: visible splats of this workgroup's partitions
     // Persistent grid, partitions drawn from kBinTicketClasses counters in separate 128-B lines (one counter would
@@ -405,7 +408,7 @@ template <int MODE>
 __global__ __launch_bounds__(256) void blend_kernel(const uint32_t* __restrict__ pairVals, const uint32_t* __restrict__ tileStart,
                                                     const uint32_t* __restrict__ tileEnd, const uint32_t* __restrict__ tileOrder,
                                                     uint32_t* __restrict__ tileCost, const SplatRec* __restrict__ recs,
-                                                    uint16_t* __restrict__ rt, RasterConsts rc) {
+                                                    uint16_t* __restrict__ rt, RasterConsts rc, int dstIsZero) {
     __shared__ float4 s_a[256];      // cx, cy, u1x, u1y      (u_k = axis_k / |axis_k|^2)
     __shared__ uint4 s_b[256];       // u2x, u2y (float bits), f16 r << 16 | f16 g, f16 b << 16 | f16 a
     __shared__ float4 s_e[256];      // half extents of the footprint's bounding box, pixels; r^2 = ln(255 a) with slack
@@ -425,7 +428,14 @@ __global__ __launch_bounds__(256) void blend_kernel(const uint32_t* __restrict__
     unsigned long long tlStage = 0, tlProc = 0, tlMark = tl0;
     if (threadIdx.x == 0 && tile < 65536u) { g_blend_tl[tile * 8 + 0] = tl0; g_blend_tl[tile * 8 + 1] = tl0; g_blend_tl[tile * 8 + 2] = end - start; g_blend_tl[tile * 8 + 3] = 0; }
 #endif
-    if (start >= end) { if (threadIdx.x == 0) tileCost[tile] = 0; return; }    // nothing lands on this tile: target unchanged
+    if (start >= end) {                                        // nothing lands on this tile: target unchanged ...
+        if (threadIdx.x == 0) tileCost[tile] = 0;
+        if (dstIsZero) {                                       // ... or cleared here, when this draw also performs the pending clear
+            const int px = (int)tx * 16 + (threadIdx.x & 15), py = (int)ty * 16 + (threadIdx.x >> 4);
+            if (px < (int)rc.width && py < (int)rc.height) *(uint2*)(rt + ((size_t)py * rc.width + (size_t)px) * 4) = make_uint2(0u, 0u);
+        }
+        return;
+    }
     uint32_t batchesWalked = 0;
 
     const int qx0 = (int)tx * 16 + (w & 1) * 8, qy0 = (int)ty * 16 + (w >> 1) * 8;
@@ -436,7 +446,7 @@ __global__ __launch_bounds__(256) void blend_kernel(const uint32_t* __restrict__
 
     PixelAcc<MODE> acc;
     uint2* dst = (uint2*)(rt + ((size_t)py * rc.width + (size_t)px) * 4);
-    acc.load(inside ? *dst : make_uint2(0u, 0u));
+    acc.load((inside && !dstIsZero) ? *dst : make_uint2(0u, 0u));
     if (tid == 0) s_done = 0;
     bool waveDone = false;
 
@@ -591,9 +601,12 @@ int32_t ensure_arena(gs_renderer* r, uint32_t numTiles) {
     r->offTileStart = off;   off += align_up((size_t)numTiles * 4, 256);
     r->offTileEnd = off;     off += align_up((size_t)numTiles * 4, 256);
     r->offTileOrder = off;   off += align_up((size_t)numTiles * 4, 256);
+    off = align_up(off, 256);
     r->frameArenaBytes = off;
     r->arenaTiles = numTiles;
-    GS_HIP(hipMalloc((void**)&r->frameArena, off));
+    GS_HIP(hipMalloc((void**)&r->frameArena, 2 * off));
+    GS_HIP(hipMemsetAsync(r->frameArena, 0, 2 * off, r->ctx->stream));
+    r->arenaIdx = 0;
     if (r->tileCost) (void)hipFree(r->tileCost);
     r->tileCost = nullptr;
     GS_HIP(hipMalloc((void**)&r->tileCost, (size_t)numTiles * 4));                      // persists across frames (not part of the zeroed arena)
@@ -656,15 +669,17 @@ int32_t enqueue_draw(gs_renderer* r, const gs_frame_params* p, gs_target* rt) {
     GS_TRY(join_sort(r));                                       // bin_emit reads order[]
     r->lastTilesX = rc.tilesX; r->lastTilesY = rc.tilesY;
 
-    BinControl* binCtl = (BinControl*)r->frameArena;
-    SortControl* pairCtl = (SortControl*)(r->frameArena + r->offPairControl);
-    unsigned long long* binStatus = (unsigned long long*)(r->frameArena + r->offBinStatus);
-    uint32_t* tileStart = (uint32_t*)(r->frameArena + r->offTileStart);
-    uint32_t* tileEnd = (uint32_t*)(r->frameArena + r->offTileEnd);
-    uint32_t* tileOrder = (uint32_t*)(r->frameArena + r->offTileOrder);
+    r->arenaIdx ^= 1;
+    uint8_t* arena = r->frameArena + (size_t)r->arenaIdx * r->frameArenaBytes;          // zeroed by the previous draw's bin_emit (or at allocation)
+    uint8_t* nextArena = r->frameArena + (size_t)(r->arenaIdx ^ 1) * r->frameArenaBytes;
+    BinControl* binCtl = (BinControl*)arena;
+    SortControl* pairCtl = (SortControl*)(arena + r->offPairControl);
+    unsigned long long* binStatus = (unsigned long long*)(arena + r->offBinStatus);
+    uint32_t* tileStart = (uint32_t*)(arena + r->offTileStart);
+    uint32_t* tileEnd = (uint32_t*)(arena + r->offTileEnd);
+    uint32_t* tileOrder = (uint32_t*)(arena + r->offTileOrder);
     const uint32_t cap = (uint32_t)r->pairCapacity;
 
-    GS_HIP(hipMemsetAsync(r->frameArena, 0, r->frameArenaBytes, st));
     prof_record(r, 3);
     const int passes = numTiles <= 256 ? 1 : (numTiles <= 65536 ? 2 : 3);
     auto binKernel = passes == 1 ? bin_emit_kernel<1> : (passes == 2 ? bin_emit_kernel<2> : bin_emit_kernel<3>);
@@ -675,7 +690,7 @@ int32_t enqueue_draw(gs_renderer* r, const gs_frame_params* p, gs_target* rt) {
     const uint32_t binCap = max((uint32_t)ctx->cuCount * (uint32_t)GS_BIN_BLOCKS_PER_CU / kBinTicketClasses * kBinTicketClasses, kBinTicketClasses);
     const uint32_t binGrid = min(div_up(r->binParts, kBinTicketClasses) * kBinTicketClasses, binCap);
     hipLaunchKernelGGL(binKernel, dim3(binGrid), dim3(kBinThreads), 0, st, r->rects, (const uint32_t*)r->visMask, r->order, r->n, rc.tilesX, r->pairKeys,
-                       r->pairVals, cap, binCtl, binStatus, pairCtl->hist, r->pairSort.groupAgg, sort_group_words(cap, passes));
+                       r->pairVals, cap, binCtl, binStatus, pairCtl->hist, r->pairSort.groupAgg, sort_group_words(cap, passes), (uint32_t*)nextArena, (uint32_t)(r->frameArenaBytes / 4));
     prof_record(r, 4);
     GS_TRY(enqueue_sort_passes(ctx, st, r->pairSort, pairCtl, r->pairKeys, r->pairVals, cap, &binCtl->pairCountClamped, passes, 255u, r, 12));
     r->lastPairPasses = (uint32_t)passes;
@@ -683,16 +698,26 @@ int32_t enqueue_draw(gs_renderer* r, const gs_frame_params* p, gs_target* rt) {
                        &binCtl->pairCountClamped, tileStart, tileEnd, numTiles);
     hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, st, tileStart, tileEnd, r->tileCost, numTiles, tileOrder);
     prof_record(r, 5);
+    const int dstIsZero = rt->clearPending ? 1 : 0;             // this draw writes every pixel of the target: the clear is folded in
+    rt->clearPending = false;
     if (r->blendMode == 0)
-        hipLaunchKernelGGL(blend_kernel<0>, dim3(numTiles), dim3(256), 0, st, r->pairVals, tileStart, tileEnd, tileOrder, r->tileCost, r->recs, rt->rgba16f, rc);
+        hipLaunchKernelGGL(blend_kernel<0>, dim3(numTiles), dim3(256), 0, st, r->pairVals, tileStart, tileEnd, tileOrder, r->tileCost, r->recs, rt->rgba16f, rc, dstIsZero);
     else
-        hipLaunchKernelGGL(blend_kernel<1>, dim3(numTiles), dim3(256), 0, st, r->pairVals, tileStart, tileEnd, tileOrder, r->tileCost, r->recs, rt->rgba16f, rc);
+        hipLaunchKernelGGL(blend_kernel<1>, dim3(numTiles), dim3(256), 0, st, r->pairVals, tileStart, tileEnd, tileOrder, r->tileCost, r->recs, rt->rgba16f, rc, dstIsZero);
     prof_record(r, 6);
     GS_HIP(hipGetLastError());
     GS_HIP(hipMemcpyAsync(r->hostBin, binCtl, sizeof(BinControl), hipMemcpyDeviceToHost, st));
     GS_HIP(hipMemcpyAsync(&r->hostSortErr->error, &pairCtl->error, 4, hipMemcpyDeviceToHost, st));
     r->frameInFlight = true;
     prof_end_frame(r);
+    return GS_OK;
+}
+
+int32_t flush_clear(gs_target* t) {
+    if (!t->clearPending) return GS_OK;
+    GS_HIP(hipSetDevice(t->ctx->device));
+    GS_HIP(hipMemsetAsync(t->rgba16f, 0, (size_t)t->width * t->height * 8, t->ctx->stream));
+    t->clearPending = false;
     return GS_OK;
 }
 

@@ -89,10 +89,13 @@ __global__ __launch_bounds__(1024) void set_indices_kernel(uint32_t* order, uint
 __global__ __launch_bounds__(256) void calc_distances_kernel(gsm::AssetView a, const uint32_t* __restrict__ order,
                                                              float m20, float m21, float m22, float m23,
                                                              uint32_t* __restrict__ keys, uint32_t* __restrict__ hist, uint32_t n,
-                                                             unsigned long long* __restrict__ groupAgg, uint32_t groupAggWords) {
+                                                             unsigned long long* __restrict__ groupAgg, uint32_t groupAggWords,
+                                                             uint32_t* __restrict__ nextControl) {
     __shared__ uint32_t s_h[4 * RADIX];
     for (int j = threadIdx.x; j < 4 * RADIX; j += 256) s_h[j] = 0;
     for (uint32_t j = blockIdx.x * 256u + threadIdx.x; j < groupAggWords; j += gridDim.x * 256u) groupAgg[j] = 0ull;   // the sort passes accumulate into it
+    // the control block (histograms, tickets, error) of the NEXT sort: the two blocks alternate, so no memset launch per sort
+    for (uint32_t j = blockIdx.x * 256u + threadIdx.x; j < (uint32_t)(sizeof(SortControl) / 4); j += gridDim.x * 256u) nextControl[j] = 0u;
     __syncthreads();
     constexpr uint32_t ILP = GS_DIST_ILP;
     constexpr uint32_t TILE = 256u * ILP;
@@ -516,14 +519,14 @@ int32_t enqueue_set_indices(gs_context* ctx, uint32_t* order, uint32_t n) {
 uint32_t sort_group_words(uint32_t nUpper, int passes) { return (uint32_t)passes * div_up(div_up(max(nUpper, 1u), PART), (uint32_t)GROUP) * RADIX; }
 
 int32_t enqueue_calc_distances(gs_context* ctx, hipStream_t stream, const gsm::AssetView& a, const uint32_t* order, const float* m, uint32_t* keys,
-                               SortControl* control, uint32_t n, SortState& st) {
-    GS_HIP(hipMemsetAsync(control, 0, sizeof(SortControl), stream));
+                               SortControl* control, SortControl* nextControl, uint32_t n, SortState& st) {
+    // `control` was zeroed by the previous sort's launch of this kernel (or at creation); this launch zeroes `nextControl`
 #ifndef GS_DIST_BLOCKS_PER_CU
 #define GS_DIST_BLOCKS_PER_CU 2      // a narrow window of sorted positions per XCD keeps the gathered sectors in its L2 (measured: 2 beats 4 and 8)
 #endif
     const uint32_t grid = (max(1u, min(div_up(n, 256u * GS_DIST_ILP), (uint32_t)ctx->cuCount * GS_DIST_BLOCKS_PER_CU)) + 7u) & ~7u;
     hipLaunchKernelGGL(calc_distances_kernel, dim3(grid), dim3(256), 0, stream, a, order, m[8], m[9], m[10], m[11], keys,
-                       control->hist, n, st.groupAgg, sort_group_words(n, 4));
+                       control->hist, n, st.groupAgg, sort_group_words(n, 4), (uint32_t*)nextControl);
     GS_HIP(hipGetLastError());
     return GS_OK;
 }
