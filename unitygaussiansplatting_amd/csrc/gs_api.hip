@@ -315,8 +315,8 @@ int32_t gs_renderer_calc_view(gs_renderer* r, const gs_frame_params* p) {
 static int32_t maybe_grow_pairs(gs_renderer* r) {
     if (!r->frameInFlight) return GS_OK;
     if (hipStreamQuery(r->ctx->stream) != hipSuccess) return GS_OK;       // still running: decide next time
-    if (r->hostBin->pairCount > r->pairCapacity) {
-        unsigned long long want = r->hostBin->pairCount + r->hostBin->pairCount / 4;
+    if (r->hostReport->pairCount > r->pairCapacity) {
+        unsigned long long want = r->hostReport->pairCount + r->hostReport->pairCount / 4;
         return gs_renderer_reserve_pairs(r, want);
     }
     return GS_OK;
@@ -482,9 +482,9 @@ int32_t gs_renderer_frame_stats(gs_renderer* r, gs_frame_stats* out) {
     out->pair_capacity = r->pairCapacity;
     out->tiles_x = r->lastTilesX; out->tiles_y = r->lastTilesY;
     if (r->frameInFlight) {
-        out->tile_pairs = r->hostBin->pairCount;
-        out->visible_splats = r->hostBin->visible;
-        out->sort_error = depthErr | r->hostSortErr->error | (r->hostBin->error & 2u);
+        out->tile_pairs = r->hostReport->pairCount;
+        out->visible_splats = r->hostReport->visible;
+        out->sort_error = depthErr | r->hostReport->pairSortError | (r->hostReport->binError & 2u);
     } else out->sort_error = depthErr;
     if (out->sort_error) return fail(GS_ERR_SORT_TIMEOUT, "a bounded look-back spin expired");
     if (r->frameInFlight && out->tile_pairs > r->pairCapacity) {

@@ -67,6 +67,12 @@ struct SortControl {
     uint32_t pad[3];
 };
 
+// What the host wants to know about a finished draw: stored by tile_order_kernel straight into mapped pinned host memory
+struct FrameReport {
+    unsigned long long pairCount;
+    uint32_t binError, pairSortError, visible, pad;
+};
+
 // The two words every workgroup hits with an atomic (ticket, visible) sit in their own 128-B lines: same-address
 // atomics serialise in one L2 channel (~11 ns each), so they must not also queue behind each other.
 struct BinControl {
@@ -166,8 +172,8 @@ struct gs_renderer {
     uint8_t* evValid = nullptr;
     int profCapacity = 0, profCur = 0, profCompleted = 0;
     // host copy of last frame's control (pinned), read lazily
-    gs::BinControl* hostBin = nullptr;
-    gs::SortControl* hostSortErr = nullptr;
+    gs::FrameReport* hostReport = nullptr;  // pinned + mapped: written by the last small kernel of a draw (no copy launch)
+    gs::FrameReport* hostReportDev = nullptr;   // its device-side address
     hipEvent_t evFork = nullptr, evSortDone = nullptr;   // main -> aux fork, aux -> main join (timing disabled)
     bool sortPending = false;               // a sort on ctx->aux has not been joined into ctx->stream yet
     uint32_t lastTilesX = 0, lastTilesY = 0, lastPairPasses = 0;

@@ -273,9 +273,15 @@ __device__ __forceinline__ uint32_t tile_bucket(uint32_t len, uint32_t lastCost)
     return 254u - min(pred, 254u);
 }
 __global__ __launch_bounds__(1024) void tile_order_kernel(const uint32_t* __restrict__ tileStart, const uint32_t* __restrict__ tileEnd,
-                                                          const uint32_t* __restrict__ tileCost, uint32_t numTiles, uint32_t* __restrict__ tileOrder) {
+                                                          const uint32_t* __restrict__ tileCost, uint32_t numTiles, uint32_t* __restrict__ tileOrder,
+                                                          const BinControl* __restrict__ binCtl, const uint32_t* __restrict__ pairSortError,
+                                                          FrameReport* __restrict__ report) {
     __shared__ uint32_t s_cnt[256], s_off[256], s_w[4];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    if (tid == 0) {     // the draw's report, straight into the host's mapped memory (visible to it once the stream is idle)
+        report->pairCount = binCtl->pairCount; report->binError = binCtl->error; report->visible = binCtl->visible;
+        report->pairSortError = *pairSortError;
+    }
     if (tid < 256) s_cnt[tid] = 0;
     __syncthreads();
     for (uint32_t t = tid; t < numTiles; t += 1024u) {
@@ -633,9 +639,9 @@ int32_t renderer_alloc_raster(gs_renderer* r) {
     GS_HIP(hipMalloc((void**)&r->pairKeys, (size_t)(r->pairCapacity + 16) * 4));
     GS_HIP(hipMalloc((void**)&r->pairVals, (size_t)(r->pairCapacity + 16) * 4));
     GS_TRY(sort_state_create(ctx, r->pairSort, (uint32_t)r->pairCapacity));
-    GS_HIP(hipHostMalloc((void**)&r->hostBin, sizeof(BinControl) + sizeof(SortControl), hipHostMallocDefault));
-    memset(r->hostBin, 0, sizeof(BinControl) + sizeof(SortControl));
-    r->hostSortErr = (SortControl*)((uint8_t*)r->hostBin + sizeof(BinControl));
+    GS_HIP(hipHostMalloc((void**)&r->hostReport, sizeof(FrameReport), hipHostMallocMapped));
+    memset(r->hostReport, 0, sizeof(FrameReport));
+    GS_HIP(hipHostGetDevicePointer((void**)&r->hostReportDev, r->hostReport, 0));
     return GS_OK;
 }
 
@@ -649,8 +655,8 @@ void renderer_free_raster(gs_renderer* r) {
     if (r->frameArena) (void)hipFree(r->frameArena);
     if (r->tileCost) (void)hipFree(r->tileCost);
     r->tileCost = nullptr;
-    if (r->hostBin) (void)hipHostFree(r->hostBin);
-    r->recs = nullptr; r->rects = nullptr; r->visMask = nullptr; r->pairKeys = r->pairVals = nullptr; r->frameArena = nullptr; r->hostBin = nullptr;
+    if (r->hostReport) (void)hipHostFree(r->hostReport);
+    r->recs = nullptr; r->rects = nullptr; r->visMask = nullptr; r->pairKeys = r->pairVals = nullptr; r->frameArena = nullptr; r->hostReport = nullptr; r->hostReportDev = nullptr;
 }
 
 int32_t enqueue_draw(gs_renderer* r, const gs_frame_params* p, gs_target* rt) {
@@ -696,7 +702,8 @@ int32_t enqueue_draw(gs_renderer* r, const gs_frame_params* p, gs_target* rt) {
     r->lastPairPasses = (uint32_t)passes;
     hipLaunchKernelGGL(tile_ranges_kernel, dim3(max(1u, min(div_up(cap, 256), (uint32_t)ctx->cuCount * 8u))), dim3(256), 0, st, r->pairKeys,
                        &binCtl->pairCountClamped, tileStart, tileEnd, numTiles);
-    hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, st, tileStart, tileEnd, r->tileCost, numTiles, tileOrder);
+    hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, st, tileStart, tileEnd, r->tileCost, numTiles, tileOrder, binCtl, &pairCtl->error,
+                       r->hostReportDev);
     prof_record(r, 5);
     const int dstIsZero = rt->clearPending ? 1 : 0;             // this draw writes every pixel of the target: the clear is folded in
     rt->clearPending = false;
@@ -706,8 +713,6 @@ int32_t enqueue_draw(gs_renderer* r, const gs_frame_params* p, gs_target* rt) {
         hipLaunchKernelGGL(blend_kernel<1>, dim3(numTiles), dim3(256), 0, st, r->pairVals, tileStart, tileEnd, tileOrder, r->tileCost, r->recs, rt->rgba16f, rc, dstIsZero);
     prof_record(r, 6);
     GS_HIP(hipGetLastError());
-    GS_HIP(hipMemcpyAsync(r->hostBin, binCtl, sizeof(BinControl), hipMemcpyDeviceToHost, st));
-    GS_HIP(hipMemcpyAsync(&r->hostSortErr->error, &pairCtl->error, 4, hipMemcpyDeviceToHost, st));
     r->frameInFlight = true;
     prof_end_frame(r);
     return GS_OK;
