@@ -52,6 +52,23 @@ int32_t hm_block_may_touch(float bcx, float bcy, float half, float cx, float cy,
     return gsm::BlockMayTouch(bcx, bcy, half, cx, cy, u1x, u1y, u2x, u2y, r2) ? 1 : 0;
 }
 float hm_log_det(float x) { return gsm::LogDet(x); }
+// early-cull property: out[i] = {culled by CalcViewGeom(allowCull), tiles of the full path's footprint}
+void hm_cull_check(const gs_asset_desc* d, const gs_frame_params* p, uint32_t* out) {
+    const gsm::AssetView a = mk(d); const gsm::FrameConsts c = fl(p);
+    gsm::EditView e; e.deletedBits = nullptr; e.cutouts = nullptr; e.cutoutCount = 0;
+    for (uint32_t i = 0; i < a.n; ++i) {
+        gsm::ViewPartial full, fast;
+        gsm::CalcViewGeom(a, c, e, i, full, false);
+        gsm::CalcViewGeom(a, c, e, i, fast, true);
+        gsm::SplatFootprint fp;
+        const bool ok = full.front && gsm::PrepareSplat(full.view, c.screenW, c.screenH, c.nearClip, c.farClip, fp);
+        out[i * 2] = fast.culled ? 1u : 0u;
+        out[i * 2 + 1] = (ok && fp.tx0 <= fp.tx1) ? (uint32_t)((fp.tx1 - fp.tx0 + 1) * (fp.ty1 - fp.ty0 + 1)) : 0u;
+        if (!fast.culled && fast.front) {       // not culled: the geometry must be the full path's, bit for bit
+            if (memcmp(&fast.view, &full.view, sizeof(gsm::ViewData)) != 0) out[i * 2] |= 2u;
+        }
+    }
+}
 uint32_t hm_f32tof16(float f) { return gsm::f32tof16(f); }
 float hm_f16tof32(uint32_t h) { return gsm::f16tof32(h); }
 }

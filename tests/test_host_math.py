@@ -160,3 +160,28 @@ def test_block_culling_never_drops_a_live_fragment(hm):
                     assert hit, f"splat {i}: quadrant ({qx},{qy}) has a live pixel but was culled"
     assert checked_tiles > 3000 and dropped_tiles > 0.05 * checked_tiles
     assert checked_quads > 10000 and dropped_quads > 0.1 * checked_quads
+
+
+@pytest.mark.parametrize("quality", ["Medium", "VeryHigh"])
+def test_early_cull_never_drops_a_drawable_splat(hm, quality):
+    """CalcViewGeom(allowCull) -- the per-frame path -- may only give up on splats whose full-path footprint is empty, and
+    must leave the geometry of every other splat bit-identical.  Cameras inside the cloud, grazing, zoomed in (huge
+    footprints), zoomed out, with splat scale 0.1..2 and a scaled/rotated object."""
+    a = small_asset(40_000, 11, quality, extent=4.0)
+    orc = O.Oracle(a)
+    culled_total = drawable_total = 0
+    cases = [((0.0, 0.0, 6.0), (0, 0, 0), 39.1, 1.0, (1, 1, 1)), ((0.3, 0.2, 0.5), (2.0, 0.1, -1.0), 60.0, 2.0, (1, 1, 1)),
+             ((0.0, 0.0, 1.2), (0, 0, 0), 10.0, 2.0, (1.5, 0.7, 1.0)), ((5.0, 4.0, 5.0), (0, 0, 0), 75.0, 0.1, (1, 1, 1)),
+             ((0.05, 3.9, 0.0), (0, 0, 0), 90.0, 1.0, (1, 1, 1)), ((-2.0, 0.5, 2.5), (3.0, 0.5, 2.4), 25.0, 1.3, (0.5, 0.5, 2.0))]
+    for k, (eye, target, fov, ss, objscale) in enumerate(cases):
+        cam = camera.Camera(position=eye, target=target, fieldOfView=fov, pixelWidth=333 + 64 * k, pixelHeight=217 + 31 * k,
+                            nearClipPlane=0.3, farClipPlane=(8.0 if k == 3 else 1000.0))
+        tr = camera.Transform(position=(0.1, -0.2, 0.3), rotation=(0.1, 0.2, 0.05, 0.9695), scale=objscale)
+        P = camera.frame_params(cam, tr, ss, 1.0, 3, False)
+        out = np.zeros((a.splatCount, 2), np.uint32)
+        hm.hm_cull_check(C.byref(orc.desc), C.byref(P), out.ctypes.data_as(C.c_void_p))
+        culled = (out[:, 0] & 1).astype(bool)
+        assert not (out[:, 0] & 2).any(), "geometry of an unculled splat differs from the full path"
+        assert not (culled & (out[:, 1] > 0)).any(), f"case {k}: {int((culled & (out[:, 1] > 0)).sum())} drawable splats were culled"
+        culled_total += int(culled.sum()); drawable_total += int((out[:, 1] > 0).sum())
+    assert culled_total > 20_000 and drawable_total > 20_000          # both outcomes are exercised

@@ -283,14 +283,15 @@ struct ViewPartial {
     uint64_t otherEnd;          // byte address one past the splat's `other` record (the u16 SH index sits just before it)
     bool shLerp;
     bool front;                 // clip.w > 0 after deletion / cutouts: the rest of the record is meaningful
+    bool culled;                // allowCull only: the splat cannot reach the screen and the geometry was not finished
 };
 
-GS_HD void CalcViewGeom(const AssetView& a, const FrameConsts& P, const EditView& E, uint32_t idx, ViewPartial& vp) {
+GS_HD void CalcViewGeom(const AssetView& a, const FrameConsts& P, const EditView& E, uint32_t idx, ViewPartial& vp, bool allowCull = false) {
     ViewData& view = vp.view;
     view.pos[0] = view.pos[1] = view.pos[2] = view.pos[3] = 0.0f;
     view.axis1[0] = view.axis1[1] = view.axis2[0] = view.axis2[1] = 0.0f;
     view.color[0] = view.color[1] = 0u;
-    vp.front = false; vp.shLerp = false; vp.otherEnd = 0u;
+    vp.front = false; vp.culled = false; vp.shLerp = false; vp.otherEnd = 0u;
     vp.shMin = { 0, 0, 0 }; vp.shMax = { 0, 0, 0 }; vp.col = { 0, 0, 0, 0 };
 
     // ---- LoadSplatData: position first (needed for the early out)
@@ -318,13 +319,58 @@ GS_HD void CalcViewGeom(const AssetView& a, const FrameConsts& P, const EditView
     if (!(view.pos[3] > 0.0f)) return;                            // behindCam
     vp.front = true;
 
-    // ---- rotation / scale
+    // ---- scale (needed first: the early cull below bounds the footprint with it)
     uint32_t otherStride = 4 + vecStride(a.scaleFmt);
     if (a.shFmt > 3) otherStride += 2;
     const uint64_t otherAddr = (uint64_t)idx * otherStride;
     vp.otherEnd = otherAddr + otherStride;
-    const V4 q = DecodeRotation(LoadUInt(a.other, otherAddr));
     V3 scale = LoadVec(a.other, otherAddr + 4, a.scaleFmt);
+    if (chunked) {
+        scale.x = lerpf(f16tof32(ck.w[10]), f16tof32(ck.w[10] >> 16), scale.x);
+        scale.y = lerpf(f16tof32(ck.w[11]), f16tof32(ck.w[11] >> 16), scale.y);
+        scale.z = lerpf(f16tof32(ck.w[12]), f16tof32(ck.w[12] >> 16), scale.z);
+        scale.x *= scale.x; scale.y *= scale.y; scale.z *= scale.z;
+        scale.x *= scale.x; scale.y *= scale.y; scale.z *= scale.z;
+        scale.x *= scale.x; scale.y *= scale.y; scale.z *= scale.z;
+    }
+    const float ss2 = P.splatScale * P.splatScale;
+
+    // ---- CalcCovariance2D, first half: the 2x3 matrix T = J * W
+    float vx = mrow(P.mv, 0, pos.x, pos.y, pos.z), vy = mrow(P.mv, 1, pos.x, pos.y, pos.z);
+    const float vz = mrow(P.mv, 2, pos.x, pos.y, pos.z);
+    const float aspect = P.p00 / P.p11;
+    const float tanFovX = 1.0f / P.p00;
+    const float tanFovY = 1.0f / (P.p11 * aspect);
+    const float limX = 1.3f * tanFovX, limY = 1.3f * tanFovY;
+    vx = fminf(fmaxf(vx / vz, -limX), limX) * vz;
+    vy = fminf(fmaxf(vy / vz, -limY), limY) * vz;
+    const float focal = P.screenW * P.p00 / 2.0f;
+    const float zz2 = vz * vz;
+    const float J00 = focal / vz, J02 = -(focal * vx) / zz2;
+    const float J11 = J00, J12 = -(focal * vy) / zz2;
+    const float T00 = fmaf(J02, P.mv[8], J00 * P.mv[0]), T01 = fmaf(J02, P.mv[9], J00 * P.mv[1]), T02 = fmaf(J02, P.mv[10], J00 * P.mv[2]);
+    const float T10 = fmaf(J12, P.mv[8], J11 * P.mv[4]), T11 = fmaf(J12, P.mv[9], J11 * P.mv[5]), T12 = fmaf(J12, P.mv[10], J11 * P.mv[6]);
+
+    // ---- early cull (only for callers that do not need the record of a splat that cannot be drawn).  Exactly as
+    // PrepareSplat: centre depth outside [near, far] => clipped.  Conservatively: the quad's half extent is at most
+    // 2 (|axis1| + |axis2|) <= 4 sqrt(2 lambda1), and lambda1 <= trace(cov2d) <= (|T0|^2 + |T1|^2) lambda_max(Sigma) + 0.6 with
+    // lambda_max(Sigma) <= splatScale^2 |R|^2 max(scale)^2  (|R|^2 <= 1.1 for a 10.10.10.2 quaternion); a centre farther than
+    // that (+5 %, + 2 px) outside the screen cannot put a fragment on it.  NaNs compare false and take the full path.
+    if (allowCull) {
+        const float w = view.pos[3];
+        if (!(w >= P.nearClip && w <= P.farClip)) { vp.culled = true; return; }
+        const float smax = fmaxf(fmaxf(fabsf(scale.x), fabsf(scale.y)), fabsf(scale.z));
+        const float t2 = dot3f(T00, T01, T02, T00, T01, T02) + dot3f(T10, T11, T12, T10, T11, T12);
+        const float lam = fmaf(t2 * (1.1f * ss2), smax * smax, 0.6f);
+        const float rad = fmaf(4.0f * 1.05f, sqrtf(2.0f * lam), 2.0f);
+        const float invw = 1.0f / w;
+        const float cx = fmaf(0.5f * (view.pos[0] * invw), P.screenW, 0.5f * P.screenW);
+        const float cy = fmaf(-0.5f * (view.pos[1] * invw), P.screenH, 0.5f * P.screenH);
+        if (cx - rad > P.screenW || cx + rad < 0.0f || cy - rad > P.screenH || cy + rad < 0.0f) { vp.culled = true; return; }
+    }
+
+    // ---- rotation
+    const V4 q = DecodeRotation(LoadUInt(a.other, otherAddr));
 
     // ---- colour texel
     uint32_t tx, ty;
@@ -343,12 +389,6 @@ GS_HD void CalcViewGeom(const AssetView& a, const FrameConsts& P, const EditView
     }
 
     if (chunked) {
-        scale.x = lerpf(f16tof32(ck.w[10]), f16tof32(ck.w[10] >> 16), scale.x);
-        scale.y = lerpf(f16tof32(ck.w[11]), f16tof32(ck.w[11] >> 16), scale.y);
-        scale.z = lerpf(f16tof32(ck.w[12]), f16tof32(ck.w[12] >> 16), scale.z);
-        scale.x *= scale.x; scale.y *= scale.y; scale.z *= scale.z;
-        scale.x *= scale.x; scale.y *= scale.y; scale.z *= scale.z;
-        scale.x *= scale.x; scale.y *= scale.y; scale.z *= scale.z;
         col.x = lerpf(f16tof32(ck.w[0]), f16tof32(ck.w[0] >> 16), col.x);
         col.y = lerpf(f16tof32(ck.w[1]), f16tof32(ck.w[1] >> 16), col.y);
         col.z = lerpf(f16tof32(ck.w[2]), f16tof32(ck.w[2] >> 16), col.z);
@@ -368,25 +408,10 @@ GS_HD void CalcViewGeom(const AssetView& a, const FrameConsts& P, const EditView
     const float m00 = r00 * scale.x, m01 = r01 * scale.y, m02 = r02 * scale.z;
     const float m10 = r10 * scale.x, m11 = r11 * scale.y, m12 = r12 * scale.z;
     const float m20 = r20 * scale.x, m21 = r21 * scale.y, m22 = r22 * scale.z;
-    const float ss2 = P.splatScale * P.splatScale;
     const float c00 = dot3f(m00, m01, m02, m00, m01, m02) * ss2, c01 = dot3f(m00, m01, m02, m10, m11, m12) * ss2, c02 = dot3f(m00, m01, m02, m20, m21, m22) * ss2;
     const float c11 = dot3f(m10, m11, m12, m10, m11, m12) * ss2, c12 = dot3f(m10, m11, m12, m20, m21, m22) * ss2, c22 = dot3f(m20, m21, m22, m20, m21, m22) * ss2;
 
-    // ---- CalcCovariance2D
-    float vx = mrow(P.mv, 0, pos.x, pos.y, pos.z), vy = mrow(P.mv, 1, pos.x, pos.y, pos.z);
-    const float vz = mrow(P.mv, 2, pos.x, pos.y, pos.z);
-    const float aspect = P.p00 / P.p11;
-    const float tanFovX = 1.0f / P.p00;
-    const float tanFovY = 1.0f / (P.p11 * aspect);
-    const float limX = 1.3f * tanFovX, limY = 1.3f * tanFovY;
-    vx = fminf(fmaxf(vx / vz, -limX), limX) * vz;
-    vy = fminf(fmaxf(vy / vz, -limY), limY) * vz;
-    const float focal = P.screenW * P.p00 / 2.0f;
-    const float zz2 = vz * vz;
-    const float J00 = focal / vz, J02 = -(focal * vx) / zz2;
-    const float J11 = J00, J12 = -(focal * vy) / zz2;
-    const float T00 = fmaf(J02, P.mv[8], J00 * P.mv[0]), T01 = fmaf(J02, P.mv[9], J00 * P.mv[1]), T02 = fmaf(J02, P.mv[10], J00 * P.mv[2]);
-    const float T10 = fmaf(J12, P.mv[8], J11 * P.mv[4]), T11 = fmaf(J12, P.mv[9], J11 * P.mv[5]), T12 = fmaf(J12, P.mv[10], J11 * P.mv[6]);
+    // ---- CalcCovariance2D, second half: cov = T * Sigma * T^T (+ the 0.3 px low-pass)
     // VT[i][j] = sum_k V[i][k] * T[j][k]
     const float VT00 = dot3f(c00, c01, c02, T00, T01, T02), VT01 = dot3f(c00, c01, c02, T10, T11, T12);
     const float VT10 = dot3f(c01, c11, c12, T00, T01, T02), VT11 = dot3f(c01, c11, c12, T10, T11, T12);

@@ -34,7 +34,10 @@ constexpr int KPT = GS_SORT_KPT;
 constexpr int PART = THREADS * KPT;
 constexpr uint32_t SPIN_LIMIT = 1u << 24;
 constexpr uint32_t TICKET_CLASSES = 16;        // partition-ticket counters per pass (one 128-B line each)
-constexpr int GROUP = 32;                     // partitions per look-back group (~sqrt of the partition count of a 6 M key sort)
+#ifndef GS_SORT_GROUP
+#define GS_SORT_GROUP 32
+#endif
+constexpr int GROUP = GS_SORT_GROUP;                     // partitions per look-back group (~sqrt of the partition count of a 6 M key sort)
 
 constexpr unsigned long long FLAG_AGG = 1ull, FLAG_INCL = 2ull;
 
