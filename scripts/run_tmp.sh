@@ -1,5 +1,7 @@
 export PYTHONPATH=$PWD
 mkdir -p gpurun_out
-bash scripts/profile_round.sh > gpurun_out/profile_round.log 2>&1; tail -3 gpurun_out/profile_round.log
-cd $GRAFT_REPO_ROOT
-timeout 900 python bench.py > gpurun_out/bench.json 2> gpurun_out/bench.err; tail -c 2500 gpurun_out/bench.json
+python scripts/bench_stages.py C2 100 2>&1 | tail -1 | cut -c1-400
+GS_NOPROF=1 python scripts/bench_stages.py C2 100 2>&1 | tail -1
+GSPLAT_OVERLAP=1 python scripts/bench_stages.py C2 100 2>&1 | tail -1 | cut -c1-400
+GSPLAT_OVERLAP=1 GS_NOPROF=1 python scripts/bench_stages.py C2 100 2>&1 | tail -1
+timeout 600 python -m pytest tests/test_gpu_draw.py -x -q -m gpu -k overlap 2>&1 | tail -2

@@ -277,17 +277,20 @@ int32_t gs_renderer_sort(gs_renderer* r, const float m[16]) {
     // SortPoints and CalcViewData are independent (the C# merely records them one after the other, :120-126): with
     // overlap on, the sort is forked onto the context's second queue here and joined by the first consumer of order[]
     // (gs_renderer_draw, or any readback), so it runs concurrently with gs_renderer_calc_view.
+    // Only the four Onesweep passes are forked: they are latency-bound with little VALU work and co-run with the VALU-bound
+    // calc_view; the key generation stays on the main stream (its random gather slows 3x next to calc_view).
+    GS_TRY(join_sort(r));
     hipStream_t st = ctx->stream;
-    if (ctx->overlap) {
-        GS_HIP(hipEventRecord(r->evFork, ctx->stream));          // after everything that still reads order[] / distances[]
-        GS_HIP(hipStreamWaitEvent(ctx->aux, r->evFork, 0));
-        st = ctx->aux;
-    } else GS_TRY(join_sort(r));
     gs::prof_record(r, 0, st);
     r->depthControlIdx ^= 1;
     SortControl* control = r->depthControl + r->depthControlIdx;
     GS_TRY(enqueue_calc_distances(ctx, st, r->asset->view, r->order, m, r->distances, control, r->depthControl + (r->depthControlIdx ^ 1), r->n, r->depthSort));
     gs::prof_record(r, 1, st);
+    if (ctx->overlap) {
+        GS_HIP(hipEventRecord(r->evFork, ctx->stream));          // after the keys, and after everything that still reads order[]
+        GS_HIP(hipStreamWaitEvent(ctx->aux, r->evFork, 0));
+        st = ctx->aux;
+    }
     GS_TRY(enqueue_sort_passes(ctx, st, r->depthSort, control, r->distances, r->order, r->n, nullptr, 4, 255u, r, 10));
     gs::prof_record(r, 2, st);
     if (ctx->overlap) {
