@@ -13,7 +13,9 @@ pytestmark = pytest.mark.gpu
 CASES = [("Medium", {}), ("High", {}), ("VeryHigh", {}),
          ("Medium", dict(formatPos=A.VectorFormat.Norm16, formatScale=A.VectorFormat.Norm6, formatSH=A.SHFormat.Float16, formatColor=A.ColorFormat.Float16x4)),
          ("Medium", dict(formatPos=A.VectorFormat.Norm6, formatScale=A.VectorFormat.Float32, formatSH=A.SHFormat.Norm11, formatColor=A.ColorFormat.Float32x4)),
-         ("Medium", dict(formatPos=A.VectorFormat.Float32, formatScale=A.VectorFormat.Norm16))]
+         ("Medium", dict(formatPos=A.VectorFormat.Float32, formatScale=A.VectorFormat.Norm16)),
+         ("Medium", dict(formatSH=A.SHFormat.Cluster16k)),                                         # fp16 palette gathered by a u16 index stored after the scale
+         ("Low", dict(formatSH=A.SHFormat.Cluster4k))]                                             # Low preset (Norm6 scale: 8-byte `other` stride), 4k palette
 
 
 @pytest.mark.parametrize("quality,fmt", CASES)

@@ -33,7 +33,9 @@ def hm(tmp_path_factory):
 
 CASES = [("Medium", {}), ("High", {}), ("VeryHigh", {}),
          ("Medium", dict(formatPos=A.VectorFormat.Norm16, formatScale=A.VectorFormat.Norm6, formatSH=A.SHFormat.Float16, formatColor=A.ColorFormat.Float16x4)),
-         ("Medium", dict(formatPos=A.VectorFormat.Norm6, formatScale=A.VectorFormat.Float32, formatSH=A.SHFormat.Norm11, formatColor=A.ColorFormat.Float32x4))]
+         ("Medium", dict(formatPos=A.VectorFormat.Norm6, formatScale=A.VectorFormat.Float32, formatSH=A.SHFormat.Norm11, formatColor=A.ColorFormat.Float32x4)),
+         ("Medium", dict(formatSH=A.SHFormat.Cluster4k)),                                          # fp16 palette + u16 index in `other` (6-byte stride: unaligned dwords)
+         ("Medium", dict(formatScale=A.VectorFormat.Norm6, formatSH=A.SHFormat.Cluster4k))]
 
 
 @pytest.mark.parametrize("quality,fmt", CASES)

@@ -13,7 +13,10 @@ the decoder in the hot path expects:
       PackSmallest3Rotation, MortonEncode3
 
 This is an import-time tool (SURVEY.md section 8f "next #1"), not part of the per-frame path.  SH
-clustering (Cluster* formats, KMeansClustering.cs) is not implemented: CreateAsset raises for it.
+clustering (Cluster* formats) produces the reference's data layout (fp16 table of K means + a u16 index per splat
+in the `other` record, GaussianSplatAssetCreator.cs:476-518,776-805) with a plain seeded mini-batch k-means; the
+reference's own KMeansClustering.cs (batched, Burst) differs in its iteration schedule, which only changes which
+palette is found, not how it is stored or decoded.
 """
 from __future__ import annotations
 
@@ -289,6 +292,37 @@ def _pad8(b: np.ndarray) -> np.ndarray:
 
 
 # --------------------------------------------------------------------------------------------------
+# ClusterSHs (:476-518): K-means over the 45-D SH vectors -> fp16 palette + per-splat index
+# --------------------------------------------------------------------------------------------------
+def ClusterSHs(sh: np.ndarray, count: int, seed: int = 0, iterations: int = 4, sample: int = 200_000):
+    """sh [N,15,3] f32 -> (means [count,45] f32, indices [N] int).  Seeded mini-batch Lloyd iterations on a subsample,
+    then one full assignment pass; distances through |a|^2 + |b|^2 - 2ab (one GEMM per block of splats)."""
+    n = len(sh)
+    x = np.ascontiguousarray(sh.reshape(n, 45), f32)
+    rng = np.random.Generator(np.random.PCG64(seed))
+    means = x[rng.choice(n, size=count, replace=False)].copy()
+
+    def assign(pts, cen):
+        out = np.empty(len(pts), np.int64)
+        c2 = (cen * cen).sum(1)
+        for i in range(0, len(pts), 16384):
+            blk = pts[i:i + 16384]
+            d = c2[None, :] - f32(2.0) * (blk @ cen.T)
+            out[i:i + 16384] = d.argmin(1)
+        return out
+
+    sub = x if n <= sample else x[rng.choice(n, size=sample, replace=False)]
+    for _ in range(iterations):
+        idx = assign(sub, means)
+        sums = np.zeros((count, 45), np.float64)
+        np.add.at(sums, idx, sub)
+        cnt = np.bincount(idx, minlength=count)
+        nz = cnt > 0
+        means[nz] = (sums[nz] / cnt[nz, None]).astype(f32)
+    return means, assign(x, means)
+
+
+# --------------------------------------------------------------------------------------------------
 # CreateAsset
 # --------------------------------------------------------------------------------------------------
 def CreateAssetFromSplats(raw: InputSplatData, quality: str = "Medium", *, formatPos=None, formatScale=None,
@@ -300,8 +334,6 @@ def CreateAssetFromSplats(raw: InputSplatData, quality: str = "Medium", *, forma
     fs = VectorFormat(fs if formatScale is None else formatScale)
     fc = ColorFormat(fc if formatColor is None else formatColor)
     fsh = SHFormat(fsh if formatSH is None else formatSH)
-    if fsh > SHFormat.Norm6:
-        raise NotImplementedError("SH clustering (Cluster* formats) is an offline k-means import step; not implemented")
     if fc == ColorFormat.BC7:
         raise NotImplementedError("BC7 colour needs a block compressor; not implemented")
 
@@ -363,9 +395,21 @@ def CreateAssetFromSplats(raw: InputSplatData, quality: str = "Medium", *, forma
     # positions (:760-774, :807-827)
     pos_bytes = _pad8(EmitEncodedVector(pos, fp).reshape(-1))
 
-    # other: rot + scale (:776-805)
+    # SH palette for the Cluster* formats: raw (not chunk-normalised) SH vectors (:286-291, :476-518)
+    sh_means = sh_index = None
+    if fsh > SHFormat.Norm6:
+        from .asset import GetSHCount
+        k = GetSHCount(fsh, n)
+        if k >= n:
+            raise ValueError(f"{fsh.name} needs more than {k} splats (the reference falls back to unclustered data there)")
+        sh_means, sh_index = ClusterSHs(s.sh.astype(f32), k)
+
+    # other: rot + scale (+ u16 SH index) (:776-805)
     rot_enc = EncodeQuatToNorm10(s.rot.astype(f32)).astype("<u4").view(np.uint8).reshape(n, 4)
-    oth = np.concatenate([rot_enc, EmitEncodedVector(scale, fs)], axis=1)
+    parts = [rot_enc, EmitEncodedVector(scale, fs)]
+    if sh_index is not None:
+        parts.append(sh_index.astype("<u2").view(np.uint8).reshape(n, 2))
+    oth = np.concatenate(parts, axis=1)
     oth_bytes = _pad8(np.ascontiguousarray(oth).reshape(-1))
 
     # colour texture (:873-932)
@@ -383,7 +427,11 @@ def CreateAssetFromSplats(raw: InputSplatData, quality: str = "Medium", *, forma
     assert len(col_bytes) == w * h * GetColorSize(fc)
 
     # SH (:934-1037)
-    if fsh == SHFormat.Float32:
+    if sh_means is not None:                           # ConvertSHClustersJob (:443-474): SHTableItemFloat16 per cluster
+        item = np.zeros((len(sh_means), 48), "<f2")
+        item[:, :45] = sh_means.astype(np.float16)
+        sh_bytes = item.view(np.uint8).reshape(-1)
+    elif fsh == SHFormat.Float32:
         item = np.zeros((n, 48), "<f4")
         item[:, :45] = sh.reshape(n, 45)
         sh_bytes = item.view(np.uint8).reshape(-1)
