@@ -246,27 +246,28 @@ __global__ __launch_bounds__(kBinThreads, GS_BIN_MINWAVES) void bin_emit_kernel(
     }
 }
 
-// tile -> [start, end) in the tile-sorted pair array
+// tile -> [start, end) in the tile-sorted pair array.  Four keys per thread from one 16-byte load (the key buffers are
+// 16-byte aligned and padded by 16 entries), plus the one key before and the one after the quad.
 __global__ __launch_bounds__(256) void tile_ranges_kernel(const uint32_t* __restrict__ pairKeys, const uint32_t* nPtr,
                                                           uint32_t* __restrict__ tileStart, uint32_t* __restrict__ tileEnd, uint32_t numTiles) {
     const uint32_t n = *nPtr;
-    for (uint32_t j = blockIdx.x * 256u + threadIdx.x; j < n; j += gridDim.x * 256u) {
-        const uint32_t t = pairKeys[j];
-        if (t >= numTiles) continue;
-        if (j == 0 || pairKeys[j - 1] != t) tileStart[t] = j;
-        if (j == n - 1 || pairKeys[j + 1] != t) tileEnd[t] = j + 1;
+    const uint32_t quads = (n + 3u) >> 2;
+    for (uint32_t q = blockIdx.x * 256u + threadIdx.x; q < quads; q += gridDim.x * 256u) {
+        const uint32_t j0 = q << 2;
+        const uint4 k4 = ((const uint4*)pairKeys)[q];
+        const uint32_t k[6] = { j0 ? pairKeys[j0 - 1u] : 0xffffffffu, k4.x, k4.y, k4.z, k4.w, (j0 + 4u < n) ? pairKeys[j0 + 4u] : 0xffffffffu };
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const uint32_t j = j0 + (uint32_t)c;
+            if (j >= n) break;
+            const uint32_t t = k[c + 1];
+            if (t >= numTiles) continue;
+            if (j == 0 || k[c] != t) tileStart[t] = j;
+            if (j == n - 1 || k[c + 2] != t) tileEnd[t] = j + 1;
+        }
     }
 }
 
-// Longest lists first.  The blend launch has ~2 workgroups per slot (3750 tiles, 2048 slots at 8 per CU) and list lengths
-// spread over 0..10^4 pairs: dispatched in screen order, the second wave of workgroups starts at 55-105 us and the long
-// lists among them finish at 190 us while the machine-wide work is only 125 us (measured per-tile timeline, C2).  The
-// hardware hands out workgroups in blockIdx order as slots free up, so a permutation of the tiles by descending list
-// cost turns the launch into longest-processing-time-first list scheduling.  The cost of a tile is not its list length
-// (pixels saturate: only 30 % of the 256-record batches are ever walked) but the number of batches it walked in the
-// PREVIOUS frame, which the blend kernel leaves in tileCost[] (cameras move slowly); a tile without history counts by
-// length.  Counting sort into 256 buckets, one workgroup; the order inside a bucket is whatever the atomics give -- the
-// image does not depend on it.
 __device__ __forceinline__ uint32_t tile_bucket(uint32_t len, uint32_t lastCost) {   // 0 = most expensive ... 255 = empty
     if (len == 0) return 255u;
     const uint32_t pred = lastCost ? lastCost * 4u : min((len + 255u) >> 8, 12u);      // batches x 4; no history: a third of a long list at most
@@ -700,7 +701,7 @@ int32_t enqueue_draw(gs_renderer* r, const gs_frame_params* p, gs_target* rt) {
     prof_record(r, 4);
     GS_TRY(enqueue_sort_passes(ctx, st, r->pairSort, pairCtl, r->pairKeys, r->pairVals, cap, &binCtl->pairCountClamped, passes, 255u, r, 12));
     r->lastPairPasses = (uint32_t)passes;
-    hipLaunchKernelGGL(tile_ranges_kernel, dim3(max(1u, min(div_up(cap, 256), (uint32_t)ctx->cuCount * 8u))), dim3(256), 0, st, r->pairKeys,
+    hipLaunchKernelGGL(tile_ranges_kernel, dim3(max(1u, min(div_up(cap, 1024), (uint32_t)ctx->cuCount * 8u))), dim3(256), 0, st, r->pairKeys,
                        &binCtl->pairCountClamped, tileStart, tileEnd, numTiles);
     hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, st, tileStart, tileEnd, r->tileCost, numTiles, tileOrder, binCtl, &pairCtl->error,
                        r->hostReportDev);
