@@ -263,6 +263,21 @@ def main():
                                     "hbm_frac": round(frame_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
                     "note": "blend_kernel is VALU-bound (exp + per-blend fp16 rounding), not HBM-bound: its hbm_frac in `stages` is not a quality measure"}
 
+        # a device-to-device copy ceiling measured on this GPU (SURVEY.md section 8d asks for it next to the 8 TB/s spec): 512 MiB read + 512 MiB written
+        try:
+            src = torch.empty(512 << 20, dtype=torch.uint8, device="cuda")
+            dst = torch.empty_like(src)
+            dst.copy_(src); torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                dst.copy_(src)
+            e1.record(); torch.cuda.synchronize()
+            roofline["measured_copy_ceiling_GBps"] = round(10 * 2 * src.numel() / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)
+            del src, dst
+        except Exception:
+            roofline["measured_copy_ceiling_GBps"] = None
+
         cpu = None
         parity = None
         if world == 1 and args.cpu_baseline == "auto":

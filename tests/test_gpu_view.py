@@ -85,3 +85,28 @@ def test_asset_hot_reload_and_invalid_assets(gpu_ctx):
     d = make_asset_desc(a, keep)
     d.pos_format = 9
     assert _lib.lib().gs_asset_create(gpu_ctx._h, C.byref(d), C.byref(h)) == -1
+
+
+def test_view_buffer_every_frame_mode_matches_on_demand(gpu_ctx):
+    """gs_renderer_set_view_buffer_mode(1) runs the reference's full CSCalcViewData every frame; the default evaluates
+    colours only for splats that reach the screen (and stops early for splats that cannot) and materialises m_GpuView in
+    gs_renderer_download_view.  Both must give the same view buffer, the same frame and the same pair / visible counts."""
+    from unitygaussiansplatting_amd.renderer import RenderTarget
+    a = small_asset(50_000, 9, "Medium")
+    cam = default_camera(W=400, H=240, az=70.0, radius=4.0)
+    res = []
+    for every in (False, True):
+        r = GaussianSplatRenderer(gpu_ctx, a)
+        r.OnEnable()
+        r.SetViewBufferMode(every)
+        rt = RenderTarget(gpu_ctx, cam.pixelWidth, cam.pixelHeight)
+        r.SortPoints(cam); r.CalcViewData(cam); rt.Clear(); r.Draw(cam, rt)
+        st = r.FrameStats()
+        img = rt.Download().copy()
+        view = r.DownloadView().copy()
+        rt.Clear(); r.Draw(cam, rt)                      # the on-demand download re-ran calc_view: the draw after it must not change
+        assert np.array_equal(rt.Download(), img)
+        res.append((img, view, st.tile_pairs, st.visible_splats))
+        r.OnDisable(); rt.Dispose()
+    assert np.array_equal(res[0][0], res[1][0]) and views_equal(res[0][1], res[1][1]) and res[0][2:] == res[1][2:]
+    assert 0 < res[0][3] < a.splatCount
