@@ -98,7 +98,7 @@ def main():
     asset = None
     if rank == 0:
         raw = scenes.make_config_splats(cfg, args.splats)
-        asset = creator.CreateAssetFromSplats(raw, cfg.quality, name=cfg.key)
+        asset = creator.CreateAssetFromSplatsNative(raw, cfg.quality, name=cfg.key)      # gs_import_encode: same bytes as the numpy importer, ~8x faster
         del raw
     th.join()
     torch = holder["torch"]

@@ -212,6 +212,30 @@ int32_t gs_target_download(gs_target* t, void* out_rgba16f, size_t bytes);   /* 
 int32_t gs_target_resolve(gs_target* t, const float background_rgba[4], float* out_rgba32f, uint8_t* out_rgba8);
 int32_t gs_target_device_ptr(gs_target* t, void** rgba16f_dev, void** resolved_rgba32f_dev);
 
+/* ---- native importer (host code, no GPU needed): GaussianSplatAssetCreator.CreateAsset minus the Unity asset database -- */
+/* InputSplatData (GaussianFileReader.cs:17-26) as separate arrays, in the PLY domain after ReorderSHs: */
+typedef struct gs_import_input {
+    uint32_t splat_count;
+    const float* pos;       /* N x 3 */
+    const float* dc0;       /* N x 3   f_dc_0..2 (raw SH0) */
+    const float* sh;        /* N x 45  15 coefficients x rgb (ReorderSHs layout, GaussianFileReader.cs:186-208) */
+    const float* opacity;   /* N       logit */
+    const float* scale;     /* N x 3   log-scale */
+    const float* rot;       /* N x 4   rot_0..3 = (w, x, y, z) */
+} gs_import_input;
+typedef struct gs_import_formats {
+    uint32_t pos_format, scale_format, color_format, sh_format;   /* gs_vector_format x2, gs_color_format, gs_sh_format */
+    uint32_t linearize;     /* 1: apply LinearizeData (GaussianFileReader.cs:211-233); 0: the arrays are already linear
+                               (dc0 = colour, opacity in 0..1, scale linear, rot = packed smallest-3 + index/3) */
+    uint32_t morton;        /* 1: reorder by the 63-bit Morton code of the position (GaussianSplatAssetCreator.cs:362-429) */
+} gs_import_formats;
+/* byte sizes of the pos, other, color, sh, chunk blobs (chunk = 0 for an all-fp32 asset); BC7 and Cluster* are GS_ERR_UNSUPPORTED_FORMAT */
+int32_t gs_import_blob_sizes(uint32_t splat_count, const gs_import_formats* formats, uint64_t sizes[5]);
+/* encodes into caller-owned host buffers of at least those sizes (blobs[4] may be NULL when sizes[4] == 0);
+ * bounds_min/max (may be NULL) receive the position bounds (GaussianSplatAsset.boundsMin/Max). */
+int32_t gs_import_encode(const gs_import_input* in, const gs_import_formats* formats, void* const blobs[5], const uint64_t sizes[5],
+                         float bounds_min[3], float bounds_max[3]);
+
 /* ---- stand-alone sorter: GpuSorting (GpuSorting.cs) ----------------------------------------------- */
 /* SupportResources.Load(count) :48-63 */
 int32_t gs_sorter_create(gs_context* ctx, uint32_t max_count, gs_sorter** out);

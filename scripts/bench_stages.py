@@ -19,7 +19,7 @@ cache = f"/tmp/gsplat_cache/{key}.json"
 if os.path.exists(cache):
     asset = GaussianSplatAsset.Load(cache)
 else:
-    asset = creator.CreateAssetFromSplats(scenes.make_config_splats(cfg), cfg.quality, name=key)
+    asset = creator.CreateAssetFromSplatsNative(scenes.make_config_splats(cfg), cfg.quality, name=key)
     asset.Save("/tmp/gsplat_cache")
 ctx = GpuContext(0)
 r = GaussianSplatRenderer(ctx, asset)

@@ -1,0 +1,79 @@
+"""The native importer (gs_import_encode, csrc/gs_import.cpp) against the numpy importer (creator.py): the five blobs and
+the bounds must be identical byte for byte, for every quality preset / format it supports, with and without LinearizeData and
+the Morton reorder, for splat counts that do and do not fill the last chunk / texture tile.  No GPU needed (host code)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from unitygaussiansplatting_amd import _lib, creator, scenes
+from unitygaussiansplatting_amd import asset as A
+from unitygaussiansplatting_amd._abi import gs_import_formats
+
+BLOBS = ("posData", "otherData", "colorData", "shData", "chunkData")
+
+
+def _same(a, b):
+    for nm in BLOBS:
+        x, y = getattr(a, nm), getattr(b, nm)
+        if x is None or y is None or len(x) == 0 or len(y) == 0:
+            assert (x is None or len(x) == 0) and (y is None or len(y) == 0), nm
+            continue
+        x, y = np.asarray(x, np.uint8), np.asarray(y, np.uint8)
+        assert len(x) == len(y), (nm, len(x), len(y))
+        bad = np.flatnonzero(x != y)
+        assert len(bad) == 0, f"{nm}: {len(bad)} bytes differ, first at {bad[:5]}"
+    assert np.array_equal(np.asarray(a.boundsMin, np.float32), np.asarray(b.boundsMin, np.float32))
+    assert np.array_equal(np.asarray(a.boundsMax, np.float32), np.asarray(b.boundsMax, np.float32))
+    assert a.dataHash == b.dataHash
+
+
+@pytest.mark.parametrize("quality", ["Medium", "High", "VeryHigh"])
+@pytest.mark.parametrize("n", [1, 255, 256, 257, 30_011])
+def test_native_importer_matches_numpy_presets(quality, n):
+    raw = scenes.make_splats(n, 100 + n, 3.0)
+    _same(creator.CreateAssetFromSplats(raw, quality), creator.CreateAssetFromSplatsNative(raw, quality))
+
+
+@pytest.mark.parametrize("fmt", [
+    dict(formatPos=A.VectorFormat.Norm16, formatScale=A.VectorFormat.Norm6, formatSH=A.SHFormat.Float16, formatColor=A.ColorFormat.Float16x4),
+    dict(formatPos=A.VectorFormat.Norm6, formatScale=A.VectorFormat.Float32, formatSH=A.SHFormat.Norm11, formatColor=A.ColorFormat.Float32x4),
+    dict(formatPos=A.VectorFormat.Float32, formatScale=A.VectorFormat.Norm16, formatSH=A.SHFormat.Float32, formatColor=A.ColorFormat.Norm8x4),
+    dict(formatPos=A.VectorFormat.Norm11, formatScale=A.VectorFormat.Norm11, formatSH=A.SHFormat.Norm6, formatColor=A.ColorFormat.Float16x4)])
+@pytest.mark.parametrize("morton,linearize", [(True, True), (False, True), (True, False)])
+def test_native_importer_matches_numpy_formats(fmt, morton, linearize):
+    raw = scenes.make_splats(5_003, 9, 2.0)
+    if not linearize:
+        raw = creator.LinearizeData(raw)
+    _same(creator.CreateAssetFromSplats(raw, "Medium", morton=morton, linearize=linearize, **fmt),
+          creator.CreateAssetFromSplatsNative(raw, "Medium", morton=morton, linearize=linearize, **fmt))
+
+
+def test_deterministic_exp_is_accurate_and_extreme_inputs_agree():
+    x = np.concatenate([np.linspace(-30, 30, 200_001), [-87.0, -86.9, 88.0, 87.9, 0.0, -0.0, 1e-8, -1e-8]]).astype(np.float32)
+    got = creator.ExpDet(x).astype(np.float64)
+    want = np.exp(x.astype(np.float64))
+    assert (np.abs(got - want) / want).max() < 2.0 ** -21
+    # degenerate inputs: identical positions (empty bounds), zero quaternion component ties, huge / tiny scales and logits
+    raw = scenes.make_splats(700, 3, 1.0)
+    raw.pos[:300] = raw.pos[0]
+    raw.rot[:50] = np.array([0.5, 0.5, 0.5, 0.5], np.float32)
+    raw.scale[50:100] = np.float32(-20.0); raw.scale[100:150] = np.float32(3.0)
+    raw.opacity[150:200] = np.float32(40.0); raw.opacity[200:250] = np.float32(-40.0)
+    raw.sh[250:300] = np.float32(0.25)
+    _same(creator.CreateAssetFromSplats(raw, "Medium"), creator.CreateAssetFromSplatsNative(raw, "Medium"))
+
+
+def test_native_importer_argument_validation():
+    lib = _lib.lib()
+    sizes = (C.c_uint64 * 5)()
+    ok = gs_import_formats(2, 2, 2, 3, 1, 1)
+    assert lib.gs_import_blob_sizes(1000, C.byref(ok), sizes) == 0
+    assert list(sizes) == [4000, 8000, 2048 * 16 * 4, 32000, 4 * 64]
+    assert lib.gs_import_blob_sizes(0, C.byref(ok), sizes) == -1
+    assert lib.gs_import_blob_sizes(1000, C.byref(gs_import_formats(2, 2, 3, 3, 1, 1)), sizes) == -3       # BC7
+    assert lib.gs_import_blob_sizes(1000, C.byref(gs_import_formats(2, 2, 2, 8, 1, 1)), sizes) == -3       # Cluster4k
+    assert lib.gs_import_blob_sizes(1000, C.byref(gs_import_formats(9, 2, 2, 3, 1, 1)), sizes) == -1
+    assert lib.gs_import_encode(None, C.byref(ok), (C.c_void_p * 5)(), sizes, None, None) == -1
+    with pytest.raises(_lib.GsError):
+        creator.CreateAssetFromSplatsNative(scenes.make_splats(5000, 3, 2.0), "Low")

@@ -45,6 +45,16 @@ class gs_cutout(C.Structure):
     _fields_ = [("matrix", C.c_float * 16), ("type_and_flags", C.c_uint32)]
 
 
+class gs_import_input(C.Structure):
+    _fields_ = [("splat_count", C.c_uint32), ("pos", C.c_void_p), ("dc0", C.c_void_p), ("sh", C.c_void_p),
+                ("opacity", C.c_void_p), ("scale", C.c_void_p), ("rot", C.c_void_p)]
+
+
+class gs_import_formats(C.Structure):
+    _fields_ = [("pos_format", C.c_uint32), ("scale_format", C.c_uint32), ("color_format", C.c_uint32), ("sh_format", C.c_uint32),
+                ("linearize", C.c_uint32), ("morton", C.c_uint32)]
+
+
 class gs_frame_stats(C.Structure):
     _fields_ = [("tile_pairs", C.c_uint64), ("pair_capacity", C.c_uint64), ("visible_splats", C.c_uint32),
                 ("tiles_x", C.c_uint32), ("tiles_y", C.c_uint32), ("sort_error", C.c_uint32)]

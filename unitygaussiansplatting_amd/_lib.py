@@ -6,7 +6,8 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-from ._abi import gs_asset_desc, gs_cutout, gs_frame_params, gs_frame_stats, gs_stage_times
+from ._abi import (gs_asset_desc, gs_cutout, gs_frame_params, gs_frame_stats, gs_import_formats, gs_import_input,
+                   gs_stage_times)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GSPLAT_LIB") or os.path.join(_HERE, "libgsplat_hip.so")   # GSPLAT_LIB: A/B a variant build
@@ -61,6 +62,9 @@ SIGNATURES = {
     "gs_target_download": (C.c_int32, [_P, _P, C.c_size_t]),
     "gs_target_resolve": (C.c_int32, [_P, C.POINTER(C.c_float), _P, _P]),
     "gs_target_device_ptr": (C.c_int32, [_P, _PP, _PP]),
+    "gs_import_blob_sizes": (C.c_int32, [C.c_uint32, C.POINTER(gs_import_formats), C.c_uint64 * 5]),
+    "gs_import_encode": (C.c_int32, [C.POINTER(gs_import_input), C.POINTER(gs_import_formats), C.c_void_p * 5, C.c_uint64 * 5,
+                                      C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "gs_sorter_create": (C.c_int32, [_P, C.c_uint32, _PP]),
     "gs_sorter_destroy": (C.c_int32, [_P]),
     "gs_sorter_dispatch": (C.c_int32, [_P, _P, _P, C.c_uint32, C.c_uint32]),

@@ -131,9 +131,26 @@ def ReadPLY(path: str) -> InputSplatData:
 # --------------------------------------------------------------------------------------------------
 # GaussianUtils.cs
 # --------------------------------------------------------------------------------------------------
+def ExpDet(x):
+    """exp(x) from fp32 operations only, one rounding each (range reduction by ln2 in two parts + Cephes' degree-5 polynomial,
+    scaled by 2^n through the exponent bits): the same bits here and in the native importer (csrc/gs_import.cpp: exp_det),
+    whatever libm / SIMD exp numpy was built with.  |rel. error| < 2^-22."""
+    x = np.clip(np.asarray(x, f32), f32(-87.0), f32(88.0))
+    n = np.rint(x * f32(1.44269504)).astype(f32)
+    r = (x - n * f32(0.693359375)).astype(f32)
+    r = (r - n * f32(-2.12194440e-4)).astype(f32)
+    p = np.full_like(r, f32(1.9875691500e-4))
+    for c in (1.3981999507e-3, 8.3334519073e-3, 4.1665795894e-2, 1.6666665459e-1, 5.0000001201e-1):
+        p = (p * r + f32(c)).astype(f32)
+    p = (p * (r * r) + r).astype(f32)
+    p = (p + f32(1.0)).astype(f32)
+    scale = ((n.astype(np.int32) + 127) << 23).astype(np.uint32).view(f32)
+    return (p * scale).astype(f32)
+
+
 def Sigmoid(v):                      # GaussianUtils.cs:9-12
     v = np.asarray(v, f32)
-    return (f32(1) / (f32(1) + np.exp(-v, dtype=f32))).astype(f32)
+    return (f32(1) / (f32(1) + ExpDet(-v))).astype(f32)
 
 
 def SH0ToColor(dc0):                 # GaussianUtils.cs:14-18
@@ -207,7 +224,7 @@ def LinearizeData(s: InputSplatData) -> InputSplatData:
     q = (wxyz / nrm)[:, [1, 2, 3, 0]]                   # NormalizeSwizzleRotation: normalize(wxyz).yzwx
     return InputSplatData(
         pos=s.pos.astype(f32), dc0=SH0ToColor(s.dc0), sh=s.sh.astype(f32),
-        opacity=Sigmoid(s.opacity), scale=np.abs(np.exp(s.scale.astype(f32), dtype=f32)).astype(f32),
+        opacity=Sigmoid(s.opacity), scale=np.abs(ExpDet(s.scale.astype(f32))).astype(f32),
         rot=PackSmallest3Rotation(q))
 
 
@@ -352,7 +369,7 @@ def CreateAssetFromSplats(raw: InputSplatData, quality: str = "Medium", *, forma
     chunk_bytes = None
     if use_chunks:                                     # CalcChunkDataJob (:520-638)
         nchunks = (n + kChunkSize - 1) // kChunkSize
-        scale = np.power(scale, f32(1.0 / 8.0)).astype(f32)
+        scale = np.sqrt(np.sqrt(np.sqrt(scale))).astype(f32)       # math.pow(s, 1/8) as three correctly rounded roots (as csrc/gs_import.cpp)
         opacity = SquareCentered01(opacity)
         pad = nchunks * kChunkSize - n
 
@@ -370,8 +387,8 @@ def CreateAssetFromSplats(raw: InputSplatData, quality: str = "Medium", *, forma
         shlo = sh.min(axis=1)
         shhi = sh.max(axis=1)                          # one shared rgb min/max over all 15 coefficients
         hmin, _ = cmin_cmax(shlo)
-        _, hmax0 = cmin_cmax(shhi)
-        hmax = np.maximum(hmax0, (hmin + f32(1.0e-5)).astype(f32)).astype(f32)
+        hmax0 = np.concatenate([shhi, np.full((pad, 3), -np.inf, f32)]).reshape(nchunks, kChunkSize, 3).max(1).astype(f32)
+        hmax = np.maximum(hmax0, (hmin + f32(1.0e-5)).astype(f32)).astype(f32)      # chunkMaxshs = max(chunkMaxshs, chunkMinshs + 1e-5) :595
 
         chunks = np.zeros(nchunks, CHUNK_DTYPE)
         for k, nm in enumerate(("posX", "posY", "posZ")):
@@ -453,6 +470,35 @@ def CreateAssetFromSplats(raw: InputSplatData, quality: str = "Medium", *, forma
                            colorData=np.ascontiguousarray(col_bytes), shData=np.ascontiguousarray(sh_bytes),
                            chunkData=chunk_bytes, boundsMin=tuple(map(float, bmin)), boundsMax=tuple(map(float, bmax)),
                            name=name)
+    a.dataHash = a.ComputeDataHash()
+    a.Validate()
+    return a
+
+
+def CreateAssetFromSplatsNative(raw: InputSplatData, quality: str = "Medium", *, formatPos=None, formatScale=None, formatColor=None,
+                                formatSH=None, name: str = "asset", morton: bool = True, linearize: bool = True) -> GaussianSplatAsset:
+    """The same asset through the native importer of libgsplat_hip.so (gs_import_encode, csrc/gs_import.cpp: multi-threaded
+    host C++).  Bit-identical to CreateAssetFromSplats for every format it supports (tests/test_import.py); BC7 / Cluster* raise."""
+    import ctypes as C
+    from . import _lib
+    from ._abi import gs_import_formats, gs_import_input
+    fp, fs, fc, fsh = QUALITY[quality]
+    fp = VectorFormat(fp if formatPos is None else formatPos)
+    fs = VectorFormat(fs if formatScale is None else formatScale)
+    fc = ColorFormat(fc if formatColor is None else formatColor)
+    fsh = SHFormat(fsh if formatSH is None else formatSH)
+    n = len(raw)
+    arrs = [np.ascontiguousarray(a, f32) for a in (raw.pos, raw.dc0, raw.sh.reshape(n, 45), raw.opacity, raw.scale, raw.rot)]
+    inp = gs_import_input(n, *[a.ctypes.data for a in arrs])
+    fmt = gs_import_formats(int(fp), int(fs), int(fc), int(fsh), int(bool(linearize)), int(bool(morton)))
+    sizes = (C.c_uint64 * 5)()
+    _lib.check(_lib.lib().gs_import_blob_sizes(n, C.byref(fmt), sizes), "gs_import_blob_sizes")
+    blobs = [np.zeros(int(sz), np.uint8) if sz else None for sz in sizes]
+    ptrs = (C.c_void_p * 5)(*[b.ctypes.data if b is not None else None for b in blobs])
+    bmin, bmax = (C.c_float * 3)(), (C.c_float * 3)()
+    _lib.check(_lib.lib().gs_import_encode(C.byref(inp), C.byref(fmt), ptrs, sizes, bmin, bmax), "gs_import_encode")
+    a = GaussianSplatAsset(splatCount=n, posFormat=fp, scaleFormat=fs, shFormat=fsh, colorFormat=fc, posData=blobs[0], otherData=blobs[1],
+                           colorData=blobs[2], shData=blobs[3], chunkData=blobs[4], boundsMin=tuple(bmin), boundsMax=tuple(bmax), name=name)
     a.dataHash = a.ComputeDataHash()
     a.Validate()
     return a

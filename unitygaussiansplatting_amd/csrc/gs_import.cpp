@@ -1,0 +1,317 @@
+// gs_import.cpp -- native importer: raw (PLY-domain) splats -> the five GaussianSplatAsset blobs.
+//
+// Host C++ (multi-threaded), no device code: asset creation is an import-time step, not part of the per-frame path
+// (SURVEY.md section 8f "next #1").  Restates, relative to /root/reference/package/:
+//   Editor/Utils/GaussianFileReader.cs :211-233   LinearizeData (normalise + swizzle rotation, exp(scale), sigmoid(opacity), SH0 -> colour)
+//   Runtime/GaussianUtils.cs           :9-95      Sigmoid, SH0ToColor, SquareCentered01, PackSmallest3Rotation, MortonEncode3
+//   Editor/GaussianSplatAssetCreator.cs :362-429  bounds + Morton reorder, :520-658 chunk bounds / normalisation,
+//                                       :705-758  Encode* / EmitEncodedVector (truncating (uint)(v * (k + 0.5f))),
+//                                       :776-805  other data, :863-932 colour texture (16x16 Morton tiles), :934-1037 SH items
+// Arithmetic is plain IEEE fp32, one rounding per operation (-ffp-contract=off), and the two transcendental steps are
+// written out (exp as Cephes-style range reduction + polynomial, x^(1/8) as three correctly rounded square roots) so that
+// the bytes are a function of this source only: unitygaussiansplatting_amd/creator.py performs the same operations with
+// numpy and tests/test_import.py requires the two to agree bit for bit.  SH clustering (Cluster*) and BC7 are not done here.
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <limits>
+#include <numeric>
+#include <thread>
+#include <vector>
+
+#include "../../include/gsplat_c.h"
+
+namespace gs {
+int32_t fail(int32_t code, const char* what);
+}
+
+namespace {
+
+constexpr uint32_t kChunk = 256, kTexWidth = 2048;
+
+template <class F> void parallel_for(size_t n, size_t grain, F f) {
+    const size_t hw = std::max(1u, std::thread::hardware_concurrency());
+    const size_t nt = std::min(hw, (n + grain - 1) / grain);
+    if (nt <= 1) { f(0, n); return; }
+    std::vector<std::thread> th;
+    const size_t per = (n + nt - 1) / nt;
+    for (size_t t = 0; t < nt; ++t) {
+        const size_t a = t * per, b = std::min(n, a + per);
+        if (a < b) th.emplace_back([=] { f(a, b); });
+    }
+    for (auto& x : th) x.join();
+}
+
+inline float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+inline uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+
+// exp(x), deterministic: n = rint(x log2 e), r = x - n ln2 (two-part), degree-5 polynomial (Cephes expf), scale by 2^n
+inline float exp_det(float x) {
+    x = std::fmin(std::fmax(x, -87.0f), 88.0f);
+    const float n = std::nearbyintf(x * 1.44269504f);
+    float r = x - n * 0.693359375f;
+    r = r - n * -2.12194440e-4f;
+    float p = 1.9875691500e-4f;
+    p = p * r + 1.3981999507e-3f;
+    p = p * r + 8.3334519073e-3f;
+    p = p * r + 4.1665795894e-2f;
+    p = p * r + 1.6666665459e-1f;
+    p = p * r + 5.0000001201e-1f;
+    p = p * (r * r) + r;
+    p = p + 1.0f;
+    return p * u2f((uint32_t)((int)n + 127) << 23);
+}
+
+inline float sgn(float x) { return x > 0.0f ? 1.0f : (x < 0.0f ? -1.0f : 0.0f); }
+inline float SquareCentered01(float x) { x -= 0.5f; x = x * (x * sgn(x)); return x * 2.0f + 0.5f; }
+inline float sat(float v) { return std::fmin(std::fmax(v, 0.0f), 1.0f); }
+inline uint32_t q(float v, float k) { return (uint32_t)(int64_t)(v * k); }          // truncating (uint)(v * (max + 0.5f))
+
+inline uint16_t f32tof16(float f) {      // round to nearest even
+    uint32_t x = f2u(f);
+    const uint32_t sign = (x >> 16) & 0x8000u;
+    x &= 0x7fffffffu;
+    if (x > 0x7f800000u) return (uint16_t)(sign | 0x7e00u);
+    if (x >= 0x477ff000u) return (uint16_t)(sign | 0x7c00u);
+    if (x < 0x38800000u) {
+        if (x < 0x33000000u) return (uint16_t)sign;
+        const uint32_t e = x >> 23, m = (x & 0x7fffffu) | 0x800000u, shift = 126u - e;
+        uint32_t r = m >> shift;
+        const uint32_t rem = m & ((1u << shift) - 1u), half = 1u << (shift - 1u);
+        if (rem > half || (rem == half && (r & 1u))) r++;
+        return (uint16_t)(sign | r);
+    }
+    uint32_t r = x - 0x38000000u;
+    const uint32_t rem = r & 0x1fffu;
+    r >>= 13;
+    if (rem > 0x1000u || (rem == 0x1000u && (r & 1u))) r++;
+    return (uint16_t)(sign | r);
+}
+
+inline uint64_t part1by2(uint64_t x) {      // GaussianUtils.cs:81-90
+    x &= 0x1fffffull;
+    x = (x ^ (x << 32)) & 0x1f00000000ffffull;
+    x = (x ^ (x << 16)) & 0x1f0000ff0000ffull;
+    x = (x ^ (x << 8)) & 0x100f00f00f00f00full;
+    x = (x ^ (x << 4)) & 0x10c30c30c30c30c3ull;
+    x = (x ^ (x << 2)) & 0x1249249249249249ull;
+    return x;
+}
+
+inline void texel_of(uint32_t idx, uint32_t& px, uint32_t& py) {       // GaussianSplatAssetCreator.cs:863-871
+    uint32_t t = idx;
+    t = (t & 0xFF) | ((t & 0xFE) << 7);
+    t &= 0x5555;
+    t = (t ^ (t >> 1)) & 0x3333;
+    t = (t ^ (t >> 2)) & 0x0f0f;
+    const uint32_t tile = idx >> 8, width = kTexWidth / 16;
+    px = (tile % width) * 16 + (t & 0xF);
+    py = (tile / width) * 16 + (t >> 8);
+}
+
+uint32_t vec_size(uint32_t f) { return f == 0 ? 12u : (f == 1 ? 6u : (f == 2 ? 4u : 2u)); }
+uint32_t color_size(uint32_t f) { return f == 0 ? 16u : (f == 1 ? 8u : 4u); }
+uint32_t sh_size(uint32_t f) { return f == 0 ? 192u : (f == 1 ? 96u : (f == 2 ? 60u : 32u)); }
+uint64_t pad8(uint64_t n) { return (n + 7) / 8 * 8; }
+
+void emit_vec(const float v[3], uint8_t* out, uint32_t fmt) {           // EmitEncodedVector :727-758 (saturating)
+    if (fmt == 0) { memcpy(out, v, 12); return; }
+    const float x = sat(v[0]), y = sat(v[1]), z = sat(v[2]);
+    if (fmt == 1) {
+        const uint16_t e[3] = { (uint16_t)q(x, 65535.5f), (uint16_t)q(y, 65535.5f), (uint16_t)q(z, 65535.5f) };
+        memcpy(out, e, 6);
+    } else if (fmt == 2) {
+        const uint32_t e = q(x, 2047.5f) | (q(y, 1023.5f) << 11) | (q(z, 2047.5f) << 21);
+        memcpy(out, &e, 4);
+    } else {
+        const uint16_t e = (uint16_t)(q(x, 63.5f) | (q(y, 31.5f) << 6) | (q(z, 31.5f) << 11));
+        memcpy(out, &e, 2);
+    }
+}
+
+struct Splat { float pos[3], dc0[3], sh[45], opacity, scale[3], rot[4]; };      // linearised
+
+void sizes_of(uint32_t n, const gs_import_formats& f, uint64_t s[5]) {
+    const uint64_t texH = ((uint64_t)(n + kTexWidth - 1) / kTexWidth + 15) / 16 * 16;
+    const bool chunks = !(f.pos_format == 0 && f.scale_format == 0 && f.color_format == 0 && f.sh_format == 0);
+    s[0] = pad8((uint64_t)n * vec_size(f.pos_format));
+    s[1] = pad8((uint64_t)n * (4 + vec_size(f.scale_format)));
+    s[2] = (uint64_t)kTexWidth * std::max<uint64_t>(texH, 16) * color_size(f.color_format);
+    s[3] = (uint64_t)n * sh_size(f.sh_format);
+    s[4] = chunks ? (uint64_t)((n + kChunk - 1) / kChunk) * 64 : 0;
+}
+
+} // namespace
+
+extern "C" {
+
+int32_t gs_import_blob_sizes(uint32_t splat_count, const gs_import_formats* f, uint64_t sizes[5]) {
+    if (!f || !sizes || splat_count == 0) return gs::fail(GS_ERR_INVALID_ARGUMENT, "null argument / no splats");
+    if (f->pos_format > 3 || f->scale_format > 3 || f->color_format > 3 || f->sh_format > 8) return gs::fail(GS_ERR_INVALID_ARGUMENT, "format enum out of range");
+    if (f->color_format == GS_COLOR_BC7 || f->sh_format > GS_SH_NORM6) return gs::fail(GS_ERR_UNSUPPORTED_FORMAT, "BC7 / Cluster* are not produced by the native importer");
+    sizes_of(splat_count, *f, sizes);
+    return GS_OK;
+}
+
+int32_t gs_import_encode(const gs_import_input* in, const gs_import_formats* f, void* const blobs[5], const uint64_t sizes[5],
+                         float bounds_min[3], float bounds_max[3]) {
+    if (!in || !f || !blobs || !sizes) return gs::fail(GS_ERR_INVALID_ARGUMENT, "null argument");
+    uint64_t need[5];
+    const int32_t rc = gs_import_blob_sizes(in->splat_count, f, need);
+    if (rc != GS_OK) return rc;
+    if (!in->pos || !in->dc0 || !in->sh || !in->opacity || !in->scale || !in->rot) return gs::fail(GS_ERR_INVALID_ARGUMENT, "an input array is null");
+    for (int k = 0; k < 5; ++k)
+        if (need[k] && (!blobs[k] || sizes[k] < need[k])) return gs::fail(GS_ERR_INVALID_ARGUMENT, "an output blob is null or too small");
+    const uint32_t n = in->splat_count;
+    const bool useChunks = need[4] != 0;
+    std::vector<Splat> s;
+    try { s.resize(n); } catch (...) { return gs::fail(GS_ERR_OUT_OF_MEMORY, "host allocation"); }
+
+    // ---- LinearizeData (GaussianFileReader.cs:211-233) or plain copy
+    parallel_for(n, 1 << 14, [&](size_t a, size_t b) {
+        for (size_t i = a; i < b; ++i) {
+            Splat& o = s[i];
+            memcpy(o.pos, in->pos + i * 3, 12);
+            memcpy(o.sh, in->sh + i * 45, 180);
+            if (!f->linearize) {
+                memcpy(o.dc0, in->dc0 + i * 3, 12); memcpy(o.scale, in->scale + i * 3, 12); memcpy(o.rot, in->rot + i * 4, 16);
+                o.opacity = in->opacity[i];
+                continue;
+            }
+            for (int c = 0; c < 3; ++c) {
+                o.dc0[c] = in->dc0[i * 3 + c] * 0.2820948f + 0.5f;                         // SH0ToColor
+                o.scale[c] = std::fabs(exp_det(in->scale[i * 3 + c]));
+            }
+            o.opacity = 1.0f / (1.0f + exp_det(-in->opacity[i]));                           // Sigmoid
+            const float* w = in->rot + i * 4;                                               // (w, x, y, z)
+            const float len = std::sqrt(((w[0] * w[0] + w[1] * w[1]) + w[2] * w[2]) + w[3] * w[3]);
+            const float qv[4] = { w[1] / len, w[2] / len, w[3] / len, w[0] / len };         // normalize(wxyz).yzwx
+            int idx = 0;                                                                    // PackSmallest3Rotation: first max wins
+            float best = std::fabs(qv[0]);
+            for (int c = 1; c < 4; ++c) if (std::fabs(qv[c]) > best) { best = std::fabs(qv[c]); idx = c; }
+            float t[4] = { qv[0], qv[1], qv[2], qv[3] };
+            if (idx == 0) { t[0] = qv[1]; t[1] = qv[2]; t[2] = qv[3]; t[3] = qv[0]; }
+            if (idx == 1) { t[0] = qv[0]; t[1] = qv[2]; t[2] = qv[3]; t[3] = qv[1]; }
+            if (idx == 2) { t[0] = qv[0]; t[1] = qv[1]; t[2] = qv[3]; t[3] = qv[2]; }
+            const float sg = t[3] >= 0.0f ? 1.0f : -1.0f;
+            for (int c = 0; c < 3; ++c) o.rot[c] = ((t[c] * sg) * 1.41421354f) * 0.5f + 0.5f;
+            o.rot[3] = (float)idx / 3.0f;
+        }
+    });
+
+    // ---- bounds + Morton reorder (GaussianSplatAssetCreator.cs:362-429)
+    float bmin[3] = { s[0].pos[0], s[0].pos[1], s[0].pos[2] }, bmax[3] = { bmin[0], bmin[1], bmin[2] };
+    for (uint32_t i = 1; i < n; ++i)
+        for (int c = 0; c < 3; ++c) { bmin[c] = std::fmin(bmin[c], s[i].pos[c]); bmax[c] = std::fmax(bmax[c], s[i].pos[c]); }
+    if (bounds_min) memcpy(bounds_min, bmin, 12);
+    if (bounds_max) memcpy(bounds_max, bmax, 12);
+    std::vector<uint32_t> order(n);
+    std::iota(order.begin(), order.end(), 0u);
+    if (f->morton) {
+        std::vector<uint64_t> code(n);
+        const float inv[3] = { 1.0f / (bmax[0] - bmin[0]), 1.0f / (bmax[1] - bmin[1]), 1.0f / (bmax[2] - bmin[2]) };
+        parallel_for(n, 1 << 15, [&](size_t a, size_t b) {
+            for (size_t i = a; i < b; ++i) {
+                uint64_t ip[3];
+                for (int c = 0; c < 3; ++c) ip[c] = (uint64_t)(uint32_t)(int64_t)(((s[i].pos[c] - bmin[c]) * inv[c]) * 2097151.0f);
+                code[i] = (part1by2(ip[2]) << 2) | (part1by2(ip[1]) << 1) | part1by2(ip[0]);
+            }
+        });
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return code[a] < code[b]; });   // (code, index)
+    }
+
+    // ---- chunk bounds and normalisation (CalcChunkDataJob :520-638), per chunk of 256 reordered splats
+    uint8_t* posOut = (uint8_t*)blobs[0];
+    uint8_t* othOut = (uint8_t*)blobs[1];
+    uint8_t* colOut = (uint8_t*)blobs[2];
+    uint8_t* shOut = (uint8_t*)blobs[3];
+    uint8_t* chkOut = (uint8_t*)blobs[4];
+    memset(posOut, 0, need[0]); memset(othOut, 0, need[1]); memset(colOut, 0, need[2]); memset(shOut, 0, need[3]);
+    const uint32_t nchunks = (n + kChunk - 1) / kChunk;
+    const uint32_t posSz = vec_size(f->pos_format), sclSz = vec_size(f->scale_format), othSz = 4 + sclSz, colSz = color_size(f->color_format),
+                   shSz = sh_size(f->sh_format);
+    parallel_for(nchunks, 16, [&](size_t ca, size_t cb) {
+        std::vector<Splat> c(kChunk);
+        for (size_t ci = ca; ci < cb; ++ci) {
+            const uint32_t first = (uint32_t)ci * kChunk, cnt = std::min(kChunk, n - first);
+            for (uint32_t k = 0; k < cnt; ++k) c[k] = s[order[first + k]];
+            if (useChunks) {
+                const float inf = std::numeric_limits<float>::infinity();
+                float pmin[3] = { inf, inf, inf }, pmax[3] = { -inf, -inf, -inf }, smin[3] = { inf, inf, inf }, smax[3] = { -inf, -inf, -inf };
+                float cmin[4] = { inf, inf, inf, inf }, cmax[4] = { -inf, -inf, -inf, -inf }, hmin[3] = { inf, inf, inf }, hmax[3] = { -inf, -inf, -inf };
+                for (uint32_t k = 0; k < cnt; ++k) {
+                    Splat& o = c[k];
+                    for (int d = 0; d < 3; ++d) o.scale[d] = std::sqrt(std::sqrt(std::sqrt(o.scale[d])));        // s^(1/8)
+                    o.opacity = SquareCentered01(o.opacity);
+                    for (int d = 0; d < 3; ++d) {
+                        pmin[d] = std::fmin(pmin[d], o.pos[d]); pmax[d] = std::fmax(pmax[d], o.pos[d]);
+                        smin[d] = std::fmin(smin[d], o.scale[d]); smax[d] = std::fmax(smax[d], o.scale[d]);
+                        cmin[d] = std::fmin(cmin[d], o.dc0[d]); cmax[d] = std::fmax(cmax[d], o.dc0[d]);
+                    }
+                    cmin[3] = std::fmin(cmin[3], o.opacity); cmax[3] = std::fmax(cmax[3], o.opacity);
+                    for (int j = 0; j < 15; ++j)
+                        for (int d = 0; d < 3; ++d) { hmin[d] = std::fmin(hmin[d], o.sh[j * 3 + d]); hmax[d] = std::fmax(hmax[d], o.sh[j * 3 + d]); }
+                }
+                for (int d = 0; d < 3; ++d) {                                             // make sure the ranges are not empty (:592-595)
+                    pmax[d] = std::fmax(pmax[d], pmin[d] + 1.0e-5f); smax[d] = std::fmax(smax[d], smin[d] + 1.0e-5f);
+                    hmax[d] = std::fmax(hmax[d], hmin[d] + 1.0e-5f);
+                }
+                for (int d = 0; d < 4; ++d) cmax[d] = std::fmax(cmax[d], cmin[d] + 1.0e-5f);
+                uint32_t w[16];
+                for (int d = 0; d < 4; ++d) w[d] = (uint32_t)f32tof16(cmin[d]) | ((uint32_t)f32tof16(cmax[d]) << 16);
+                for (int d = 0; d < 3; ++d) { w[4 + 2 * d] = f2u(pmin[d]); w[5 + 2 * d] = f2u(pmax[d]); }
+                for (int d = 0; d < 3; ++d) w[10 + d] = (uint32_t)f32tof16(smin[d]) | ((uint32_t)f32tof16(smax[d]) << 16);
+                for (int d = 0; d < 3; ++d) w[13 + d] = (uint32_t)f32tof16(hmin[d]) | ((uint32_t)f32tof16(hmax[d]) << 16);
+                memcpy(chkOut + ci * 64, w, 64);
+                for (uint32_t k = 0; k < cnt; ++k) {                                      // normalise with the fp32 (un-rounded) bounds (:613-637)
+                    Splat& o = c[k];
+                    for (int d = 0; d < 3; ++d) {
+                        o.pos[d] = (o.pos[d] - pmin[d]) / (pmax[d] - pmin[d]);
+                        o.scale[d] = (o.scale[d] - smin[d]) / (smax[d] - smin[d]);
+                        o.dc0[d] = (o.dc0[d] - cmin[d]) / (cmax[d] - cmin[d]);
+                    }
+                    o.opacity = (o.opacity - cmin[3]) / (cmax[3] - cmin[3]);
+                    for (int j = 0; j < 15; ++j)
+                        for (int d = 0; d < 3; ++d) o.sh[j * 3 + d] = (o.sh[j * 3 + d] - hmin[d]) / (hmax[d] - hmin[d]);
+                }
+            }
+            for (uint32_t k = 0; k < cnt; ++k) {
+                const Splat& o = c[k];
+                const uint32_t i = first + k;
+                emit_vec(o.pos, posOut + (size_t)i * posSz, f->pos_format);
+                // other: rotation 10.10.10.2 + scale (:776-805)
+                const uint32_t enc = q(o.rot[0], 1023.5f) | (q(o.rot[1], 1023.5f) << 10) | (q(o.rot[2], 1023.5f) << 20) | (q(o.rot[3], 3.5f) << 30);
+                memcpy(othOut + (size_t)i * othSz, &enc, 4);
+                emit_vec(o.scale, othOut + (size_t)i * othSz + 4, f->scale_format);
+                // colour texel (:873-932)
+                uint32_t px, py;
+                texel_of(i, px, py);
+                uint8_t* t = colOut + ((size_t)py * kTexWidth + px) * colSz;
+                const float col[4] = { o.dc0[0], o.dc0[1], o.dc0[2], o.opacity };
+                if (f->color_format == 0) memcpy(t, col, 16);
+                else if (f->color_format == 1) { uint16_t h[4]; for (int d = 0; d < 4; ++d) h[d] = f32tof16(col[d]); memcpy(t, h, 8); }
+                else { const uint32_t e = q(sat(col[0]), 255.5f) | (q(sat(col[1]), 255.5f) << 8) | (q(sat(col[2]), 255.5f) << 16) | (q(sat(col[3]), 255.5f) << 24); memcpy(t, &e, 4); }
+                // SH item (:934-1037)
+                uint8_t* sp = shOut + (size_t)i * shSz;
+                if (f->sh_format == 0) memcpy(sp, o.sh, 180);
+                else if (f->sh_format == 1) { uint16_t h[45]; for (int d = 0; d < 45; ++d) h[d] = f32tof16(o.sh[d]); memcpy(sp, h, 90); }
+                else if (f->sh_format == 2) {
+                    for (int j = 0; j < 15; ++j) {       // CreateSHDataJob does not saturate
+                        const uint32_t e = q(o.sh[j * 3], 2047.5f) | (q(o.sh[j * 3 + 1], 1023.5f) << 11) | (q(o.sh[j * 3 + 2], 2047.5f) << 21);
+                        memcpy(sp + j * 4, &e, 4);
+                    }
+                } else {
+                    for (int j = 0; j < 15; ++j) {
+                        const uint16_t e = (uint16_t)(q(o.sh[j * 3], 31.5f) | (q(o.sh[j * 3 + 1], 63.5f) << 5) | (q(o.sh[j * 3 + 2], 31.5f) << 11));
+                        memcpy(sp + j * 2, &e, 2);
+                    }
+                }
+            }
+        }
+    });
+    return GS_OK;
+}
+
+} // extern "C"

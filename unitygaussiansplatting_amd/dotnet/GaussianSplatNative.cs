@@ -94,6 +94,14 @@ namespace GaussianSplatting.Runtime
         [DllImport(Lib)] public static extern int gs_target_resolve(IntPtr target, float[] backgroundRgba4, IntPtr dstRgba32f, IntPtr dstRgba8);
         [DllImport(Lib)] public static extern int gs_target_device_ptr(IntPtr target, out IntPtr rgba16fDev, out IntPtr resolvedDev);
 
+        // native importer (host code): GaussianSplatAssetCreator.CreateAsset without the asset database
+        [StructLayout(LayoutKind.Sequential)]
+        public struct ImportInput { public uint splatCount; public IntPtr pos, dc0, sh, opacity, scale, rot; }
+        [StructLayout(LayoutKind.Sequential)]
+        public struct ImportFormats { public uint posFormat, scaleFormat, colorFormat, shFormat, linearize, morton; }
+        [DllImport(Lib)] public static extern int gs_import_blob_sizes(uint splatCount, ref ImportFormats formats, [Out] ulong[] sizes5);
+        [DllImport(Lib)] public static extern int gs_import_encode(ref ImportInput input, ref ImportFormats formats, IntPtr[] blobs5, ulong[] sizes5, float[] boundsMin3, float[] boundsMax3);
+
         [DllImport(Lib)] public static extern int gs_sorter_create(IntPtr ctx, uint maxCount, out IntPtr sorter);
         [DllImport(Lib)] public static extern int gs_sorter_destroy(IntPtr sorter);
         [DllImport(Lib)] public static extern int gs_sorter_dispatch(IntPtr sorter, IntPtr keysDev, IntPtr valuesDev, uint count, uint keyBits);
