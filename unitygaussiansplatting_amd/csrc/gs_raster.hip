@@ -61,6 +61,19 @@ __device__ __forceinline__ void hist_add_aggregated(uint32_t* h, uint32_t d, boo
     if (active) atomicAdd(&h[d], 1u);                      // many distinct values left: plain per-lane adds
 }
 
+// inclusive max-scan over the 64 lanes in 6 DPP steps (v_max_u32 with a DPP source: no LDS / bpermute round trips)
+__device__ __forceinline__ uint32_t wave_incl_max_scan_dpp(uint32_t v) {
+#define GS_DPP(x, ctrl, rowmask) (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(x), ctrl, rowmask, 0xf, false)
+    v = max(v, GS_DPP(v, 0x111, 0xf));      // row_shr:1
+    v = max(v, GS_DPP(v, 0x112, 0xf));      // row_shr:2
+    v = max(v, GS_DPP(v, 0x114, 0xf));      // row_shr:4
+    v = max(v, GS_DPP(v, 0x118, 0xf));      // row_shr:8
+    v = max(v, GS_DPP(v, 0x142, 0xa));      // row_bcast:15 -> rows 1 and 3
+    v = max(v, GS_DPP(v, 0x143, 0xc));      // row_bcast:31 -> rows 2 and 3
+#undef GS_DPP
+    return v;
+}
+
 __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += (uint32_t)__shfl_xor((int)v, o, 64);
@@ -93,6 +106,7 @@ __global__ __launch_bounds__(kBinThreads, GS_BIN_MINWAVES) void bin_emit_kernel(
     __shared__ uint32_t s_off[4][SUB * 64];
     __shared__ uint32_t s_sid[4][SUB * 64];
     __shared__ uint2 s_rect[4][SUB * 64];
+    __shared__ uint32_t s_mark[4][64];
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     for (int j = tid; j < 3 * 256; j += kBinThreads) s_hist[j] = 0;
@@ -195,28 +209,45 @@ __global__ __launch_bounds__(kBinThreads, GS_BIN_MINWAVES) void bin_emit_kernel(
     uint32_t* offs = s_off[w];
     uint32_t* sids = s_sid[w];
     uint2* rcts = s_rect[w];
+    uint32_t* mark = s_mark[w];
+    mark[lane] = 0u;
     uint32_t run = 0;                                            // wave-local exclusive offset, wave-uniform
 #pragma unroll
     for (int sb = 0; sb < kBinItems / SUB; ++sb) {
         const uint32_t subStart = run;
+        uint32_t offsR[SUB], cntR[SUB];
 #pragma unroll
         for (int kk = 0; kk < SUB; ++kk) {
             const int k = sb * SUB + kk;
             const uint32_t c = (rc[k].y & 0xffffu) * (rc[k].y >> 16);
             const uint32_t incl = wave_incl_scan_u32(c, lane);
+            offsR[kk] = run + incl - c; cntR[kk] = c;
             offs[kk * 64 + lane] = run + incl - c;
             sids[kk * 64 + lane] = sid[k];
             rcts[kk * 64 + lane] = rc[k];
             run += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
         }
         __builtin_amdgcn_wave_barrier();
+        uint32_t carry = 0;                                      // owner (+1) of the slot before j0 (wave-uniform)
         for (uint32_t j0 = subStart; j0 < run; j0 += 64u) {       // wave-uniform trip count
             const uint32_t j = j0 + (uint32_t)lane;
             const bool act = j < run;
-            uint32_t e = 0;                                      // largest e with offs[e] <= j: the position that owns slot j
+            // Which position owns output slot j?  Every non-empty position whose first slot falls into this batch of 64
+            // drops its index (+1) at that slot; an inclusive max-scan over the lanes (positions ascend with the slots)
+            // carries it forward, `carry` across batches.  One LDS write/read pair and 6 DPP steps instead of an 8-step
+            // binary search through LDS (8 dependent round trips).
 #pragma unroll
-            for (uint32_t step = (SUB * 64) / 2; step > 0; step >>= 1)
-                if (offs[e + step] <= j) e += step;
+            for (int kk = 0; kk < SUB; ++kk) {
+                const uint32_t d = offsR[kk] - j0;
+                if (cntR[kk] != 0u && d < 64u) mark[d] = (uint32_t)(kk * 64 + lane) + 1u;
+            }
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t m = mark[lane];
+            __builtin_amdgcn_wave_barrier();
+            mark[lane] = 0u;
+            const uint32_t e1 = max(wave_incl_max_scan_dpp(m), carry);
+            carry = (uint32_t)__builtin_amdgcn_readlane((int)e1, 63);
+            const uint32_t e = max(e1, 1u) - 1u;
             const uint32_t o = j - offs[e];
             const uint2 r = rcts[e];
             const uint32_t s = sids[e];
