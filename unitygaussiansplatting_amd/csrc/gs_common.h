@@ -32,7 +32,10 @@ constexpr int kSortThreads = 256;
 constexpr int kSortKPT = 16;              // keys per thread
 constexpr int kSortPart = kSortThreads * kSortKPT;   // 4096 keys per partition
 constexpr int kBinThreads = 256;
-constexpr int kBinItems = 16;             // sorted positions per thread
+#ifndef GS_BIN_ITEMS
+#define GS_BIN_ITEMS 8       // 2048 positions per partition: ~3 rounds of partitions over the persistent grid balance better than 1.5 (measured)
+#endif
+constexpr int kBinItems = GS_BIN_ITEMS;   // sorted positions per thread
 constexpr int kBinPart = kBinThreads * kBinItems;
 constexpr uint32_t kBinTicketClasses = 16;
 constexpr int kEvPerFrame = 14;           // hipEvents per profiled frame

@@ -726,7 +726,7 @@ int32_t enqueue_draw(gs_renderer* r, const gs_frame_params* p, gs_target* rt) {
     auto binKernel = passes == 1 ? bin_emit_kernel<1> : (passes == 2 ? bin_emit_kernel<2> : bin_emit_kernel<3>);
     // persistent: as many workgroups as are resident at once, a multiple of the ticket classes
 #ifndef GS_BIN_BLOCKS_PER_CU
-#define GS_BIN_BLOCKS_PER_CU 4      // 110 VGPRs: four 256-thread workgroups per CU
+#define GS_BIN_BLOCKS_PER_CU 5      // 90 VGPRs at 8 positions per thread: five 256-thread workgroups per CU
 #endif
     const uint32_t binCap = max((uint32_t)ctx->cuCount * (uint32_t)GS_BIN_BLOCKS_PER_CU / kBinTicketClasses * kBinTicketClasses, kBinTicketClasses);
     const uint32_t binGrid = min(div_up(r->binParts, kBinTicketClasses) * kBinTicketClasses, binCap);
