@@ -577,7 +577,7 @@ int32_t gs_target_resolve(gs_target* t, const float bg[4], float* out32, uint8_t
     if (!t || !bg) return fail(GS_ERR_INVALID_ARGUMENT, "null argument");
     GS_TRY(bind_device(t->ctx));
     GS_TRY(flush_clear(t));
-    GS_TRY(enqueue_resolve(t, bg));
+    GS_TRY(enqueue_resolve(t, bg, out8 != nullptr));
     const size_t px = (size_t)t->width * t->height;
     if (out32) GS_HIP(hipMemcpyAsync(out32, t->resolved, px * 16, hipMemcpyDeviceToHost, t->ctx->stream));
     if (out8) GS_HIP(hipMemcpyAsync(out8, t->resolved8, px * 4, hipMemcpyDeviceToHost, t->ctx->stream));

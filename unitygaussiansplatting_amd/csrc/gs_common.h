@@ -212,6 +212,6 @@ void flatten_params(const gs_frame_params* p, gsm::FrameConsts& c);
 int32_t renderer_alloc_raster(gs_renderer* r);
 void renderer_free_raster(gs_renderer* r);
 int32_t enqueue_draw(gs_renderer* r, const gs_frame_params* p, gs_target* rt);
-int32_t enqueue_resolve(gs_target* t, const float bg[4]);
+int32_t enqueue_resolve(gs_target* t, const float bg[4], bool want8);
 int32_t flush_clear(gs_target* t);          // perform a pending gs_target_clear now
 } // namespace gs

@@ -761,14 +761,14 @@ int32_t flush_clear(gs_target* t) {
     return GS_OK;
 }
 
-int32_t enqueue_resolve(gs_target* t, const float bg[4]) {
+int32_t enqueue_resolve(gs_target* t, const float bg[4], bool want8) {
     const uint32_t numPix = t->width * t->height;
     if (!t->resolved) {
         GS_HIP(hipMalloc((void**)&t->resolved, (size_t)numPix * 16));
         GS_HIP(hipMalloc((void**)&t->resolved8, (size_t)numPix * 4));
     }
     hipLaunchKernelGGL(resolve_kernel, dim3(div_up(numPix, 256)), dim3(256), 0, t->ctx->stream, t->rgba16f, numPix, bg[0], bg[1], bg[2], bg[3],
-                       t->resolved, t->resolved8);
+                       t->resolved, want8 ? t->resolved8 : (uint8_t*)nullptr);      // the sRGB 8-bit image (3 powf per pixel) only when asked for
     GS_HIP(hipGetLastError());
     return GS_OK;
 }
