@@ -204,6 +204,7 @@ def main():
     r.SetProfiling(min(args.steps, 1024))
     elapsed_instr = run_region(fi)
     st = r.FrameStats()                   # raises if the last frame overflowed / a sort spin expired
+    frame_ms = r.FrameTimes()             # per-frame GPU durations of the instrumented pass (key generation .. blend)
     stage = r.StageTimes()
     r.SetProfiling(0)
 
@@ -257,6 +258,8 @@ def main():
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "alg_bytes_per_launch": int(dom_bytes), "avg_launch_ms": round(dom_ms, 4), "frames_averaged": int(stage.frames),
                     "instrumented_ms_per_step": round(elapsed_instr / args.steps * 1e3, 4),
+                    "instrumented_frame_gpu_ms": ({"median": round(float(np.median(frame_ms)), 4), "p95": round(float(np.percentile(frame_ms, 95)), 4),
+                                                   "max": round(float(frame_ms.max()), 4), "frames": int(len(frame_ms))} if len(frame_ms) else None),
                     "timing": "hipEvents on the launching stream over a second pass of the same K frames (the events add ~50 us/frame, so ms_per_step is timed without them)",
                     "kernel_ms_per_frame": {k: round(v, 4) for k, v in ktime.items()},
                     "whole_frame": {"alg_MB": round(frame_bytes / 1e6, 1), "GBps": round(frame_bytes / (ms_per_step * 1e-3) / 1e9, 1),

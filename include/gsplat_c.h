@@ -199,7 +199,10 @@ int32_t gs_renderer_download_distances(gs_renderer* r, uint32_t* out, size_t cou
 int32_t gs_renderer_upload_order(gs_renderer* r, const uint32_t* in, size_t count);
 int32_t gs_renderer_download_view(gs_renderer* r, void* out, size_t bytes);             /* N x 40 B SplatViewData */
 int32_t gs_renderer_frame_stats(gs_renderer* r, gs_frame_stats* out);                   /* blocks; reports + clears overflow/timeouts */
-int32_t gs_renderer_stage_times(gs_renderer* r, gs_stage_times* out);                   /* blocks */
+int32_t gs_renderer_stage_times(gs_renderer* r, gs_stage_times* out);                   /* blocks; resets the ring */
+/* per-frame GPU durations (first kernel of the frame to the end of the blend, ms) of the frames in the profiling ring;
+ * call before gs_renderer_stage_times.  Blocks. */
+int32_t gs_renderer_frame_times(gs_renderer* r, float* out_ms, int32_t capacity, int32_t* count);
 
 /* ---- render target: the _GaussianSplatRT temporary (GaussianSplatRenderer.cs:194-196) ------------- */
 int32_t gs_target_create(gs_context* ctx, uint32_t width, uint32_t height, gs_target** out);

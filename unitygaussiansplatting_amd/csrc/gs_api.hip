@@ -500,6 +500,25 @@ int32_t gs_renderer_frame_stats(gs_renderer* r, gs_frame_stats* out) {
     return GS_OK;
 }
 
+int32_t gs_renderer_frame_times(gs_renderer* r, float* out_ms, int32_t capacity, int32_t* count) {
+    if (!r || !out_ms || !count || capacity < 0) return fail(GS_ERR_INVALID_ARGUMENT, "bad argument");
+    *count = 0;
+    if (!r->ev) return fail(GS_ERR_INVALID_ARGUMENT, "profiling was never enabled");
+    GS_TRY(bind_device(r->ctx));
+    GS_HIP(hipStreamSynchronize(r->ctx->aux));
+    GS_HIP(hipStreamSynchronize(r->ctx->stream));
+    const int slots = r->profCompleted < r->profCapacity ? r->profCompleted : r->profCapacity;
+    for (int sidx = 0; sidx < slots && *count < capacity; ++sidx) {
+        const int base = sidx * kEvPerFrame;
+        // first event of the frame: key generation if the frame sorted, else calc_view; last: after the blend
+        const int first = r->evValid[base + 0] ? 0 : 7;
+        float ms = 0.f;
+        if (r->evValid[base + first] && r->evValid[base + 6] && hipEventElapsedTime(&ms, r->ev[base + first], r->ev[base + 6]) == hipSuccess)
+            out_ms[(*count)++] = ms;
+    }
+    return GS_OK;
+}
+
 int32_t gs_renderer_stage_times(gs_renderer* r, gs_stage_times* out) {
     if (!r || !out) return fail(GS_ERR_INVALID_ARGUMENT, "null argument");
     memset(out, 0, sizeof(*out));

@@ -85,6 +85,7 @@ namespace GaussianSplatting.Runtime
         [DllImport(Lib)] public static extern int gs_renderer_upload_order(IntPtr renderer, uint[] src, UIntPtr count);
         [DllImport(Lib)] public static extern int gs_renderer_download_view(IntPtr renderer, IntPtr dst, UIntPtr bytes);
         [DllImport(Lib)] public static extern int gs_renderer_frame_stats(IntPtr renderer, out FrameStats stats);
+        [DllImport(Lib)] public static extern int gs_renderer_frame_times(IntPtr renderer, [Out] float[] ms, int capacity, out int count);
         [DllImport(Lib)] public static extern int gs_renderer_stage_times(IntPtr renderer, out StageTimes times);
 
         [DllImport(Lib)] public static extern int gs_target_create(IntPtr ctx, uint width, uint height, out IntPtr target);

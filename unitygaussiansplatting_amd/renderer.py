@@ -342,6 +342,13 @@ class GaussianSplatRenderer:
         check(_lib.lib().gs_renderer_frame_stats(self._r_h, C.byref(s)), "gs_renderer_frame_stats")
         return s
 
+    def FrameTimes(self, capacity: int = 4096) -> np.ndarray:
+        """GPU duration (ms) of every frame in the profiling ring; call before StageTimes (which resets the ring)."""
+        out = np.zeros(capacity, np.float32)
+        cnt = C.c_int32()
+        check(_lib.lib().gs_renderer_frame_times(self._r_h, _fptr(out), capacity, C.byref(cnt)), "gs_renderer_frame_times")
+        return out[:cnt.value].copy()
+
     def StageTimes(self) -> gs_stage_times:
         t = gs_stage_times()
         check(_lib.lib().gs_renderer_stage_times(self._r_h, C.byref(t)), "gs_renderer_stage_times")
