@@ -4,17 +4,18 @@
 // "Blend OneMinusDstAlpha One" :10-12 into an RGBA16F target, GaussianSplatRenderer.cs:156-166,194-196) and
 // GaussianComposite.shader:25-39.  MI355X has no rasteriser/ROP, so the draw is:
 //   0. (gs_view.hip) calc_view culls each splat like the rasteriser would and writes, in splat order, a 32-byte
-//                  record rec[s] (centre, axes, rgba16f) and its inclusive 16x16-tile rectangle rect[s].
-//   1. bin_emit:   for sorted position i (front to back): gather rect[order[i]] (8 B) and emit one (tile, splat)
-//                  pair per overlapped tile.  Pair offsets come from a single-pass chained scan (decoupled
-//                  look-back) so pairs are emitted in i order.
+//                  record rec[s] (centre, axes, rgba16f), its inclusive 16x16-tile rectangle rect[s] and 1 visibility bit.
+//   1. bin_emit:   for sorted position i (front to back): visibility bit, then gather rect[order[i]] (8 B) and emit one
+//                  (tile, splat) pair per overlapped tile.  Pair offsets come from a single-pass chained scan (decoupled
+//                  look-back) so pairs are emitted in i order.  Persistent grid, ticketed partitions.
 //   2. pair sort:  STABLE Onesweep sort of the pairs by tile id only (2 passes for <= 65536 tiles): every
 //                  tile's list is then already depth ordered -- no per-tile depth sort.
-//   3. ranges:     tile -> [start, end) in the sorted pair array.
+//   3. ranges:     tile -> [start, end) in the sorted pair array; order: tiles by descending cost (previous frame's).
 //   4. blend:      one 256-thread workgroup per tile, one pixel per lane, each wave owns an 8x8 quadrant.
-//                  The tile's list is streamed in batches of 256 records staged in LDS; each wave culls the
-//                  batch against its quadrant with a ballot and walks only the survivors, broadcasting the
-//                  record through v_readlane (scalar operands), blending front-to-back in registers.
+//                  The tile's list is streamed in batches of 256 records staged in LDS (software-pipelined loads); each
+//                  wave culls the batch against its quadrant (bounding box + separating-axis test) with a ballot and walks
+//                  only the survivors, reading the record with wave-uniform LDS loads, blending front-to-back in registers.
+//                  It also performs a pending gs_target_clear (it writes every pixel of the target).
 // Semantics (DESIGN.md "compositor semantics") are those of the reference rasteriser: oriented quad |q|<=2,
 // alpha = saturate(exp(-|q|^2) * a), discard < 1/255, dst = src*(1-dst.a) + dst, fp16 rounding per blend.
 #include "gs_common.h"

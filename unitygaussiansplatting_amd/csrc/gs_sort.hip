@@ -5,16 +5,18 @@
 //   DeviceRadixSort.hlsl:42,163,428,451 + SortCommon.hlsl   InitDeviceRadixSort / Upsweep / Scan / Downsweep
 //   GpuSorting.cs:142-198             the 13-dispatch reduce-then-scan driver
 // with a Onesweep LSD radix sort (8-bit digits): ONE histogram sweep for all passes (fused into the key
-// generation) + one chained-scan binning kernel per pass with decoupled look-back.  Contract kept:
+// generation) + one chained-scan binning kernel per pass with a two-level decoupled look-back.  Contract kept:
 // stable, ascending, (uint32 key, uint32 payload) pairs (KEY_UINT PAYLOAD_UINT SHOULD_ASCEND SORT_PAIRS).
 //
 // gfx950 specifics: 64-lane waves -- ranking is a wave-level multi-split from 8 __ballot()s per key (one per
-// digit bit) and a 64-bit popcount below the lane; per-wave digit histograms live in LDS; inter-workgroup
+// digit bit, folded with one v_bitop3 per 32-lane half) and v_mbcnt below the lane; per-wave digit histograms live in LDS; inter-workgroup
 // look-back words are single 8-byte {epoch, flag, value} granules written/read with relaxed AGENT-scope atomics
 // (the per-XCD L2s are not coherent, see MI355X_MICROARCH.md "inter-workgroup visibility"; the granule carries
 // its own tag so no fence is needed and no status memset between passes: each pass uses a fresh epoch).
-// Partitions are handed out by an atomic ticket inside a persistent grid, so a workgroup only ever waits on
-// partitions that are already running; every spin is bounded and reports GS_ERR_SORT_TIMEOUT instead of hanging.
+// Partitions are handed out by atomic tickets (16 counters in separate cache lines) inside a persistent grid, so a
+// workgroup only ever waits on partitions that are running; all partitions of a pass are resident at once, so the
+// look-back goes through per-group aggregates (32 partitions) instead of a chain of INCLUSIVE hand-offs; every spin is
+// bounded and reports GS_ERR_SORT_TIMEOUT instead of hanging.  Design notes and measurements: DESIGN.md section 4.1.
 #include "gs_common.h"
 
 namespace gs {
