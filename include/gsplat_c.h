@@ -239,6 +239,14 @@ int32_t gs_import_blob_sizes(uint32_t splat_count, const gs_import_formats* form
 int32_t gs_import_encode(const gs_import_input* in, const gs_import_formats* formats, void* const blobs[5], const uint64_t sizes[5],
                          float bounds_min[3], float bounds_max[3]);
 
+/* PLY input (PLYFileReader.cs:25-76 header rules; GaussianFileReader.cs:80-208 attribute mapping + ReorderSHs): binary
+ * little-endian, float properties; x y z f_dc_0..2 opacity scale_0..2 rot_0..3 required, f_rest_* optional (0 if absent).
+ * The arrays gs_ply_arrays points `out` at are owned by the handle and valid until gs_ply_close. */
+typedef struct gs_ply gs_ply;
+int32_t gs_ply_open(const char* path, gs_ply** out, uint32_t* splat_count);
+int32_t gs_ply_arrays(const gs_ply* ply, gs_import_input* out);
+int32_t gs_ply_close(gs_ply* ply);
+
 /* ---- stand-alone sorter: GpuSorting (GpuSorting.cs) ----------------------------------------------- */
 /* SupportResources.Load(count) :48-63 */
 int32_t gs_sorter_create(gs_context* ctx, uint32_t max_count, gs_sorter** out);

@@ -77,3 +77,36 @@ def test_native_importer_argument_validation():
     assert lib.gs_import_encode(None, C.byref(ok), (C.c_void_p * 5)(), sizes, None, None) == -1
     with pytest.raises(_lib.GsError):
         creator.CreateAssetFromSplatsNative(scenes.make_splats(5000, 3, 2.0), "Low")
+
+
+def test_native_ply_reader_matches_numpy(tmp_path):
+    raw = scenes.make_splats(3_001, 21, 2.0)
+    path = str(tmp_path / "scene.ply")
+    creator.WritePLY(path, raw)
+    a, b = creator.ReadPLY(path), creator.ReadPLYNative(path)
+    for nm in ("pos", "dc0", "sh", "opacity", "scale", "rot"):
+        assert np.array_equal(getattr(a, nm), getattr(b, nm)), nm
+    assert np.array_equal(b.pos, raw.pos) and np.array_equal(b.sh, raw.sh)
+    # PLY in -> asset out, natively end to end, equals the numpy path
+    _same(creator.CreateAssetFromSplats(a, "Medium"), creator.CreateAssetFromSplatsNative(b, "Medium"))
+    # header rules of PLYFileReader.cs: ascii / big-endian files are refused, a missing required property too
+    txt = open(path, "rb").read()
+    bad = str(tmp_path / "ascii.ply")
+    open(bad, "wb").write(txt.replace(b"binary_little_endian", b"ascii"))
+    with pytest.raises(_lib.GsError):
+        creator.ReadPLYNative(bad)
+    bad2 = str(tmp_path / "noopacity.ply")
+    open(bad2, "wb").write(txt.replace(b"property float opacity", b"property float opacitx"))
+    with pytest.raises(_lib.GsError):
+        creator.ReadPLYNative(bad2)
+    with pytest.raises(_lib.GsError):
+        creator.ReadPLYNative(str(tmp_path / "missing.ply"))
+    # a file without f_rest_* properties: SH = 0 (GaussianFileReader.cs: absent attributes stay default)
+    hdr, body = txt.split(b"end_header\n", 1)
+    lines = [l for l in hdr.split(b"\n") if l and not l.startswith(b"property float f_rest_")]
+    arr = np.frombuffer(body, "<f4").reshape(-1, 62)
+    keep = [i for i, nm in enumerate(creator.PLY_ATTRS) if not nm.startswith("f_rest_")]
+    slim = str(tmp_path / "slim.ply")
+    open(slim, "wb").write(b"\n".join(lines) + b"\nend_header\n" + np.ascontiguousarray(arr[:, keep]).tobytes())
+    c, d = creator.ReadPLY(slim), creator.ReadPLYNative(slim)
+    assert np.array_equal(c.sh, d.sh) and not d.sh.any() and np.array_equal(c.rot, d.rot) and np.array_equal(d.pos, raw.pos)

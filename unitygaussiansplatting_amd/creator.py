@@ -504,6 +504,24 @@ def CreateAssetFromSplatsNative(raw: InputSplatData, quality: str = "Medium", *,
     return a
 
 
+def ReadPLYNative(path: str) -> InputSplatData:
+    """ReadPLY through the native reader (gs_ply_open / gs_ply_arrays, csrc/gs_import.cpp); the arrays are copied out."""
+    import ctypes as C
+    from . import _lib
+    from ._abi import gs_import_input
+    h, n = C.c_void_p(), C.c_uint32()
+    _lib.check(_lib.lib().gs_ply_open(path.encode(), C.byref(h), C.byref(n)), "gs_ply_open")
+    try:
+        arr = gs_import_input()
+        _lib.check(_lib.lib().gs_ply_arrays(h, C.byref(arr)), "gs_ply_arrays")
+        cnt = n.value
+        get = lambda ptr, k: np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_float)), shape=(cnt * k,)).copy()
+        return InputSplatData(pos=get(arr.pos, 3).reshape(cnt, 3), dc0=get(arr.dc0, 3).reshape(cnt, 3), sh=get(arr.sh, 45).reshape(cnt, 15, 3),
+                              opacity=get(arr.opacity, 1), scale=get(arr.scale, 3).reshape(cnt, 3), rot=get(arr.rot, 4).reshape(cnt, 4))
+    finally:
+        _lib.lib().gs_ply_close(h)
+
+
 def CreateAsset(ply_path: str, quality: str = "Medium", **kw) -> GaussianSplatAsset:
     """PLY file -> asset (ReadFile + LinearizeData + CreateAsset)."""
     return CreateAssetFromSplats(ReadPLY(ply_path), quality, **kw)

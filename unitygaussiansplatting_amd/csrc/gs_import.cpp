@@ -12,11 +12,14 @@
 // the bytes are a function of this source only: unitygaussiansplatting_amd/creator.py performs the same operations with
 // numpy and tests/test_import.py requires the two to agree bit for bit.  SH clustering (Cluster*) and BC7 are not done here.
 #include <algorithm>
+#include <cstdio>
+#include <string>
 #include <atomic>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
 #include <limits>
+#include <new>
 #include <numeric>
 #include <thread>
 #include <vector>
@@ -311,6 +314,102 @@ int32_t gs_import_encode(const gs_import_input* in, const gs_import_formats* f, 
             }
         }
     });
+    return GS_OK;
+}
+
+// ---- PLY reader: PLYFileReader.cs:25-76 (header), GaussianFileReader.cs:80-208 (PLYDataToSplats + ReorderSHs) ----------
+struct gs_ply {
+    uint32_t count = 0;
+    std::vector<float> pos, dc0, sh, opacity, scale, rot;
+};
+
+static bool read_line(FILE* f, std::string& line) {        // PLYFileReader.ReadLine: up to '\n', a trailing '\r' dropped
+    line.clear();
+    int c;
+    bool any = false;
+    while ((c = fgetc(f)) != EOF) {
+        any = true;
+        if (c == '\n') break;
+        line.push_back((char)c);
+    }
+    if (!line.empty() && line.back() == '\r') line.pop_back();
+    return any;
+}
+
+int32_t gs_ply_open(const char* path, gs_ply** out, uint32_t* splat_count) {
+    if (!path || !out) return gs::fail(GS_ERR_INVALID_ARGUMENT, "null argument");
+    *out = nullptr;
+    FILE* f = fopen(path, "rb");
+    if (!f) return gs::fail(GS_ERR_INVALID_ASSET, "PLY file cannot be opened");
+    struct Attr { std::string name; int type; int offset; };                    // type: 1 float, 2 double, 3 uchar, 0 none
+    std::vector<Attr> attrs;
+    long long count = 0;
+    int stride = 0;
+    bool le = false;
+    std::string line;
+    for (int li = 0; li < 9000; ++li) {
+        if (!read_line(f, line) || line == "end_header" || line.empty()) break;
+        std::vector<std::string> tok;
+        size_t a = 0;
+        for (;;) { const size_t b = line.find(' ', a); tok.push_back(line.substr(a, b == std::string::npos ? b : b - a)); if (b == std::string::npos) break; a = b + 1; }
+        if (tok.size() == 3 && tok[0] == "format" && tok[1] == "binary_little_endian" && tok[2] == "1.0") le = true;
+        if (tok.size() == 3 && tok[0] == "element" && tok[1] == "vertex") count = atoll(tok[2].c_str());
+        if (tok.size() == 3 && tok[0] == "property") {
+            const int type = tok[1] == "float" ? 1 : (tok[1] == "double" ? 2 : (tok[1] == "uchar" ? 3 : 0));
+            attrs.push_back({ tok[2], type, stride });
+            stride += type == 1 ? 4 : (type == 2 ? 8 : (type == 3 ? 1 : 0));
+        }
+    }
+    if (!le) { fclose(f); return gs::fail(GS_ERR_INVALID_ASSET, "PLY not supported: needs to be binary, little endian PLY format"); }
+    if (count <= 0 || count > (1ll << 30) || stride <= 0) { fclose(f); return gs::fail(GS_ERR_INVALID_ASSET, "PLY has no vertices"); }
+    auto find = [&](const std::string& nm) { for (auto& at : attrs) if (at.name == nm && at.type == 1) return at.offset; return -1; };
+    const char* required[] = { "x", "y", "z", "f_dc_0", "f_dc_1", "f_dc_2", "opacity", "scale_0", "scale_1", "scale_2", "rot_0", "rot_1", "rot_2", "rot_3" };
+    for (const char* r : required)
+        if (find(r) < 0) { fclose(f); return gs::fail(GS_ERR_INVALID_ASSET, "PLY file is probably not a Gaussian Splat file (a required float property is missing)"); }
+    gs_ply* p = new (std::nothrow) gs_ply();
+    std::vector<uint8_t> body;
+    try {
+        body.resize((size_t)count * stride);
+        p->count = (uint32_t)count;
+        p->pos.resize((size_t)count * 3); p->dc0.resize((size_t)count * 3); p->sh.assign((size_t)count * 45, 0.0f);
+        p->opacity.resize(count); p->scale.resize((size_t)count * 3); p->rot.resize((size_t)count * 4);
+    } catch (...) { fclose(f); delete p; return gs::fail(GS_ERR_OUT_OF_MEMORY, "host allocation"); }
+    const size_t got = fread(body.data(), 1, body.size(), f);
+    fclose(f);
+    if (got != body.size()) { delete p; return gs::fail(GS_ERR_INVALID_ASSET, "PLY read error: fewer data bytes than the header announces"); }
+    const int ox[3] = { find("x"), find("y"), find("z") }, od[3] = { find("f_dc_0"), find("f_dc_1"), find("f_dc_2") };
+    const int os[3] = { find("scale_0"), find("scale_1"), find("scale_2") }, orr[4] = { find("rot_0"), find("rot_1"), find("rot_2"), find("rot_3") };
+    const int oo = find("opacity");
+    int orest[45];
+    for (int k = 0; k < 45; ++k) orest[k] = find("f_rest_" + std::to_string(k));
+    const int strideC = stride;
+    parallel_for((size_t)count, 1 << 14, [&](size_t a, size_t b) {
+        for (size_t i = a; i < b; ++i) {
+            const uint8_t* v = body.data() + i * strideC;
+            auto ld = [&](int off) { float x = 0.0f; if (off >= 0) memcpy(&x, v + off, 4); return x; };
+            for (int c = 0; c < 3; ++c) { p->pos[i * 3 + c] = ld(ox[c]); p->dc0[i * 3 + c] = ld(od[c]); p->scale[i * 3 + c] = ld(os[c]); }
+            for (int c = 0; c < 4; ++c) p->rot[i * 4 + c] = ld(orr[c]);
+            p->opacity[i] = ld(oo);
+            // ReorderSHs: the file holds 15 R, 15 G, 15 B; the splat wants 15 x (r, g, b)
+            for (int j = 0; j < 15; ++j)
+                for (int c = 0; c < 3; ++c) p->sh[i * 45 + j * 3 + c] = ld(orest[c * 15 + j]);
+        }
+    });
+    *out = p;
+    if (splat_count) *splat_count = p->count;
+    return GS_OK;
+}
+
+int32_t gs_ply_arrays(const gs_ply* ply, gs_import_input* out) {
+    if (!ply || !out) return gs::fail(GS_ERR_INVALID_ARGUMENT, "null argument");
+    out->splat_count = ply->count;
+    out->pos = ply->pos.data(); out->dc0 = ply->dc0.data(); out->sh = ply->sh.data();
+    out->opacity = ply->opacity.data(); out->scale = ply->scale.data(); out->rot = ply->rot.data();
+    return GS_OK;
+}
+
+int32_t gs_ply_close(gs_ply* ply) {
+    delete ply;
     return GS_OK;
 }
 

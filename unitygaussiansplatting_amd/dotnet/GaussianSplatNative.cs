@@ -103,6 +103,10 @@ namespace GaussianSplatting.Runtime
         [DllImport(Lib)] public static extern int gs_import_blob_sizes(uint splatCount, ref ImportFormats formats, [Out] ulong[] sizes5);
         [DllImport(Lib)] public static extern int gs_import_encode(ref ImportInput input, ref ImportFormats formats, IntPtr[] blobs5, ulong[] sizes5, float[] boundsMin3, float[] boundsMax3);
 
+        [DllImport(Lib)] public static extern int gs_ply_open([MarshalAs(UnmanagedType.LPStr)] string path, out IntPtr ply, out uint splatCount);
+        [DllImport(Lib)] public static extern int gs_ply_arrays(IntPtr ply, out ImportInput arrays);
+        [DllImport(Lib)] public static extern int gs_ply_close(IntPtr ply);
+
         [DllImport(Lib)] public static extern int gs_sorter_create(IntPtr ctx, uint maxCount, out IntPtr sorter);
         [DllImport(Lib)] public static extern int gs_sorter_destroy(IntPtr sorter);
         [DllImport(Lib)] public static extern int gs_sorter_dispatch(IntPtr sorter, IntPtr keysDev, IntPtr valuesDev, uint count, uint keyBits);
