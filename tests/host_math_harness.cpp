@@ -15,7 +15,7 @@ static gsm::FrameConsts fl(const gs_frame_params* p) {
     gsm::FrameConsts c;
     memcpy(c.mv, p->matrix_mv, 48); memcpy(c.o2w, p->matrix_object_to_world, 48); memcpy(c.w2o, p->matrix_world_to_object, 48);
     memcpy(c.vp, p->matrix_vp, 64);
-    c.p00 = p->proj_m00; c.p11 = p->proj_m11; c.screenW = p->screen_w; c.screenH = p->screen_h;
+    gsm::FrameConstsFromProjection(c, p->proj_m00, p->proj_m11, p->screen_w); c.screenW = p->screen_w; c.screenH = p->screen_h;
     c.camx = p->cam_pos_world[0]; c.camy = p->cam_pos_world[1]; c.camz = p->cam_pos_world[2];
     c.splatScale = p->splat_scale; c.opacityScale = p->opacity_scale; c.shOrder = p->sh_order; c.shOnly = p->sh_only;
     c.nearClip = p->near_clip; c.farClip = p->far_clip;

@@ -39,7 +39,8 @@ struct FrameConsts {            // gs_frame_params flattened for kernel argument
     float o2w[12];              // rows 0..2 of _MatrixObjectToWorld
     float w2o[12];              // rows 0..2 of _MatrixWorldToObject (3x3 part used)
     float vp[16];               // UNITY_MATRIX_VP
-    float p00, p11, screenW, screenH;
+    float limX, limY, focal;    // 1.3 tanFovX, 1.3 tanFovY, W P00 / 2 of CalcCovariance2D: per-frame constants, see FrameConstsFromProjection
+    float screenW, screenH;
     float camx, camy, camz;
     float splatScale, opacityScale;
     uint32_t shOrder, shOnly;
@@ -52,6 +53,18 @@ struct EditView {
     const uint32_t* cutouts;        // cutoutCount x 17 dwords: float4x4 (rows of 4) + typeAndFlags
     uint32_t cutoutCount;
 };
+
+// The camera-only part of CalcCovariance2D (GaussianSplatting.hlsl:62-72), evaluated once per frame on the host with the
+// same fp32 operations the shader performs per splat (aspect = P00/P11; tanFovX = 1/P00; tanFovY = 1/(P11 aspect) -- which is
+// 1/P00 again, a quirk of the reference that is kept; focal = W P00 / 2): three IEEE divisions less per splat.
+GS_HD void FrameConstsFromProjection(FrameConsts& c, float p00, float p11, float screenW) {
+    const float aspect = p00 / p11;
+    const float tanFovX = 1.0f / p00;
+    const float tanFovY = 1.0f / (p11 * aspect);
+    c.limX = 1.3f * tanFovX;
+    c.limY = 1.3f * tanFovY;
+    c.focal = screenW * p00 / 2.0f;
+}
 
 struct ViewData { float pos[4]; float axis1[2]; float axis2[2]; uint32_t color[2]; };   // 40 B SplatViewData
 
@@ -338,13 +351,9 @@ GS_HD void CalcViewGeom(const AssetView& a, const FrameConsts& P, const EditView
     // ---- CalcCovariance2D, first half: the 2x3 matrix T = J * W
     float vx = mrow(P.mv, 0, pos.x, pos.y, pos.z), vy = mrow(P.mv, 1, pos.x, pos.y, pos.z);
     const float vz = mrow(P.mv, 2, pos.x, pos.y, pos.z);
-    const float aspect = P.p00 / P.p11;
-    const float tanFovX = 1.0f / P.p00;
-    const float tanFovY = 1.0f / (P.p11 * aspect);
-    const float limX = 1.3f * tanFovX, limY = 1.3f * tanFovY;
+    const float limX = P.limX, limY = P.limY, focal = P.focal;
     vx = fminf(fmaxf(vx / vz, -limX), limX) * vz;
     vy = fminf(fmaxf(vy / vz, -limY), limY) * vz;
-    const float focal = P.screenW * P.p00 / 2.0f;
     const float zz2 = vz * vz;
     const float J00 = focal / vz, J02 = -(focal * vx) / zz2;
     const float J11 = J00, J12 = -(focal * vy) / zz2;

@@ -178,7 +178,7 @@ void flatten_params(const gs_frame_params* p, gsm::FrameConsts& c) {
     memcpy(c.o2w, p->matrix_object_to_world, 12 * sizeof(float));
     memcpy(c.w2o, p->matrix_world_to_object, 12 * sizeof(float));
     memcpy(c.vp, p->matrix_vp, 16 * sizeof(float));
-    c.p00 = p->proj_m00; c.p11 = p->proj_m11; c.screenW = p->screen_w; c.screenH = p->screen_h;
+    gsm::FrameConstsFromProjection(c, p->proj_m00, p->proj_m11, p->screen_w); c.screenW = p->screen_w; c.screenH = p->screen_h;
     c.camx = p->cam_pos_world[0]; c.camy = p->cam_pos_world[1]; c.camz = p->cam_pos_world[2];
     c.splatScale = p->splat_scale; c.opacityScale = p->opacity_scale;
     c.shOrder = p->sh_order; c.shOnly = p->sh_only;
