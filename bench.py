@@ -201,7 +201,7 @@ def main():
     # ---- the same K frames again with the per-stage hipEvents recorded (14 per frame, on the stream each kernel is
     #      launched on).  The events themselves cost ~50 us of a 0.78 ms frame (every record is a barrier + signal packet
     #      between two kernels), so the headline time comes from the region above and the per-kernel durations from this one.
-    r.SetProfiling(min(args.steps, 1024))
+    r.SetProfiling(min(args.steps + 1, 1024))       # a ring: one spare slot so that the first frame's events are not recycled
     elapsed_instr = run_region(fi)
     st = r.FrameStats()                   # raises if the last frame overflowed / a sort spin expired
     frame_ms = r.FrameTimes()             # per-frame GPU durations of the instrumented pass (key generation .. blend)

@@ -196,3 +196,25 @@ def test_overlapped_sort_queue_gives_identical_frames(gpu_ctx):
     gpu_ctx.SetOverlap(False)
     for x, y in zip(frames[False], frames[True]):
         assert np.array_equal(x, y)
+
+
+def test_profiling_ring_reports_stage_and_frame_times(gpu_ctx):
+    """gs_renderer_set_profiling + gs_renderer_frame_times / gs_renderer_stage_times: one GPU duration per profiled frame,
+    stage means that add up to about a frame, and the ring resets after stage_times."""
+    a = small_asset(120_000, 5, "Medium")
+    r = GaussianSplatRenderer(gpu_ctx, a)
+    r.OnEnable()
+    rt = RenderTarget(gpu_ctx, 640, 360)
+    r.SetProfiling(6)                                   # a ring: the slot after the last recorded frame is being reused, so keep spare slots
+    for f in range(4):
+        cam = default_camera(W=640, H=360, az=30.0 + 5.0 * f)
+        r.SortPoints(cam); r.CalcViewData(cam); rt.Clear(); r.Draw(cam, rt)
+    ft = r.FrameTimes()
+    st = r.StageTimes()
+    assert len(ft) == 4 and (ft > 0).all() and (ft < 50.0).all()
+    parts = st.calc_distances_ms + st.sort_ms + st.calc_view_ms + st.bin_ms + st.pair_sort_ms + st.blend_ms
+    assert st.frames == 4 and 0 < parts <= 1.05 * float(ft.mean()) + 0.05 and abs(st.total_ms - parts) < 1e-4
+    assert st.onesweep_depth_ms > 0 and st.onesweep_pairs_ms > 0 and 1 <= st.onesweep_pair_launches <= 3
+    assert len(r.FrameTimes()) == 0                     # stage_times reset the ring
+    r.SetProfiling(0)
+    r.OnDisable(); rt.Dispose()
