@@ -19,6 +19,7 @@ static gsm::FrameConsts fl(const gs_frame_params* p) {
     c.camx = p->cam_pos_world[0]; c.camy = p->cam_pos_world[1]; c.camz = p->cam_pos_world[2];
     c.splatScale = p->splat_scale; c.opacityScale = p->opacity_scale; c.shOrder = p->sh_order; c.shOnly = p->sh_only;
     c.nearClip = p->near_clip; c.farClip = p->far_clip;
+    gsm::FrameConstsChunkCull(c);
     return c;
 }
 extern "C" {
@@ -68,6 +69,12 @@ void hm_cull_check(const gs_asset_desc* d, const gs_frame_params* p, uint32_t* o
             if (memcmp(&fast.view, &full.view, sizeof(gsm::ViewData)) != 0) out[i * 2] |= 2u;
         }
     }
+}
+// whole-chunk cull: out[ci] = 1 if the chunk is culled; returns cullOn
+uint32_t hm_chunk_cull(const gs_asset_desc* d, const gs_frame_params* p, uint8_t* out) {
+    const gsm::AssetView a = mk(d); const gsm::FrameConsts c = fl(p);
+    for (uint32_t ci = 0; ci < a.chunkCount; ++ci) out[ci] = gsm::ChunkOutside(a, c, ci) ? 1 : 0;
+    return c.cullOn;
 }
 uint32_t hm_f32tof16(float f) { return gsm::f32tof16(f); }
 float hm_f16tof32(uint32_t h) { return gsm::f16tof32(h); }

@@ -187,3 +187,37 @@ def test_early_cull_never_drops_a_drawable_splat(hm, quality):
         assert not (culled & (out[:, 1] > 0)).any(), f"case {k}: {int((culled & (out[:, 1] > 0)).sum())} drawable splats were culled"
         culled_total += int(culled.sum()); drawable_total += int((out[:, 1] > 0).sum())
     assert culled_total > 20_000 and drawable_total > 20_000          # both outcomes are exercised
+
+
+def test_chunk_cull_never_drops_a_drawable_splat(hm):
+    """ChunkOutside (whole 256-splat chunks skipped by the per-frame calc_view) may only fire for chunks in which no splat
+    has a non-empty footprint in the full path; and it must fire often enough to matter.  Same adversarial cameras as the
+    per-splat early cull, plus an orthographic-like projection for which the cull must switch itself off."""
+    hm.hm_chunk_cull.restype = C.c_uint32
+    a = small_asset(60_000, 11, "Medium", extent=4.0)
+    orc = O.Oracle(a)
+    nch = (a.splatCount + 255) // 256
+    culled_chunks = drawable_total = 0
+    cases = [((0.0, 0.0, 6.0), (0, 0, 0), 39.1, 1.0, (1, 1, 1)), ((0.3, 0.2, 0.5), (2.0, 0.1, -1.0), 60.0, 2.0, (1, 1, 1)),
+             ((0.0, 0.0, 1.2), (0, 0, 0), 10.0, 2.0, (1.5, 0.7, 1.0)), ((5.0, 4.0, 5.0), (0, 0, 0), 75.0, 0.1, (1, 1, 1)),
+             ((0.05, 3.9, 0.0), (0, 0, 0), 90.0, 1.0, (1, 1, 1)), ((-2.0, 0.5, 2.5), (3.0, 0.5, 2.4), 25.0, 1.3, (0.5, 0.5, 2.0)),
+             ((9.0, 1.0, 0.0), (20.0, 1.0, 0.0), 39.1, 1.0, (1, 1, 1))]                       # looking away from the scene
+    for k, (eye, target, fov, ss, objscale) in enumerate(cases):
+        cam = camera.Camera(position=eye, target=target, fieldOfView=fov, pixelWidth=333 + 64 * k, pixelHeight=217 + 31 * k,
+                            nearClipPlane=0.3, farClipPlane=(8.0 if k == 3 else 1000.0))
+        tr = camera.Transform(position=(0.1, -0.2, 0.3), rotation=(0.1, 0.2, 0.05, 0.9695), scale=objscale)
+        P = camera.frame_params(cam, tr, ss, 1.0, 3, False)
+        out = np.zeros((a.splatCount, 2), np.uint32)
+        hm.hm_cull_check(C.byref(orc.desc), C.byref(P), out.ctypes.data_as(C.c_void_p))
+        cc = np.zeros(nch, np.uint8)
+        assert hm.hm_chunk_cull(C.byref(orc.desc), C.byref(P), cc.ctypes.data_as(C.c_void_p)) == 1
+        per_splat = np.repeat(cc, 256)[:a.splatCount].astype(bool)
+        bad = per_splat & (out[:, 1] > 0)
+        assert not bad.any(), f"case {k}: {int(bad.sum())} drawable splats sit in culled chunks"
+        culled_chunks += int(cc.sum()); drawable_total += int((out[:, 1] > 0).sum())
+    assert culled_chunks > 0.3 * nch * len(cases) / 2 and drawable_total > 20_000
+    # a projection whose clip.w is not the view depth: the cull must disable itself
+    P = camera.frame_params(camera.Camera(), camera.Transform())
+    P.matrix_vp[12:16] = [0.0, 0.0, 0.0, 1.0]
+    cc = np.zeros(nch, np.uint8)
+    assert hm.hm_chunk_cull(C.byref(orc.desc), C.byref(P), cc.ctypes.data_as(C.c_void_p)) == 0 and not cc.any()

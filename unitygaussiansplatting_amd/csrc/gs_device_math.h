@@ -40,6 +40,8 @@ struct FrameConsts {            // gs_frame_params flattened for kernel argument
     float w2o[12];              // rows 0..2 of _MatrixWorldToObject (3x3 part used)
     float vp[16];               // UNITY_MATRIX_VP
     float limX, limY, focal;    // 1.3 tanFovX, 1.3 tanFovY, W P00 / 2 of CalcCovariance2D: per-frame constants, see FrameConstsFromProjection
+    float cullKx, cullKy, cullMx, cullMy;   // whole-chunk frustum cull (ChunkOutside), see FrameConstsChunkCull
+    uint32_t cullOn;
     float screenW, screenH;
     float camx, camy, camz;
     float splatScale, opacityScale;
@@ -262,6 +264,63 @@ struct SHFromBlob {
     GS_HD void begin(const uint8_t* p, uint32_t f) { sp = p; fmt = f; }
     GS_HD V3 load(int k) const { return LoadSH(sp, fmt, k); }
 };
+
+// Whole-chunk cull (per-frame path only).  A chunk's 256 splats lie in the box [posMin, posMax] of its ChunkInfo and are no
+// larger than its scale maximum, so if all 8 corners of the box are on the outer side of one frustum plane -- pushed out
+// by a bound on the footprint radius -- no splat of the chunk can be drawn and its workgroup stops before decoding anything.
+// Footprint half extent <= 4 sqrt(2 lambda1), lambda1 <= (|T0|^2 + |T1|^2) 1.1 s^2 smax^2 + 0.6 (as in CalcViewGeom's early cull),
+// |T0|^2 + |T1|^2 <= (focal / w)^2 G with G = 2 (|mv0|^2 + |mv1|^2 + (limX^2 + limY^2) |mv2|^2)  =>  half extent <=
+// K focal smax / w + 4.4 px with K = 4 sqrt(2.2 G s^2).  "Right of the screen" (cx - extent > W) becomes the LINEAR test
+// x - w (1 + 13.2 / W) - (2 K focal / W) smax > 0 on clip coordinates (slack: K is taken 5 % larger, 6.6 px instead of 4.9);
+// likewise left / top / bottom; the depth planes are the rasteriser's own centre-depth rule.  Needs clip.w = |view z|
+// (a perspective projection whose last row is (0, 0, -1, 0)); the host checks that and switches the cull off otherwise.
+GS_HD void FrameConstsChunkCull(FrameConsts& c) {
+    const float g0 = dot3f(c.mv[0], c.mv[1], c.mv[2], c.mv[0], c.mv[1], c.mv[2]), g1 = dot3f(c.mv[4], c.mv[5], c.mv[6], c.mv[4], c.mv[5], c.mv[6]);
+    const float g2 = dot3f(c.mv[8], c.mv[9], c.mv[10], c.mv[8], c.mv[9], c.mv[10]);
+    const float G = 2.0f * (g0 + g1 + (c.limX * c.limX + c.limY * c.limY) * g2);
+    const float K = 4.2f * sqrtf(2.2f * G * (c.splatScale * c.splatScale));
+    c.cullKx = 2.0f * K * c.focal / c.screenW;
+    c.cullKy = 2.0f * K * c.focal / c.screenH;
+    c.cullMx = 1.0f + 13.2f / c.screenW;
+    c.cullMy = 1.0f + 13.2f / c.screenH;
+    // clip.w of a point must equal -(mv row 2).point: compare row 3 of vp * o2w with -row 2 of mv
+    bool ok = true;
+    for (int k = 0; k < 4; ++k) {
+        float r = 0.0f;
+        for (int j = 0; j < 3; ++j) r += c.vp[12 + j] * c.o2w[j * 4 + k];
+        if (k == 3) r += c.vp[15];
+        const float want = -c.mv[8 + k];
+        if (!(fabsf(r - want) <= 1.0e-4f * (fabsf(want) + 1.0f))) ok = false;
+    }
+    if (!(K > 0.0f) || !(K < 3.0e30f)) ok = false;
+    c.cullOn = ok ? 1u : 0u;
+}
+
+// corner: 0..7 (bit 0 = x max, bit 1 = y max, bit 2 = z max).  planes[p] = this corner is on the outer side of plane p
+// (0 right, 1 left, 2 above-or-below +y, 3 the other y side, 4 nearer than near, 5 beyond far).
+GS_HD uint32_t ChunkCornerOutside(const AssetView& a, const FrameConsts& P, uint32_t chunkIdx, uint32_t corner) {
+    const uint8_t* ck = a.chunk + (uint64_t)chunkIdx * 64;
+    const float px = u2f(ld32a(ck, 16 + ((corner & 1u) ? 4 : 0))), py = u2f(ld32a(ck, 24 + ((corner & 2u) ? 4 : 0))), pz = u2f(ld32a(ck, 32 + ((corner & 4u) ? 4 : 0)));
+    float sm = fmaxf(fmaxf(f16tof32(ld32a(ck, 40) >> 16), f16tof32(ld32a(ck, 44) >> 16)), f16tof32(ld32a(ck, 48) >> 16));
+    sm *= sm; sm *= sm; sm *= sm;                                   // the asset stores scale^(1/8)
+    const float wx = mrow(P.o2w, 0, px, py, pz), wy = mrow(P.o2w, 1, px, py, pz), wz = mrow(P.o2w, 2, px, py, pz);
+    const float x = mrow(P.vp, 0, wx, wy, wz), y = mrow(P.vp, 1, wx, wy, wz), w = mrow(P.vp, 3, wx, wy, wz);
+    const float cxs = P.cullKx * sm, cys = P.cullKy * sm;
+    uint32_t m = 0;
+    if (x - w * P.cullMx - cxs > 0.0f) m |= 1u;
+    if (-x - w * P.cullMx - cxs > 0.0f) m |= 2u;
+    if (y - w * P.cullMy - cys > 0.0f) m |= 4u;
+    if (-y - w * P.cullMy - cys > 0.0f) m |= 8u;
+    if (w < P.nearClip) m |= 16u;
+    if (w > P.farClip) m |= 32u;
+    return m;
+}
+GS_HD bool ChunkOutside(const AssetView& a, const FrameConsts& P, uint32_t chunkIdx) {       // scalar form (host tests)
+    if (!P.cullOn || chunkIdx >= a.chunkCount) return false;
+    uint32_t all = 63u;
+    for (uint32_t c = 0; c < 8; ++c) all &= ChunkCornerOutside(a, P, chunkIdx, c);
+    return all != 0u;
+}
 
 // IsSplatCut (SplatUtilities.compute:164-187); pos is the object-space position
 GS_HD bool IsSplatCut(const EditView& e, float px, float py, float pz) {

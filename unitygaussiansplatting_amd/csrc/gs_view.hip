@@ -122,6 +122,18 @@ __global__ __launch_bounds__(256) void calc_view_kernel(gsm::AssetView a, gsm::F
             visible = ok && fp.tx0 <= fp.tx1;
         }
     } else {
+        // whole-chunk frustum cull: lane c & 7 tests corner c of the chunk's position box against the 6 (pushed-out) planes
+        if (P.cullOn && blockIdx.x < a.chunkCount) {
+            const uint32_t m = gsm::ChunkCornerOutside(a, P, blockIdx.x, threadIdx.x & 7u);
+            bool outside = false;
+#pragma unroll
+            for (int pl = 0; pl < 6; ++pl) outside = outside || __all((m >> pl) & 1u);      // all 8 corners beyond plane pl
+            if (outside) {                                                                    // workgroup-uniform
+                if (idx < a.n) rects[idx] = make_uint2(0u, 0u);
+                if ((threadIdx.x & 63u) == 0u && idx < a.n) visMask[idx >> 6] = 0ull;
+                return;
+            }
+        }
         if (threadIdx.x == 0) s_any = 0;
         if (idx < a.n) {
             gsm::CalcViewGeom(a, P, E, idx, vp, true);             // early out for splats that cannot reach the screen
@@ -183,6 +195,7 @@ void flatten_params(const gs_frame_params* p, gsm::FrameConsts& c) {
     c.splatScale = p->splat_scale; c.opacityScale = p->opacity_scale;
     c.shOrder = p->sh_order; c.shOnly = p->sh_only;
     c.nearClip = p->near_clip; c.farClip = p->far_clip;
+    gsm::FrameConstsChunkCull(c);
 }
 
 template <bool FULL>
