@@ -69,3 +69,16 @@ def test_product_code_never_references_the_oracle():
                 # comments may cite the oracle; code may not bind it: its symbols (gso_*), its library, its binding module
                 assert "gso_" not in txt and "oracle_lib" not in txt and "libgs_oracle" not in txt, f
                 assert not re.search(r'#include\s*"[^"]*oracle', txt), f
+
+
+def test_header_is_plain_c99_and_the_dotnet_binding_covers_it():
+    """include/gsplat_c.h must compile as C99 (it is the boundary a non-C++ host binds), and the shipped P/Invoke file must
+    declare every function the header does -- no more, no fewer."""
+    import re
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = os.path.join(root, "include", "gsplat_c.h")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-fsyntax-only", "-x", "c", hdr])
+    names = set(re.findall(r"\b(gs_[a-z0-9_]+)\s*\(", open(hdr).read()))
+    cs = open(os.path.join(root, "unitygaussiansplatting_amd", "dotnet", "GaussianSplatNative.cs")).read()
+    assert set(re.findall(r"extern\s+\w+\s+(gs_[a-z0-9_]+)\s*\(", cs)) == names
