@@ -20,16 +20,13 @@ f32 = np.float32
 
 
 def mat_mul(a: np.ndarray, b: np.ndarray) -> np.ndarray:
-    """Matrix4x4.operator*: res[i][j] = a[i][0]*b[0][j] + a[i][1]*b[1][j] + ... in float32, no FMA."""
+    """Matrix4x4.operator*: res[i][j] = a[i][0]*b[0][j] + a[i][1]*b[1][j] + ... in float32, no FMA, left to right.
+    (Four rank-1 float32 products added in order: every element sees exactly the scalar sequence of roundings.)"""
     a = np.asarray(a, f32); b = np.asarray(b, f32)
-    out = np.zeros((4, 4), f32)
-    for i in range(4):
-        for j in range(4):
-            acc = f32(a[i, 0] * b[0, j])
-            for k in range(1, 4):
-                acc = f32(acc + f32(a[i, k] * b[k, j]))
-            out[i, j] = acc
-    return out
+    acc = a[:, 0:1] * b[0:1, :]
+    for k in range(1, 4):
+        acc = acc + a[:, k:k + 1] * b[k:k + 1, :]
+    return acc.astype(f32)
 
 
 def quat_to_mat3(q: Sequence[float]) -> np.ndarray:
