@@ -82,3 +82,17 @@ def test_header_is_plain_c99_and_the_dotnet_binding_covers_it():
     names = set(re.findall(r"\b(gs_[a-z0-9_]+)\s*\(", open(hdr).read()))
     cs = open(os.path.join(root, "unitygaussiansplatting_amd", "dotnet", "GaussianSplatNative.cs")).read()
     assert set(re.findall(r"extern\s+\w+\s+(gs_[a-z0-9_]+)\s*\(", cs)) == names
+
+
+def test_plain_c_program_links_and_runs(tmp_path):
+    """tests/abi_smoke.c: a C99 translation unit that includes the header, links libgsplat_hip.so and uses the ABI."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    _lib.lib()                                     # makes sure the library is built
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    exe = str(tmp_path / "abi_smoke")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", os.path.join(root, "tests", "abi_smoke.c"), "-o", exe,
+                           "-L" + libdir, "-l:" + os.path.basename(_lib.LIB_PATH), "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    assert "abi_smoke ok" in out.stdout
