@@ -384,10 +384,8 @@ GS_HD void CalcViewGeom(const AssetView& a, const FrameConsts& P, const EditView
     view.pos[2] = mrow(P.vp, 2, wx, wy, wz);
     view.pos[3] = mrow(P.vp, 3, wx, wy, wz);
     // deleted? (:204-214) / cutouts (:216-220): centerClipPos.w = 0, the rest of the clip position is kept
-#ifndef GS_EXP_NO_EDIT              // timing experiment only
     if (E.deletedBits && ((E.deletedBits[idx >> 5] >> (idx & 31u)) & 1u)) view.pos[3] = 0.0f;
     if (E.cutoutCount && IsSplatCut(E, pos.x, pos.y, pos.z)) view.pos[3] = 0.0f;
-#endif
     if (!(view.pos[3] > 0.0f)) return;                            // behindCam
     vp.front = true;
 

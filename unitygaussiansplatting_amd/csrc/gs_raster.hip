@@ -342,12 +342,6 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(const uint32_t* __rest
     }
 }
 
-// XCD-aware bijective block -> tile map: consecutive tiles (which share splat records) stay on one XCD's L2
-__device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t total) {
-    const uint32_t q = total >> 3, r = total & 7u, xcd = b & 7u, k = b >> 3;
-    return (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + k;
-}
-
 // gfx950 mixed-precision FMA (v_fma_mix*): fp32 fma whose sources may be fp16 halves of a register and whose result
 // is either fp32 or RTNE-rounded into one fp16 half of the destination (the other half is preserved).  LLVM selects the
 // same instructions for  (half)fmaf(a, b, (float)h)  (so their semantics are fp32-fma-then-round), but only when its
@@ -455,11 +449,7 @@ __global__ __launch_bounds__(256) void blend_kernel(const uint32_t* __restrict__
     __shared__ int s_done;
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-#ifdef GS_EXP_BLEND_SCREEN_ORDER
-    const uint32_t tile = xcd_remap(blockIdx.x, rc.tilesX * rc.tilesY);
-#else
     const uint32_t tile = tileOrder[blockIdx.x];
-#endif
     const uint32_t tx = tile % rc.tilesX, ty = tile / rc.tilesX;
     const uint32_t start = tileStart[tile], end = tileEnd[tile];
 #ifdef GS_EXP_BLEND_TIMELINE
@@ -539,11 +529,9 @@ __global__ __launch_bounds__(256) void blend_kernel(const uint32_t* __restrict__
                     const float4 ra = s_a[j];
                     const float4 re = s_e[j];
                     hit = (ra.x + re.x >= qminx) && (ra.x - re.x <= qmaxx) && (ra.y + re.y >= qminy) && (ra.y - re.y <= qmaxy);
-#ifndef GS_EXP_BLEND_NOSAT
                     // oriented test: 30 % of the bounding-box survivors cannot put a live fragment on this 8x8 quadrant
                     const uint4 rb = s_b[j];
                     hit = hit && gsm::BlockMayTouch((float)qx0 + 4.0f, (float)qy0 + 4.0f, 3.5f, ra.x, ra.y, ra.z, ra.w, gsm::u2f(rb.x), gsm::u2f(rb.y), re.z);
-#endif
                 }
                 unsigned long long mask = __ballot(hit);
 #ifdef GS_EXP_BLEND_TIMELINE

@@ -124,22 +124,12 @@ __global__ __launch_bounds__(256) void calc_distances_kernel(gsm::AssetView a, c
         uint32_t key[ILP];
 #pragma unroll
         for (uint32_t k = 0; k < ILP; ++k) {
-#if defined(GS_EXP_DIST_NOGATHER)          // timing experiments only (wrong keys)
-            key[k] = oi[k] * 2654435761u;
-#elif defined(GS_EXP_DIST_NOCHUNK)
-            { const gsm::V3 pp = gsm::LoadVec(a.pos, (uint64_t)(oi[k] == 0xffffffffu ? 0u : oi[k]) * gsm::vecStride(a.posFmt), a.posFmt);
-              key[k] = gsm::FloatToSortableUint(fmaf(m22, pp.z, fmaf(m21, pp.y, fmaf(m20, pp.x, m23)))); }
-#else
             key[k] = (oi[k] != 0xffffffffu) ? gsm::SortKey(a, oi[k], m20, m21, m22, m23) : 0u;
-#endif
         }
 #pragma unroll
         for (uint32_t k = 0; k < ILP; ++k) {
             if (oi[k] == 0xffffffffu) continue;
             keys[base + k * 256u] = key[k];
-#ifdef GS_EXP_DIST_NOHIST
-            continue;
-#endif
             lds_hist_add(s_h, key[k] & 255u);
             lds_hist_add(s_h + RADIX, (key[k] >> 8) & 255u);
             lds_hist_add(s_h + 2 * RADIX, (key[k] >> 16) & 255u);
