@@ -381,3 +381,59 @@ def test_view_data_against_an_independent_float64_derivation():
     want_rgba = np.concatenate([rgb, alpha[:, None]], 1)
     err = np.abs(got_rgba[front] - want_rgba[front]) / np.maximum(np.abs(want_rgba[front]), 1.0)
     assert err.max() < 1.5e-3                                             # fp16 storage: 2^-11 relative + fp32 evaluation
+
+
+def test_composite_against_an_independent_numpy_rasteriser():
+    """Second opinion on the draw: a vectorised numpy float64 rasteriser written from RenderGaussianSplats.shader's semantics
+    (instanced quads in order[], q = [axis1 axis2]^-1 (p - c), |q| <= 2, alpha = saturate(exp(-|q|^2) a), discard < 1/255,
+    dst = src (1 - dst.a) + dst with the RGBA16F target rounded after every blend; centre-depth clipping; NaN / w <= 0 skipped)
+    over a real view buffer.  The oracle's exact mode must match it to within one fp16 rounding of the accumulated value."""
+    from common import default_camera, small_asset
+    from unitygaussiansplatting_amd import camera as cam_mod
+    a = small_asset(3000, 17, "Medium", extent=1.5)
+    cam = default_camera(W=96, H=64, az=35.0, radius=3.0)
+    cam.nearClipPlane, cam.farClipPlane = 1.5, 4.0                     # cuts into the cloud: depth clipping is exercised
+    tr = cam_mod.Transform()
+    orc = O.Oracle(a)
+    orc.sort(cam_mod.sort_matrix(cam, tr.localToWorldMatrix))
+    P = cam_mod.frame_params(cam, tr)
+    v = orc.calc_view(P).copy()
+    ref = O.f16_to_f32(orc.draw(P, 0)).astype(np.float64)
+
+    W, H = 96, 64
+    acc = np.zeros((H, W, 4), np.float16)
+    ys, xs = np.mgrid[0:H, 0:W]
+    px, py = xs + 0.5, ys + 0.5
+    h = lambda u: np.uint16(u & 0xffff).view(np.float16).astype(np.float64)
+    drawn = 0
+    for s in orc.order:
+        pos = v["pos"][s].astype(np.float64); w = pos[3]
+        if not (w > 0) or w < cam.nearClipPlane or w > cam.farClipPlane:
+            continue
+        a1, a2 = v["axis1"][s].astype(np.float64), v["axis2"][s].astype(np.float64)
+        if not (np.isfinite(a1).all() and np.isfinite(a2).all()):
+            continue
+        c0, c1 = int(v["color"][s][0]), int(v["color"][s][1])
+        rgb = np.array([h(c0 >> 16), h(c0), h(c1 >> 16)]); al = h(c1)
+        cx = (0.5 + 0.5 * pos[0] / w) * W; cy = (0.5 - 0.5 * pos[1] / w) * H
+        dx, dy = px - cx, py - cy
+        det = a1[0] * a2[1] - a1[1] * a2[0]
+        q1 = (dx * a2[1] - dy * a2[0]) / det                                # inverse of the 2x2 [axis1 axis2] by Cramer's rule
+        q2 = (-dx * a1[1] + dy * a1[0]) / det
+        alpha = np.clip(np.exp(-(q1 * q1 + q2 * q2)) * al, 0.0, 1.0)
+        live = (np.abs(q1) <= 2.0) & (np.abs(q2) <= 2.0) & (alpha >= 1.0 / 255.0)
+        if not live.any():
+            continue
+        drawn += 1
+        t = 1.0 - acc[..., 3].astype(np.float64)
+        src = np.concatenate([rgb[None, None, :] * alpha[..., None], alpha[..., None]], axis=2)
+        new = (src * t[..., None] + acc.astype(np.float64)).astype(np.float16)
+        acc = np.where(live[..., None], new, acc)
+    assert drawn > 300
+    got = acc.astype(np.float64)
+    d = np.abs(got - ref)
+    ulp = np.maximum(np.abs(ref), 2.0 ** -14) * 2.0 ** -10                   # one fp16 ulp of the value
+    # exp() and the fp32 (oracle) vs fp64 (here) product can flip a rounding now and then; a flipped rounding is one ulp
+    assert (d <= 2.0 * ulp + 1e-7).all(), float((d / ulp).max())
+    assert (d == 0).mean() > 0.97
+    assert ref[..., 3].max() > 0.9 and (ref[..., 3] == 0).any()
