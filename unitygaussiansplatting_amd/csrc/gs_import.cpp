@@ -34,6 +34,7 @@ namespace {
 
 constexpr uint32_t kChunk = 256, kTexWidth = 2048;
 
+// f(a, b) over [0, n) in contiguous ranges, one per hardware thread; ranges whose thread cannot be created run on the caller
 template <class F> void parallel_for(size_t n, size_t grain, F f) {
     const size_t hw = std::max(1u, std::thread::hardware_concurrency());
     const size_t nt = std::min(hw, (n + grain - 1) / grain);
@@ -42,7 +43,9 @@ template <class F> void parallel_for(size_t n, size_t grain, F f) {
     const size_t per = (n + nt - 1) / nt;
     for (size_t t = 0; t < nt; ++t) {
         const size_t a = t * per, b = std::min(n, a + per);
-        if (a < b) th.emplace_back([=] { f(a, b); });
+        if (a >= b) continue;
+        try { th.emplace_back([=] { f(a, b); }); }
+        catch (...) { f(a, b); }                  // std::system_error (thread limit) / bad_alloc: do the range here
     }
     for (auto& x : th) x.join();
 }
@@ -158,8 +161,18 @@ int32_t gs_import_blob_sizes(uint32_t splat_count, const gs_import_formats* f, u
     return GS_OK;
 }
 
+static int32_t import_encode_impl(const gs_import_input* in, const gs_import_formats* f, void* const blobs[5], const uint64_t sizes[5],
+                                  float bounds_min[3], float bounds_max[3]);
+
 int32_t gs_import_encode(const gs_import_input* in, const gs_import_formats* f, void* const blobs[5], const uint64_t sizes[5],
                          float bounds_min[3], float bounds_max[3]) {
+    try { return import_encode_impl(in, f, blobs, sizes, bounds_min, bounds_max); }      // nothing may throw across the C boundary
+    catch (const std::bad_alloc&) { return gs::fail(GS_ERR_OUT_OF_MEMORY, "host allocation"); }
+    catch (...) { return gs::fail(GS_ERR_INVALID_ARGUMENT, "unexpected failure in the importer"); }
+}
+
+static int32_t import_encode_impl(const gs_import_input* in, const gs_import_formats* f, void* const blobs[5], const uint64_t sizes[5],
+                                  float bounds_min[3], float bounds_max[3]) {
     if (!in || !f || !blobs || !sizes) return gs::fail(GS_ERR_INVALID_ARGUMENT, "null argument");
     uint64_t need[5];
     const int32_t rc = gs_import_blob_sizes(in->splat_count, f, need);
@@ -336,7 +349,15 @@ static bool read_line(FILE* f, std::string& line) {        // PLYFileReader.Read
     return any;
 }
 
+static int32_t ply_open_impl(const char* path, gs_ply** out, uint32_t* splat_count);
+
 int32_t gs_ply_open(const char* path, gs_ply** out, uint32_t* splat_count) {
+    try { return ply_open_impl(path, out, splat_count); }
+    catch (const std::bad_alloc&) { return gs::fail(GS_ERR_OUT_OF_MEMORY, "host allocation"); }
+    catch (...) { return gs::fail(GS_ERR_INVALID_ASSET, "unexpected failure while reading the PLY file"); }
+}
+
+static int32_t ply_open_impl(const char* path, gs_ply** out, uint32_t* splat_count) {
     if (!path || !out) return gs::fail(GS_ERR_INVALID_ARGUMENT, "null argument");
     *out = nullptr;
     FILE* f = fopen(path, "rb");
@@ -367,6 +388,7 @@ int32_t gs_ply_open(const char* path, gs_ply** out, uint32_t* splat_count) {
     for (const char* r : required)
         if (find(r) < 0) { fclose(f); return gs::fail(GS_ERR_INVALID_ASSET, "PLY file is probably not a Gaussian Splat file (a required float property is missing)"); }
     gs_ply* p = new (std::nothrow) gs_ply();
+    if (!p) { fclose(f); return gs::fail(GS_ERR_OUT_OF_MEMORY, "host allocation"); }
     std::vector<uint8_t> body;
     try {
         body.resize((size_t)count * stride);
