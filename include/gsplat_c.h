@@ -210,7 +210,7 @@ int32_t gs_target_destroy(gs_target* t);
 int32_t gs_target_clear(gs_target* t);                                  /* ClearRenderTarget(Color, (0,0,0,0)) */
 int32_t gs_target_download(gs_target* t, void* out_rgba16f, size_t bytes);   /* W*H*8 B, row 0 = top; blocks */
 /* GaussianComposite.shader:25-39 + its "Blend SrcAlpha OneMinusSrcAlpha": out = lerp(bg, GammaToLinearSpace(C/A), A).
- * Writes W*H*4 floats (linear RGBA, out.a = A + bg.a*(1-A)) into a device buffer owned by the target, then
+ * Writes W*H*4 floats (linear RGBA; out.a = A*A + bg.a*(1-A): the pass has no separate alpha blend factors) into a device buffer owned by the target, then
  * optionally copies it to `out_rgba32f` (may be NULL) and/or an sRGB-encoded 8-bit image `out_rgba8` (may be NULL). */
 int32_t gs_target_resolve(gs_target* t, const float background_rgba[4], float* out_rgba32f, uint8_t* out_rgba8);
 int32_t gs_target_device_ptr(gs_target* t, void** rgba16f_dev, void** resolved_rgba32f_dev);

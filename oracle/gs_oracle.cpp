@@ -39,7 +39,16 @@ struct f4 { float x, y, z, w; };
 
 inline float dot3(f3 a, f3 b) { return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)); }
 inline float dot2(float ax, float ay, float bx, float by) { return fmaf(ay, by, ax * bx); }
-inline float lerpf(float a, float b, float t) { return fmaf(t, b - a, a); }            // HLSL lerp: a + t*(b-a)
+// Sensitivity switches (tests only; gso_set_canon).  HLSL leaves two evaluations to the GPU compiler: whether lerp's
+// a + t*(b-a) is contracted into an FMA, and whether x / (2^k-1) is a true IEEE division or a multiply by a reciprocal.
+// The canonical forms (flags = 0: fused lerp, rounded reciprocal) are what the HIP kernels implement; bit 0 selects the
+// unfused lerp of SURVEY.md Appendix B, bit 1 the IEEE division of Appendix A, so that tests/test_canon_sensitivity.py can
+// MEASURE what the choice moves.
+int g_canon = 0;
+inline float lerpf(float a, float b, float t) {                                          // HLSL lerp: a + t*(b-a)
+    if (g_canon & 1) { const float d = b - a; const float m = t * d; return a + m; }     // three roundings (-ffp-contract=off)
+    return fmaf(t, b - a, a);
+}
 inline float saturatef(float x) { return fminf(fmaxf(x, 0.0f), 1.0f); }
 inline float signf(float x) { return (x > 0.0f) ? 1.0f : ((x < 0.0f) ? -1.0f : 0.0f); }
 // mul(M, float4(v,1)) row r of a row-major 4x4
@@ -153,10 +162,12 @@ inline uint32_t LoadUInt(const uint8_t* p, uint64_t a) { return load_u32(p, a); 
 // fp32-rounded reciprocal (DESIGN.md canonical arithmetic #2)
 constexpr float R63 = 1.0f / 63.0f, R31 = 1.0f / 31.0f, R2047 = 1.0f / 2047.0f, R1023 = 1.0f / 1023.0f,
                 R65535 = 1.0f / 65535.0f, R255 = 1.0f / 255.0f;
-inline f3 DecodePacked_6_5_5(uint32_t e) { return { (float)(e & 63) * R63, (float)((e >> 6) & 31) * R31, (float)((e >> 11) & 31) * R31 }; }
-inline f3 DecodePacked_5_6_5(uint32_t e) { return { (float)(e & 31) * R31, (float)((e >> 5) & 63) * R63, (float)((e >> 11) & 31) * R31 }; }
-inline f3 DecodePacked_11_10_11(uint32_t e) { return { (float)(e & 2047) * R2047, (float)((e >> 11) & 1023) * R1023, (float)((e >> 21) & 2047) * R2047 }; }
-inline f3 DecodePacked_16_16_16(uint32_t e0, uint32_t e1) { return { (float)(e0 & 65535) * R65535, (float)((e0 >> 16) & 65535) * R65535, (float)(e1 & 65535) * R65535 }; }
+// field / (2^bits - 1): canonical = multiply by the rounded reciprocal; g_canon bit 1 = IEEE division (sensitivity only)
+inline float unorm(uint32_t field, float k, float rk) { return (g_canon & 2) ? (float)field / k : (float)field * rk; }
+inline f3 DecodePacked_6_5_5(uint32_t e) { return { unorm(e & 63, 63.0f, R63), unorm((e >> 6) & 31, 31.0f, R31), unorm((e >> 11) & 31, 31.0f, R31) }; }
+inline f3 DecodePacked_5_6_5(uint32_t e) { return { unorm(e & 31, 31.0f, R31), unorm((e >> 5) & 63, 63.0f, R63), unorm((e >> 11) & 31, 31.0f, R31) }; }
+inline f3 DecodePacked_11_10_11(uint32_t e) { return { unorm(e & 2047, 2047.0f, R2047), unorm((e >> 11) & 1023, 1023.0f, R1023), unorm((e >> 21) & 2047, 2047.0f, R2047) }; }
+inline f3 DecodePacked_16_16_16(uint32_t e0, uint32_t e1) { return { unorm(e0 & 65535, 65535.0f, R65535), unorm((e0 >> 16) & 65535, 65535.0f, R65535), unorm(e1 & 65535, 65535.0f, R65535) }; }
 
 inline uint32_t vec_stride(uint32_t fmt) { return fmt == 0 ? 12u : fmt == 1 ? 6u : fmt == 2 ? 4u : 2u; }
 
@@ -214,7 +225,7 @@ inline float InvSquareCentered01(float x) {
 
 // GaussianSplatting.hlsl:219-229 DecodeRotation(DecodePacked_10_10_10_2(enc)).  round(pq.w*3) == the 2-bit field.
 inline f4 DecodeRotation(uint32_t enc) {
-    const float px = (float)(enc & 1023) * R1023, py = (float)((enc >> 10) & 1023) * R1023, pz = (float)((enc >> 20) & 1023) * R1023;
+    const float px = unorm(enc & 1023, 1023.0f, R1023), py = unorm((enc >> 10) & 1023, 1023.0f, R1023), pz = unorm((enc >> 20) & 1023, 1023.0f, R1023);
     const uint32_t idx = (enc >> 30) & 3;
     const float SQRT2 = 1.41421356237f, INV_SQRT2 = 0.70710678118f;
     const float qx = fmaf(px, SQRT2, -INV_SQRT2), qy = fmaf(py, SQRT2, -INV_SQRT2), qz = fmaf(pz, SQRT2, -INV_SQRT2);
@@ -259,7 +270,7 @@ SplatData LoadSplatData(const Asset& a, uint32_t idx) {
         col = { f16tof32(lo), f16tof32(lo >> 16), f16tof32(hi), f16tof32(hi >> 16) };
     } else {
         const uint32_t e = load_u32(a.color, texel * 4);        // R8G8B8A8_UNorm: x/255
-        col = { (float)(e & 255) * R255, (float)((e >> 8) & 255) * R255, (float)((e >> 16) & 255) * R255, (float)(e >> 24) * R255 };
+        col = { unorm(e & 255, 255.0f, R255), unorm((e >> 8) & 255, 255.0f, R255), unorm((e >> 16) & 255, 255.0f, R255), unorm(e >> 24, 255.0f, R255) };
     }
 
     uint32_t shIndex = idx;
@@ -383,7 +394,7 @@ ViewData CalcViewDataOne(const Asset& a, const gs_frame_params& P, uint32_t idx,
     // cutouts (:216-220)
     if (IsSplatCut(cutouts, cutoutCount, splat.pos)) clip[3] = 0.0f;
     for (int k = 0; k < 4; ++k) view.pos[k] = clip[k];
-    const bool behindCam = !(clip[3] > 0.0f);                     // centerClipPos.w <= 0 (NaN counts as behind)
+    const bool behindCam = clip[3] <= 0.0f;                        // SplatUtilities.compute:223, literally (a NaN w is not "behind")
     if (behindCam) return view;
 
     // CalcMatrixFromRotationScale (GaussianSplatting.hlsl:29-46): mul(mr, diag(scale))
@@ -559,6 +570,9 @@ void gso_set_num_threads(int32_t n) {
 #endif
 }
 
+void gso_set_canon(int32_t flags) { g_canon = flags; }
+int32_t gso_get_canon(void) { return g_canon; }
+
 // half conversion exposed for the f16 known-answer tests
 uint16_t gso_f32tof16(float f) { return f32tof16(f); }
 float gso_f16tof32(uint16_t h) { return f16tof32(h); }
@@ -722,7 +736,7 @@ void gso_resolve(const uint16_t* rt, uint32_t W, uint32_t H, const float* bg, fl
                 const float lin = s * fmaf(s, fmaf(s, 0.305306011f, 0.682171111f), 0.012522878f);
                 o[c] = fmaf(A, lin - bg[c], bg[c]);
             }
-            o[3] = fmaf(A, 1.0f - bg[3], bg[3]);
+            o[3] = fmaf(A, A - bg[3], bg[3]);                            // the blend state has no separate alpha factors: A*A + bg.a*(1-A)
         }
         if (out32f) for (int c = 0; c < 4; ++c) out32f[i * 4 + c] = o[c];
         if (out8) {

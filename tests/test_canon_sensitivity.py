@@ -1,0 +1,113 @@
+"""What do the two "canonical arithmetic" choices move?  (CPU only; VERDICT round 1, weak #1.)
+
+HLSL leaves two evaluations of this path to the GPU compiler / driver:
+  * lerp(a, b, t) = a + t*(b - a): contracted into an FMA or not (GaussianSplatting.hlsl:565-603, LoadSplatPos :394-421);
+  * x / (2^k - 1) in DecodePacked_* (:261-300): a true IEEE division or a multiply by a reciprocal.
+The oracle and the HIP kernels fix them as "fused lerp, multiply by the fp32-rounded reciprocal" (DESIGN.md section 5); SURVEY.md
+Appendix A/B wrote down the other reading (unfused lerp, IEEE division).  Neither is "the" reference -- the reference's
+result depends on the GPU it runs on -- so this test MEASURES the difference between the readings with the oracle's
+sensitivity switches (gso_set_canon) on the C1 scene (100 k splats, Medium, 640x360) and on a High-preset scene, and
+asserts that it stays inside the tolerances the parity tests state: the depth ORDER may differ only where keys tie or
+neighbour (a handful of adjacent swaps), view records by ~1e-7 relative (positions) / < 0.1 px (axes; up to 2 % of an axis whose eigenvalues nearly tie), the RGBA16F framebuffer by
+<= 2^-8 * max(1, |c|) per channel and the resolved 8-bit image by <= 1/255.  The measured numbers are printed (pytest -s) and recorded in DESIGN.md section 5.
+"""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from unitygaussiansplatting_amd import camera, creator, scenes
+
+
+def _frame(orc, cam, tr):
+    ms = camera.sort_matrix(cam, tr.localToWorldMatrix)
+    P = camera.frame_params(cam, tr)
+    orc.reset_order()
+    orc.sort(ms)
+    keys_sorted = orc.keys.copy()
+    order = orc.order.copy()
+    orc.reset_order()
+    keys = orc.calc_distances(ms).copy()               # keys in splat-index order (identity order)
+    orc.order[:] = order
+    view = orc.calc_view(P).copy()
+    rt = orc.draw(P, 0)
+    r32, r8 = O.resolve(rt, (0.0, 0.0, 0.0, 1.0))
+    return dict(keys=keys, keys_sorted=keys_sorted, order=order, view=view, rt=rt, r8=r8, pairs=orc.tile_pairs, visible=orc.visible)
+
+
+def measure(quality: str, n: int, seed: int, extent: float, W: int, H: int):
+    raw = scenes.make_splats(n, seed, extent)
+    a = creator.CreateAssetFromSplats(raw, quality, name=f"canon_{quality}")
+    cam = camera.Camera(position=scenes.orbit_eye(2.0 * extent, 0.0, 0.0), pixelWidth=W, pixelHeight=H)
+    tr = camera.Transform()
+    orc = O.Oracle(a)
+    rows = {}
+    try:
+        O.lib().gso_set_canon(0)
+        base = _frame(orc, cam, tr)
+        for flags, label in ((1, "unfused lerp"), (2, "IEEE division"), (3, "both (SURVEY App. A/B)")):
+            O.lib().gso_set_canon(flags)
+            f = _frame(orc, cam, tr)
+            kd = f["keys"].astype(np.int64) - base["keys"].astype(np.int64)
+            moved = f["order"] != base["order"]
+            # how far does a splat move in the order?  (rank displacement)
+            rank_b = np.empty(n, np.int64); rank_b[base["order"]] = np.arange(n)
+            rank_f = np.empty(n, np.int64); rank_f[f["order"]] = np.arange(n)
+            vb, vf = base["view"], f["view"]
+            front = (vb["pos"][:, 3] > 0) & (vf["pos"][:, 3] > 0)
+            # relative to the record's own magnitude (a component that is ~0 by cancellation has no meaningful ulp)
+            pos_b, pos_f = vb["pos"][front].astype(np.float64), vf["pos"][front].astype(np.float64)
+            pos_rel = np.abs(pos_b - pos_f).max(1) / np.maximum(np.abs(pos_b).max(1), 1e-30)
+            ax_b = np.concatenate([vb["axis1"], vb["axis2"]], 1)[front].astype(np.float64)
+            ax_f = np.concatenate([vf["axis1"], vf["axis2"]], 1)[front].astype(np.float64)
+            fin = np.isfinite(ax_b).all(1) & np.isfinite(ax_f).all(1)
+            ax_rel = np.abs(ax_b[fin] - ax_f[fin]).max(1) / np.maximum(np.abs(ax_b[fin]).max(1), 1e-30)
+            ax_px = np.abs(ax_b[fin] - ax_f[fin]).max(1)
+            col_b = vb["color"].view(np.uint16).reshape(n, 4)[front].view(np.float16).astype(np.float32)
+            col_f = vf["color"].view(np.uint16).reshape(n, 4)[front].view(np.float16).astype(np.float32)
+            rb, rf = O.f16_to_f32(base["rt"]), O.f16_to_f32(f["rt"])
+            d = np.abs(rb - rf)
+            rel = d / np.maximum(1.0, np.abs(rb))
+            rows[label] = dict(
+                keys_changed=int((kd != 0).sum()), key_max_abs_diff=int(np.abs(kd).max()),
+                order_entries_changed=int(moved.sum()), max_rank_displacement=int(np.abs(rank_b - rank_f).max()),
+                view_records_changed=int((vb.view(np.uint32).reshape(n, 10) != vf.view(np.uint32).reshape(n, 10)).any(1).sum()),
+                view_pos_max_rel=float(pos_rel.max()), view_axis_max_rel=float(ax_rel.max()), view_axis_max_abs_px=float(ax_px.max()),
+                nan_axes_delta=int((~np.isfinite(ax_f).all(1)).sum()) - int((~np.isfinite(ax_b).all(1)).sum()),
+                view_colour_max_abs=float(np.abs(col_b - col_f).max()) if col_b.size else 0.0,
+                pairs_delta=int(f["pairs"]) - int(base["pairs"]), visible_delta=int(f["visible"]) - int(base["visible"]),
+                rt_pixels_changed=int((base["rt"] != f["rt"]).any(2).sum()), rt_max_abs=float(d.max()), rt_max_rel=float(rel.max()),
+                r8_pixels_changed=int((base["r8"] != f["r8"]).any(2).sum()),
+                r8_max_diff=int(np.abs(base["r8"].astype(np.int32) - f["r8"].astype(np.int32)).max()))
+    finally:
+        O.lib().gso_set_canon(0)
+    return n, W * H, rows
+
+
+CASES = {"C1 (100k Medium 640x360)": ("Medium", 100_000, 1, 3.0, 640, 360), "High (60k, 480x270)": ("High", 60_000, 7, 3.0, 480, 270)}
+
+
+@pytest.mark.parametrize("case", list(CASES))
+def test_canonical_arithmetic_choice_stays_inside_the_stated_tolerances(case):
+    n, px, rows = measure(*CASES[case])
+    print(f"\n{case}: N = {n}, {px} pixels")
+    for label, r in rows.items():
+        print(f"  {label:24s} " + ", ".join(f"{k}={v:.3g}" if isinstance(v, float) else f"{k}={v}" for k, v in r.items()))
+    for label, r in rows.items():
+        assert r["key_max_abs_diff"] <= 4, (label, r)                # keys are the depth's bits: a few ulps (measured: 1)
+        assert r["max_rank_displacement"] <= 8, (label, r)           # the order only changes between depth-neighbours (measured: <= 2)
+        assert r["view_pos_max_rel"] <= 1e-5 and r["view_axis_max_rel"] <= 0.05 and r["view_axis_max_abs_px"] <= 0.1, (label, r)
+        assert r["view_colour_max_abs"] <= 2.0 ** -9, (label, r)     # colours are fp16 in the record: 1-2 fp16 ulps
+        assert abs(r["pairs_delta"]) <= max(8, n // 5000) and abs(r["visible_delta"]) <= max(4, n // 20000), (label, r)
+        # Measured: up to 1.6 * 2^-9 on < 1 % of the pixels -- i.e. the reading of the HLSL moves the framebuffer MORE than the
+        # HIP kernels differ from the oracle (<= 2^-9, tests/test_gpu_draw.py).  The bar for the choice itself is 2^-8 and at
+        # most 1/255 on the resolved 8-bit image (GaussianSplatValidator.cs counts a pixel as different from 3/255).
+        assert r["rt_max_rel"] <= 2.0 ** -8, (label, r)
+        assert r["r8_max_diff"] <= 1, (label, r)
+
+
+if __name__ == "__main__":
+    for c in CASES:
+        n, px, rows = measure(*CASES[c])
+        print(f"{c}: N = {n}, {px} pixels")
+        for label, r in rows.items():
+            print("  ", label, r)

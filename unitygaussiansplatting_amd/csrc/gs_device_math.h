@@ -386,7 +386,7 @@ GS_HD void CalcViewGeom(const AssetView& a, const FrameConsts& P, const EditView
     // deleted? (:204-214) / cutouts (:216-220): centerClipPos.w = 0, the rest of the clip position is kept
     if (E.deletedBits && ((E.deletedBits[idx >> 5] >> (idx & 31u)) & 1u)) view.pos[3] = 0.0f;
     if (E.cutoutCount && IsSplatCut(E, pos.x, pos.y, pos.z)) view.pos[3] = 0.0f;
-    if (!(view.pos[3] > 0.0f)) return;                            // behindCam
+    if (view.pos[3] <= 0.0f) return;                               // behindCam (:223), literally: a NaN w is not "behind" (it is never drawn: PrepareSplat)
     vp.front = true;
 
     // ---- scale (needed first: the early cull below bounds the footprint with it)

@@ -602,7 +602,7 @@ __global__ __launch_bounds__(256) void resolve_kernel(const uint16_t* __restrict
             const float lin = s * fmaf(s, fmaf(s, 0.305306011f, 0.682171111f), 0.012522878f);   // UnityCG GammaToLinearSpace
             o[c] = fmaf(A, lin - bg[c], bg[c]);
         }
-        o[3] = fmaf(A, 1.0f - bga, bga);
+        o[3] = fmaf(A, A - bga, bga);        // no separate alpha blend factors in the reference: dst.a = A*A + bg.a*(1-A)
     }
     ((float4*)out32)[i] = make_float4(o[0], o[1], o[2], o[3]);
     if (out8) {
