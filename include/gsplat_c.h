@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GS_ABI_VERSION 3
+#define GS_ABI_VERSION 4
 
 typedef enum gs_error {
     GS_OK = 0,
@@ -198,6 +198,12 @@ int32_t gs_renderer_download_order(gs_renderer* r, uint32_t* out, size_t count);
 int32_t gs_renderer_download_distances(gs_renderer* r, uint32_t* out, size_t count);    /* m_GpuSortDistances (sorted keys after a sort) */
 int32_t gs_renderer_upload_order(gs_renderer* r, const uint32_t* in, size_t count);
 int32_t gs_renderer_download_view(gs_renderer* r, void* out, size_t bytes);             /* N x 40 B SplatViewData */
+/* What the last gs_renderer_calc_view left for the compositor (the per-frame launch, NOT the on-demand full kernel), in
+ * splat-index order; any pointer may be NULL:
+ *   recs      N x 32 B  {cx, cy, axis1.xy, axis2.xy (float, pixels, y down), f16 r<<16|g, f16 b<<16|a}; only meaningful where visible
+ *   rects     N x 2 u32 {tile x0 | y0 << 16, tiles wide | tiles high << 16} of the footprint's inclusive 16x16-tile rectangle; 0,0 = not drawn
+ *   vis_mask  ceil(N/64) u64, bit s = splat s reaches at least one tile */
+int32_t gs_renderer_download_raster_records(gs_renderer* r, void* recs, uint32_t* rects, uint64_t* vis_mask);
 int32_t gs_renderer_frame_stats(gs_renderer* r, gs_frame_stats* out);                   /* blocks; reports + clears overflow/timeouts */
 int32_t gs_renderer_stage_times(gs_renderer* r, gs_stage_times* out);                   /* blocks; resets the ring */
 /* per-frame GPU durations (first kernel of the frame to the end of the blend, ms) of the frames in the profiling ring;

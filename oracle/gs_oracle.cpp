@@ -479,6 +479,7 @@ struct Prepared {
     float a1x, a1y, a2x, a2y;
     float u1x, u1y, u2x, u2y; // axis_k / |axis_k|^2
     float r, g, b, a;       // colour as the vertex shader unpacks it (f16 -> f32)
+    float w;                // view depth of the centre (clip.w): the depth every fragment of the quad is tested with
     int x0, x1, y0, y1;     // pixel rect of the quad's bounding box, clamped to the screen (x0>x1 => nothing)
     int tx0, tx1, ty0, ty1; // 16x16 tile rect of the *tight* footprint used by the shipped binning kernel
     bool valid;
@@ -511,6 +512,7 @@ Prepared prepare(const ViewData& v, const gs_frame_params& P) {
     if (!(finitef(v.axis1[0]) && finitef(v.axis1[1]) && finitef(v.axis2[0]) && finitef(v.axis2[1]))) return p;
     p.r = f16tof32(v.color[0] >> 16); p.g = f16tof32(v.color[0]); p.b = f16tof32(v.color[1] >> 16); p.a = f16tof32(v.color[1]);
     if (!(p.a >= 1.0f / 255.0f)) return p;                       // alpha = saturate(e*a) <= a < 1/255: every fragment discards
+    p.w = w;
     const float invw = 1.0f / w;
     p.cx = fmaf(0.5f * (v.pos[0] * invw), W, 0.5f * W);          // (0.5 + 0.5*ndc.x) * W
     p.cy = fmaf(-0.5f * (v.pos[1] * invw), H, 0.5f * H);         // (0.5 - 0.5*ndc.y) * H   (image rows top-down)
@@ -647,16 +649,43 @@ void gso_calc_view_ex(const gs_asset_desc* d, const gs_frame_params* P, const gs
 }
 void gso_calc_view(const gs_asset_desc* d, const gs_frame_params* P, void* view_out) { gso_calc_view_ex(d, P, nullptr, 0, nullptr, view_out); }
 
+// prepare() of every splat in index order, in the layout of gs_renderer_download_raster_records (include/gsplat_c.h):
+// recs N x 8 u32 (written only for splats that reach a tile), rects N x 2 u32, vis ceil(N/64) u64.
+void gso_raster_records(const void* view_in, uint32_t n, const gs_frame_params* P, uint32_t* recs, uint32_t* rects, uint64_t* vis) {
+    const ViewData* view = (const ViewData*)view_in;
+    const int64_t words = ((int64_t)n + 63) / 64;
+#pragma omp parallel for schedule(static)
+    for (int64_t wd = 0; wd < words; ++wd) {
+        uint64_t bits = 0;
+        for (int64_t i = wd * 64; i < std::min<int64_t>((wd + 1) * 64, n); ++i) {
+            const Prepared p = prepare(view[i], *P);
+            const bool visible = p.valid && p.tx0 <= p.tx1;
+            rects[i * 2] = rects[i * 2 + 1] = 0u;
+            std::memset(recs + i * 8, 0, 32);
+            if (!visible) continue;
+            bits |= 1ull << (i & 63);
+            rects[i * 2] = (uint32_t)p.tx0 | ((uint32_t)p.ty0 << 16);
+            rects[i * 2 + 1] = (uint32_t)(p.tx1 - p.tx0 + 1) | ((uint32_t)(p.ty1 - p.ty0 + 1) << 16);
+            const float f[6] = { p.cx, p.cy, p.a1x, p.a1y, p.a2x, p.a2y };
+            std::memcpy(recs + i * 8, f, 24);
+            recs[i * 8 + 6] = view[i].color[0]; recs[i * 8 + 7] = view[i].color[1];
+        }
+        vis[wd] = bits;
+    }
+}
+
 // The DrawProcedural of GaussianSplatRenderer.cs:156-166 with RenderGaussianSplats.shader, executed splat by
 // splat in order[] (instance order), "Blend OneMinusDstAlpha One" into an RGBA16F target (rt, W*H*4 halfs,
 // row 0 = top).  mode 0: the ROP rounds to fp16 after every blend; mode 1: fp32 accumulation, a pixel stops
 // once 1-A < 1/4096 (the shipped "fast" mode), rounded to fp16 once at the end.
 // tile_pairs_out (optional) = number of (16x16 tile, splat) overlaps of the shipped binning's footprint.
 // Parallel over row bands; each band walks all splats in order, so the result is independent of thread count.
-int32_t gso_draw(const void* view_in, const uint32_t* order, uint32_t n, const gs_frame_params* P, int32_t mode,
-                 uint16_t* rt, uint64_t* tile_pairs_out, uint32_t* visible_out) {
-    const ViewData* view = (const ViewData*)view_in;
+// `win` = {x0, y0, x1, y1} inclusive pixel window (fragments outside are not evaluated; rt is still the full W x H target),
+// so a 50 M-splat / 4K frame can be checked on a crop in seconds.  The pair / visible counts always cover the whole screen.
+static int32_t draw_impl(const ViewData* view, const uint32_t* order, uint32_t n, const gs_frame_params* P, int32_t mode,
+                         uint16_t* rt, uint64_t* tile_pairs_out, uint32_t* visible_out, const int win[4], const float* scene_depth) {
     const int W = (int)P->screen_w, H = (int)P->screen_h;
+    const int wx0 = std::max(0, win[0]), wy0 = std::max(0, win[1]), wx1 = std::min(W - 1, win[2]), wy1 = std::min(H - 1, win[3]);
     std::vector<Prepared> prep(n);
     uint64_t pairs = 0; uint32_t visible = 0;
 #pragma omp parallel for schedule(static) reduction(+ : pairs, visible)
@@ -669,34 +698,64 @@ int32_t gso_draw(const void* view_in, const uint32_t* order, uint32_t n, const g
     }
     if (tile_pairs_out) *tile_pairs_out = pairs;
     if (visible_out) *visible_out = visible;
+    if (wx0 > wx1 || wy0 > wy1) return 0;
 
     int nthreads = 1;
 #ifdef _OPENMP
     nthreads = omp_get_max_threads();
 #endif
-    const int bands = std::max(1, std::min(H, nthreads * 4));
+    // Row bands; every band gets the list of draw positions whose quad touches it, in draw order (a counting sort over the
+    // bands), so the work is O(n + overlaps) whatever the band count and the result is independent of the thread count.
+    const int winH = wy1 - wy0 + 1;
+    const int bands = std::max(1, std::min(winH, nthreads * 4));
+    auto band_of = [&](int y) { return (int)(((int64_t)(y - wy0) * bands) / winH); };          // y in [wy0, wy1]
+    std::vector<uint64_t> start((size_t)bands + 1, 0);
+    for (uint32_t i = 0; i < n; ++i) {
+        const Prepared& p = prep[i];
+        if (!p.valid || p.x0 > p.x1 || p.x1 < wx0 || p.x0 > wx1) continue;
+        const int y0 = std::max(p.y0, wy0), y1 = std::min(p.y1, wy1);
+        if (y0 > y1) continue;
+        for (int b = band_of(y0); b <= band_of(y1); ++b) start[(size_t)b + 1]++;
+    }
+    for (int b = 0; b < bands; ++b) start[(size_t)b + 1] += start[b];
+    std::vector<uint32_t> list(start[bands]);
+    {
+        std::vector<uint64_t> cur(start.begin(), start.end() - 1);
+        for (uint32_t i = 0; i < n; ++i) {
+            const Prepared& p = prep[i];
+            if (!p.valid || p.x0 > p.x1 || p.x1 < wx0 || p.x0 > wx1) continue;
+            const int y0 = std::max(p.y0, wy0), y1 = std::min(p.y1, wy1);
+            if (y0 > y1) continue;
+            for (int b = band_of(y0); b <= band_of(y1); ++b) list[cur[b]++] = i;
+        }
+    }
 #pragma omp parallel for schedule(dynamic, 1)
     for (int band = 0; band < bands; ++band) {
-        const int yb0 = (int)((int64_t)H * band / bands), yb1 = (int)((int64_t)H * (band + 1) / bands) - 1;
+        // rows of this band: the y with band_of(y) == band
+        int yb0 = wy0 + (int)(((int64_t)band * winH + bands - 1) / bands), yb1 = wy0 + (int)(((int64_t)(band + 1) * winH + bands - 1) / bands) - 1;
         if (yb0 > yb1) continue;
         const int rows = yb1 - yb0 + 1;
         std::vector<float> acc((size_t)rows * W * 4);
         for (int y = 0; y < rows; ++y)
-            for (int x = 0; x < W; ++x)
+            for (int x = wx0; x <= wx1; ++x)
                 for (int c = 0; c < 4; ++c) acc[((size_t)y * W + x) * 4 + c] = f16tof32(rt[((size_t)(yb0 + y) * W + x) * 4 + c]);
-        for (uint32_t i = 0; i < n; ++i) {
-            const Prepared& p = prep[i];
-            if (!p.valid || p.x0 > p.x1) continue;
+        for (uint64_t li = start[band]; li < start[(size_t)band + 1]; ++li) {
+            const Prepared& p = prep[list[li]];
             const int y0 = std::max(p.y0, yb0), y1 = std::min(p.y1, yb1);
+            const int x0 = std::max(p.x0, wx0), x1 = std::min(p.x1, wx1);
             for (int py = y0; py <= y1; ++py) {
                 const float dy = ((float)py + 0.5f) - p.cy;
                 float* row = &acc[(size_t)(py - yb0) * W * 4];
-                for (int px = p.x0; px <= p.x1; ++px) {
+                for (int px = x0; px <= x1; ++px) {
                     const float dx = ((float)px + 0.5f) - p.cx;
                     // interpolated quad coordinate (i.pos of the v2f): q = [axis1 axis2]^-1 * delta, axes orthogonal
                     const float q1 = fmaf(dy, p.u1y, dx * p.u1x);
                     const float q2 = fmaf(dy, p.u2y, dx * p.u2x);
                     if (!(fabsf(q1) <= 2.0f && fabsf(q2) <= 2.0f)) continue;     // outside the quad
+                    // depth test against the scene (ZTest LEqual, ZWrite Off: RenderGaussianSplats.shader:10 + the camera's depth
+                    // attachment, GaussianSplatRenderer.cs:195): all four vertices share the centre's depth, so the whole quad
+                    // has the view depth clip.w; scene_depth holds the opaque scene's view depth per pixel
+                    if (scene_depth && !(p.w <= scene_depth[(size_t)py * W + px])) continue;
                     float* d = row + (size_t)px * 4;
                     if (mode == 1 && (1.0f - d[3]) < (1.0f / 4096.0f)) continue; // fast mode: pixel finished
                     const float power = -fmaf(q2, q2, q1 * q1);                 // frag: -dot(i.pos, i.pos)
@@ -714,10 +773,23 @@ int32_t gso_draw(const void* view_in, const uint32_t* order, uint32_t n, const g
             }
         }
         for (int y = 0; y < rows; ++y)
-            for (int x = 0; x < W; ++x)
+            for (int x = wx0; x <= wx1; ++x)
                 for (int c = 0; c < 4; ++c) rt[((size_t)(yb0 + y) * W + x) * 4 + c] = f32tof16(acc[((size_t)y * W + x) * 4 + c]);
     }
     return 0;
+}
+
+int32_t gso_draw(const void* view_in, const uint32_t* order, uint32_t n, const gs_frame_params* P, int32_t mode,
+                 uint16_t* rt, uint64_t* tile_pairs_out, uint32_t* visible_out) {
+    const int win[4] = { 0, 0, (int)P->screen_w - 1, (int)P->screen_h - 1 };
+    return draw_impl((const ViewData*)view_in, order, n, P, mode, rt, tile_pairs_out, visible_out, win, nullptr);
+}
+// window = {x0, y0, x1, y1} inclusive, or NULL for the whole target; scene_depth = W*H view depths of the opaque scene, or NULL
+int32_t gso_draw_ex(const void* view_in, const uint32_t* order, uint32_t n, const gs_frame_params* P, int32_t mode,
+                    uint16_t* rt, uint64_t* tile_pairs_out, uint32_t* visible_out, const int32_t* window, const float* scene_depth) {
+    int win[4] = { 0, 0, (int)P->screen_w - 1, (int)P->screen_h - 1 };
+    if (window) for (int k = 0; k < 4; ++k) win[k] = window[k];
+    return draw_impl((const ViewData*)view_in, order, n, P, mode, rt, tile_pairs_out, visible_out, win, scene_depth);
 }
 
 // GaussianComposite.shader:25-39 with "Blend SrcAlpha OneMinusSrcAlpha" onto a constant background.

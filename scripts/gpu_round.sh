@@ -1,18 +1,22 @@
 #!/bin/bash
 # One GPU-box call: parity tests, A/B stage timings of the library variants, rocprofv3 kernel stats, the bench line.
-# Usage (from the repo root on the box): bash scripts/gpu_round.sh [tests] [variants] [prof] [bench]
+# Usage (from the repo root on the box): bash scripts/gpu_round.sh [tests] [tests_noc4] [variants] [prof] [bench] [stages]
 export PYTHONPATH=$PWD
 O=$PWD/gpurun_out; mkdir -p $O
 WHAT="${@:-tests variants prof bench}"
 for w in $WHAT; do
 case $w in
 tests)
-  timeout 1500 python -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" | tee -a $O/pytest_gpu.log; tail -5 $O/pytest_gpu.log;;
+  timeout 1700 python -m pytest tests -m gpu -x -q --durations=8 > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" | tee -a $O/pytest_gpu.log; tail -15 $O/pytest_gpu.log;;
+tests_noc4)
+  GSPLAT_SKIP_C4=1 timeout 1200 python -m pytest tests -m gpu -x -q --durations=8 > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" | tee -a $O/pytest_gpu.log; tail -15 $O/pytest_gpu.log;;
+stages)
+  timeout 300 python scripts/bench_stages.py C2 30 2>&1 | tail -1 | tee $O/stages.log;;
 variants)
   : > $O/variants.log
   timeout 300 python scripts/bench_stages.py C2 30 2>&1 | tail -1 | tee -a $O/variants.log
-  GSPLAT_OVERLAP=1 timeout 200 python scripts/bench_stages.py C2 30 2>&1 | tail -1 | sed 's/"lib": "default"/"lib": "default-overlap"/' | tee -a $O/variants.log
   for v in unitygaussiansplatting_amd/variants/*.so; do
+    [ -e "$v" ] || continue
     GSPLAT_LIB=$PWD/$v timeout 200 python scripts/bench_stages.py C2 30 2>&1 | tail -1 | tee -a $O/variants.log
   done;;
 prof)

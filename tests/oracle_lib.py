@@ -77,16 +77,28 @@ class Oracle:
                                _p(db) if db is not None else None, _p(self.view))
         return self.view
 
-    def draw(self, params: gs_frame_params, mode: int = 0, rt: np.ndarray | None = None):
+    def draw(self, params: gs_frame_params, mode: int = 0, rt: np.ndarray | None = None, window=None, scene_depth: np.ndarray | None = None):
+        """window = (x0, y0, x1, y1) inclusive: only those pixels are composited (the rest of rt is left alone);
+        scene_depth = H x W float32 view depths of the opaque scene (a fragment is kept iff the splat's clip.w <= depth)."""
         W, H = int(params.screen_w), int(params.screen_h)
         if rt is None:
             rt = np.zeros((H, W, 4), np.uint16)
         pairs = C.c_uint64(0)
         vis = C.c_uint32(0)
-        lib().gso_draw(_p(self.view), _p(self.order), C.c_uint32(self.n), C.byref(params), C.c_int32(mode), _p(rt),
-                       C.byref(pairs), C.byref(vis))
+        win = (C.c_int32 * 4)(*[int(v) for v in window]) if window is not None else None
+        sd = np.ascontiguousarray(scene_depth, np.float32) if scene_depth is not None else None
+        lib().gso_draw_ex(_p(self.view), _p(self.order), C.c_uint32(self.n), C.byref(params), C.c_int32(mode), _p(rt),
+                          C.byref(pairs), C.byref(vis), win, _p(sd) if sd is not None else None)
         self.tile_pairs, self.visible = pairs.value, vis.value
         return rt
+
+    def raster_records(self, params: gs_frame_params):
+        """prepare() of every splat: (recs N x 8 u32, rects N x 2 u32, vis ceil(N/64) u64), gs_renderer_download_raster_records' layout."""
+        recs = np.zeros((self.n, 8), np.uint32)
+        rects = np.zeros((self.n, 2), np.uint32)
+        vis = np.zeros((self.n + 63) // 64, np.uint64)
+        lib().gso_raster_records(_p(self.view), C.c_uint32(self.n), C.byref(params), _p(recs), _p(rects), _p(vis))
+        return recs, rects, vis
 
     def decode_all(self) -> np.ndarray:
         out = np.zeros((self.n, 59), np.float32)

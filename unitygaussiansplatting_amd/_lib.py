@@ -54,6 +54,7 @@ SIGNATURES = {
     "gs_renderer_download_distances": (C.c_int32, [_P, _P, C.c_size_t]),
     "gs_renderer_upload_order": (C.c_int32, [_P, _P, C.c_size_t]),
     "gs_renderer_download_view": (C.c_int32, [_P, _P, C.c_size_t]),
+    "gs_renderer_download_raster_records": (C.c_int32, [_P, _P, _P, _P]),
     "gs_renderer_frame_stats": (C.c_int32, [_P, C.POINTER(gs_frame_stats)]),
     "gs_renderer_frame_times": (C.c_int32, [_P, C.POINTER(C.c_float), C.c_int32, C.POINTER(C.c_int32)]),
     "gs_renderer_stage_times": (C.c_int32, [_P, C.POINTER(gs_stage_times)]),

@@ -160,6 +160,14 @@ int32_t gs_asset_create(gs_context* ctx, const gs_asset_desc* d, gs_asset** out)
     const void* src[5] = { d->pos_data, d->other_data, d->color_data, d->sh_data, d->chunk_data };
     for (int k = 0; k < 4; ++k)
         if (have[k] < need[k]) { set_error_detail("blob %d too small: %llu < %llu", k, (unsigned long long)have[k], (unsigned long long)need[k]); return GS_ERR_INVALID_ASSET; }
+    if (d->memory_kind == 1) {
+        // borrowed device blobs: the decoders read aligned dwords (4-byte aligned bases) and the 2-byte-aligned dword stitching
+        // of LoadUInt / LoadUShort may touch the dword after the last record (owned uploads are padded by 16 bytes)
+        for (int k = 0; k < 5; ++k)
+            if (src[k] && (((uintptr_t)src[k]) & 3u)) return fail(GS_ERR_INVALID_ARGUMENT, "borrowed blobs must be 4-byte aligned");
+        for (int k : {0, 1, 3})
+            if (have[k] < need[k] + 4) { set_error_detail("borrowed blob %d needs 4 readable bytes after its last record (declare size >= %llu)", k, (unsigned long long)(need[k] + 4)); return GS_ERR_INVALID_ASSET; }
+    }
     uint32_t chunkCount = 0;
     if (d->chunk_data && d->chunk_size) {
         chunkCount = (uint32_t)(d->chunk_size / 64);
@@ -224,8 +232,9 @@ int32_t gs_renderer_create(gs_context* ctx, gs_asset* asset, gs_renderer** out) 
     int32_t rc = GS_OK;
     auto chk = [&](hipError_t e, const char* what) { if (rc == GS_OK && e != hipSuccess) rc = fail_hip(e, what, __FILE__, __LINE__); };
     chk(hipMalloc((void**)&r->view, (size_t)r->n * sizeof(gsm::ViewData) + 64), "alloc view");
-    chk(hipMalloc((void**)&r->distances, (size_t)(r->n + 16) * 4), "alloc distances");
-    chk(hipMalloc((void**)&r->order, (size_t)(r->n + 16) * 4), "alloc order");
+    chk(hipMalloc((void**)&r->keyBySplat, ((size_t)r->n + 16) * 4), "alloc sort keys");
+    chk(hipMalloc((void**)&r->distances, ((size_t)r->n + 16) * 4), "alloc distances");
+    chk(hipMalloc((void**)&r->order, ((size_t)r->n + 16) * 4), "alloc order");
     chk(hipMalloc((void**)&r->depthControl, 2 * sizeof(SortControl)), "alloc sort control");
     if (rc == GS_OK) chk(hipMemsetAsync(r->depthControl, 0, 2 * sizeof(SortControl), ctx->stream), "clear sort control");
     chk(hipEventCreateWithFlags(&r->evFork, hipEventDisableTiming), "create event");
@@ -247,6 +256,7 @@ int32_t gs_renderer_destroy(gs_renderer* r) {
     if (r->evFork) (void)hipEventDestroy(r->evFork);
     if (r->evSortDone) (void)hipEventDestroy(r->evSortDone);
     if (r->view) (void)hipFree(r->view);
+    if (r->keyBySplat) (void)hipFree(r->keyBySplat);
     if (r->distances) (void)hipFree(r->distances);
     if (r->order) (void)hipFree(r->order);
     if (r->depthControl) (void)hipFree(r->depthControl);
@@ -278,20 +288,22 @@ int32_t gs_renderer_sort(gs_renderer* r, const float m[16]) {
     // overlap on, the sort is forked onto the context's second queue here and joined by the first consumer of order[]
     // (gs_renderer_draw, or any readback), so it runs concurrently with gs_renderer_calc_view.
     // Only the four Onesweep passes are forked: they are latency-bound with little VALU work and co-run with the VALU-bound
-    // calc_view; the key generation stays on the main stream (its random gather slows 3x next to calc_view).
+    // calc_view; the key generation stays on the main stream.
     GS_TRY(join_sort(r));
     hipStream_t st = ctx->stream;
     gs::prof_record(r, 0, st);
     r->depthControlIdx ^= 1;
     SortControl* control = r->depthControl + r->depthControlIdx;
-    GS_TRY(enqueue_calc_distances(ctx, st, r->asset->view, r->order, m, r->distances, control, r->depthControl + (r->depthControlIdx ^ 1), r->n, r->depthSort));
+    // CSCalcDistances: keys of all splats in index order (+ the digit histograms); the gather through the previous order
+    // (_SplatSortKeys, SplatUtilities.compute:76) is the first Onesweep pass's key load
+    GS_TRY(enqueue_sort_keys(ctx, st, r->asset->view, m, r->keyBySplat, control, r->depthControl + (r->depthControlIdx ^ 1), r->n, r->depthSort));
     gs::prof_record(r, 1, st);
     if (ctx->overlap) {
         GS_HIP(hipEventRecord(r->evFork, ctx->stream));          // after the keys, and after everything that still reads order[]
         GS_HIP(hipStreamWaitEvent(ctx->aux, r->evFork, 0));
         st = ctx->aux;
     }
-    GS_TRY(enqueue_sort_passes(ctx, st, r->depthSort, control, r->distances, r->order, r->n, nullptr, 4, 255u, r, 10));
+    GS_TRY(enqueue_sort_passes(ctx, st, r->depthSort, control, r->distances, r->order, r->n, nullptr, 4, 255u, r, 10, 8, r->keyBySplat));
     gs::prof_record(r, 2, st);
     if (ctx->overlap) {
         GS_HIP(hipEventRecord(r->evSortDone, ctx->aux));
@@ -314,14 +326,14 @@ int32_t gs_renderer_calc_view(gs_renderer* r, const gs_frame_params* p) {
     return GS_OK;
 }
 
-// host-side read of the previous frame's pair count: grow the pair buffers before they overflow again
+// Grow the pair buffers before they overflow again.  The report of a draw is stored by its tile_order kernel straight
+// into mapped pinned host memory (before the blend even starts), so whatever it holds is the most recent draw that got
+// that far -- also in a pipelined loop in which the host runs ahead and the stream is never idle.  An overflowing scene is
+// therefore noticed within the pipeline depth, not only when the caller polls gs_renderer_frame_stats.
 static int32_t maybe_grow_pairs(gs_renderer* r) {
     if (!r->frameInFlight) return GS_OK;
-    if (hipStreamQuery(r->ctx->stream) != hipSuccess) return GS_OK;       // still running: decide next time
-    if (r->hostReport->pairCount > r->pairCapacity) {
-        unsigned long long want = r->hostReport->pairCount + r->hostReport->pairCount / 4;
-        return gs_renderer_reserve_pairs(r, want);
-    }
+    const unsigned long long seen = *(volatile unsigned long long*)&r->hostReport->pairCount;
+    if (seen > r->pairCapacity) return gs_renderer_reserve_pairs(r, seen + seen / 4);
     return GS_OK;
 }
 
@@ -348,10 +360,17 @@ int32_t gs_renderer_set_cutouts(gs_renderer* r, const gs_cutout* cutouts, uint32
     static_assert(sizeof(gs_cutout) == 17 * 4, "gs_cutout is 17 dwords");
     GS_TRY(bind_device(r->ctx));
     if (count) {
-        if (!r->cutouts) {
-            GS_HIP(hipMalloc((void**)&r->cutouts, (size_t)GS_MAX_CUTOUTS * sizeof(gs_cutout)));
-            GS_HIP(hipHostMalloc((void**)&r->cutoutsHost, (size_t)GS_MAX_CUTOUTS * sizeof(gs_cutout), hipHostMallocDefault));
-            GS_HIP(hipEventCreateWithFlags(&r->cutoutsCopied, hipEventDisableTiming));
+        if (!r->cutouts) {                                   // all three resources or none
+            uint32_t* dev = nullptr; uint8_t* host = nullptr; hipEvent_t ev = nullptr;
+            hipError_t e = hipMalloc((void**)&dev, (size_t)GS_MAX_CUTOUTS * sizeof(gs_cutout));
+            if (e == hipSuccess) e = hipHostMalloc((void**)&host, (size_t)GS_MAX_CUTOUTS * sizeof(gs_cutout), hipHostMallocDefault);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+            if (e != hipSuccess) {
+                if (dev) (void)hipFree(dev);
+                if (host) (void)hipHostFree(host);
+                return fail_hip(e, "allocate cutout buffers", __FILE__, __LINE__);
+            }
+            r->cutouts = dev; r->cutoutsHost = host; r->cutoutsCopied = ev;
             r->cutoutsHostCount = 0;
         }
         // the C# re-uploads the buffer every CalcViewData (UpdateCutoutsBuffer); here an unchanged set costs nothing.
@@ -404,12 +423,19 @@ int32_t gs_renderer_set_profiling(gs_renderer* r, int32_t frames) {
     GS_TRY(bind_device(r->ctx));
     if (frames > r->profCapacity) {
         GS_HIP(hipStreamSynchronize(r->ctx->stream));
-        if (r->ev) { for (int k = 0; k < r->profCapacity * kEvPerFrame; ++k) (void)hipEventDestroy(r->ev[k]); delete[] r->ev; delete[] r->evValid; r->ev = nullptr; }
-        r->ev = new (std::nothrow) hipEvent_t[(size_t)frames * kEvPerFrame];
-        r->evValid = new (std::nothrow) uint8_t[(size_t)frames * kEvPerFrame];
-        if (!r->ev || !r->evValid) return fail(GS_ERR_OUT_OF_MEMORY, "host allocation");
-        r->profCapacity = frames;
-        for (int k = 0; k < frames * kEvPerFrame; ++k) GS_HIP(hipEventCreate(&r->ev[k]));
+        const size_t cnt = (size_t)frames * kEvPerFrame;
+        hipEvent_t* ev = new (std::nothrow) hipEvent_t[cnt]();            // value-initialised: null handles
+        uint8_t* valid = new (std::nothrow) uint8_t[cnt]();
+        hipError_t e = (ev && valid) ? hipSuccess : hipErrorOutOfMemory;
+        size_t made = 0;
+        for (; e == hipSuccess && made < cnt; ++made) e = hipEventCreate(&ev[made]);
+        if (e != hipSuccess) {                                            // the renderer keeps its previous ring
+            for (size_t k = 0; ev && k < made; ++k) if (ev[k]) (void)hipEventDestroy(ev[k]);
+            delete[] ev; delete[] valid;
+            return fail_hip(e, "create profiling events", __FILE__, __LINE__);
+        }
+        if (r->ev) { for (int k = 0; k < r->profCapacity * kEvPerFrame; ++k) (void)hipEventDestroy(r->ev[k]); delete[] r->ev; delete[] r->evValid; }
+        r->ev = ev; r->evValid = valid; r->profCapacity = frames;
     }
     r->profiling = frames > 0;
     r->profCur = 0; r->profCompleted = 0;
@@ -420,18 +446,21 @@ int32_t gs_renderer_set_profiling(gs_renderer* r, int32_t frames) {
 int32_t gs_renderer_reserve_pairs(gs_renderer* r, uint64_t cap) {
     if (!r) return fail(GS_ERR_INVALID_ARGUMENT, "renderer is null");
     if (cap <= r->pairCapacity) return GS_OK;
-    if (cap > 0xfffffff0ull) cap = 0xfffffff0ull;
-    if (cap <= r->pairCapacity) return GS_OK;
+    if (cap > kSortMaxCount) cap = kSortMaxCount;          // 32-bit byte offsets inside the sort kernels
+    if (cap <= r->pairCapacity) return fail(GS_ERR_PAIR_OVERFLOW, "the frame needs more than 2^30 (tile, splat) pairs");
     GS_TRY(bind_device(r->ctx));
     GS_HIP(hipStreamSynchronize(r->ctx->stream));
+    // new buffers first; the renderer only changes once every allocation has succeeded
+    uint32_t *nk = nullptr, *nv = nullptr;
+    SortState ns;
+    hipError_t e = hipMalloc((void**)&nk, ((size_t)cap + 16) * 4);
+    if (e == hipSuccess) e = hipMalloc((void**)&nv, ((size_t)cap + 16) * 4);
+    int32_t rc = e == hipSuccess ? sort_state_create(r->ctx, ns, (uint32_t)cap) : fail_hip(e, "grow pair buffers", __FILE__, __LINE__);
+    if (rc != GS_OK) { if (nk) (void)hipFree(nk); if (nv) (void)hipFree(nv); sort_state_destroy(ns); return rc; }
     if (r->pairKeys) (void)hipFree(r->pairKeys);
     if (r->pairVals) (void)hipFree(r->pairVals);
-    r->pairKeys = r->pairVals = nullptr;
     sort_state_destroy(r->pairSort);
-    r->pairCapacity = cap;
-    GS_HIP(hipMalloc((void**)&r->pairKeys, (size_t)(cap + 16) * 4));
-    GS_HIP(hipMalloc((void**)&r->pairVals, (size_t)(cap + 16) * 4));
-    GS_TRY(sort_state_create(r->ctx, r->pairSort, (uint32_t)cap));
+    r->pairKeys = nk; r->pairVals = nv; r->pairSort = ns; r->pairCapacity = cap;
     return GS_OK;
 }
 
@@ -472,6 +501,18 @@ int32_t gs_renderer_download_view(gs_renderer* r, void* out, size_t bytes) {
         r->viewMaterialised = true;
     }
     return download(r->ctx, out, r->view, bytes);
+}
+
+int32_t gs_renderer_download_raster_records(gs_renderer* r, void* recs, uint32_t* rects, uint64_t* vis_mask) {
+    if (!r) return fail(GS_ERR_INVALID_ARGUMENT, "renderer is null");
+    if (!r->viewValid) return fail(GS_ERR_INVALID_ARGUMENT, "gs_renderer_calc_view has not run");
+    GS_TRY(bind_device(r->ctx));
+    hipStream_t st = r->ctx->stream;
+    if (recs) GS_HIP(hipMemcpyAsync(recs, r->recs, (size_t)r->n * sizeof(SplatRec), hipMemcpyDeviceToHost, st));
+    if (rects) GS_HIP(hipMemcpyAsync(rects, r->rects, (size_t)r->n * sizeof(uint2), hipMemcpyDeviceToHost, st));
+    if (vis_mask) GS_HIP(hipMemcpyAsync(vis_mask, r->visMask, ((size_t)r->n + 63) / 64 * 8, hipMemcpyDeviceToHost, st));
+    GS_HIP(hipStreamSynchronize(st));
+    return GS_OK;
 }
 
 int32_t gs_renderer_frame_stats(gs_renderer* r, gs_frame_stats* out) {

@@ -54,12 +54,13 @@ static_assert(sizeof(SplatRec) == 32, "SplatRec is 32 B");
 struct SortState {
     uint32_t* altKeys = nullptr;
     uint32_t* altVals = nullptr;
-    unsigned long long* status = nullptr;   // maxParts x 256 words {epoch:30 | flag:2 | value:32}
+    uint32_t* status = nullptr;             // maxParts x 256 words {epoch:18 | count:14}: a partition's digit counts
     unsigned long long* groupAgg = nullptr; // 4 passes x maxGroups x 256 words {members:24 | sum:40}, zeroed per sort
+    unsigned long long* groupIncl = nullptr;// maxGroups x 256 words {epoch:32 | inclusive prefix:32} through the end of a group
     uint32_t maxGroups = 0;
     uint32_t maxCount = 0;
     uint32_t maxParts = 0;
-    uint32_t epoch = 0;                     // last epoch used on `status` (30 bits, never 0)
+    uint32_t epoch = 0;                     // last epoch used on `status` / `groupIncl` (18 bits, never 0)
 };
 
 // small per-sort control block (zeroed by one memset before each sort)
@@ -134,6 +135,7 @@ struct gs_renderer {
     uint32_t n = 0;
     // reference buffers (GaussianSplatRenderer.cs:407,431-432)
     gsm::ViewData* view = nullptr;          // m_GpuView
+    uint32_t* keyBySplat = nullptr;         // N x u32: the frame's sort key of every splat, in splat-index order
     uint32_t* distances = nullptr;          // m_GpuSortDistances
     uint32_t* order = nullptr;              // m_GpuSortKeys (_OrderBuffer)
     gs::SortState depthSort;
@@ -191,18 +193,22 @@ void prof_end_frame(gs_renderer* r);
 // sort entry points (gs_sort.hip)
 int32_t sort_state_create(gs_context* ctx, SortState& st, uint32_t maxCount);
 void sort_state_destroy(SortState& st);
-// CSCalcDistances + fused 4x256 histogram
-int32_t enqueue_calc_distances(gs_context* ctx, hipStream_t st, const gsm::AssetView& a, const uint32_t* order, const float* matSort,
-                               uint32_t* keys, SortControl* control, SortControl* nextControl, uint32_t n, SortState& sort);
+// keys of all splats in index order (CSCalcDistances' arithmetic) + the four digit histograms; the gather through the
+// previous order is done by the first sort pass (enqueue_sort_passes with gatherKeys)
+int32_t enqueue_sort_keys(gs_context* ctx, hipStream_t st, const gsm::AssetView& a, const float* matSort, uint32_t* keyBySplat,
+                          SortControl* control, SortControl* nextControl, uint32_t n, SortState& sort);
 uint32_t sort_group_words(uint32_t nUpper, int passes);   // 8-byte words of SortState::groupAgg a sort of nUpper keys uses (to be zeroed before the passes)
 int32_t enqueue_histogram(gs_context* ctx, hipStream_t st, const uint32_t* keys, uint32_t n, const uint32_t* nPtr, int passes, uint32_t lastMask,
                           SortControl* control, SortState& sort);
 // `passes` Onesweep passes.  The raw digit histograms must already be in control->hist and sort.groupAgg zeroed.  Result ends in (keys, vals) when
 // passes is even, otherwise it is copied back.
 // profR/evFirst: optional hipEvent slots (evFirst = just before the first Onesweep launch, evFirst + 1 = after the last)
+// bitsPerPass: digit width (6..8; the histograms in control->hist must have been taken with the same width).
+// gatherKeys != null (8-bit passes, an even number of them): the first pass reads its keys as gatherKeys[vals[i]].
 int32_t enqueue_sort_passes(gs_context* ctx, hipStream_t stream, SortState& st, SortControl* control, uint32_t* keys, uint32_t* vals,
                             uint32_t nUpper, const uint32_t* nPtr, int passes, uint32_t lastMask = 255u,
-                            gs_renderer* profR = nullptr, int evFirst = -1);
+                            gs_renderer* profR = nullptr, int evFirst = -1, int bitsPerPass = 8, const uint32_t* gatherKeys = nullptr);
+constexpr uint32_t kSortMaxCount = 1u << 30;   // 32-bit byte offsets inside the sort kernels
 int32_t enqueue_set_indices(gs_context* ctx, uint32_t* order, uint32_t n);
 // view (gs_view.hip)
 int32_t enqueue_calc_view(gs_context* ctx, const gsm::AssetView& a, const gs_frame_params* p, const gsm::EditView& e, gsm::ViewData* out,

@@ -193,10 +193,10 @@ GS_HD ChunkRaw LoadChunk(const uint8_t* chunk, uint32_t ci) {
     return c;
 }
 
-// LoadSplatPos (GaussianSplatting.hlsl:394-421)
-GS_HD V3 LoadSplatPos(const AssetView& a, uint32_t idx) {
+// LoadSplatPos (GaussianSplatting.hlsl:394-421); ci = idx >> 8, passed separately so that a caller whose workgroup is aligned
+// to the 256-splat chunks can hand in a wave-uniform value (the ChunkInfo loads then become scalar loads)
+GS_HD V3 LoadSplatPosChunk(const AssetView& a, uint32_t idx, uint32_t ci) {
     V3 p = LoadVec(a.pos, (uint64_t)idx * vecStride(a.posFmt), a.posFmt);
-    const uint32_t ci = idx >> 8;
     if (ci < a.chunkCount) {
         const uint8_t* c = a.chunk + (uint64_t)ci * 64;
         p.x = lerpf(u2f(ld32a(c, 16)), u2f(ld32a(c, 20)), p.x);
@@ -205,12 +205,15 @@ GS_HD V3 LoadSplatPos(const AssetView& a, uint32_t idx) {
     }
     return p;
 }
+GS_HD V3 LoadSplatPos(const AssetView& a, uint32_t idx) { return LoadSplatPosChunk(a, idx, idx >> 8); }
 
 // CSCalcDistances body (SplatUtilities.compute:76-81): key of the splat `origIdx` under sort-matrix row 2
-GS_HD uint32_t SortKey(const AssetView& a, uint32_t origIdx, float m20, float m21, float m22, float m23) {
-    const V3 p = LoadSplatPos(a, origIdx);
+GS_HD uint32_t SortKeyOf(const V3& p, float m20, float m21, float m22, float m23) {
     const float z = fmaf(m22, p.z, fmaf(m21, p.y, fmaf(m20, p.x, m23)));
     return FloatToSortableUint(z);
+}
+GS_HD uint32_t SortKey(const AssetView& a, uint32_t origIdx, float m20, float m21, float m22, float m23) {
+    return SortKeyOf(LoadSplatPos(a, origIdx), m20, m21, m22, m23);
 }
 
 GS_HD void SplatIndexToPixelIndex(uint32_t idx, uint32_t& x, uint32_t& y) {

@@ -21,6 +21,8 @@
 #include <limits>
 #include <new>
 #include <numeric>
+#include <exception>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -34,20 +36,30 @@ namespace {
 
 constexpr uint32_t kChunk = 256, kTexWidth = 2048;
 
-// f(a, b) over [0, n) in contiguous ranges, one per hardware thread; ranges whose thread cannot be created run on the caller
+// f(a, b) over [0, n) in contiguous ranges, one per hardware thread; ranges whose thread cannot be created run on the caller.
+// An exception thrown inside a worker (e.g. bad_alloc of a per-range vector) is carried back and rethrown on the calling
+// thread after all workers have joined, where the entry point's catch turns it into an error code (an exception escaping
+// a std::thread would call std::terminate).
 template <class F> void parallel_for(size_t n, size_t grain, F f) {
     const size_t hw = std::max(1u, std::thread::hardware_concurrency());
     const size_t nt = std::min(hw, (n + grain - 1) / grain);
     if (nt <= 1) { f(0, n); return; }
     std::vector<std::thread> th;
+    std::mutex mu;
+    std::exception_ptr first;
+    auto guarded = [&](size_t a, size_t b) {
+        try { f(a, b); }
+        catch (...) { std::lock_guard<std::mutex> g(mu); if (!first) first = std::current_exception(); }
+    };
     const size_t per = (n + nt - 1) / nt;
     for (size_t t = 0; t < nt; ++t) {
         const size_t a = t * per, b = std::min(n, a + per);
         if (a >= b) continue;
-        try { th.emplace_back([=] { f(a, b); }); }
-        catch (...) { f(a, b); }                  // std::system_error (thread limit) / bad_alloc: do the range here
+        try { th.emplace_back([=, &guarded] { guarded(a, b); }); }
+        catch (...) { guarded(a, b); }            // std::system_error (thread limit) / bad_alloc: do the range here
     }
     for (auto& x : th) x.join();
+    if (first) std::rethrow_exception(first);
 }
 
 inline float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }

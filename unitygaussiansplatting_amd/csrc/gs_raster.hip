@@ -98,7 +98,7 @@ __global__ __launch_bounds__(kBinThreads, GS_BIN_MINWAVES) void bin_emit_kernel(
                                                                 uint32_t* __restrict__ pairKeys, uint32_t* __restrict__ pairVals,
                                                                 uint32_t capacity, BinControl* ctl, unsigned long long* binStatus,
                                                                 uint32_t* pairHist, unsigned long long* __restrict__ groupAgg, uint32_t groupAggWords,
-                                                                uint32_t* __restrict__ nextArena, uint32_t nextArenaWords) {
+                                                                uint32_t* __restrict__ nextArena, uint32_t nextArenaWords, uint32_t digitBits) {
     constexpr int SUB = 4;                                   // k's per emission batch: 256 positions per wave
     __shared__ uint32_t s_hist[3 * 256];
     __shared__ uint32_t s_wtot[4], s_wvis[4];
@@ -115,6 +115,7 @@ __global__ __launch_bounds__(kBinThreads, GS_BIN_MINWAVES) void bin_emit_kernel(
     // the zero-initialised per-draw arena of the NEXT draw (the two copies alternate: no memset launch per draw)
     for (uint32_t j = blockIdx.x * (uint32_t)kBinThreads + (uint32_t)tid; j < nextArenaWords; j += gridDim.x * (uint32_t)kBinThreads) nextArena[j] = 0u;
     const uint32_t numParts = (n + kBinPart - 1) / kBinPart;
+    const uint32_t digitMask = (1u << digitBits) - 1u;          // the pair sort's digit width (6..8 bits by tile count)
     uint32_t visAcc = 0;                                         // thread 0: visible splats of this workgroup's partitions
     // Persistent grid, partitions drawn from kBinTicketClasses counters in separate 128-B lines (one counter would
     // serialise ~1500 same-address atomics, 12 ns each, at the start of the kernel): ticket t of class c = partition
@@ -260,10 +261,10 @@ __global__ __launch_bounds__(kBinThreads, GS_BIN_MINWAVES) void bin_emit_kernel(
             if (wr) {
                 pairKeys[gi] = tile;
                 pairVals[gi] = s;                                // payload = splat index: the blend kernel reads rec[splat]
-                atomicAdd(&s_hist[tile & 255u], 1u);             // neighbouring slots are neighbouring tiles: distinct bins
+                atomicAdd(&s_hist[tile & digitMask], 1u);        // neighbouring slots are neighbouring tiles: distinct bins
             }
-            if (PASSES >= 2) hist_add_aggregated(s_hist + 256, (tile >> 8) & 255u, wr);
-            if (PASSES >= 3) hist_add_aggregated(s_hist + 512, (tile >> 16) & 255u, wr);
+            if (PASSES >= 2) hist_add_aggregated(s_hist + 256, (tile >> digitBits) & digitMask, wr);
+            if (PASSES >= 3) hist_add_aggregated(s_hist + 512, (tile >> (2u * digitBits)) & digitMask, wr);
         }
         __builtin_amdgcn_wave_barrier();
     }
@@ -657,11 +658,11 @@ int32_t renderer_alloc_raster(gs_renderer* r) {
     if (r->pairCapacity == 0) {
         unsigned long long cap = (unsigned long long)r->n * 8ull;
         if (cap < (1ull << 22)) cap = 1ull << 22;
-        if (cap > 0xfffffff0ull) cap = 0xfffffff0ull;
+        if (cap > kSortMaxCount) cap = kSortMaxCount;           // 32-bit byte offsets inside the sort kernels
         r->pairCapacity = cap;
     }
-    GS_HIP(hipMalloc((void**)&r->pairKeys, (size_t)(r->pairCapacity + 16) * 4));
-    GS_HIP(hipMalloc((void**)&r->pairVals, (size_t)(r->pairCapacity + 16) * 4));
+    GS_HIP(hipMalloc((void**)&r->pairKeys, ((size_t)r->pairCapacity + 16) * 4));
+    GS_HIP(hipMalloc((void**)&r->pairVals, ((size_t)r->pairCapacity + 16) * 4));
     GS_TRY(sort_state_create(ctx, r->pairSort, (uint32_t)r->pairCapacity));
     GS_HIP(hipHostMalloc((void**)&r->hostReport, sizeof(FrameReport), hipHostMallocMapped));
     memset(r->hostReport, 0, sizeof(FrameReport));
@@ -711,7 +712,12 @@ int32_t enqueue_draw(gs_renderer* r, const gs_frame_params* p, gs_target* rt) {
     const uint32_t cap = (uint32_t)r->pairCapacity;
 
     prof_record(r, 3);
-    const int passes = numTiles <= 256 ? 1 : (numTiles <= 65536 ? 2 : 3);
+    // digit width of the pair sort by tile count: 12-bit tile ids sort in two 6-bit passes (6 ballots per key instead of 8,
+    // 64 status words per partition instead of 256), 13..14 bits in two 7-bit passes
+    int passes, bits;
+    if (numTiles <= 256) { passes = 1; bits = numTiles <= 64 ? 6 : (numTiles <= 128 ? 7 : 8); }
+    else if (numTiles <= 65536) { passes = 2; bits = numTiles <= 4096 ? 6 : (numTiles <= 16384 ? 7 : 8); }
+    else { passes = 3; bits = 8; }
     auto binKernel = passes == 1 ? bin_emit_kernel<1> : (passes == 2 ? bin_emit_kernel<2> : bin_emit_kernel<3>);
     // persistent: as many workgroups as are resident at once, a multiple of the ticket classes
 #ifndef GS_BIN_BLOCKS_PER_CU
@@ -720,9 +726,9 @@ int32_t enqueue_draw(gs_renderer* r, const gs_frame_params* p, gs_target* rt) {
     const uint32_t binCap = max((uint32_t)ctx->cuCount * (uint32_t)GS_BIN_BLOCKS_PER_CU / kBinTicketClasses * kBinTicketClasses, kBinTicketClasses);
     const uint32_t binGrid = min(div_up(r->binParts, kBinTicketClasses) * kBinTicketClasses, binCap);
     hipLaunchKernelGGL(binKernel, dim3(binGrid), dim3(kBinThreads), 0, st, r->rects, (const uint32_t*)r->visMask, r->order, r->n, rc.tilesX, r->pairKeys,
-                       r->pairVals, cap, binCtl, binStatus, pairCtl->hist, r->pairSort.groupAgg, sort_group_words(cap, passes), (uint32_t*)nextArena, (uint32_t)(r->frameArenaBytes / 4));
+                       r->pairVals, cap, binCtl, binStatus, pairCtl->hist, r->pairSort.groupAgg, sort_group_words(cap, passes), (uint32_t*)nextArena, (uint32_t)(r->frameArenaBytes / 4), (uint32_t)bits);
     prof_record(r, 4);
-    GS_TRY(enqueue_sort_passes(ctx, st, r->pairSort, pairCtl, r->pairKeys, r->pairVals, cap, &binCtl->pairCountClamped, passes, 255u, r, 12));
+    GS_TRY(enqueue_sort_passes(ctx, st, r->pairSort, pairCtl, r->pairKeys, r->pairVals, cap, &binCtl->pairCountClamped, passes, 255u, r, 12, bits));
     r->lastPairPasses = (uint32_t)passes;
     hipLaunchKernelGGL(tile_ranges_kernel, dim3(max(1u, min(div_up(cap, 1024), (uint32_t)ctx->cuCount * 8u))), dim3(256), 0, st, r->pairKeys,
                        &binCtl->pairCountClamped, tileStart, tileEnd, numTiles);

@@ -8,15 +8,22 @@
 // generation) + one chained-scan binning kernel per pass with a two-level decoupled look-back.  Contract kept:
 // stable, ascending, (uint32 key, uint32 payload) pairs (KEY_UINT PAYLOAD_UINT SHOULD_ASCEND SORT_PAIRS).
 //
-// gfx950 specifics: 64-lane waves -- ranking is a wave-level multi-split from 8 __ballot()s per key (one per
-// digit bit, folded with one v_bitop3 per 32-lane half) and v_mbcnt below the lane; per-wave digit histograms live in LDS; inter-workgroup
-// look-back words are single 8-byte {epoch, flag, value} granules written/read with relaxed AGENT-scope atomics
-// (the per-XCD L2s are not coherent, see MI355X_MICROARCH.md "inter-workgroup visibility"; the granule carries
-// its own tag so no fence is needed and no status memset between passes: each pass uses a fresh epoch).
+// gfx950 specifics: 64-lane waves -- ranking is a wave-level multi-split from one __ballot() per digit bit (folded
+// with one v_bitop3 per 32-lane half) and v_mbcnt below the lane; per-wave digit histograms live in LDS; inter-workgroup
+// look-back words are self-tagged granules -- a 4-byte {epoch:18, count:14} word per (partition, digit), published four
+// digits at a time with one 16-byte write-through (sc1) store, and 8-byte {epoch, value} / {members, sum} words per
+// (group of 32 partitions, digit) -- written/read with AGENT-scope relaxed accesses (the per-XCD L2s are not coherent, see
+// MI355X_MICROARCH.md "inter-workgroup visibility"; every granule carries its own tag so no fence is needed and no
+// status memset between passes: each pass uses a fresh epoch).
 // Partitions are handed out by atomic tickets (16 counters in separate cache lines) inside a persistent grid, so a
 // workgroup only ever waits on partitions that are running; all partitions of a pass are resident at once, so the
 // look-back goes through per-group aggregates (32 partitions) instead of a chain of INCLUSIVE hand-offs; every spin is
 // bounded and reports GS_ERR_SORT_TIMEOUT instead of hanging.  Design notes and measurements: DESIGN.md section 4.1.
+//
+// Depth sort of a frame (gs_renderer_sort): sort_keys_kernel writes key[s] for every splat s in INDEX order (coalesced
+// position reads; the four digit histograms do not depend on the order) and the first Onesweep pass gathers
+// key[order[i]] itself (GATHER instantiation), so CSCalcDistances' random access is a single 4-byte gather hidden
+// inside a pass that is resident anyway, instead of a kernel of its own that waits on a position + ChunkInfo gather.
 #include "gs_common.h"
 
 namespace gs {
@@ -41,16 +48,18 @@ constexpr uint32_t TICKET_CLASSES = 16;        // partition-ticket counters per 
 #endif
 constexpr int GROUP = GS_SORT_GROUP;                     // partitions per look-back group (~sqrt of the partition count of a 6 M key sort)
 
-constexpr unsigned long long FLAG_AGG = 1ull, FLAG_INCL = 2ull;
-
-__device__ __forceinline__ unsigned long long pack_status(uint32_t epoch, unsigned long long flag, uint32_t value) {
-    return ((unsigned long long)epoch << 34) | (flag << 32) | (unsigned long long)value;
-}
-__device__ __forceinline__ unsigned long long ld_status(const unsigned long long* p) {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void st_status(unsigned long long* p, unsigned long long v) {
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+// per-(partition, digit) status word: {epoch:18 | count:14}; valid for a pass iff its epoch field equals the pass's epoch
+constexpr uint32_t COUNT_BITS = 14, EPOCH_MASK = (1u << 18) - 1u;
+static_assert(PART < (1 << COUNT_BITS), "a partition's digit count must fit the status word");
+__device__ __forceinline__ uint32_t pack_status(uint32_t epoch, uint32_t count) { return (epoch << COUNT_BITS) | count; }
+__device__ __forceinline__ uint32_t ld_status(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ unsigned long long ld_word64(const unsigned long long* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_word64(unsigned long long* p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// 16-byte write-through store (agent scope): four status words in ONE fabric write (scalar sc1 stores cost one fabric
+// write each whatever their size, MI355X_MICROARCH.md).  The trailing s_nop keeps hipcc's hazard tracking honest.
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void st16_sc1(uint32_t* p, u32x4 v) {
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
 }
 
 // 32-bit element index on a wave-uniform base pointer: lets the compiler use the SGPR-base + 32-bit-VGPR-offset
@@ -84,65 +93,6 @@ __global__ __launch_bounds__(1024) void set_indices_kernel(uint32_t* order, uint
     if (i < n) order[i] = i;
 }
 
-// CSCalcDistances fused with the 4 digit histograms of the Onesweep sort.
-// The kernel is a dependent chain  order[i] -> pos[order[i]] (random 4..12-B gather) -> key  per splat, i.e. pure memory
-// latency: each thread carries GS_DIST_ILP independent chains (all index loads first, then all gathers), and the grid is
-// sized for full occupancy, so that enough gathers are in flight to cover the ~2 us round trip of a miss.
-#ifndef GS_DIST_ILP
-#define GS_DIST_ILP 4
-#endif
-__global__ __launch_bounds__(256) void calc_distances_kernel(gsm::AssetView a, const uint32_t* __restrict__ order,
-                                                             float m20, float m21, float m22, float m23,
-                                                             uint32_t* __restrict__ keys, uint32_t* __restrict__ hist, uint32_t n,
-                                                             unsigned long long* __restrict__ groupAgg, uint32_t groupAggWords,
-                                                             uint32_t* __restrict__ nextControl) {
-    __shared__ uint32_t s_h[4 * RADIX];
-    for (int j = threadIdx.x; j < 4 * RADIX; j += 256) s_h[j] = 0;
-    for (uint32_t j = blockIdx.x * 256u + threadIdx.x; j < groupAggWords; j += gridDim.x * 256u) groupAgg[j] = 0ull;   // the sort passes accumulate into it
-    // the control block (histograms, tickets, error) of the NEXT sort: the two blocks alternate, so no memset launch per sort
-    for (uint32_t j = blockIdx.x * 256u + threadIdx.x; j < (uint32_t)(sizeof(SortControl) / 4); j += gridDim.x * 256u) nextControl[j] = 0u;
-    __syncthreads();
-    constexpr uint32_t ILP = GS_DIST_ILP;
-    constexpr uint32_t TILE = 256u * ILP;
-    // XCD-aware traversal.  Workgroup b runs on XCD b % 8 (MI355X_MICROARCH.md), each XCD has its own 4 MB L2, and the
-    // gather pos[order[i]] fetches a whole 64-byte sector (16 Norm11 positions) per splat.  The asset is in Morton order,
-    // so the 16 splats of a sector are spatial neighbours and therefore close in DEPTH ORDER too: if one XCD walks a
-    // contiguous eighth of the sorted positions front to back, the other 15 accesses of a sector arrive at the same L2
-    // while the sector is still resident, instead of 16 fetches spread over 8 L2s.
-    const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3, slots = gridDim.x >> 3;     // gridDim.x is a multiple of 8
-    const uint32_t tilesTotal = (n + TILE - 1u) / TILE;
-    const uint32_t tilesPerXcd = (tilesTotal + 7u) / 8u;
-    const uint32_t tileEnd = min(tilesTotal, (xcd + 1u) * tilesPerXcd);
-    for (uint32_t tile = xcd * tilesPerXcd + slot; tile < tileEnd; tile += slots) {
-        const uint32_t base = tile * TILE + threadIdx.x;
-        uint32_t oi[ILP];
-#pragma unroll
-        for (uint32_t k = 0; k < ILP; ++k) {
-            const uint32_t i = base + k * 256u;
-            oi[k] = (i < n) ? order[i] : 0xffffffffu;
-        }
-        uint32_t key[ILP];
-#pragma unroll
-        for (uint32_t k = 0; k < ILP; ++k) {
-            key[k] = (oi[k] != 0xffffffffu) ? gsm::SortKey(a, oi[k], m20, m21, m22, m23) : 0u;
-        }
-#pragma unroll
-        for (uint32_t k = 0; k < ILP; ++k) {
-            if (oi[k] == 0xffffffffu) continue;
-            keys[base + k * 256u] = key[k];
-            lds_hist_add(s_h, key[k] & 255u);
-            lds_hist_add(s_h + RADIX, (key[k] >> 8) & 255u);
-            lds_hist_add(s_h + 2 * RADIX, (key[k] >> 16) & 255u);
-            lds_hist_add(s_h + 3 * RADIX, key[k] >> 24);
-        }
-    }
-    __syncthreads();
-    for (int j = threadIdx.x; j < 4 * RADIX; j += 256) {
-        const uint32_t c = s_h[j];
-        if (c) atomicAdd(&hist[j], c);
-    }
-}
-
 // stand-alone histogram (gs_sorter path): `passes` digit histograms of keys[0..n)
 __global__ __launch_bounds__(256) void histogram_kernel(const uint32_t* __restrict__ keys, uint32_t nImm, const uint32_t* nPtr,
                                                         int passes, uint32_t lastMask, uint32_t* __restrict__ hist,
@@ -163,7 +113,60 @@ __global__ __launch_bounds__(256) void histogram_kernel(const uint32_t* __restri
     }
 }
 
+// Sort keys of all splats in INDEX order + the 4 digit histograms of the Onesweep sort (they do not depend on the order):
+// key[s] = FloatToSortableUint(dot(matrix row 2, (pos[s], 1))), CSCalcDistances' arithmetic (SplatUtilities.compute:76-81)
+// with the gather through _SplatSortKeys left to the first sort pass.  Streaming: 4..12 B in, 4 B out per splat.  One
+// 1024-thread workgroup per CU (few workgroups = few flushes of the LDS histograms into the 1024 global bins, whose
+// same-address atomics serialise), each thread keeps ILP chunks in flight; a quarter of a workgroup = one 256-splat chunk,
+// so ChunkInfo is wave-uniform.
+#ifndef GS_KEYS_ILP
+#define GS_KEYS_ILP 4
+#endif
+__global__ __launch_bounds__(1024) void sort_keys_kernel(gsm::AssetView a, float m20, float m21, float m22, float m23,
+                                                         uint32_t* __restrict__ keyBySplat, uint32_t* __restrict__ hist, uint32_t n,
+                                                         unsigned long long* __restrict__ groupAgg, uint32_t groupAggWords,
+                                                         uint32_t* __restrict__ nextControl) {
+    __shared__ uint32_t s_h[4 * RADIX];
+    for (int j = threadIdx.x; j < 4 * RADIX; j += 1024) s_h[j] = 0;
+    for (uint32_t j = blockIdx.x * 1024u + threadIdx.x; j < groupAggWords; j += gridDim.x * 1024u) groupAgg[j] = 0ull;   // the sort passes accumulate into it
+    // the control block (histograms, tickets, error) of the NEXT sort: the two blocks alternate, so no memset launch per sort
+    for (uint32_t j = blockIdx.x * 1024u + threadIdx.x; j < (uint32_t)(sizeof(SortControl) / 4); j += gridDim.x * 1024u) nextControl[j] = 0u;
+    __syncthreads();
+    constexpr uint32_t ILP = GS_KEYS_ILP;
+    const uint32_t chunks = (n + 255u) >> 8;
+    const uint32_t sub = threadIdx.x >> 8, t = threadIdx.x & 255u;
+    for (uint32_t c0 = blockIdx.x * (4u * ILP); c0 < chunks; c0 += gridDim.x * (4u * ILP)) {
+        gsm::V3 p[ILP];
+#pragma unroll
+        for (uint32_t k = 0; k < ILP; ++k) {
+            const uint32_t ci = __builtin_amdgcn_readfirstlane(c0 + k * 4u + sub);       // wave-uniform: 4 waves per chunk
+            const uint32_t idx = ci * 256u + t;
+            p[k] = gsm::V3{0.f, 0.f, 0.f};
+            if (idx < n) p[k] = gsm::LoadSplatPosChunk(a, idx, ci);
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < ILP; ++k) {
+            const uint32_t idx = (c0 + k * 4u + sub) * 256u + t;
+            if (idx >= n) continue;
+            const uint32_t key = gsm::SortKeyOf(p[k], m20, m21, m22, m23);
+            keyBySplat[idx] = key;
+            lds_hist_add(s_h, key & 255u);
+            lds_hist_add(s_h + RADIX, (key >> 8) & 255u);
+            lds_hist_add(s_h + 2 * RADIX, (key >> 16) & 255u);
+            lds_hist_add(s_h + 3 * RADIX, key >> 24);
+        }
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < 4 * RADIX; j += 1024) {
+        const uint32_t c = s_h[j];
+        if (c) atomicAdd(&hist[j], c);
+    }
+}
+
 // One Onesweep pass: reads (keysIn, valsIn), writes (keysOut, valsOut) stably partitioned by digit (key>>shift)&mask.
+// BITS = digit width (8 for the depth sort; 6..8 for the tile-pair sort, whose keys have 12..16 significant bits: fewer
+// ballots per key, fewer status words per partition).  GATHER = first pass of a frame's depth sort: the key of position
+// i is keysIn[valsIn[i]] (keysIn = keys by splat index, valsIn = the previous order) -- CSCalcDistances' gather.
 // Register diet (the kernel is latency-bound, so resident waves matter): payloads are loaded only after the keys
 // have left the registers for LDS, local positions overwrite the ranks, and the digit of each output slot is kept
 // packed 4 per register instead of a 32-bit global index per slot.
@@ -174,39 +177,47 @@ __device__ unsigned long long g_timeline[16384 * 16];
 #define GS_TL(k) do { } while (0)
 #endif
 #ifndef GS_SORT_LOOKBACK_BATCH
-#define GS_SORT_LOOKBACK_BATCH 8
+#define GS_SORT_LOOKBACK_BATCH 16
 #endif
 #ifndef GS_SORT_MINWAVES
 #define GS_SORT_MINWAVES 6      // <= 80 VGPRs: three 512-thread workgroups per CU (a handful of loop-invariant values spill to scratch)
 #endif
+template <int BITS, bool GATHER>
 __global__ __launch_bounds__(THREADS, GS_SORT_MINWAVES) void onesweep_kernel(const uint32_t* __restrict__ keysIn, const uint32_t* __restrict__ valsIn,
                                                            uint32_t* __restrict__ keysOut, uint32_t* __restrict__ valsOut,
-                                                           const uint32_t* __restrict__ hist, unsigned long long* status,
-                                                           unsigned long long* groupAgg, uint32_t* ticket, uint32_t* error, uint32_t nImm, const uint32_t* nPtr,
-                                                           uint32_t shift, uint32_t epoch, uint32_t digitMask) {
-    __shared__ uint32_t s_hist[WAVES * RADIX];   // per-wave digit counts -> wave-exclusive offsets
-    __shared__ uint32_t s_lbase[RADIX];          // exclusive digit offsets inside the partition
-    __shared__ uint32_t s_gbase[RADIX];          // global index of local slot j with digit d = s_gbase[d] + j
+                                                           const uint32_t* __restrict__ hist, uint32_t* status,
+                                                           unsigned long long* groupAgg, unsigned long long* groupIncl, uint32_t* ticket, uint32_t* error,
+                                                           uint32_t nImm, const uint32_t* nPtr, uint32_t shift, uint32_t epoch, uint32_t digitMask) {
+    constexpr int RDX = 1 << BITS;                   // digits of this pass
+    constexpr int DW = (RDX + 63) / 64;              // waves that own digits
+    __shared__ uint32_t s_hist[WAVES * RDX];         // per-wave digit counts -> wave-exclusive offsets
+    __shared__ uint32_t s_lbase[RDX];                // exclusive digit offsets inside the partition
+    __shared__ uint32_t s_gbase[RDX];                // global index of local slot j with digit d = s_gbase[d] + j
+    __shared__ __attribute__((aligned(16))) uint32_t s_pub[RDX];   // this partition's status words, published 4 per store
     __shared__ uint32_t s_buf[PART];
-    __shared__ uint32_t s_wtot[WAVES];
-    __shared__ uint32_t s_htot[RADIX / 64];
+    __shared__ uint32_t s_wtot[DW];
+    __shared__ uint32_t s_htot[DW];
     __shared__ uint32_t s_part;
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const uint32_t n = nPtr ? min(*nPtr, nImm) : nImm;
     const uint32_t numParts = (n + PART - 1) / PART;
 
-    // global exclusive digit offsets = exclusive scan of this pass's 256-bin histogram (raw counts, accumulated by the key
-    // generation / histogram kernel): every workgroup scans it for itself instead of a separate 1-workgroup launch
+    // global exclusive digit offsets = exclusive scan of this pass's histogram (raw counts, accumulated by the key
+    // generation / binning / histogram kernel): every workgroup scans it for itself instead of a separate 1-workgroup launch
     uint32_t histExcl = 0;
-    if (tid < RADIX) {
+    bool digitLive = false;                            // some key of the whole input holds this digit
+    if (tid < RDX) {
         const uint32_t c = hist[tid];
+        digitLive = c != 0u;
         const uint32_t incl = wave_incl_scan(c, lane);
         if (lane == 63) s_htot[w] = incl;
         histExcl = incl - c;
     }
+    bool quadLive = false;                             // threads < RDX/4 publish four digits' status words at a time
+    if (tid < RDX / 4) { const uint4 h4 = ((const uint4*)hist)[tid]; quadLive = (h4.x | h4.y | h4.z | h4.w) != 0u; }
     __syncthreads();
-    if (tid < RADIX)
+    if (tid < RDX)
         for (int k = 0; k < w; ++k) histExcl += s_htot[k];
 
     for (;;) {
@@ -224,7 +235,7 @@ __global__ __launch_bounds__(THREADS, GS_SORT_MINWAVES) void onesweep_kernel(con
             const uint32_t cls = blockIdx.x % TICKET_CLASSES;
             s_part = __hip_atomic_fetch_add(ticket + cls * 32u, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * TICKET_CLASSES + cls;
         }
-        for (int k = tid; k < WAVES * RADIX; k += THREADS) s_hist[k] = 0;
+        for (int k = tid; k < WAVES * RDX; k += THREADS) s_hist[k] = 0;
         __syncthreads();
         const uint32_t part = s_part;
         if (part >= numParts) break;
@@ -241,7 +252,22 @@ __global__ __launch_bounds__(THREADS, GS_SORT_MINWAVES) void onesweep_kernel(con
         // full partitions (all but the last) take the unconditional path: wave-uniform base + lane*4 + immediate
         uint32_t key[KPT];
         const bool full = valid == (uint32_t)PART;
-        if (full) {
+        if (GATHER) {
+            // the previous order first (coalesced), then one independent 4-byte gather per key: KPT of them in flight per thread
+            if (full) {
+                const uint32_t* vp = valsIn + waveBase;
+#pragma unroll
+                for (int k = 0; k < KPT; ++k) key[k] = ldg32(vp + k * 64, (uint32_t)lane);
+#pragma unroll
+                for (int k = 0; k < KPT; ++k) key[k] = ldg32(keysIn, key[k]);
+            } else {
+#pragma unroll
+                for (int k = 0; k < KPT; ++k) {
+                    const uint32_t gi = waveBase + (uint32_t)k * 64u + lane;
+                    key[k] = (gi < n) ? ldg32(keysIn, ldg32(valsIn, gi)) : 0xffffffffu;
+                }
+            }
+        } else if (full) {
             const uint32_t* kp = keysIn + waveBase;
 #pragma unroll
             for (int k = 0; k < KPT; ++k) key[k] = ldg32(kp + k * 64, (uint32_t)lane);
@@ -260,9 +286,9 @@ __global__ __launch_bounds__(THREADS, GS_SORT_MINWAVES) void onesweep_kernel(con
           asm volatile("" :: "v"(x)); }                     // wait for the key loads before the timestamp
 #endif
         GS_TL(2);                                           // keys arrived
-        // ---- rank inside the wave: multi-split by 8 ballots, running per-wave LDS histogram ------------
+        // ---- rank inside the wave: multi-split by one ballot per digit bit, running per-wave LDS histogram ------------
         uint32_t pos[KPT];                                   // rank now, local position later
-        uint32_t* wh = s_hist + w * RADIX;
+        uint32_t* wh = s_hist + w * RDX;
 #pragma unroll
         for (int k = 0; k < KPT; ++k) {
             const uint32_t d = (key[k] >> shift) & digitMask;
@@ -271,7 +297,7 @@ __global__ __launch_bounds__(THREADS, GS_SORT_MINWAVES) void onesweep_kernel(con
             // instructions per bit where the generic select/xor/and sequence the compiler emits takes 10.
             uint32_t mlo = ~0u, mhi = ~0u;
 #pragma unroll
-            for (int b = 0; b < 8; ++b) {
+            for (int b = 0; b < BITS; ++b) {
                 const uint32_t sb = (uint32_t)__builtin_amdgcn_sbfe((int)d, (unsigned)b, 1u);
                 const unsigned long long bal = __ballot((int)sb < 0);
                 mlo = __builtin_amdgcn_bitop3_b32(mlo, (uint32_t)bal, sb, 0x90);
@@ -292,35 +318,37 @@ __global__ __launch_bounds__(THREADS, GS_SORT_MINWAVES) void onesweep_kernel(con
         GS_TL(3);                                           // ranked
 
         // ---- partition digit counts, wave-exclusive offsets, local exclusive scan over digits --------
-        // (threads >= RADIX only help with loads/stores; digit `tid` is owned by thread tid < RADIX)
+        // (threads >= RDX only help with loads/stores; digit `tid` is owned by thread tid < RDX)
         uint32_t total = 0, lbase = 0;
-        unsigned long long* myStatus = status + (size_t)part * RADIX + (tid & (RADIX - 1));
-        if (tid < RADIX) {
+        if (tid < RDX) {
 #pragma unroll
             for (int k = 0; k < WAVES; ++k) {
-                const uint32_t c = s_hist[k * RADIX + tid];
-                s_hist[k * RADIX + tid] = total;
+                const uint32_t c = s_hist[k * RDX + tid];
+                s_hist[k * RDX + tid] = total;
                 total += c;
             }
-            // publish this partition's digit count right away (decoupled look-back: successors need only this)
-            st_status(myStatus, pack_status(epoch, part == 0 ? FLAG_INCL : FLAG_AGG, total));
-            // ... and add it to the aggregate of this partition's group of GROUP consecutive partitions: one 64-bit word per
-            // (group, digit) = members published << 40 | sum of their counts, so a reader sees a consistent pair
-            __hip_atomic_fetch_add(groupAgg + (size_t)(part / GROUP) * RADIX + tid, (1ull << 40) | (unsigned long long)total, __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT);
+            s_pub[tid] = pack_status(epoch, total);
+            // add the count to the aggregate of this partition's group of GROUP consecutive partitions: one 64-bit word per
+            // (group, digit) = members published << 40 | sum of their counts, so a reader sees a consistent pair.  A digit that
+            // no key of the whole input holds is never looked up by anyone: nothing is published for it.
+            if (digitLive)
+                __hip_atomic_fetch_add(groupAgg + (size_t)(part / GROUP) * RADIX + tid, (1ull << 40) | (unsigned long long)total, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
             const uint32_t incl = wave_incl_scan(total, lane);
             if (lane == 63) s_wtot[w] = incl;
             lbase = incl - total;
         }
         __syncthreads();
-        if (tid < RADIX) {
+        if (tid < RDX) {
             uint32_t wbase = 0;
 #pragma unroll
-            for (int k = 0; k < RADIX / 64; ++k) wbase += (k < w) ? s_wtot[k] : 0u;
+            for (int k = 0; k < DW; ++k) wbase += (k < w) ? s_wtot[k] : 0u;
             lbase += wbase;
             s_lbase[tid] = lbase;
-
         }
+        // publish this partition's digit counts (decoupled look-back: successors need only this), four digits per 16-byte
+        // write-through store; quads of digits that no key of the whole input holds are never looked up: skipped
+        if (tid < RDX / 4 && quadLive) st16_sc1(status + (size_t)part * RDX + (size_t)tid * 4, *(const u32x4*)&s_pub[tid * 4]);
         __syncthreads();
 
         // ---- scatter keys through LDS so that global writes are runs of equal digits -------------------
@@ -346,18 +374,18 @@ __global__ __launch_bounds__(THREADS, GS_SORT_MINWAVES) void onesweep_kernel(con
         GS_TL(4);                                           // keys scattered to LDS, payload loads issued
         // ---- look back over earlier partitions for digit `tid` (keys are parked in LDS by now, so the batch of
         //      status words below replaces the key registers instead of adding to them) ------------------------
-        if (tid < RADIX) {
+        if (tid < RDX) {
             uint32_t exclPrefix = 0;
-            // A digit this partition does not hold needs no base (s_gbase[d] is never read) and its INCLUSIVE word is never
-            // required by anyone (successors pass over the AGGREGATE 0 / use the group aggregates), so its look-back is
-            // skipped: in the passes over the high key bytes almost every digit is empty almost everywhere.
+            // A digit this partition does not hold needs no base (s_gbase[d] is never read), so its look-back is skipped:
+            // in the passes over the high key bytes almost every digit is empty almost everywhere.
             if (part > 0 && total > 0) {
                 // Every partition of a pass is resident at once (persistent grid) and all of them finish ranking at about the
                 // same time, so a plain decoupled look-back degenerates into a serial chain of INCLUSIVE hand-offs sweeping
                 // over the partitions (measured: 23 us of a 39 us pass for 749 partitions).  Two levels remove the chain:
-                //   1. walk the earlier partitions of the own group (< GROUP words, AGGREGATE or INCLUSIVE),
-                //   2. then whole groups: the group's last partition if it is already INCLUSIVE, else the group aggregate
-                //      once all GROUP members have added to it -- which depends on ranking only, not on anyone's look-back.
+                //   1. sum the counts of the earlier partitions of the own group (< GROUP status words),
+                //   2. then whole groups, nearest first: the group's inclusive prefix if its last partition has published one,
+                //      else the group aggregate once all GROUP members have added to it -- which depends on ranking only,
+                //      not on anyone's look-back.
                 // LB words are requested per round and consumed in order.
                 constexpr int LB = GS_SORT_LOOKBACK_BATCH;
                 const int grp = (int)(part / GROUP), grpStart = grp * GROUP;
@@ -371,26 +399,23 @@ __global__ __launch_bounds__(THREADS, GS_SORT_MINWAVES) void onesweep_kernel(con
 #ifdef GS_EXP_SORT_TIMELINE
                     ++tlRounds;
 #endif
-                    unsigned long long sv[LB];
+                    uint32_t sv[LB];
 #pragma unroll
                     for (int b = 0; b < LB; ++b) {
                         const int qi = q - b;
-                        sv[b] = qi >= grpStart ? ld_status(status + (size_t)qi * RADIX + tid) : 0ull;
+                        sv[b] = qi >= grpStart ? ld_status(status + (size_t)qi * RDX + tid) : 0u;
                     }
                     int consumed = 0;
 #pragma unroll
                     for (int b = 0; b < LB; ++b) {
-                        if (done || consumed != b) continue;                         // stop at the first word that is not ready
-                        const uint32_t e = (uint32_t)(sv[b] >> 34);
-                        const uint32_t f = (uint32_t)(sv[b] >> 32) & 3u;
-                        if (e == epoch && f != 0) {
-                            exclPrefix += (uint32_t)sv[b];
+                        if (consumed != b || q - b < grpStart) continue;             // stop at the first word that is not ready
+                        if ((sv[b] >> COUNT_BITS) == epoch) {
+                            exclPrefix += sv[b] & ((1u << COUNT_BITS) - 1u);
                             consumed = b + 1;
-                            if (f == (uint32_t)FLAG_INCL) done = true;
                         }
                     }
                     q -= consumed;
-                    if (!done && consumed == 0) {
+                    if (consumed == 0) {
                         if (++spins > SPIN_LIMIT) { atomicOr(error, 1u); done = true; }
                         __builtin_amdgcn_s_sleep(1);
                     }
@@ -400,22 +425,20 @@ __global__ __launch_bounds__(THREADS, GS_SORT_MINWAVES) void onesweep_kernel(con
 #ifdef GS_EXP_SORT_TIMELINE
                     ++tlRounds;
 #endif
-                    constexpr int GB = LB / 2 > 0 ? LB / 2 : 1;
-                    unsigned long long last[GB], agg[GB];
+                    constexpr int GB = 4;
+                    unsigned long long incl[GB], agg[GB];
 #pragma unroll
                     for (int b = 0; b < GB; ++b) {
                         const int jj = j - b;
-                        last[b] = jj >= 0 ? ld_status(status + ((size_t)(jj + 1) * GROUP - 1) * RADIX + tid) : 0ull;
-                        agg[b] = jj >= 0 ? __hip_atomic_load(groupAgg + (size_t)jj * RADIX + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+                        incl[b] = jj >= 0 ? ld_word64(groupIncl + (size_t)jj * RADIX + tid) : 0ull;
+                        agg[b] = jj >= 0 ? ld_word64(groupAgg + (size_t)jj * RADIX + tid) : 0ull;
                     }
                     int consumed = 0;
 #pragma unroll
                     for (int b = 0; b < GB; ++b) {
                         if (done || consumed != b || j - b < 0) continue;
-                        const uint32_t e = (uint32_t)(last[b] >> 34);
-                        const uint32_t f = (uint32_t)(last[b] >> 32) & 3u;
-                        if (e == epoch && f == (uint32_t)FLAG_INCL) {              // everything up to the end of group j-b
-                            exclPrefix += (uint32_t)last[b];
+                        if ((uint32_t)(incl[b] >> 32) == epoch) {                  // everything up to the end of group j-b
+                            exclPrefix += (uint32_t)incl[b];
                             consumed = b + 1;
                             done = true;
                         } else if ((uint32_t)(agg[b] >> 40) == (uint32_t)GROUP) {  // all members of group j-b have ranked
@@ -429,11 +452,14 @@ __global__ __launch_bounds__(THREADS, GS_SORT_MINWAVES) void onesweep_kernel(con
                         __builtin_amdgcn_s_sleep(1);
                     }
                 }
-                st_status(myStatus, pack_status(epoch, FLAG_INCL, exclPrefix + total));
 #ifdef GS_EXP_SORT_TIMELINE
                 if (tid == 0 && part < 16384u) { g_timeline[part * 16u + 10] = tlRounds; g_timeline[part * 16u + 11] = (unsigned long long)((int)part - 1 - q) + (unsigned long long)(grp - 1 - j) * 1000ull; g_timeline[part * 16u + 12] = spins; }
 #endif
             }
+            // the last partition of a group that knows its prefix publishes the group's inclusive prefix: a shortcut for
+            // every later group's level 2 (those that find it stop there; those that do not use the aggregates)
+            if ((part % GROUP) == (uint32_t)(GROUP - 1) && (total > 0 || part == 0))
+                st_word64(groupIncl + (size_t)(part / GROUP) * RADIX + tid, ((unsigned long long)epoch << 32) | (unsigned long long)(exclPrefix + total));
             s_gbase[tid] = histExcl + exclPrefix - lbase;
         }
         GS_TL(5);                                           // look-back done (thread 0 = digit 0)
@@ -485,15 +511,17 @@ extern "C" int32_t gs_debug_read_sort_timeline(void* out, size_t bytes) {
 #endif
 
 int32_t sort_state_create(gs_context* ctx, SortState& st, uint32_t maxCount) {
-    (void)ctx;
+    if (maxCount > kSortMaxCount) return fail(GS_ERR_INVALID_ARGUMENT, "sort capacity above 2^30 keys");
     st.maxCount = maxCount;
     st.maxParts = div_up(maxCount > 0 ? maxCount : 1, PART);
-    GS_HIP(hipMalloc((void**)&st.altKeys, (size_t)(maxCount + 16) * 4));
-    GS_HIP(hipMalloc((void**)&st.altVals, (size_t)(maxCount + 16) * 4));
-    GS_HIP(hipMalloc((void**)&st.status, (size_t)st.maxParts * RADIX * 8));
-    GS_HIP(hipMemsetAsync(st.status, 0, (size_t)st.maxParts * RADIX * 8, ctx->stream));
+    GS_HIP(hipMalloc((void**)&st.altKeys, ((size_t)maxCount + 16) * 4));
+    GS_HIP(hipMalloc((void**)&st.altVals, ((size_t)maxCount + 16) * 4));
+    GS_HIP(hipMalloc((void**)&st.status, (size_t)st.maxParts * RADIX * 4));
+    GS_HIP(hipMemsetAsync(st.status, 0, (size_t)st.maxParts * RADIX * 4, ctx->stream));
     st.maxGroups = div_up(st.maxParts, (uint32_t)GROUP);
     GS_HIP(hipMalloc((void**)&st.groupAgg, (size_t)4 * st.maxGroups * RADIX * 8));
+    GS_HIP(hipMalloc((void**)&st.groupIncl, (size_t)st.maxGroups * RADIX * 8));
+    GS_HIP(hipMemsetAsync(st.groupIncl, 0, (size_t)st.maxGroups * RADIX * 8, ctx->stream));
     return GS_OK;
 }
 
@@ -502,6 +530,7 @@ void sort_state_destroy(SortState& st) {
     if (st.altVals) (void)hipFree(st.altVals);
     if (st.status) (void)hipFree(st.status);
     if (st.groupAgg) (void)hipFree(st.groupAgg);
+    if (st.groupIncl) (void)hipFree(st.groupIncl);
     st = SortState();
 }
 
@@ -513,14 +542,12 @@ int32_t enqueue_set_indices(gs_context* ctx, uint32_t* order, uint32_t n) {
 
 uint32_t sort_group_words(uint32_t nUpper, int passes) { return (uint32_t)passes * div_up(div_up(max(nUpper, 1u), PART), (uint32_t)GROUP) * RADIX; }
 
-int32_t enqueue_calc_distances(gs_context* ctx, hipStream_t stream, const gsm::AssetView& a, const uint32_t* order, const float* m, uint32_t* keys,
-                               SortControl* control, SortControl* nextControl, uint32_t n, SortState& st) {
+int32_t enqueue_sort_keys(gs_context* ctx, hipStream_t stream, const gsm::AssetView& a, const float* m, uint32_t* keyBySplat,
+                          SortControl* control, SortControl* nextControl, uint32_t n, SortState& st) {
     // `control` was zeroed by the previous sort's launch of this kernel (or at creation); this launch zeroes `nextControl`
-#ifndef GS_DIST_BLOCKS_PER_CU
-#define GS_DIST_BLOCKS_PER_CU 2      // a narrow window of sorted positions per XCD keeps the gathered sectors in its L2 (measured: 2 beats 4 and 8)
-#endif
-    const uint32_t grid = (max(1u, min(div_up(n, 256u * GS_DIST_ILP), (uint32_t)ctx->cuCount * GS_DIST_BLOCKS_PER_CU)) + 7u) & ~7u;
-    hipLaunchKernelGGL(calc_distances_kernel, dim3(grid), dim3(256), 0, stream, a, order, m[8], m[9], m[10], m[11], keys,
+    const uint32_t chunks = div_up(n, 256u);
+    const uint32_t grid = max(1u, min(div_up(chunks, 4u * GS_KEYS_ILP), (uint32_t)ctx->cuCount));
+    hipLaunchKernelGGL(sort_keys_kernel, dim3(grid), dim3(1024), 0, stream, a, m[8], m[9], m[10], m[11], keyBySplat,
                        control->hist, n, st.groupAgg, sort_group_words(n, 4), (uint32_t*)nextControl);
     GS_HIP(hipGetLastError());
     return GS_OK;
@@ -536,8 +563,9 @@ int32_t enqueue_histogram(gs_context* ctx, hipStream_t stream, const uint32_t* k
 }
 
 int32_t enqueue_sort_passes(gs_context* ctx, hipStream_t stream, SortState& st, SortControl* control, uint32_t* keys, uint32_t* vals, uint32_t nUpper,
-                            const uint32_t* nPtr, int passes, uint32_t lastMask, gs_renderer* profR, int evFirst) {
+                            const uint32_t* nPtr, int passes, uint32_t lastMask, gs_renderer* profR, int evFirst, int bits, const uint32_t* gatherKeys) {
     if (passes < 1 || passes > 4) return fail(GS_ERR_INVALID_ARGUMENT, "sort passes");
+    if (bits < 6 || bits > 8 || (gatherKeys && bits != 8)) return fail(GS_ERR_INVALID_ARGUMENT, "sort digit width");
     if (nUpper > st.maxCount) return fail(GS_ERR_INVALID_ARGUMENT, "sort count exceeds sorter capacity");
     if (nUpper == 0) return GS_OK;
     const uint32_t parts = div_up(nUpper, PART);
@@ -547,16 +575,28 @@ int32_t enqueue_sort_passes(gs_context* ctx, hipStream_t stream, SortState& st, 
     const uint32_t grid = min(div_up(parts, TICKET_CLASSES) * TICKET_CLASSES, capacity);
     uint32_t *ks = keys, *vs = vals, *kd = st.altKeys, *vd = st.altVals;
     const uint32_t groups = div_up(parts, (uint32_t)GROUP);
+    const uint32_t fullMask = (1u << bits) - 1u;
     // st.groupAgg[passes][groups][256] accumulates: it was zeroed by the kernel that produced the keys / their histograms
     if (profR && evFirst >= 0) prof_record(profR, evFirst, stream);
     for (int p = 0; p < passes; ++p) {
-        uint32_t epoch = (++st.epoch) & 0x3fffffffu;
-        if (epoch == 0) {   // 30-bit epoch wrapped: wipe the status array (it may hold every old epoch), restart at 1
-            GS_HIP(hipMemsetAsync(st.status, 0, (size_t)st.maxParts * RADIX * 8, stream));
+        uint32_t epoch = (++st.epoch) & EPOCH_MASK;
+        if (epoch == 0) {   // 18-bit epoch wrapped: wipe the tagged words (they may hold every old epoch), restart at 1
+            GS_HIP(hipMemsetAsync(st.status, 0, (size_t)st.maxParts * RADIX * 4, stream));
+            GS_HIP(hipMemsetAsync(st.groupIncl, 0, (size_t)st.maxGroups * RADIX * 8, stream));
             st.epoch = epoch = 1;
         }
-        hipLaunchKernelGGL(onesweep_kernel, dim3(grid), dim3(THREADS), 0, stream, ks, vs, kd, vd, control->hist + RADIX * p,
-                           st.status, st.groupAgg + (size_t)p * groups * RADIX, control->tickets[p], &control->error, nUpper, nPtr, (uint32_t)(8 * p), epoch, p == passes - 1 ? lastMask : 255u);
+        const uint32_t* hist = control->hist + RADIX * p;
+        unsigned long long* agg = st.groupAgg + (size_t)p * groups * RADIX;
+        const uint32_t mask = p == passes - 1 ? (lastMask & fullMask) : fullMask;
+        const uint32_t shift = (uint32_t)(bits * p);
+#define GS_LAUNCH_ONESWEEP(B, G, KIN) \
+        hipLaunchKernelGGL((onesweep_kernel<B, G>), dim3(grid), dim3(THREADS), 0, stream, KIN, vs, kd, vd, hist, st.status, agg, st.groupIncl, \
+                           control->tickets[p], &control->error, nUpper, nPtr, shift, epoch, mask)
+        if (p == 0 && gatherKeys) GS_LAUNCH_ONESWEEP(8, true, gatherKeys);
+        else if (bits == 8) GS_LAUNCH_ONESWEEP(8, false, ks);
+        else if (bits == 7) GS_LAUNCH_ONESWEEP(7, false, ks);
+        else GS_LAUNCH_ONESWEEP(6, false, ks);
+#undef GS_LAUNCH_ONESWEEP
         uint32_t* t = ks; ks = kd; kd = t;
         t = vs; vs = vd; vd = t;
     }

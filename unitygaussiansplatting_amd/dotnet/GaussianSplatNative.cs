@@ -84,6 +84,7 @@ namespace GaussianSplatting.Runtime
         [DllImport(Lib)] public static extern int gs_renderer_download_distances(IntPtr renderer, uint[] dst, UIntPtr count);
         [DllImport(Lib)] public static extern int gs_renderer_upload_order(IntPtr renderer, uint[] src, UIntPtr count);
         [DllImport(Lib)] public static extern int gs_renderer_download_view(IntPtr renderer, IntPtr dst, UIntPtr bytes);
+        [DllImport(Lib)] public static extern int gs_renderer_download_raster_records(IntPtr renderer, IntPtr recs, IntPtr rects, IntPtr visMask);
         [DllImport(Lib)] public static extern int gs_renderer_frame_stats(IntPtr renderer, out FrameStats stats);
         [DllImport(Lib)] public static extern int gs_renderer_frame_times(IntPtr renderer, [Out] float[] ms, int capacity, out int count);
         [DllImport(Lib)] public static extern int gs_renderer_stage_times(IntPtr renderer, out StageTimes times);

@@ -336,6 +336,16 @@ class GaussianSplatRenderer:
         check(_lib.lib().gs_renderer_download_view(self._r_h, out.ctypes.data, out.nbytes), "gs_renderer_download_view")
         return out
 
+    def DownloadRasterRecords(self):
+        """(recs N x 8 u32, rects N x 2 u32, vis_mask ceil(N/64) u64) as the per-frame calc_view launch left them."""
+        n = self.m_SplatCount
+        recs = np.empty((n, 8), np.uint32)
+        rects = np.empty((n, 2), np.uint32)
+        vis = np.empty((n + 63) // 64, np.uint64)
+        check(_lib.lib().gs_renderer_download_raster_records(self._r_h, recs.ctypes.data, rects.ctypes.data, vis.ctypes.data),
+              "gs_renderer_download_raster_records")
+        return recs, rects, vis
+
     def FrameStats(self) -> gs_frame_stats:
         """Blocks.  Raises GsError(GS_ERR_PAIR_OVERFLOW) if the frame overflowed the pair buffer (it is grown: draw again)."""
         s = gs_frame_stats()
