@@ -10,9 +10,15 @@ All inputs are resident in HBM before the timed region.  The camera orbits by 0.
 
     python bench.py [--gpus N --steps K --warmup W] [--config C2] [--blend exact|fast] [--cpu-baseline auto|off]
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): view-parallel.  Rank 0 builds the asset, its five
-blobs are broadcast once over RCCL (torch.distributed, backend "nccl"), every rank renders its own camera
-(azimuth rank*45 deg); no per-frame collective.  value = all ranks' splats*frames / max-over-ranks time.
+N > 1: view-parallel, one rank per GPU.  Launched either by the driver (python -m torch.distributed.run ... bench.py --gpus N:
+RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment) or bare (`python bench.py --gpus N`: the script re-executes
+itself under torch.distributed.run on 127.0.0.1 and fails loudly if the box has fewer than N GPUs).  Rank 0 builds the
+asset and uploads it; the five blobs are broadcast once with the library's own RCCL communicator (gs_comm_create /
+gs_asset_broadcast: ncclBroadcast per blob over xGMI; the 128-byte unique id travels through torch.distributed); every
+rank then renders its own camera (azimuth rank*45 deg) with no per-frame collective.  torch.distributed (backend
+"nccl" = RCCL) provides the barriers and the max-over-ranks reduction of the timed region.
+value = all ranks' splats*frames / max-over-ranks time.  --config C5: the C2 asset, 8 cameras at 1920x1080 dealt
+round-robin to the ranks (view k -> rank k % N), a step = every rank renders each of its views once.
 
 Prints ONE JSON line on rank 0 (see DESIGN.md "measurement" for the byte formulas behind `roofline`).
 """
@@ -32,6 +38,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_ACHIEVABLE_GBS = 6300.0   # the same guide's measured float4-copy rate (79 % of the spec peak)
 
 
 def parse():
@@ -44,6 +51,7 @@ def parse():
     ap.add_argument("--blend", default="exact", choices=["exact", "fast"])
     ap.add_argument("--cpu-baseline", default="auto", choices=["auto", "off"])
     ap.add_argument("--sort-nth-frame", type=int, default=1)
+    ap.add_argument("--broadcast", action="store_true", help="go through gs_comm_create / gs_asset_broadcast even with one rank")
     return ap.parse_args()
 
 
@@ -64,17 +72,36 @@ def stage_bytes(n, P, vis, W, H, asset, passes_pair):
         "bin": n * (4 + 0.125) + vis * 8 + P * 8,                # order + visibility bit per position, rect per visible splat, (tile, splat) pairs out
         "pair_sort": P * 16 * passes_pair + P * 4,               # Onesweep passes over the pairs + tile-range scan of the keys
         "blend": P * (4 + 32) + W * H * 16,                      # pair index + record per pair, RT read + write
-        "resolve": W * H * (8 + 16 + 4),                         # RGBA16F in, float RGBA + RGBA8 out
+        "resolve": W * H * (8 + 16),                             # RGBA16F in, float RGBA out (the 8-bit sRGB image is written only on request)
     }
+
+
+def respawn_under_torchrun(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: run N ranks of this script under torch.distributed.run on this node."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(respawn_under_torchrun(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        args.gpus = world
+    if world != args.gpus:
+        if world > 1:
+            args.gpus = world
+        else:
+            raise SystemExit(f"bench.py --gpus {args.gpus}: WORLD_SIZE is {world}; launch {args.gpus} ranks (or run it bare, it spawns them itself)")
 
     # torch is plumbing here (device memory for the broadcast blobs, barrier, synchronize); its first import on a
     # fresh box takes a minute or two, so it is overlapped with building the synthetic scene.
@@ -105,6 +132,8 @@ def main():
     t_build = time.perf_counter() - t_build
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (torch.cuda.is_available() is False); there is no CPU fallback")
+    if torch.cuda.device_count() < world or local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"bench.py --gpus {world}: this box exposes {torch.cuda.device_count()} GPU(s); refusing to report a multi-GPU number")
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
@@ -112,26 +141,37 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
-    # ---- asset residency: blobs live in torch CUDA tensors; rank 0's are broadcast over RCCL/xGMI ------------
+    # ---- asset residency: rank 0 uploads the blobs (gs_asset_create); with N > 1 they are broadcast once through the
+    #      library's own RCCL communicator (gs_comm_create + gs_asset_broadcast; only the unique id goes through torch) ----
     from unitygaussiansplatting_amd import parallel
-    t0 = time.perf_counter()
-    meta, blobs = parallel.broadcast_asset(asset, torch, dist, rank, world, torch.device("cuda", local_rank))
-    torch.cuda.synchronize()
-    t_bcast = time.perf_counter() - t0
-
     ctx = GpuContext(local_rank)
-    r = GaussianSplatRenderer(ctx)
-    asset_meta = parallel.asset_from_meta(meta)          # formats/count only (no host blobs on ranks > 0)
-    r.m_Asset = asset if asset is not None else asset_meta
+    r = GaussianSplatRenderer(ctx, asset)
     r.m_SortNthFrame = args.sort_nth_frame
-    parallel.attach_device_asset(r, meta, blobs)         # gs_asset_create(memory_kind = device) + gs_renderer_create
+    t0 = time.perf_counter()
+    comm = None
+    if world > 1 or args.broadcast:
+        uid = [parallel.Comm.UniqueId() if rank == 0 else None]
+        if dist is not None:
+            dist.broadcast_object_list(uid, src=0)
+        comm = parallel.Comm(ctx, world, rank, uid[0])
+        comm.BroadcastAsset(r, root=0)                 # gs_asset_create on rank 0, ncclBroadcast per blob, gs_renderer_create everywhere
+    else:
+        r.CreateResourcesForAsset()
+    ctx.Synchronize()
+    t_bcast = time.perf_counter() - t0
     r.blendMode = 0 if args.blend == "exact" else 1
     W, H = cfg.width, cfg.height
-    rt = RenderTarget(ctx, W, H)
-    n = meta["splatCount"]
+    n = r.splatCount
+    asset_bytes = sum(int(len(getattr(r.m_Asset, nm))) for nm in parallel.BLOB_NAMES if getattr(r.m_Asset, nm) is not None) if rank == 0 else 0
 
-    def cam_at(frame):
-        az = rank * 45.0 + 0.25 * frame
+    # views of this rank: one camera per rank (azimuth rank*45 deg), or C5's 8 cameras dealt round-robin
+    num_views = 8 if args.config == "C5" else world
+    my_views = parallel.assign_views(num_views, world)[rank]
+    rts = [RenderTarget(ctx, W, H) for _ in my_views]
+    rt = rts[0]
+
+    def cam_at(frame, view=None):
+        az = (my_views[0] if view is None else view) * 45.0 + 0.25 * frame
         return camera.Camera(position=scenes.orbit_eye(cfg.eye_radius, cfg.eye_elev_deg, az), pixelWidth=W, pixelHeight=H,
                              fieldOfView=cfg.fov_y)
 
@@ -141,8 +181,11 @@ def main():
     total_frames = max(args.warmup, 1) + args.steps + 2
     prepared = []
     for i in range(total_frames):
-        cam = cam_at(i)
-        prepared.append((r.SortMatrix(cam), r.FrameParams(cam)))
+        per_view = []
+        for v in my_views:
+            cam = cam_at(i, v)
+            per_view.append((r.SortMatrix(cam), r.FrameParams(cam)))
+        prepared.append(per_view)
     r.UpdateCutoutsBuffer()
     check(_lib.lib().gs_renderer_set_blend_mode(r._r_h, int(r.blendMode)), "gs_renderer_set_blend_mode")
     bg = np.asarray((0.0, 0.0, 0.0, 1.0), np.float32)
@@ -150,13 +193,13 @@ def main():
     lib_ = _lib.lib()
 
     def frame(i, cam=None):
-        m16, p = prepared[i]
-        if i % r.m_SortNthFrame == 0:
-            r.SortPointsPrepared(m16)
-        r.CalcViewDataPrepared(p)
-        rt.Clear()
-        r.DrawPrepared(p, rt)
-        check(lib_.gs_target_resolve(rt._h, bgp, None, None), "gs_target_resolve")
+        for (m16, p), t in zip(prepared[i], rts):
+            if i % r.m_SortNthFrame == 0:
+                r.SortPointsPrepared(m16)
+            r.CalcViewDataPrepared(p)
+            t.Clear()
+            r.DrawPrepared(p, t)
+            check(lib_.gs_target_resolve(t._h, bgp, None, None), "gs_target_resolve")
 
     def full_sync():
         ctx.Synchronize()
@@ -208,28 +251,23 @@ def main():
     # ---- the same K frames again with the per-stage hipEvents recorded (14 per frame, on the stream each kernel is
     #      launched on).  The events themselves cost ~50 us of a 0.78 ms frame (every record is a barrier + signal packet
     #      between two kernels), so the headline time comes from the region above and the per-kernel durations from this one.
-    r.SetProfiling(min(args.steps + 1, 1024))       # a ring: one spare slot so that the first frame's events are not recycled
+    r.SetProfiling(min((args.steps + 1) * len(my_views), 1024))       # a ring: one spare slot so that the first frame's events are not recycled
+    rt.SetProfiling(True)                           # the composite is a target method: its own event pairs on the same stream
     elapsed_instr = run_region(fi)
+    resolve_ms, _ = rt.ResolveTime()
+    rt.SetProfiling(False)
     st = r.FrameStats()                   # raises if the last frame overflowed / a sort spin expired
     frame_ms = r.FrameTimes()             # per-frame GPU durations of the instrumented pass (key generation .. blend)
     stage = r.StageTimes()
     r.SetProfiling(0)
 
     ms_per_step = elapsed / args.steps * 1e3
-    msplats = n * args.steps * world / elapsed / 1e6
+    msplats = n * args.steps * num_views / elapsed / 1e6
 
     if rank == 0:
         P = int(st.tile_pairs)
         numTiles = st.tiles_x * st.tiles_y
         passes_pair = 1 if numTiles <= 256 else (2 if numTiles <= 65536 else 3)
-        # resolve is timed separately (it is a target method, outside the renderer's event ring)
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        ctx.Synchronize()
-        t_r = time.perf_counter()
-        for _ in range(20):
-            rt.ResolveAsync((0.0, 0.0, 0.0, 1.0))
-        ctx.Synchronize()
-        resolve_ms = (time.perf_counter() - t_r) / 20 * 1e3
         vis = int(st.visible_splats)
         sb = stage_bytes(n, P, vis, W, H, r.m_Asset, passes_pair)
         times = {"calc_distances": stage.calc_distances_ms, "sort": stage.sort_ms, "calc_view": stage.calc_view_ms,
@@ -263,6 +301,7 @@ def main():
                 traffic = None
         roofline = {"bound": "hbm", "kernel": dom, "launches_per_frame": launches[dom], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                    "achievable_peak": HBM_ACHIEVABLE_GBS, "frac_of_achievable": round(achieved / HBM_ACHIEVABLE_GBS, 4),
                     "alg_bytes_per_launch": int(dom_bytes), "avg_launch_ms": round(dom_ms, 4), "frames_averaged": int(stage.frames),
                     "instrumented_ms_per_step": round(elapsed_instr / args.steps * 1e3, 4),
                     "instrumented_frame_gpu_ms": ({"median": round(float(np.median(frame_ms)), 4), "p95": round(float(np.percentile(frame_ms, 95)), 4),
@@ -290,22 +329,25 @@ def main():
 
         cpu = None
         parity = None
-        if world == 1 and args.cpu_baseline == "auto":
+        if world == 1 and args.cpu_baseline == "auto" and n <= 10_000_000 and args.config != "C5":
             cpu, parity = cpu_baseline(asset, r, rt, cam_at(fi + args.steps - 1), n, W, H, r.blendMode)
 
         ref_msplats = 6_131_954 / 6.8e-3 / 1e6      # 6.8 ms/frame, RTX 3080 Ti, real bicycle scene
         out = {
-            "metric": "Msplats/s rendered (sort+view+composite), bicycle-sized 6.1M splats @1200x797; ms/frame in ms_per_step",
+            "metric": f"Msplats/s rendered (sort+view+composite+resolve), {cfg.label}; ms/frame in ms_per_step",
             "value": round(msplats, 2), "unit": "Msplats/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": round(msplats / world / ref_msplats, 3) if args.config == "C2" and not args.splats else None,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong" if args.config == "C5" else "weak",
+            # BASELINE.md's only number (6.8 ms/frame, RTX 3080 Ti) is for the REAL bicycle scene; this is the synthetic stand-in of
+            # the same size, so the ratio is context, not a like-for-like comparison (config.baseline_note)
+            "vs_baseline": round(msplats / num_views / ref_msplats, 3) if args.config == "C2" and not args.splats else None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": cfg.label + (f" [splat count overridden to {n}]" if args.splats else ""),
-                       "splats": n, "resolution": [W, H], "asset_MB": round(sum(b.numel() for b in blobs if b is not None) / 1e6, 1),
+                       "splats": n, "resolution": [W, H], "asset_MB": round(asset_bytes / 1e6, 1), "views": num_views, "views_per_rank": len(my_views),
                        "blend": args.blend, "sort_nth_frame": args.sort_nth_frame, "view_buffer": "on demand (gs_renderer_download_view)",
                        "sort_queue_overlap": os.environ.get("GSPLAT_OVERLAP", "0") == "1", "tile_pairs_P": P, "visible_splats": int(st.visible_splats),
-                       "parallelism": f"view-parallel x{world} (one camera per GPU, asset broadcast once over RCCL)" if world > 1 else "single GPU",
-                       "baseline_note": "vs_baseline = per-GPU Msplats/s / 901.8 (reference: 6.8 ms/frame on RTX 3080 Ti, real INRIA bicycle, BASELINE.md)"},
+                       "parallelism": (f"view-parallel x{world} (one camera per GPU, asset broadcast once by gs_asset_broadcast = ncclBroadcast per blob)" if world > 1 else "single GPU"),
+                       "rccl_ranks": (comm.nranks if comm is not None else 0),
+                       "baseline_note": "vs_baseline = per-view Msplats/s / 901.8 (reference: 6.8 ms/frame on RTX 3080 Ti with the REAL INRIA bicycle, whose overdraw is far higher than this synthetic scene's: context only)"},
             "first_frame_ms": round(first_frame_ms, 3) if first_frame_ms is not None else None,
             "roofline": roofline, "stages": stages, "cpu_baseline": cpu, "parity_vs_oracle": parity,
             "setup_s": {"scene_build": round(t_build, 1), "asset_broadcast": round(t_bcast, 3)},
@@ -313,6 +355,9 @@ def main():
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
+    if comm is not None:
+        comm.Dispose()
+    if dist is not None:
         dist.destroy_process_group()
 
 

@@ -40,7 +40,8 @@ typedef enum gs_error {
     GS_ERR_INVALID_ASSET = -5,      /* blob sizes do not match splat_count/formats (C#: HasValidAsset, GaussianSplatRenderer.cs:361-368) */
     GS_ERR_PAIR_OVERFLOW = -6,      /* tile-pair buffer too small for this frame; the renderer grew it -- draw again */
     GS_ERR_SORT_TIMEOUT = -7,       /* a bounded spin in the sort's look-back expired (never expected; reported instead of hanging) */
-    GS_ERR_NO_DEVICE = -8
+    GS_ERR_NO_DEVICE = -8,
+    GS_ERR_COMM = -9                /* RCCL: library not loadable, or a collective failed; gs_last_error_string() has the detail */
 } gs_error;
 
 /* GaussianSplatAsset.cs:31-37 / :51-57 / :70-81 */
@@ -56,6 +57,7 @@ typedef struct gs_asset gs_asset;
 typedef struct gs_renderer gs_renderer;
 typedef struct gs_target gs_target;
 typedef struct gs_sorter gs_sorter;
+typedef struct gs_comm gs_comm;
 
 /* The five blobs of a GaussianSplatAsset (GaussianSplatAsset.cs:205-229), as uploaded by
  * GaussianSplatRenderer.CreateResourcesForAsset (GaussianSplatRenderer.cs:373-405). */
@@ -154,6 +156,26 @@ int32_t gs_asset_splat_count(const gs_asset* asset, uint32_t* out);
 /* device addresses + sizes of pos, other, color, sh, chunk (for an RCCL broadcast by the host) */
 int32_t gs_asset_device_blobs(const gs_asset* asset, void* ptrs[5], uint64_t sizes[5]);
 
+/* splat_count, pos_format, scale_format, color_format, sh_format, chunk count (what a rank that received the asset by
+ * gs_asset_broadcast needs to know about it) */
+int32_t gs_asset_info(const gs_asset* asset, uint32_t out[6]);
+
+/* ---- multi-GPU: view-parallel rendering, one context (= one GPU) per rank ------------------------------------------
+ * The path shards by camera: every GPU holds a replica of the immutable asset and renders its own view, so the only
+ * exchange is the load-time broadcast of the five blobs -- ncclBroadcast over xGMI, called directly from this library
+ * (librccl is dlopen'ed on first use; GSPLAT_RCCL_LIB overrides its path).  The reference is single-GPU: nothing to cite.
+ * Usage: one rank calls gs_comm_unique_id and hands the 128 bytes to every rank over any host channel; every rank then
+ * calls gs_comm_create (collective) with its own context, the same id and its rank; the rank that loaded the asset is
+ * `root` of gs_asset_broadcast (collective), after which every rank creates its renderer on the asset it got. */
+#define GS_COMM_ID_BYTES 128
+int32_t gs_comm_unique_id(uint8_t id_out[GS_COMM_ID_BYTES]);                                   /* ncclGetUniqueId */
+int32_t gs_comm_create(gs_context* ctx, int32_t nranks, int32_t rank, const uint8_t id[GS_COMM_ID_BYTES], gs_comm** out);   /* ncclCommInitRank */
+int32_t gs_comm_destroy(gs_comm* comm);
+int32_t gs_comm_info(const gs_comm* comm, int32_t* nranks, int32_t* rank);
+/* On `root`: asset_on_root = the asset to replicate (of the comm's context), *out = the same handle.  Elsewhere:
+ * asset_on_root is ignored, *out = a new asset owning device copies of the blobs (destroy it with gs_asset_destroy).  Blocks. */
+int32_t gs_asset_broadcast(gs_comm* comm, gs_asset* asset_on_root, int32_t root, gs_asset** out);
+
 /* ---- renderer (per GaussianSplatRenderer component) ---------------------------------------------- */
 /* allocates m_GpuView (N x 40 B), m_GpuSortDistances, m_GpuSortKeys, the sorter's SupportResources and the
  * tile-binning buffers; runs CSSetIndices (GaussianSplatRenderer.cs:407,423-445). */
@@ -220,6 +242,10 @@ int32_t gs_target_download(gs_target* t, void* out_rgba16f, size_t bytes);   /* 
  * optionally copies it to `out_rgba32f` (may be NULL) and/or an sRGB-encoded 8-bit image `out_rgba8` (may be NULL). */
 int32_t gs_target_resolve(gs_target* t, const float background_rgba[4], float* out_rgba32f, uint8_t* out_rgba8);
 int32_t gs_target_device_ptr(gs_target* t, void** rgba16f_dev, void** resolved_rgba32f_dev);
+/* enabled != 0: every gs_target_resolve is bracketed by hipEvents on the context's stream (a ring of 64);
+ * gs_target_resolve_time blocks, returns the mean GPU duration (ms) of the resolves recorded since the last call and resets. */
+int32_t gs_target_set_profiling(gs_target* t, int32_t enabled);
+int32_t gs_target_resolve_time(gs_target* t, float* mean_ms, int32_t* count);
 
 /* ---- native importer (host code, no GPU needed): GaussianSplatAssetCreator.CreateAsset minus the Unity asset database -- */
 /* InputSplatData (GaussianFileReader.cs:17-26) as separate arrays, in the PLY domain after ReorderSHs: */

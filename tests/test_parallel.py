@@ -79,3 +79,59 @@ def test_two_rank_gloo_broadcast_and_view_sharding(tmp_path):
         P = camera.frame_params(cam, tr)
         orc.calc_view(P)
         assert np.array_equal(orc.draw(P), np.load(tmp_path / f"view{v}.npy")), v
+
+
+def test_bench_gpus_2_without_gpus_fails_loudly():
+    """`python bench.py --gpus 2` with no launcher spawns its own ranks; on a box with fewer GPUs it must exit non-zero and
+    print no result line (it used to run one rank silently and report n_gpus = 1)."""
+    import subprocess
+    if os.path.exists("/dev/kfd"):
+        import torch
+        if torch.cuda.device_count() >= 2:
+            pytest.skip("this box really has 2 GPUs")
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "C1", "--steps", "1", "--warmup", "1",
+                        "--cpu-baseline", "off"], capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode != 0
+    assert '"n_gpus"' not in p.stdout
+    assert "GPU" in (p.stderr + p.stdout)
+
+
+@pytest.mark.gpu
+def test_rccl_asset_broadcast_single_rank(gpu_ctx):
+    """gs_comm_create / gs_asset_broadcast with nranks = 1 (librccl called directly from the library): the asset that comes
+    out renders the same frame as one created by gs_asset_create; argument validation of the comm entry points."""
+    import ctypes as C
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from common import default_camera, small_asset
+    from unitygaussiansplatting_amd import _lib, parallel
+    from unitygaussiansplatting_amd.renderer import GaussianSplatRenderer, RenderTarget
+    a = small_asset(20000, 5, "Medium")
+    cam = default_camera()
+    frames = []
+    for use_comm in (False, True):
+        r = GaussianSplatRenderer(gpu_ctx, a)
+        comm = None
+        if use_comm:
+            comm = parallel.Comm(gpu_ctx, 1, 0, parallel.Comm.UniqueId())
+            nr, rk = C.c_int32(), C.c_int32()
+            assert _lib.lib().gs_comm_info(comm._h, C.byref(nr), C.byref(rk)) == 0 and (nr.value, rk.value) == (1, 0)
+            comm.BroadcastAsset(r, root=0)
+        else:
+            r.CreateResourcesForAsset()
+        rt = RenderTarget(gpu_ctx, cam.pixelWidth, cam.pixelHeight)
+        r.SortPoints(cam); r.CalcViewData(cam); rt.Clear(); r.Draw(cam, rt)
+        frames.append((rt.Download(), r.DownloadOrder()))
+        r.DisposeResourcesForAsset()
+        rt.Dispose()
+        if comm is not None:
+            out = C.c_void_p()
+            assert _lib.lib().gs_asset_broadcast(comm._h, None, 0, C.byref(out)) == -1          # the root must pass an asset
+            assert _lib.lib().gs_asset_broadcast(comm._h, None, 3, C.byref(out)) == -1          # root out of range
+            comm.Dispose()
+    assert np.array_equal(frames[0][0], frames[1][0]) and np.array_equal(frames[0][1], frames[1][1])
+    bad = C.c_void_p()
+    uid = (C.c_uint8 * 128).from_buffer_copy(parallel.Comm.UniqueId())
+    assert _lib.lib().gs_comm_create(gpu_ctx._h, 2, 5, uid, C.byref(bad)) == -1                  # rank out of range

@@ -37,6 +37,12 @@ SIGNATURES = {
     "gs_asset_destroy": (C.c_int32, [_P]),
     "gs_asset_splat_count": (C.c_int32, [_P, C.POINTER(C.c_uint32)]),
     "gs_asset_device_blobs": (C.c_int32, [_P, C.c_void_p * 5, C.c_uint64 * 5]),
+    "gs_asset_info": (C.c_int32, [_P, C.c_uint32 * 6]),
+    "gs_comm_unique_id": (C.c_int32, [C.c_uint8 * 128]),
+    "gs_comm_create": (C.c_int32, [_P, C.c_int32, C.c_int32, C.c_uint8 * 128, _PP]),
+    "gs_comm_destroy": (C.c_int32, [_P]),
+    "gs_comm_info": (C.c_int32, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "gs_asset_broadcast": (C.c_int32, [_P, _P, C.c_int32, _PP]),
     "gs_renderer_create": (C.c_int32, [_P, _P, _PP]),
     "gs_renderer_destroy": (C.c_int32, [_P]),
     "gs_renderer_reset_order": (C.c_int32, [_P]),
@@ -64,6 +70,8 @@ SIGNATURES = {
     "gs_target_download": (C.c_int32, [_P, _P, C.c_size_t]),
     "gs_target_resolve": (C.c_int32, [_P, C.POINTER(C.c_float), _P, _P]),
     "gs_target_device_ptr": (C.c_int32, [_P, _PP, _PP]),
+    "gs_target_set_profiling": (C.c_int32, [_P, C.c_int32]),
+    "gs_target_resolve_time": (C.c_int32, [_P, C.POINTER(C.c_float), C.POINTER(C.c_int32)]),
     "gs_import_blob_sizes": (C.c_int32, [C.c_uint32, C.POINTER(gs_import_formats), C.c_uint64 * 5]),
     "gs_import_encode": (C.c_int32, [C.POINTER(gs_import_input), C.POINTER(gs_import_formats), C.c_void_p * 5, C.c_uint64 * 5,
                                       C.POINTER(C.c_float), C.POINTER(C.c_float)]),

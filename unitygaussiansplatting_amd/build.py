@@ -8,7 +8,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libgsplat_hip.so")
-SOURCES = ["gs_api.hip", "gs_sort.hip", "gs_view.hip", "gs_raster.hip", "gs_import.cpp"]
+SOURCES = ["gs_api.hip", "gs_sort.hip", "gs_view.hip", "gs_raster.hip", "gs_comm.hip", "gs_import.cpp"]
 HEADERS = ["gs_common.h", "gs_device_math.h", os.path.join("..", "..", "include", "gsplat_c.h")]
 # -ffp-contract=off: the kernels' arithmetic is written with explicit fmaf(); nothing else may fuse, so that
 # results match the oracle's canonical arithmetic bit for bit.
@@ -38,7 +38,7 @@ def build_variant(name: str, defines, verbose: bool = False) -> str:
     out_dir = os.path.join(HERE, "variants")
     os.makedirs(out_dir, exist_ok=True)
     out = os.path.join(out_dir, name + ".so")
-    cmd = [hipcc()] + FLAGS + ["-D" + d for d in defines] + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", out]
+    cmd = [hipcc()] + FLAGS + ["-D" + d for d in defines] + [os.path.join(CSRC, s) for s in SOURCES] + ["-ldl", "-o", out]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
@@ -48,7 +48,7 @@ def build_variant(name: str, defines, verbose: bool = False) -> str:
 def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not needs_build():
         return LIB
-    cmd = [hipcc()] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
+    cmd = [hipcc()] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-ldl", "-o", LIB]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)

@@ -69,6 +69,7 @@ const char* gs_error_string(int32_t err) {
         case GS_ERR_PAIR_OVERFLOW: return "tile-pair buffer overflow (buffer was grown; render the frame again)";
         case GS_ERR_SORT_TIMEOUT: return "sort look-back timed out";
         case GS_ERR_NO_DEVICE: return "no HIP device";
+        case GS_ERR_COMM: return "RCCL communication error";
         default: return "unknown error";
     }
 }
@@ -211,6 +212,12 @@ int32_t gs_asset_destroy(gs_asset* a) {
 int32_t gs_asset_splat_count(const gs_asset* a, uint32_t* out) {
     if (!a || !out) return fail(GS_ERR_INVALID_ARGUMENT, "null argument");
     *out = a->view.n;
+    return GS_OK;
+}
+
+int32_t gs_asset_info(const gs_asset* a, uint32_t out[6]) {
+    if (!a || !out) return fail(GS_ERR_INVALID_ARGUMENT, "null argument");
+    out[0] = a->view.n; out[1] = a->view.posFmt; out[2] = a->view.scaleFmt; out[3] = a->view.colorFmt; out[4] = a->view.shFmt; out[5] = a->view.chunkCount;
     return GS_OK;
 }
 
@@ -617,6 +624,7 @@ int32_t gs_target_destroy(gs_target* t) {
     if (t->rgba16f) (void)hipFree(t->rgba16f);
     if (t->resolved) (void)hipFree(t->resolved);
     if (t->resolved8) (void)hipFree(t->resolved8);
+    if (t->rev) { for (int k = 0; k < 2 * gs_target::kResolveRing; ++k) if (t->rev[k]) (void)hipEventDestroy(t->rev[k]); delete[] t->rev; }
     delete t;
     return GS_OK;
 }
@@ -637,11 +645,46 @@ int32_t gs_target_resolve(gs_target* t, const float bg[4], float* out32, uint8_t
     if (!t || !bg) return fail(GS_ERR_INVALID_ARGUMENT, "null argument");
     GS_TRY(bind_device(t->ctx));
     GS_TRY(flush_clear(t));
+    const int slot = t->revCount % gs_target::kResolveRing;
+    if (t->profiling && t->rev) GS_HIP(hipEventRecord(t->rev[2 * slot], t->ctx->stream));
     GS_TRY(enqueue_resolve(t, bg, out8 != nullptr));
+    if (t->profiling && t->rev) { GS_HIP(hipEventRecord(t->rev[2 * slot + 1], t->ctx->stream)); t->revCount++; }
     const size_t px = (size_t)t->width * t->height;
     if (out32) GS_HIP(hipMemcpyAsync(out32, t->resolved, px * 16, hipMemcpyDeviceToHost, t->ctx->stream));
     if (out8) GS_HIP(hipMemcpyAsync(out8, t->resolved8, px * 4, hipMemcpyDeviceToHost, t->ctx->stream));
     if (out32 || out8) GS_HIP(hipStreamSynchronize(t->ctx->stream));
+    return GS_OK;
+}
+
+int32_t gs_target_set_profiling(gs_target* t, int32_t enabled) {
+    if (!t) return fail(GS_ERR_INVALID_ARGUMENT, "target is null");
+    GS_TRY(bind_device(t->ctx));
+    if (enabled && !t->rev) {
+        const int cnt = 2 * gs_target::kResolveRing;
+        hipEvent_t* ev = new (std::nothrow) hipEvent_t[cnt]();
+        if (!ev) return fail(GS_ERR_OUT_OF_MEMORY, "host allocation");
+        for (int k = 0; k < cnt; ++k)
+            if (hipEventCreate(&ev[k]) != hipSuccess) { for (int j = 0; j < k; ++j) (void)hipEventDestroy(ev[j]); delete[] ev; return fail(GS_ERR_HIP, "hipEventCreate"); }
+        t->rev = ev;
+    }
+    t->profiling = enabled != 0;
+    t->revCount = 0;
+    return GS_OK;
+}
+
+int32_t gs_target_resolve_time(gs_target* t, float* mean_ms, int32_t* count) {
+    if (!t || !mean_ms) return fail(GS_ERR_INVALID_ARGUMENT, "null argument");
+    *mean_ms = 0.f;
+    if (count) *count = 0;
+    if (!t->rev) return fail(GS_ERR_INVALID_ARGUMENT, "profiling was never enabled on this target");
+    GS_TRY(bind_device(t->ctx));
+    GS_HIP(hipStreamSynchronize(t->ctx->stream));
+    const int n = t->revCount < gs_target::kResolveRing ? t->revCount : gs_target::kResolveRing;
+    double sum = 0.0; int got = 0;
+    for (int k = 0; k < n; ++k) { float ms = 0.f; if (hipEventElapsedTime(&ms, t->rev[2 * k], t->rev[2 * k + 1]) == hipSuccess) { sum += ms; got++; } }
+    if (got) *mean_ms = (float)(sum / got);
+    if (count) *count = got;
+    t->revCount = 0;
     return GS_OK;
 }
 

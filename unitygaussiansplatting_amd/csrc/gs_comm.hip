@@ -1,0 +1,192 @@
+// gs_comm.hip -- multi-GPU: the one exchange the path has, the load-time broadcast of the asset blobs.
+//
+// The reference is single-GPU; this layer is new.  The render path shards by VIEW: every GPU holds a replica of the
+// immutable GaussianSplatAsset blobs (GaussianSplatAsset.cs:205-229) and runs sort -> view data -> composite on its own
+// camera, so there is no per-frame collective.  At load, the rank that has the asset broadcasts the five blobs to the
+// others: one ncclBroadcast per blob (296 MB for the bicycle-sized Medium asset -- five large messages over xGMI, not
+// thousands of small ones), on the context's stream, through RCCL called DIRECTLY from this library (no torch, no MPI:
+// a .NET host binds these entry points with P/Invoke like the rest of the ABI and moves the 128-byte unique id over any
+// channel it has).  librccl is loaded on first use (dlopen), so a single-GPU host never pays for it and the library has
+// no link-time dependency on it; a copy already loaded by the process (e.g. the one inside PyTorch) is reused.
+#include <dlfcn.h>
+#include <stdlib.h>
+
+#include <new>
+
+#include <rccl/rccl.h>
+
+#include "gs_common.h"
+
+static_assert(NCCL_UNIQUE_ID_BYTES == GS_COMM_ID_BYTES, "gs_comm id size = ncclUniqueId");
+
+namespace {
+
+struct Rccl {
+    void* handle = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    bool ok = false;
+};
+
+Rccl& rccl() {
+    static Rccl r = [] {
+        Rccl x;
+        const char* names[] = { getenv("GSPLAT_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" };
+        for (int pass = 0; pass < 2 && !x.handle; ++pass)               // pass 0: a copy the process has loaded already
+            for (const char* nm : names) {
+                if (!nm || !nm[0]) continue;
+                x.handle = dlopen(nm, RTLD_NOW | RTLD_LOCAL | (pass == 0 ? RTLD_NOLOAD : 0));
+                if (x.handle) break;
+            }
+        if (!x.handle) return x;
+        x.GetUniqueId = (decltype(x.GetUniqueId))dlsym(x.handle, "ncclGetUniqueId");
+        x.CommInitRank = (decltype(x.CommInitRank))dlsym(x.handle, "ncclCommInitRank");
+        x.CommDestroy = (decltype(x.CommDestroy))dlsym(x.handle, "ncclCommDestroy");
+        x.Broadcast = (decltype(x.Broadcast))dlsym(x.handle, "ncclBroadcast");
+        x.GetErrorString = (decltype(x.GetErrorString))dlsym(x.handle, "ncclGetErrorString");
+        x.ok = x.GetUniqueId && x.CommInitRank && x.CommDestroy && x.Broadcast && x.GetErrorString;
+        return x;
+    }();
+    return r;
+}
+
+int32_t need_rccl() {
+    if (!rccl().ok) return gs::fail(GS_ERR_COMM, "librccl could not be loaded (set GSPLAT_RCCL_LIB to its path)");
+    return GS_OK;
+}
+
+int32_t fail_nccl(ncclResult_t e, const char* what) {
+    gs::set_error_detail("%s failed: %s", what, rccl().GetErrorString ? rccl().GetErrorString(e) : "?");
+    return GS_ERR_COMM;
+}
+
+#define GS_NCCL(call)                                         \
+    do {                                                      \
+        ncclResult_t _e = (call);                             \
+        if (_e != ncclSuccess) return fail_nccl(_e, #call);   \
+    } while (0)
+
+constexpr uint64_t kHeaderMagic = 0x3154414c50534753ull;        // "GSSPLAT1"
+
+} // namespace
+
+struct gs_comm {
+    gs_context* ctx = nullptr;
+    ncclComm_t comm = nullptr;
+    int nranks = 1, rank = 0;
+    uint64_t* headerDev = nullptr;          // 16 x u64 scratch for the asset header
+};
+
+using namespace gs;
+
+extern "C" {
+
+int32_t gs_comm_unique_id(uint8_t id_out[GS_COMM_ID_BYTES]) {
+    if (!id_out) return fail(GS_ERR_INVALID_ARGUMENT, "id_out is null");
+    GS_TRY(need_rccl());
+    ncclUniqueId id;
+    GS_NCCL(rccl().GetUniqueId(&id));
+    memcpy(id_out, id.internal, GS_COMM_ID_BYTES);
+    return GS_OK;
+}
+
+int32_t gs_comm_create(gs_context* ctx, int32_t nranks, int32_t rank, const uint8_t id[GS_COMM_ID_BYTES], gs_comm** out) {
+    if (!ctx || !id || !out) return fail(GS_ERR_INVALID_ARGUMENT, "null argument");
+    *out = nullptr;
+    if (nranks < 1 || rank < 0 || rank >= nranks) return fail(GS_ERR_INVALID_ARGUMENT, "rank / nranks out of range");
+    GS_TRY(need_rccl());
+    GS_HIP(hipSetDevice(ctx->device));
+    gs_comm* c = new (std::nothrow) gs_comm();
+    if (!c) return fail(GS_ERR_OUT_OF_MEMORY, "host allocation");
+    c->ctx = ctx; c->nranks = nranks; c->rank = rank;
+    ncclUniqueId uid;
+    memcpy(uid.internal, id, GS_COMM_ID_BYTES);
+    ncclResult_t e = rccl().CommInitRank(&c->comm, nranks, uid, rank);          // collective: returns once every rank has joined
+    if (e != ncclSuccess) { delete c; return fail_nccl(e, "ncclCommInitRank"); }
+    if (hipMalloc((void**)&c->headerDev, 16 * sizeof(uint64_t)) != hipSuccess) { (void)rccl().CommDestroy(c->comm); delete c; return fail(GS_ERR_OUT_OF_MEMORY, "comm scratch"); }
+    *out = c;
+    return GS_OK;
+}
+
+int32_t gs_comm_destroy(gs_comm* c) {
+    if (!c) return GS_OK;
+    (void)hipSetDevice(c->ctx->device);
+    (void)hipStreamSynchronize(c->ctx->stream);
+    if (c->comm && rccl().ok) (void)rccl().CommDestroy(c->comm);
+    if (c->headerDev) (void)hipFree(c->headerDev);
+    delete c;
+    return GS_OK;
+}
+
+int32_t gs_comm_info(const gs_comm* c, int32_t* nranks, int32_t* rank) {
+    if (!c) return fail(GS_ERR_INVALID_ARGUMENT, "comm is null");
+    if (nranks) *nranks = c->nranks;
+    if (rank) *rank = c->rank;
+    return GS_OK;
+}
+
+// Collective over `comm`.  On `root`, `asset_on_root` is the asset to replicate (created on the comm's context) and *out
+// receives the same handle; on every other rank `asset_on_root` is ignored and *out receives a new asset that owns
+// device copies of the five blobs.  Blocks until the blobs have arrived (a load-time operation).
+int32_t gs_asset_broadcast(gs_comm* c, gs_asset* asset_on_root, int32_t root, gs_asset** out) {
+    if (!c || !out) return fail(GS_ERR_INVALID_ARGUMENT, "null argument");
+    *out = nullptr;
+    if (root < 0 || root >= c->nranks) return fail(GS_ERR_INVALID_ARGUMENT, "root out of range");
+    const bool isRoot = c->rank == root;
+    if (isRoot && (!asset_on_root || asset_on_root->ctx != c->ctx)) return fail(GS_ERR_INVALID_ARGUMENT, "the root must pass an asset of the comm's context");
+    gs_context* ctx = c->ctx;
+    GS_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+
+    // ---- header: formats, count, blob sizes
+    uint64_t h[16] = {0};
+    if (isRoot) {
+        const gsm::AssetView& v = asset_on_root->view;
+        h[0] = kHeaderMagic; h[1] = v.n; h[2] = v.posFmt; h[3] = v.scaleFmt; h[4] = v.colorFmt; h[5] = v.shFmt; h[6] = v.chunkCount;
+        for (int k = 0; k < 5; ++k) h[7 + k] = asset_on_root->blobs[k] ? asset_on_root->sizes[k] : 0;
+        GS_HIP(hipMemcpyAsync(c->headerDev, h, sizeof(h), hipMemcpyHostToDevice, st));
+    }
+    GS_NCCL(rccl().Broadcast(c->headerDev, c->headerDev, sizeof(h), ncclUint8, root, c->comm, st));
+    GS_HIP(hipMemcpyAsync(h, c->headerDev, sizeof(h), hipMemcpyDeviceToHost, st));
+    GS_HIP(hipStreamSynchronize(st));
+    if (h[0] != kHeaderMagic || h[1] == 0) return fail(GS_ERR_COMM, "asset broadcast: bad header received");
+
+    gs_asset* a = asset_on_root;
+    if (!isRoot) {
+        a = new (std::nothrow) gs_asset();
+        if (!a) return fail(GS_ERR_OUT_OF_MEMORY, "host allocation");
+        a->ctx = ctx; a->owned = true;
+        for (int k = 0; k < 5; ++k) {
+            a->sizes[k] = h[7 + k];
+            if (!a->sizes[k]) continue;
+            hipError_t e = hipMalloc(&a->blobs[k], a->sizes[k] + 16);           // + the decoders' tail pad, as gs_asset_create
+            if (e == hipSuccess) e = hipMemsetAsync((uint8_t*)a->blobs[k] + a->sizes[k], 0, 16, st);
+            if (e != hipSuccess) {
+                // every rank must still take part in the remaining broadcasts or the others would hang: receive into nothing is
+                // not possible, so fail loudly on this rank only after draining what can be drained
+                gs_asset_destroy(a);
+                return fail_hip(e, "asset broadcast: allocate blob", __FILE__, __LINE__);
+            }
+        }
+    }
+    // ---- the blobs, one broadcast each (in place on the root)
+    for (int k = 0; k < 5; ++k) {
+        if (!h[7 + k]) continue;
+        ncclResult_t e = rccl().Broadcast(a->blobs[k], a->blobs[k], (size_t)h[7 + k], ncclUint8, root, c->comm, st);
+        if (e != ncclSuccess) { if (!isRoot) gs_asset_destroy(a); return fail_nccl(e, "ncclBroadcast(blob)"); }
+    }
+    { hipError_t e = hipStreamSynchronize(st); if (e != hipSuccess) { if (!isRoot) gs_asset_destroy(a); return fail_hip(e, "asset broadcast sync", __FILE__, __LINE__); } }
+    if (!isRoot) {
+        a->view.pos = (const uint8_t*)a->blobs[0]; a->view.other = (const uint8_t*)a->blobs[1]; a->view.color = (const uint8_t*)a->blobs[2];
+        a->view.sh = (const uint8_t*)a->blobs[3]; a->view.chunk = (const uint8_t*)a->blobs[4];
+        a->view.n = (uint32_t)h[1]; a->view.posFmt = (uint32_t)h[2]; a->view.scaleFmt = (uint32_t)h[3];
+        a->view.colorFmt = (uint32_t)h[4]; a->view.shFmt = (uint32_t)h[5]; a->view.chunkCount = (uint32_t)h[6];
+    }
+    *out = a;
+    return GS_OK;
+}
+
+} // extern "C"

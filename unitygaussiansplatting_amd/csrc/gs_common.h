@@ -127,6 +127,11 @@ struct gs_target {
                                             // draw writes every pixel itself (no 8 B/px memset); any other reader clears first
     float* resolved = nullptr;              // W*H*4 floats, lazily allocated
     uint8_t* resolved8 = nullptr;
+    // optional timing of gs_target_resolve: a ring of event pairs on the context's stream
+    static constexpr int kResolveRing = 64;
+    hipEvent_t* rev = nullptr;              // 2 x kResolveRing events, or null (profiling off)
+    bool profiling = false;
+    int revCount = 0;                       // resolves recorded since the last read (may exceed the ring: the oldest are overwritten)
 };
 
 struct gs_renderer {

@@ -378,7 +378,9 @@ __global__ __launch_bounds__(THREADS, GS_SORT_MINWAVES) void onesweep_kernel(con
             uint32_t exclPrefix = 0;
             // A digit this partition does not hold needs no base (s_gbase[d] is never read), so its look-back is skipped:
             // in the passes over the high key bytes almost every digit is empty almost everywhere.
-            if (part > 0 && total > 0) {
+            // (digitLive: the 0xffffffff dummies that pad the last partition are counted in `total` but are not part of the input;
+            // nobody publishes a digit that only they hold.)
+            if (part > 0 && total > 0 && digitLive) {
                 // Every partition of a pass is resident at once (persistent grid) and all of them finish ranking at about the
                 // same time, so a plain decoupled look-back degenerates into a serial chain of INCLUSIVE hand-offs sweeping
                 // over the partitions (measured: 23 us of a 39 us pass for 749 partitions).  Two levels remove the chain:
@@ -458,7 +460,7 @@ __global__ __launch_bounds__(THREADS, GS_SORT_MINWAVES) void onesweep_kernel(con
             }
             // the last partition of a group that knows its prefix publishes the group's inclusive prefix: a shortcut for
             // every later group's level 2 (those that find it stop there; those that do not use the aggregates)
-            if ((part % GROUP) == (uint32_t)(GROUP - 1) && (total > 0 || part == 0))
+            if ((part % GROUP) == (uint32_t)(GROUP - 1) && total > 0 && digitLive)
                 st_word64(groupIncl + (size_t)(part / GROUP) * RADIX + tid, ((unsigned long long)epoch << 32) | (unsigned long long)(exclPrefix + total));
             s_gbase[tid] = histExcl + exclPrefix - lbase;
         }

@@ -63,6 +63,15 @@ namespace GaussianSplatting.Runtime
         [DllImport(Lib)] public static extern int gs_asset_destroy(IntPtr asset);
         [DllImport(Lib)] public static extern int gs_asset_splat_count(IntPtr asset, out uint count);
         [DllImport(Lib)] public static extern int gs_asset_device_blobs(IntPtr asset, [Out] IntPtr[] ptrs5, [Out] ulong[] sizes5);
+        [DllImport(Lib)] public static extern int gs_asset_info(IntPtr asset, [Out] uint[] out6);
+
+        // multi-GPU (view-parallel): one context per GPU, the asset broadcast once over RCCL
+        public const int GS_COMM_ID_BYTES = 128;
+        [DllImport(Lib)] public static extern int gs_comm_unique_id([Out] byte[] id128);
+        [DllImport(Lib)] public static extern int gs_comm_create(IntPtr ctx, int nranks, int rank, byte[] id128, out IntPtr comm);
+        [DllImport(Lib)] public static extern int gs_comm_destroy(IntPtr comm);
+        [DllImport(Lib)] public static extern int gs_comm_info(IntPtr comm, out int nranks, out int rank);
+        [DllImport(Lib)] public static extern int gs_asset_broadcast(IntPtr comm, IntPtr assetOnRoot, int root, out IntPtr asset);
 
         [DllImport(Lib)] public static extern int gs_renderer_create(IntPtr ctx, IntPtr asset, out IntPtr renderer);
         [DllImport(Lib)] public static extern int gs_renderer_destroy(IntPtr renderer);
@@ -95,6 +104,8 @@ namespace GaussianSplatting.Runtime
         [DllImport(Lib)] public static extern int gs_target_download(IntPtr target, IntPtr dstRgba16f, UIntPtr bytes);
         [DllImport(Lib)] public static extern int gs_target_resolve(IntPtr target, float[] backgroundRgba4, IntPtr dstRgba32f, IntPtr dstRgba8);
         [DllImport(Lib)] public static extern int gs_target_device_ptr(IntPtr target, out IntPtr rgba16fDev, out IntPtr resolvedDev);
+        [DllImport(Lib)] public static extern int gs_target_set_profiling(IntPtr target, int enabled);
+        [DllImport(Lib)] public static extern int gs_target_resolve_time(IntPtr target, out float meanMs, out int count);
 
         // native importer (host code): GaussianSplatAssetCreator.CreateAsset without the asset database
         [StructLayout(LayoutKind.Sequential)]

@@ -4,8 +4,11 @@ The reference is single-GPU, single-process; this l
 naturally by *view*: every GPU holds a replica of the immutable asset blobs and runs the whole per-camera path
 (sort -> view data -> composite) on its own camera, so there is NO per-frame collective.  The only exchange is
 at load time: rank `root` broadcasts the five GaussianSplatAsset blobs (pos / other / color / sh / chunk) to
-every rank with torch.distributed (backend "nccl" = RCCL over xGMI on MI355X; "gloo" in the CPU tests), and the
-renderer adopts the received device buffers without a copy (gs_asset_desc.memory_kind = 1).
+every rank.  Two transports:
+  * `Comm` -- the product path: the library's own RCCL communicator (gs_comm_* / gs_asset_broadcast of include/gsplat_c.h,
+    ncclBroadcast per blob on the context's stream); only the 128-byte unique id travels over a host channel;
+  * `broadcast_asset` -- torch.distributed tensors adopted without a copy (gs_asset_desc.memory_kind = 1): what the
+    world-size-2 gloo tests exercise on CPU boxes.
 """
 from __future__ import annotations
 
@@ -14,9 +17,71 @@ from typing import List, Optional, Sequence, Tuple
 
 import numpy as np
 
-from .asset import ColorFormat, GaussianSplatAsset, SHFormat, VectorFormat
+from .asset import ColorFormat, GaussianSplatAsset, SHFormat, VectorFormat, kCurrentVersion
 
 BLOB_NAMES = ("posData", "otherData", "colorData", "shData", "chunkData")
+
+
+class Comm:
+    """gs_comm: one RCCL rank bound to a GpuContext.  `uid` = Comm.UniqueId() of ONE rank, handed to all ranks by the host."""
+
+    def __init__(self, ctx, nranks: int, rank: int, uid: bytes):
+        from . import _lib
+        from ._lib import check
+        assert len(uid) == 128
+        self.ctx, self.nranks, self.rank = ctx, nranks, rank
+        self._h = C.c_void_p()
+        buf = (C.c_uint8 * 128).from_buffer_copy(uid)
+        check(_lib.lib().gs_comm_create(ctx._h, nranks, rank, buf, C.byref(self._h)), "gs_comm_create")
+        ctx._adopt(self)
+
+    @staticmethod
+    def UniqueId() -> bytes:
+        from . import _lib
+        from ._lib import check
+        buf = (C.c_uint8 * 128)()
+        check(_lib.lib().gs_comm_unique_id(buf), "gs_comm_unique_id")
+        return bytes(buf)
+
+    def BroadcastAsset(self, renderer, root: int = 0) -> None:
+        """CreateResourcesForAsset across ranks: on `root` the renderer's m_Asset (host blobs) is uploaded as usual, then the
+        device blobs are broadcast; every rank ends with an asset handle + renderer, and m_Asset describing it."""
+        from . import _lib
+        from ._abi import make_asset_desc
+        from ._lib import check
+        l = _lib.lib()
+        src = C.c_void_p()
+        if self.rank == root:
+            keep: list = []
+            desc = make_asset_desc(renderer.m_Asset, keep)
+            check(l.gs_asset_create(self.ctx._h, C.byref(desc), C.byref(src)), "gs_asset_create")
+        out = C.c_void_p()
+        check(l.gs_asset_broadcast(self._h, src, root, C.byref(out)), "gs_asset_broadcast")
+        renderer._asset_h = out
+        info = (C.c_uint32 * 6)()
+        check(l.gs_asset_info(out, info), "gs_asset_info")
+        if self.rank != root:
+            sizes = (C.c_uint64 * 5)()
+            ptrs = (C.c_void_p * 5)()
+            check(l.gs_asset_device_blobs(out, ptrs, sizes), "gs_asset_device_blobs")
+            renderer.m_Asset = asset_from_meta(dict(splatCount=int(info[0]), posFormat=int(info[1]), scaleFormat=int(info[2]), colorFormat=int(info[3]),
+                                                    shFormat=int(info[4]), formatVersion=kCurrentVersion,
+                                                    dataHash="", name="broadcast", boundsMin=(0, 0, 0), boundsMax=(0, 0, 0), sizes=[int(x) for x in sizes]))
+        check(l.gs_renderer_create(self.ctx._h, renderer._asset_h, C.byref(renderer._r_h)), "gs_renderer_create")
+        renderer.m_SplatCount = int(info[0])
+        renderer.m_PrevAsset, renderer.m_PrevHash = renderer.m_Asset, (renderer.m_Asset.dataHash if renderer.m_Asset else None)
+
+    def Dispose(self) -> None:
+        if self._h:
+            from . import _lib
+            _lib.lib().gs_comm_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.Dispose()
+        except Exception:
+            pass
 
 
 def assign_views(num_views: int, world_size: int) -> List[List[int]]:

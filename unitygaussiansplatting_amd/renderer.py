@@ -111,6 +111,15 @@ class RenderTarget:
         bg = np.asarray(background, np.float32)
         check(_lib.lib().gs_target_resolve(self._h, _fptr(bg), None, None), "gs_target_resolve")
 
+    def SetProfiling(self, enabled: bool) -> None:
+        check(_lib.lib().gs_target_set_profiling(self._h, int(bool(enabled))), "gs_target_set_profiling")
+
+    def ResolveTime(self) -> Tuple[float, int]:
+        """(mean GPU ms, count) of the resolves since the last call (hipEvents on the context's stream); blocks."""
+        ms, cnt = C.c_float(), C.c_int32()
+        check(_lib.lib().gs_target_resolve_time(self._h, C.byref(ms), C.byref(cnt)), "gs_target_resolve_time")
+        return ms.value, cnt.value
+
     def Dispose(self) -> None:
         if self._h:
             _lib.lib().gs_target_destroy(self._h)
