@@ -35,7 +35,7 @@ typedef enum gs_error {
     GS_OK = 0,
     GS_ERR_INVALID_ARGUMENT = -1,   /* null handle, bad size, bad enum (C#: ArgumentOutOfRangeException, GaussianSplatAsset.cs:47,66) */
     GS_ERR_HIP = -2,                /* a HIP runtime call failed; gs_last_error_string() has the detail */
-    GS_ERR_UNSUPPORTED_FORMAT = -3, /* BC7 colour (needs a block decoder) */
+    GS_ERR_UNSUPPORTED_FORMAT = -3, /* a format / mode this build does not implement (e.g. the debug box render modes) */
     GS_ERR_OUT_OF_MEMORY = -4,
     GS_ERR_INVALID_ASSET = -5,      /* blob sizes do not match splat_count/formats (C#: HasValidAsset, GaussianSplatRenderer.cs:361-368) */
     GS_ERR_PAIR_OVERFLOW = -6,      /* tile-pair buffer too small for this frame; the renderer grew it -- draw again */
@@ -51,6 +51,11 @@ typedef enum gs_sh_format {
     GS_SH_FLOAT32 = 0, GS_SH_FLOAT16 = 1, GS_SH_NORM11 = 2, GS_SH_NORM6 = 3,
     GS_SH_CLUSTER64K = 4, GS_SH_CLUSTER32K = 5, GS_SH_CLUSTER16K = 6, GS_SH_CLUSTER8K = 7, GS_SH_CLUSTER4K = 8
 } gs_sh_format;
+
+/* GaussianSplatRenderer.RenderMode (GaussianSplatRenderer.cs:217-223) */
+typedef enum gs_render_mode {
+    GS_RENDER_SPLATS = 0, GS_RENDER_DEBUG_POINTS = 1, GS_RENDER_DEBUG_POINT_INDICES = 2, GS_RENDER_DEBUG_BOXES = 3, GS_RENDER_DEBUG_CHUNK_BOUNDS = 4
+} gs_render_mode;
 
 typedef struct gs_context gs_context;
 typedef struct gs_asset gs_asset;
@@ -208,6 +213,12 @@ int32_t gs_renderer_set_cutouts(gs_renderer* r, const gs_cutout* cutouts, uint32
 /* m_GpuEditDeleted + _SplatBitsValid (GaussianSplatRenderer.cs:497,501; SplatUtilities.compute:204-214): one bit per
  * splat, bit set = deleted (clip.w = 0).  `words` = ceil(N/32) host uint32s, copied; NULL => _SplatBitsValid = 0. */
 int32_t gs_renderer_set_deleted_bits(gs_renderer* r, const uint32_t* words, size_t word_count);
+/* m_RenderMode + m_PointDisplaySize (GaussianSplatRenderer.cs:241-242; material choice :126-131).  DebugPoints / DebugPointIndices
+ * (GaussianDebugRenderPoints.shader) draw every splat as an opaque screen-space square of `point_display_size` pixels, nearest
+ * wins (ZWrite On), colour = saturate(DC colour) or an index code; gs_renderer_draw then neither needs gs_renderer_sort nor
+ * gs_renderer_calc_view.  DebugBoxes / DebugChunkBounds (GaussianDebugRenderBoxes.shader) are accepted here and refused by
+ * gs_renderer_draw with GS_ERR_UNSUPPORTED_FORMAT (editor visualisations, not built). */
+int32_t gs_renderer_set_render_mode(gs_renderer* r, int32_t mode, float point_display_size);
 /* 0 (default): "exact" -- accumulate in fp16 (RTNE after every blend, like the RGBA16F ROP).
  * 1: "fast" -- accumulate in fp32, stop a pixel when 1-A < 1/4096. */
 int32_t gs_renderer_set_blend_mode(gs_renderer* r, int32_t mode);
@@ -236,6 +247,14 @@ int32_t gs_renderer_frame_times(gs_renderer* r, float* out_ms, int32_t capacity,
 int32_t gs_target_create(gs_context* ctx, uint32_t width, uint32_t height, gs_target** out);
 int32_t gs_target_destroy(gs_target* t);
 int32_t gs_target_clear(gs_target* t);                                  /* ClearRenderTarget(Color, (0,0,0,0)) */
+/* The depth attachment of the splat RT: the reference binds the camera's depth buffer next to it (SetRenderTarget(
+ * GaussianSplatRT, CurrentActive), GaussianSplatRenderer.cs:195; URP: activeDepthTexture, GaussianSplatURPFeature.cs:54-66)
+ * and draws the splats with ZTest LEqual, ZWrite Off (RenderGaussianSplats.shader:10), so opaque scene geometry occludes
+ * them.  `depth` = W*H floats, row 0 = top: the VIEW depth (clip.w, in world units along the camera axis) of the opaque
+ * scene at each pixel (+inf where there is none); a splat fragment survives iff the splat's centre depth <= it (all four
+ * vertices of a splat quad share the centre's depth).  memory_kind 0: host memory, copied (stream-ordered);
+ * 1: device memory, BORROWED until the next call.  NULL: no depth attachment (default). */
+int32_t gs_target_set_scene_depth(gs_target* t, const float* depth, int32_t memory_kind);
 int32_t gs_target_download(gs_target* t, void* out_rgba16f, size_t bytes);   /* W*H*8 B, row 0 = top; blocks */
 /* GaussianComposite.shader:25-39 + its "Blend SrcAlpha OneMinusSrcAlpha": out = lerp(bg, GammaToLinearSpace(C/A), A).
  * Writes W*H*4 floats (linear RGBA; out.a = A*A + bg.a*(1-A): the pass has no separate alpha blend factors) into a device buffer owned by the target, then

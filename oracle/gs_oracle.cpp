@@ -237,6 +237,68 @@ inline f4 DecodeRotation(uint32_t enc) {
     return q;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// BC7 (BPTC) texel fetch: what `_SplatColor.Load` returns for ColorFormat.BC7 (RGBA_BC7_UNorm; GaussianSplatAsset.cs:56,169).
+// The block is decoded by a sequential bit reader into all 16 texels (a different structure from the kernel's single-texel
+// decoder, gs_device_math.h); both are checked against Pillow's decoder by tests/test_bc7.py.  Tables: Khronos Data Format
+// Specification "BPTC" (partition shapes as per-texel subset numbers, anchors of the 2nd / 3rd subset).
+// ---------------------------------------------------------------------------------------------
+const uint16_t BC7_P2[64] = { 0xcccc, 0x8888, 0xeeee, 0xecc8, 0xc880, 0xfeec, 0xfec8, 0xec80, 0xc800, 0xffec, 0xfe80, 0xe800, 0xffe8, 0xff00, 0xfff0, 0xf000, 0xf710, 0x8e, 0x7100, 0x8ce, 0x8c, 0x7310, 0x3100, 0x8cce, 0x88c, 0x3110, 0x6666, 0x366c, 0x17e8, 0xff0, 0x718e, 0x399c, 0xaaaa, 0xf0f0, 0x5a5a, 0x33cc, 0x3c3c, 0x55aa, 0x9696, 0xa55a, 0x73ce, 0x13c8, 0x324c, 0x3bdc, 0x6996, 0xc33c, 0x9966, 0x660, 0x272, 0x4e4, 0x4e40, 0x2720, 0xc936, 0x936c, 0x39c6, 0x639c, 0x9336, 0x9cc6, 0x817e, 0xe718, 0xccf0, 0xfcc, 0x7744, 0xee22 };
+const uint32_t BC7_P3[64] = { 0xaa685050, 0x6a5a5040, 0x5a5a4200, 0x5450a0a8, 0xa5a50000, 0xa0a05050, 0x5555a0a0, 0x5a5a5050, 0xaa550000, 0xaa555500, 0xaaaa5500, 0x90909090, 0x94949494, 0xa4a4a4a4, 0xa9a59450, 0x2a0a4250, 0xa5945040, 0xa425054, 0xa5a5a500, 0x55a0a0a0, 0xa8a85454, 0x6a6a4040, 0xa4a45000, 0x1a1a0500, 0x50a4a4, 0xaaa59090, 0x14696914, 0x69691400, 0xa08585a0, 0xaa821414, 0x50a4a450, 0x6a5a0200, 0xa9a58000, 0x5090a0a8, 0xa8a09050, 0x24242424, 0xaa5500, 0x24924924, 0x24499224, 0x50a50a50, 0x500aa550, 0xaaaa4444, 0x66660000, 0xa5a0a5a0, 0x50a050a0, 0x69286928, 0x44aaaa44, 0x66666600, 0xaa444444, 0x54a854a8, 0x95809580, 0x96969600, 0xa85454a8, 0x80959580, 0xaa141414, 0x96960000, 0xaaaa1414, 0xa05050a0, 0xa0a5a5a0, 0x96000000, 0x40804080, 0xa9a8a9a8, 0xaaaaaa44, 0x2a4a5254 };
+const uint8_t BC7_A2[64] = { 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 2, 8, 2, 2, 8, 8, 15, 2, 8, 2, 2, 8, 8, 2, 2, 15, 15, 6, 8, 2, 8, 15, 15, 2, 8, 2, 2, 2, 15, 15, 6, 6, 2, 6, 8, 15, 15, 2, 2, 15, 15, 15, 15, 15, 2, 2, 15 };
+const uint8_t BC7_A3A[64] = { 3, 3, 15, 15, 8, 3, 15, 15, 8, 8, 6, 6, 6, 5, 3, 3, 3, 3, 8, 15, 3, 3, 6, 10, 5, 8, 8, 6, 8, 5, 15, 15, 8, 15, 3, 5, 6, 10, 8, 15, 15, 3, 15, 5, 15, 15, 15, 15, 3, 15, 5, 5, 5, 8, 5, 10, 5, 10, 8, 13, 15, 12, 3, 3 };
+const uint8_t BC7_A3B[64] = { 15, 8, 8, 3, 15, 15, 3, 8, 15, 15, 15, 15, 15, 15, 15, 8, 15, 8, 15, 3, 15, 8, 15, 8, 3, 15, 6, 10, 15, 15, 10, 8, 15, 3, 15, 10, 10, 8, 9, 10, 6, 15, 8, 15, 3, 6, 6, 8, 15, 3, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 3, 15, 15, 8 };
+const int BC7_MODE[8][10] = {   // subsets, partition bits, rotation, index selection, colour bits, alpha bits, endpoint p-bits, shared p-bits, index bits, 2nd index bits
+    {3, 4, 0, 0, 4, 0, 1, 0, 3, 0}, {2, 6, 0, 0, 6, 0, 0, 1, 3, 0}, {3, 6, 0, 0, 5, 0, 0, 0, 2, 0}, {2, 6, 0, 0, 7, 0, 1, 0, 2, 0},
+    {1, 0, 2, 1, 5, 6, 0, 0, 2, 3}, {1, 0, 2, 0, 7, 8, 0, 0, 2, 2}, {1, 0, 0, 0, 7, 7, 1, 0, 4, 0}, {2, 6, 0, 0, 5, 5, 1, 0, 2, 0} };
+const int BC7_W2[4] = {0, 21, 43, 64}, BC7_W3[8] = {0, 9, 18, 27, 37, 46, 55, 64}, BC7_W4[16] = {0, 4, 9, 13, 17, 21, 26, 30, 34, 38, 43, 47, 51, 55, 60, 64};
+
+struct BitReader {
+    const uint8_t* p; int pos;
+    int get(int n) { int v = 0; for (int k = 0; k < n; ++k, ++pos) v |= ((p[pos >> 3] >> (pos & 7)) & 1) << k; return v; }
+};
+
+void bc7_decode_block(const uint8_t* block, uint8_t out[16][4]) {
+    std::memset(out, 0, 64);
+    int mode = 0;
+    while (mode < 8 && !((block[0] >> mode) & 1)) ++mode;
+    if (mode == 8) return;                                     // reserved: zeros
+    const int* M = BC7_MODE[mode];
+    const int ns = M[0], cb = M[4], ab = M[5], ib = M[8], ib2 = M[9];
+    BitReader br{block, mode + 1};
+    const int shape = br.get(M[1]), rot = br.get(M[2]), isel = br.get(M[3]);
+    int ep[6][4];
+    for (int ch = 0; ch < 3; ++ch) for (int e = 0; e < 2 * ns; ++e) ep[e][ch] = br.get(cb);
+    for (int e = 0; e < 2 * ns; ++e) ep[e][3] = ab ? br.get(ab) : 255;
+    int cbits = cb, abits = ab;
+    if (M[6]) { for (int e = 0; e < 2 * ns; ++e) { const int pb = br.get(1); for (int ch = 0; ch < (ab ? 4 : 3); ++ch) ep[e][ch] = (ep[e][ch] << 1) | pb; } cbits++; if (ab) abits++; }
+    else if (M[7]) { for (int sub = 0; sub < ns; ++sub) { const int pb = br.get(1); for (int e = 2 * sub; e < 2 * sub + 2; ++e) for (int ch = 0; ch < 3; ++ch) ep[e][ch] = (ep[e][ch] << 1) | pb; } cbits++; }
+    for (int e = 0; e < 2 * ns; ++e) {
+        for (int ch = 0; ch < 3; ++ch) { const int x = ep[e][ch] << (8 - cbits); ep[e][ch] = x | (x >> cbits); }
+        if (ab) { const int x = ep[e][3] << (8 - abits); ep[e][3] = x | (x >> abits); }
+    }
+    int subset[16], anchor[3] = {0, -1, -1};
+    for (int t = 0; t < 16; ++t) subset[t] = ns == 1 ? 0 : (ns == 2 ? (BC7_P2[shape] >> t) & 1 : (BC7_P3[shape] >> (2 * t)) & 3);
+    if (ns == 2) anchor[1] = BC7_A2[shape];
+    if (ns == 3) { anchor[1] = BC7_A3A[shape]; anchor[2] = BC7_A3B[shape]; }
+    int i1[16], i2[16];
+    for (int t = 0; t < 16; ++t) i1[t] = br.get(t == anchor[subset[t]] ? ib - 1 : ib);
+    for (int t = 0; t < 16; ++t) i2[t] = ib2 ? br.get(t == 0 ? ib2 - 1 : ib2) : 0;
+    auto weight = [](int bits, int i) { return bits == 2 ? BC7_W2[i] : (bits == 3 ? BC7_W3[i] : BC7_W4[i]); };
+    for (int t = 0; t < 16; ++t) {
+        const int* e0 = ep[2 * subset[t]]; const int* e1 = ep[2 * subset[t] + 1];
+        int ci = i1[t], cbt = ib, ai = ib2 ? i2[t] : i1[t], abt = ib2 ? ib2 : ib;
+        if (isel) { std::swap(ci, ai); std::swap(cbt, abt); }
+        const int wc = weight(cbt, ci), wa = weight(abt, ai);
+        int px[4];
+        for (int ch = 0; ch < 3; ++ch) px[ch] = ((64 - wc) * e0[ch] + wc * e1[ch] + 32) >> 6;
+        px[3] = ((64 - wa) * e0[3] + wa * e1[3] + 32) >> 6;
+        if (rot) std::swap(px[3], px[rot - 1]);
+        for (int ch = 0; ch < 4; ++ch) out[t][ch] = (uint8_t)px[ch];
+    }
+}
+
 struct SplatData {      // GaussianSplatting.hlsl:134-137,209-216
     f3 pos; f4 rot; f3 scale; float opacity;
     f3 col; f3 sh[15];
@@ -268,6 +330,11 @@ SplatData LoadSplatData(const Asset& a, uint32_t idx) {
     } else if (a.colorFmt == 1) {
         const uint32_t lo = load_u32(a.color, texel * 8), hi = load_u32(a.color, texel * 8 + 4);
         col = { f16tof32(lo), f16tof32(lo >> 16), f16tof32(hi), f16tof32(hi >> 16) };
+    } else if (a.colorFmt == 3) {                               // RGBA_BC7_UNorm: 16-byte blocks of 4x4 texels, 512 blocks per row
+        uint8_t px[16][4];
+        bc7_decode_block(a.color + ((uint64_t)(cy >> 2) * 512 + (cx >> 2)) * 16, px);
+        const uint8_t* t = px[(cy & 3) * 4 + (cx & 3)];
+        col = { unorm(t[0], 255.0f, R255), unorm(t[1], 255.0f, R255), unorm(t[2], 255.0f, R255), unorm(t[3], 255.0f, R255) };
     } else {
         const uint32_t e = load_u32(a.color, texel * 4);        // R8G8B8A8_UNorm: x/255
         col = { unorm(e & 255, 255.0f, R255), unorm((e >> 8) & 255, 255.0f, R255), unorm((e >> 16) & 255, 255.0f, R255), unorm(e >> 24, 255.0f, R255) };
@@ -501,6 +568,15 @@ inline float log_det(float x) {
 
 inline bool finitef(float v) { return std::isfinite(v); }
 
+// HLSL exp(x).  DXC lowers it to the DXIL Exp opcode, which is base 2: exp(x) = exp2(x * log2(e)), the product rounded to
+// fp32 -- and that first rounding, not the exp2 unit, is the larger part of the result's error for the |x| of a gaussian's
+// tail (|x| * 2^-24 relative).  Canonical form: the fp32 product, then the correctly rounded exp2.
+// What remains between this and a GPU is the <= 1 ulp of its exp2 instruction (v_exp_f32 on gfx950).
+inline float exp_canon(float x) {
+    const float y = x * 1.44269504088896340736f;
+    return (float)std::exp2((double)y);
+}
+
 // Shared definition of "is this splat drawn at all, and where": see DESIGN.md "compositor semantics".
 Prepared prepare(const ViewData& v, const gs_frame_params& P) {
     Prepared p; std::memset(&p, 0, sizeof(p));
@@ -637,6 +713,7 @@ void gso_decode_all(const gs_asset_desc* d, float* out /* n x 59 */) {
 #pragma omp parallel for schedule(static)
     for (int64_t i = 0; i < (int64_t)a.n; ++i) gso_decode_splat(d, (uint32_t)i, out + i * 59);
 }
+void gso_bc7_decode_block(const uint8_t* block, uint8_t* out64) { uint8_t px[16][4]; bc7_decode_block(block, px); std::memcpy(out64, px, 64); }
 void gso_pixel_index(uint32_t idx, uint32_t* xy) { SplatIndexToPixelIndex(idx, xy[0], xy[1]); }
 
 // SplatUtilities.compute:189-252 CSCalcViewData over all splats; deleted_bits may be null (_SplatBitsValid = 0)
@@ -759,7 +836,7 @@ static int32_t draw_impl(const ViewData* view, const uint32_t* order, uint32_t n
                     float* d = row + (size_t)px * 4;
                     if (mode == 1 && (1.0f - d[3]) < (1.0f / 4096.0f)) continue; // fast mode: pixel finished
                     const float power = -fmaf(q2, q2, q1 * q1);                 // frag: -dot(i.pos, i.pos)
-                    float alpha = expf(power);
+                    float alpha = exp_canon(power);
                     alpha = saturatef(alpha * p.a);
                     if (alpha < 1.0f / 255.0f) continue;                        // discard
                     const float t = 1.0f - d[3];                                 // OneMinusDstAlpha
@@ -790,6 +867,46 @@ int32_t gso_draw_ex(const void* view_in, const uint32_t* order, uint32_t n, cons
     int win[4] = { 0, 0, (int)P->screen_w - 1, (int)P->screen_h - 1 };
     if (window) for (int k = 0; k < 4; ++k) win[k] = window[k];
     return draw_impl((const ViewData*)view_in, order, n, P, mode, rt, tile_pairs_out, visible_out, win, scene_depth);
+}
+
+// RenderMode.DebugPoints / DebugPointIndices (GaussianDebugRenderPoints.shader:28-63; GaussianSplatRenderer.cs:126-131,148-161):
+// instanced quads in splat-INDEX order, `size` pixels wide around the projected centre, opaque (no blend), ZWrite On with the
+// default ZTest LEqual (a later instance at the same depth overwrites).  Depth is compared as the view depth clip.w
+// (monotonic in the depth-buffer value of a perspective camera).  Sequential over splats: the reference order.
+void gso_draw_debug_points(const gs_asset_desc* d, const gs_frame_params* P, int32_t display_index, float size, uint16_t* rt, const float* scene_depth) {
+    const Asset a = make_asset(d);
+    const int W = (int)P->screen_w, H = (int)P->screen_h;
+    std::vector<float> z((size_t)W * H, INFINITY);
+    if (scene_depth) std::memcpy(z.data(), scene_depth, (size_t)W * H * 4);
+    const float h = 0.5f * size;
+    for (uint32_t idx = 0; idx < a.n; ++idx) {
+        const SplatData sp = LoadSplatData(a, idx);
+        const f3 wp = { mul_row(P->matrix_object_to_world, 0, sp.pos), mul_row(P->matrix_object_to_world, 1, sp.pos), mul_row(P->matrix_object_to_world, 2, sp.pos) };
+        const float cxc = mul_row(P->matrix_vp, 0, wp), cyc = mul_row(P->matrix_vp, 1, wp), w = mul_row(P->matrix_vp, 3, wp);
+        if (!(w >= P->near_clip && w <= P->far_clip)) continue;           // the quad lies at one depth: clipped as a whole
+        const float invw = 1.0f / w;
+        const float cx = fmaf(0.5f * (cxc * invw), (float)W, 0.5f * (float)W), cy = fmaf(-0.5f * (cyc * invw), (float)H, 0.5f * (float)H);
+        if (!(std::isfinite(cx) && std::isfinite(cy))) continue;
+        f3 col = { saturatef(sp.col.x), saturatef(sp.col.y), saturatef(sp.col.z) };
+        if (display_index) {
+            const float f = (float)idx / (float)a.n;
+            const float r = f * 100.0f, g = f * 10.0f;
+            col = { r - floorf(r), g - floorf(g), f };
+        }
+        for (int py = 0; py < H; ++py) {
+            const float fy = (float)py + 0.5f;
+            if (!(fy >= cy - h && fy < cy + h)) continue;                  // top-left rule
+            for (int px = 0; px < W; ++px) {
+                const float fx = (float)px + 0.5f;
+                if (!(fx >= cx - h && fx < cx + h)) continue;
+                float& zz = z[(size_t)py * W + px];
+                if (!(w <= zz)) continue;                                  // ZTest LEqual
+                zz = w;                                                    // ZWrite On
+                uint16_t* o = rt + ((size_t)py * W + px) * 4;
+                o[0] = f32tof16(col.x); o[1] = f32tof16(col.y); o[2] = f32tof16(col.z); o[3] = f32tof16(1.0f);
+            }
+        }
+    }
 }
 
 // GaussianComposite.shader:25-39 with "Blend SrcAlpha OneMinusSrcAlpha" onto a constant background.

@@ -40,3 +40,16 @@ def views_equal(got: np.ndarray, want: np.ndarray) -> bool:
     gf, wf = g[:, :8].view(np.float32), w[:, :8].view(np.float32)
     both_nan = np.isnan(gf) & np.isnan(wf)
     return bool(((g[:, :8] == w[:, :8]) | both_nan).all() and (g[:, 8:] == w[:, 8:]).all())
+
+
+RT_TOL = 2.0 ** -9
+
+
+def rt_err(img: np.ndarray, ref: np.ndarray) -> float:
+    """Parity metric of the RGBA16F target: max over pixels and channels of |a - b| / max(1, |b|).
+    The accumulator is fp16: a value c in [2^k, 2^(k+1)) has an ulp of 2^(k-10), and premultiplied splat colours are not
+    clamped to 1 (SH can push them above), so an absolute bound has to scale with the value: 2^-9 is two fp16 ulps of
+    any c in [0.5, 1) and at most two ulps of every larger c."""
+    a = np.ascontiguousarray(img, np.uint16).view(np.float16).astype(np.float32)
+    b = np.ascontiguousarray(ref, np.uint16).view(np.float16).astype(np.float32)
+    return float((np.abs(a - b) / np.maximum(1.0, np.abs(b))).max())

@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 
 import oracle_lib as O
-from common import default_camera, small_asset, views_equal
+from common import RT_TOL, default_camera, rt_err, small_asset, views_equal
 from unitygaussiansplatting_amd import camera
 from unitygaussiansplatting_amd._abi import VIEW_DTYPE, gs_cutout
 from unitygaussiansplatting_amd.cutout import GaussianCutout, Type, shader_data_array
@@ -180,8 +180,8 @@ def test_gpu_view_and_frame_with_cutouts_and_deleted_bits(gpu_ctx, quality):
         assert views_equal(got, want), (name, use_bits)
         orc.sort(camera.sort_matrix(cam, tr.localToWorldMatrix))
         ref = orc.draw(P, 0)
-        d = np.abs(O.f16_to_f32(rt.Download()) - O.f16_to_f32(ref))
-        assert d.max() <= 2.0 ** -9, (name, use_bits, d.max())
+        e = rt_err(rt.Download(), ref)
+        assert e <= RT_TOL, (name, use_bits, e)
         assert r.FrameStats().tile_pairs == orc.tile_pairs
     r.OnDisable()
 

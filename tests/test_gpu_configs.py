@@ -18,19 +18,17 @@ import numpy as np
 import pytest
 
 import oracle_lib as O
-from common import views_equal
+from common import RT_TOL, rt_err, views_equal
 from unitygaussiansplatting_amd import camera, creator, scenes
 from unitygaussiansplatting_amd.renderer import GaussianSplatRenderer, RenderTarget
 
 pytestmark = pytest.mark.gpu
 
-TOL = 2.0 ** -9
+TOL = RT_TOL
 
 
 def rt_close(img, ref):
-    a, b = O.f16_to_f32(img), O.f16_to_f32(ref)
-    d = np.abs(a - b) / np.maximum(1.0, np.abs(b))
-    return float(d.max()), float((img == ref).all(axis=-1).mean())
+    return rt_err(img, ref), float((img == ref).all(axis=-1).mean())
 
 
 def cam_of(cfg, az=0.0):

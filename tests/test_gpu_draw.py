@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 import oracle_lib as O
-from common import default_camera, diff_pixels, psnr8, small_asset
+from common import RT_TOL, default_camera, diff_pixels, psnr8, rt_err, small_asset
 from unitygaussiansplatting_amd import camera
 from unitygaussiansplatting_amd._lib import GsError
 from unitygaussiansplatting_amd.renderer import GaussianSplatRenderer, GaussianSplatRenderSystem, RenderTarget
@@ -46,8 +46,8 @@ def render_both(gpu_ctx, a, cam, mode=0, tr=None, **fields):
 def test_framebuffer_parity(gpu_ctx, W, H, mode):
     a = small_asset(60_000, 5, "Medium")
     res = render_both(gpu_ctx, a, default_camera(W=W, H=H, az=40.0), mode)
-    d = np.abs(O.f16_to_f32(res["img"]) - O.f16_to_f32(res["ref"]))
-    assert d.max() <= (2.0 ** -9 if mode == 0 else 4e-3), d.max()
+    e = rt_err(res["img"], res["ref"])
+    assert e <= (RT_TOL if mode == 0 else 4e-3), e
     assert res["st"].tile_pairs == res["orc"].tile_pairs and res["st"].visible_splats == res["orc"].visible
     assert (res["img"] == res["ref"]).all(axis=2).mean() > 0.995
     assert psnr8(res["o8"], res["r8"]) >= 50.0 and diff_pixels(res["o8"], res["r8"]) == 0
@@ -61,8 +61,7 @@ def test_framebuffer_parity(gpu_ctx, W, H, mode):
 def test_framebuffer_parity_other_formats(gpu_ctx, quality):
     a = small_asset(40_000, 8, quality)
     res = render_both(gpu_ctx, a, default_camera(W=500, H=300, az=-30.0), 0, m_SplatScale=1.5, m_OpacityScale=0.7, m_SHOrder=2)
-    d = np.abs(O.f16_to_f32(res["img"]) - O.f16_to_f32(res["ref"]))
-    assert d.max() <= 2.0 ** -9
+    assert rt_err(res["img"], res["ref"]) <= RT_TOL
     assert res["st"].tile_pairs == res["orc"].tile_pairs
 
 
@@ -102,7 +101,7 @@ def test_pair_buffer_overflow_is_reported_and_recovered(gpu_ctx):
     orc.calc_view(P)
     ref = orc.draw(P, 0)
     assert st.tile_pairs == orc.tile_pairs
-    assert np.abs(O.f16_to_f32(rt.Download()) - O.f16_to_f32(ref)).max() <= 2.0 ** -9
+    assert rt_err(rt.Download(), ref) <= RT_TOL
     r.OnDisable()
 
 
@@ -132,12 +131,12 @@ def test_two_objects_render_order_and_accumulating_draw(gpu_ctx):
     sysm.OnPreCullCamera(cam, rt)
     assert [g for g in sysm.m_ActiveSplats] == [r1, r2]              # r1 is nearer to the camera at z=+6
     img = rt.Download()
-    assert np.abs(O.f16_to_f32(img) - O.f16_to_f32(oracle_frame([(r1, a1), (r2, a2)]))).max() <= 2.0 ** -9
+    assert rt_err(img, oracle_frame([(r1, a1), (r2, a2)])) <= RT_TOL
     r2.m_RenderOrder = 5                                              # now r2 is drawn first (on top)
     sysm.OnPreCullCamera(cam, rt)
     assert sysm.m_ActiveSplats == [r2, r1]
     img2 = rt.Download()
-    assert np.abs(O.f16_to_f32(img2) - O.f16_to_f32(oracle_frame([(r2, a2), (r1, a1)]))).max() <= 2.0 ** -9
+    assert rt_err(img2, oracle_frame([(r2, a2), (r1, a1)])) <= RT_TOL
     assert (img != img2).any()
     for r in (r1, r2):
         r.OnDisable()

@@ -54,6 +54,7 @@ SIGNATURES = {
     "gs_renderer_set_deleted_bits": (C.c_int32, [_P, _P, C.c_size_t]),
     "gs_renderer_set_view_buffer_mode": (C.c_int32, [_P, C.c_int32]),
     "gs_renderer_set_blend_mode": (C.c_int32, [_P, C.c_int32]),
+    "gs_renderer_set_render_mode": (C.c_int32, [_P, C.c_int32, C.c_float]),
     "gs_renderer_set_profiling": (C.c_int32, [_P, C.c_int32]),
     "gs_renderer_reserve_pairs": (C.c_int32, [_P, C.c_uint64]),
     "gs_renderer_download_order": (C.c_int32, [_P, _P, C.c_size_t]),
@@ -67,6 +68,7 @@ SIGNATURES = {
     "gs_target_create": (C.c_int32, [_P, C.c_uint32, C.c_uint32, _PP]),
     "gs_target_destroy": (C.c_int32, [_P]),
     "gs_target_clear": (C.c_int32, [_P]),
+    "gs_target_set_scene_depth": (C.c_int32, [_P, _P, C.c_int32]),
     "gs_target_download": (C.c_int32, [_P, _P, C.c_size_t]),
     "gs_target_resolve": (C.c_int32, [_P, C.POINTER(C.c_float), _P, _P]),
     "gs_target_device_ptr": (C.c_int32, [_P, _PP, _PP]),

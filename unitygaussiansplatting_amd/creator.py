@@ -351,9 +351,6 @@ def CreateAssetFromSplats(raw: InputSplatData, quality: str = "Medium", *, forma
     fs = VectorFormat(fs if formatScale is None else formatScale)
     fc = ColorFormat(fc if formatColor is None else formatColor)
     fsh = SHFormat(fsh if formatSH is None else formatSH)
-    if fc == ColorFormat.BC7:
-        raise NotImplementedError("BC7 colour needs a block compressor; not implemented")
-
     s = LinearizeData(raw) if linearize else raw
     if morton:
         s, bmin, bmax = ReorderMorton(s)
@@ -437,6 +434,11 @@ def CreateAssetFromSplats(raw: InputSplatData, quality: str = "Medium", *, forma
         col_bytes = tex.astype("<f4").view(np.uint8).reshape(-1)
     elif fc == ColorFormat.Float16x4:
         col_bytes = tex.astype("<f2").view(np.uint8).reshape(-1)
+    elif fc == ColorFormat.BC7:
+        # EditorUtility.CompressTexture(tex, BC7, 100) (:900-903).  Unity's compressor cannot be reproduced; every block is
+        # encoded in mode 6 here (bc7.py) -- a conforming stream that any BC7 decoder, ours included, reads like Unity's
+        from . import bc7
+        col_bytes = bc7.encode_texture_mode6(tex.reshape(h, w, 4))
     else:
         p = _sat(tex)
         enc = _q(p[:, 0], 255) | (_q(p[:, 1], 255) << 8) | (_q(p[:, 2], 255) << 16) | (_q(p[:, 3], 255) << 24)

@@ -148,11 +148,10 @@ int32_t gs_asset_create(gs_context* ctx, const gs_asset_desc* d, gs_asset** out)
     *out = nullptr;
     if (d->splat_count == 0) return fail(GS_ERR_INVALID_ASSET, "splat_count is 0");
     if (d->pos_format > 3 || d->scale_format > 3 || d->color_format > 3 || d->sh_format > 8) return fail(GS_ERR_INVALID_ARGUMENT, "format enum out of range");
-    if (d->color_format == GS_COLOR_BC7) return fail(GS_ERR_UNSUPPORTED_FORMAT, "BC7 colour is not supported");
     if (!d->pos_data || !d->other_data || !d->color_data || !d->sh_data) return fail(GS_ERR_INVALID_ASSET, "a required blob is null");
     const uint64_t n = d->splat_count;
     const uint64_t vs[4] = {12, 6, 4, 2};
-    const uint64_t cs[3] = {16, 8, 4};
+    const uint64_t cs[4] = {16, 8, 4, 1};               // bytes per texel; BC7: 16-byte blocks of 4x4 texels
     const uint64_t otherStride = 4 + vs[d->scale_format] + (d->sh_format > 3 ? 2 : 0);
     const uint64_t texH = ((n + 2047) / 2048 + 15) / 16 * 16;
     const uint64_t need[5] = { n * vs[d->pos_format], n * otherStride, 2048 * texH * cs[d->color_format],
@@ -325,7 +324,7 @@ int32_t gs_renderer_calc_view(gs_renderer* r, const gs_frame_params* p) {
     rec_ev(r, 7);
     gsm::EditView e;
     e.deletedBits = r->deletedBits; e.cutouts = r->cutouts; e.cutoutCount = r->cutoutCount;
-    GS_TRY(enqueue_calc_view(r->ctx, r->asset->view, p, e, r->view, r->recs, r->rects, r->visMask, r->alwaysWriteView));
+    GS_TRY(enqueue_calc_view(r->ctx, r->asset->view, p, e, view_outputs(r), r->alwaysWriteView));
     r->viewMaterialised = r->alwaysWriteView;
     r->lastParams = *p;
     r->viewW = p->screen_w; r->viewH = p->screen_h; r->viewNear = p->near_clip; r->viewFar = p->far_clip; r->viewValid = true;
@@ -349,6 +348,8 @@ int32_t gs_renderer_draw(gs_renderer* r, const gs_frame_params* p, gs_target* rt
     if (rt->ctx != r->ctx) return fail(GS_ERR_INVALID_ARGUMENT, "target belongs to another context");
     if ((uint32_t)p->screen_w != rt->width || (uint32_t)p->screen_h != rt->height) return fail(GS_ERR_INVALID_ARGUMENT, "screen_w/h do not match the target");
     GS_TRY(bind_device(r->ctx));
+    if (r->renderMode == GS_RENDER_DEBUG_POINTS || r->renderMode == GS_RENDER_DEBUG_POINT_INDICES) return enqueue_debug_points(r, p, rt);
+    if (r->renderMode != GS_RENDER_SPLATS) return fail(GS_ERR_UNSUPPORTED_FORMAT, "DebugBoxes / DebugChunkBounds render modes are not built");
     GS_TRY(maybe_grow_pairs(r));
     return enqueue_draw(r, p, rt);
 }
@@ -416,6 +417,14 @@ int32_t gs_renderer_set_deleted_bits(gs_renderer* r, const uint32_t* words, size
 int32_t gs_renderer_set_view_buffer_mode(gs_renderer* r, int32_t every_frame) {
     if (!r) return fail(GS_ERR_INVALID_ARGUMENT, "renderer is null");
     r->alwaysWriteView = every_frame != 0;
+    return GS_OK;
+}
+
+int32_t gs_renderer_set_render_mode(gs_renderer* r, int32_t mode, float point_display_size) {
+    if (!r || mode < GS_RENDER_SPLATS || mode > GS_RENDER_DEBUG_CHUNK_BOUNDS) return fail(GS_ERR_INVALID_ARGUMENT, "render mode out of range");
+    if (!(point_display_size >= 0.0f) || point_display_size > 4096.0f) return fail(GS_ERR_INVALID_ARGUMENT, "point_display_size out of range");
+    r->renderMode = mode;
+    r->pointDisplaySize = point_display_size;
     return GS_OK;
 }
 
@@ -504,7 +513,7 @@ int32_t gs_renderer_download_view(gs_renderer* r, void* out, size_t bytes) {
         GS_TRY(bind_device(r->ctx));
         gsm::EditView e;
         e.deletedBits = r->deletedBits; e.cutouts = r->cutouts; e.cutoutCount = r->cutoutCount;
-        GS_TRY(enqueue_calc_view(r->ctx, r->asset->view, &r->lastParams, e, r->view, r->recs, r->rects, r->visMask, true));
+        GS_TRY(enqueue_calc_view(r->ctx, r->asset->view, &r->lastParams, e, view_outputs(r), true));
         r->viewMaterialised = true;
     }
     return download(r->ctx, out, r->view, bytes);
@@ -624,6 +633,8 @@ int32_t gs_target_destroy(gs_target* t) {
     if (t->rgba16f) (void)hipFree(t->rgba16f);
     if (t->resolved) (void)hipFree(t->resolved);
     if (t->resolved8) (void)hipFree(t->resolved8);
+    if (t->sceneDepthOwned) (void)hipFree(t->sceneDepthOwned);
+    if (t->zbuf) (void)hipFree(t->zbuf);
     if (t->rev) { for (int k = 0; k < 2 * gs_target::kResolveRing; ++k) if (t->rev[k]) (void)hipEventDestroy(t->rev[k]); delete[] t->rev; }
     delete t;
     return GS_OK;
@@ -632,6 +643,19 @@ int32_t gs_target_destroy(gs_target* t) {
 int32_t gs_target_clear(gs_target* t) {
     if (!t) return fail(GS_ERR_INVALID_ARGUMENT, "target is null");
     t->clearPending = true;                 // the next draw writes every pixel (blend kernel); anything else clears first
+    return GS_OK;
+}
+
+int32_t gs_target_set_scene_depth(gs_target* t, const float* depth, int32_t memory_kind) {
+    if (!t || (memory_kind != 0 && memory_kind != 1)) return fail(GS_ERR_INVALID_ARGUMENT, "bad argument");
+    GS_TRY(bind_device(t->ctx));
+    if (!depth) { t->sceneDepth = nullptr; return GS_OK; }      // a buffer we own stays allocated for the next host upload
+    if (memory_kind == 1) { t->sceneDepth = depth; return GS_OK; }
+    const size_t bytes = (size_t)t->width * t->height * sizeof(float);
+    if (!t->sceneDepthOwned) GS_HIP(hipMalloc((void**)&t->sceneDepthOwned, bytes));
+    GS_HIP(hipMemcpyAsync(t->sceneDepthOwned, depth, bytes, hipMemcpyHostToDevice, t->ctx->stream));
+    GS_HIP(hipStreamSynchronize(t->ctx->stream));               // `depth` is only read during the call
+    t->sceneDepth = t->sceneDepthOwned;
     return GS_OK;
 }
 

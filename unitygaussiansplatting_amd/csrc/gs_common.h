@@ -50,6 +50,15 @@ struct alignas(16) SplatRec {
 };
 static_assert(sizeof(SplatRec) == 32, "SplatRec is 32 B");
 
+// everything calc_view writes (all in splat-index order)
+struct ViewOutputs {
+    gsm::ViewData* view;            // N x 40 B SplatViewData (FULL launches only)
+    SplatRec* recs;                 // N x 32 B blend records (visible splats only)
+    uint2* rects;                   // N x 8 B tile rectangles
+    unsigned long long* visMask;    // 1 bit per splat
+    float* recW;                    // N x 4 B view depth (clip.w) of visible splats: the scene-depth test and the debug point modes
+};
+
 // Onesweep look-back state for one sort (shared by all passes: every pass uses a fresh epoch)
 struct SortState {
     uint32_t* altKeys = nullptr;
@@ -125,6 +134,11 @@ struct gs_target {
     uint16_t* rgba16f = nullptr;            // W*H*4 halfs
     bool clearPending = false;              // gs_target_clear was called and nothing has touched the target since: the next
                                             // draw writes every pixel itself (no 8 B/px memset); any other reader clears first
+    // optional depth attachment (the camera's depth buffer the reference draws the splats against, GaussianSplatRenderer.cs:195):
+    // W*H view depths of the opaque scene; a fragment survives iff the splat's clip.w <= depth
+    const float* sceneDepth = nullptr;      // device
+    float* sceneDepthOwned = nullptr;       // the copy made of a host buffer (sceneDepth points at it), or null
+    unsigned long long* zbuf = nullptr;     // W*H x u64 {view depth bits, ~splat index}: the depth buffer of the debug point modes (all ones = empty)
     float* resolved = nullptr;              // W*H*4 floats, lazily allocated
     uint8_t* resolved8 = nullptr;
     // optional timing of gs_target_resolve: a ring of event pairs on the context's stream
@@ -148,6 +162,7 @@ struct gs_renderer {
     int depthControlIdx = 0;                   // the block the last / current sort uses
     // compositor buffers
     gs::SplatRec* recs = nullptr;           // N x 32 B, indexed by splat (written by calc_view)
+    float* recW = nullptr;                  // N x 4 B: clip.w of the visible splats
     uint2* rects = nullptr;                 // N x 8 B: x = tx0 | ty0 << 16, y = tiles wide | tiles high << 16 (0 = culled)
     unsigned long long* visMask = nullptr;  // ceil(N/64) x 8 B: bit s = splat s reaches at least one tile (written by calc_view)
     // edit state read by calc_view (m_GpuEditDeleted / m_GpuEditCutouts, GaussianSplatRenderer.cs:266,269)
@@ -176,6 +191,8 @@ struct gs_renderer {
     uint32_t* tileCost = nullptr;           // arenaTiles x u32: 256-record batches each tile walked in the previous draw (scheduling hint)
     uint32_t binParts = 0;
     int blendMode = 0;
+    int renderMode = 0;                     // gs_render_mode (GaussianSplatRenderer.RenderMode, :126-131)
+    float pointDisplaySize = 3.0f;          // m_PointDisplaySize
     // profiling: a ring of per-frame hipEvent sets (slot advances at the end of gs_renderer_draw)
     bool profiling = false;
     hipEvent_t* ev = nullptr;               // profCapacity x kEvPerFrame
@@ -216,13 +233,14 @@ int32_t enqueue_sort_passes(gs_context* ctx, hipStream_t stream, SortState& st, 
 constexpr uint32_t kSortMaxCount = 1u << 30;   // 32-bit byte offsets inside the sort kernels
 int32_t enqueue_set_indices(gs_context* ctx, uint32_t* order, uint32_t n);
 // view (gs_view.hip)
-int32_t enqueue_calc_view(gs_context* ctx, const gsm::AssetView& a, const gs_frame_params* p, const gsm::EditView& e, gsm::ViewData* out,
-                          SplatRec* recs, uint2* rects, unsigned long long* visMask, bool full);
+int32_t enqueue_calc_view(gs_context* ctx, const gsm::AssetView& a, const gs_frame_params* p, const gsm::EditView& e, const ViewOutputs& out, bool full);
+ViewOutputs view_outputs(gs_renderer* r);
 void flatten_params(const gs_frame_params* p, gsm::FrameConsts& c);
 // raster (gs_raster.hip)
 int32_t renderer_alloc_raster(gs_renderer* r);
 void renderer_free_raster(gs_renderer* r);
 int32_t enqueue_draw(gs_renderer* r, const gs_frame_params* p, gs_target* rt);
+int32_t enqueue_debug_points(gs_renderer* r, const gs_frame_params* p, gs_target* rt);   // RenderMode.DebugPoints / DebugPointIndices
 int32_t enqueue_resolve(gs_target* t, const float bg[4], bool want8);
 int32_t flush_clear(gs_target* t);          // perform a pending gs_target_clear now
 } // namespace gs

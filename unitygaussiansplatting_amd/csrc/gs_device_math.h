@@ -325,6 +325,141 @@ GS_HD bool ChunkOutside(const AssetView& a, const FrameConsts& P, uint32_t chunk
     return all != 0u;
 }
 
+
+// ---- BC7 (BPTC) block decode: ColorFormat.BC7 = GraphicsFormat.RGBA_BC7_UNorm (GaussianSplatAsset.cs:56,169), the colour
+// texture of the VeryLow preset (GaussianSplatAssetCreator.cs:198,893-910), sampled by _SplatColor.Load in LoadSplatData.
+// The texture unit decodes the 16-byte block of the 4x4 texels around the splat's texel; here: one block load + the decode
+// of that ONE texel.  Format: Khronos Data Format Specification, "BPTC"; the partition / anchor tables are those of
+// unitygaussiansplatting_amd/bc7.py, extracted from and cross-checked against an independent decoder (Pillow) by
+// tests/test_bc7.py.  Returns r | g << 8 | b << 16 | a << 24.
+GS_HD uint32_t bc7_bits(uint64_t lo, uint64_t hi, uint32_t pos, uint32_t n) {      // n <= 8 bits at bit `pos` of the 128-bit block
+    uint64_t v;
+    if (pos >= 64u) v = hi >> (pos - 64u);
+    else v = (lo >> pos) | (pos ? (hi << (64u - pos)) : 0ull);
+    return (uint32_t)v & ((1u << n) - 1u);
+}
+GS_HD uint32_t DecodeBC7Texel(const uint8_t* block, uint32_t texel) {
+        static constexpr uint16_t kP2[64] = { 0xcccc, 0x8888, 0xeeee, 0xecc8, 0xc880, 0xfeec, 0xfec8, 0xec80, 0xc800, 0xffec, 0xfe80, 0xe800, 0xffe8, 0xff00, 0xfff0, 0xf000, 0xf710, 0x8e, 0x7100, 0x8ce, 0x8c, 0x7310, 0x3100, 0x8cce, 0x88c, 0x3110, 0x6666, 0x366c, 0x17e8, 0xff0, 0x718e, 0x399c, 0xaaaa, 0xf0f0, 0x5a5a, 0x33cc, 0x3c3c, 0x55aa, 0x9696, 0xa55a, 0x73ce, 0x13c8, 0x324c, 0x3bdc, 0x6996, 0xc33c, 0x9966, 0x660, 0x272, 0x4e4, 0x4e40, 0x2720, 0xc936, 0x936c, 0x39c6, 0x639c, 0x9336, 0x9cc6, 0x817e, 0xe718, 0xccf0, 0xfcc, 0x7744, 0xee22 };
+        static constexpr uint32_t kP3[64] = { 0xaa685050, 0x6a5a5040, 0x5a5a4200, 0x5450a0a8, 0xa5a50000, 0xa0a05050, 0x5555a0a0, 0x5a5a5050, 0xaa550000, 0xaa555500, 0xaaaa5500, 0x90909090, 0x94949494, 0xa4a4a4a4, 0xa9a59450, 0x2a0a4250, 0xa5945040, 0xa425054, 0xa5a5a500, 0x55a0a0a0, 0xa8a85454, 0x6a6a4040, 0xa4a45000, 0x1a1a0500, 0x50a4a4, 0xaaa59090, 0x14696914, 0x69691400, 0xa08585a0, 0xaa821414, 0x50a4a450, 0x6a5a0200, 0xa9a58000, 0x5090a0a8, 0xa8a09050, 0x24242424, 0xaa5500, 0x24924924, 0x24499224, 0x50a50a50, 0x500aa550, 0xaaaa4444, 0x66660000, 0xa5a0a5a0, 0x50a050a0, 0x69286928, 0x44aaaa44, 0x66666600, 0xaa444444, 0x54a854a8, 0x95809580, 0x96969600, 0xa85454a8, 0x80959580, 0xaa141414, 0x96960000, 0xaaaa1414, 0xa05050a0, 0xa0a5a5a0, 0x96000000, 0x40804080, 0xa9a8a9a8, 0xaaaaaa44, 0x2a4a5254 };
+        static constexpr uint8_t kA2[64] = { 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 2, 8, 2, 2, 8, 8, 15, 2, 8, 2, 2, 8, 8, 2, 2, 15, 15, 6, 8, 2, 8, 15, 15, 2, 8, 2, 2, 2, 15, 15, 6, 6, 2, 6, 8, 15, 15, 2, 2, 15, 15, 15, 15, 15, 2, 2, 15 };
+        static constexpr uint8_t kA3a[64] = { 3, 3, 15, 15, 8, 3, 15, 15, 8, 8, 6, 6, 6, 5, 3, 3, 3, 3, 8, 15, 3, 3, 6, 10, 5, 8, 8, 6, 8, 5, 15, 15, 8, 15, 3, 5, 6, 10, 8, 15, 15, 3, 15, 5, 15, 15, 15, 15, 3, 15, 5, 5, 5, 8, 5, 10, 5, 10, 8, 13, 15, 12, 3, 3 };
+        static constexpr uint8_t kA3b[64] = { 15, 8, 8, 3, 15, 15, 3, 8, 15, 15, 15, 15, 15, 15, 15, 8, 15, 8, 15, 3, 15, 8, 15, 8, 3, 15, 6, 10, 15, 15, 10, 8, 15, 3, 15, 10, 10, 8, 9, 10, 6, 15, 8, 15, 3, 6, 6, 8, 15, 3, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 3, 15, 15, 8 };
+        // per mode: subsets, partition bits, rotation bits, index-selection bits, colour bits, alpha bits, endpoint p-bits, shared p-bits,
+        // index bits, secondary index bits -- packed 4 bits each, lowest nibble first
+        static constexpr uint64_t kMode[8] = { 0x301040043ull, 0x310060062ull, 0x200050063ull, 0x201070062ull, 0x3200651201ull, 0x2200870201ull, 0x401770001ull, 0x201550062ull };
+        static constexpr uint8_t kW2[4] = { 0, 21, 43, 64 };
+        static constexpr uint8_t kW3[8] = { 0, 9, 18, 27, 37, 46, 55, 64 };
+        static constexpr uint8_t kW4[16] = { 0, 4, 9, 13, 17, 21, 26, 30, 34, 38, 43, 47, 51, 55, 60, 64 };
+    const uint64_t lo = (uint64_t)ld32a(block, 0) | ((uint64_t)ld32a(block, 4) << 32), hi = (uint64_t)ld32a(block, 8) | ((uint64_t)ld32a(block, 12) << 32);
+    const uint32_t m8 = (uint32_t)lo & 255u;
+    if (m8 == 0u) return 0u;                                              // reserved mode: the block decodes to zero
+    uint32_t mode = 0;
+    while (!((m8 >> mode) & 1u)) ++mode;
+    const uint64_t mi = kMode[mode];
+    const uint32_t ns = (uint32_t)(mi & 15), pb = (uint32_t)(mi >> 4) & 15, rb = (uint32_t)(mi >> 8) & 15, isb = (uint32_t)(mi >> 12) & 15,
+                   cb = (uint32_t)(mi >> 16) & 15, ab = (uint32_t)(mi >> 20) & 15, epb = (uint32_t)(mi >> 24) & 15, spb = (uint32_t)(mi >> 28) & 15,
+                   ib = (uint32_t)(mi >> 32) & 15, ib2 = (uint32_t)(mi >> 36) & 15;
+    uint32_t pos = mode + 1u;
+    const uint32_t shape = bc7_bits(lo, hi, pos, pb); pos += pb;
+    const uint32_t rot = bc7_bits(lo, hi, pos, rb); pos += rb;
+    const uint32_t isel = bc7_bits(lo, hi, pos, isb); pos += isb;
+    uint32_t s = 0, an1 = 16u, an2 = 16u;                                 // subset of the texel, anchors of subsets 1 and 2
+    if (ns == 2u) { s = (kP2[shape] >> texel) & 1u; an1 = kA2[shape]; }
+    else if (ns == 3u) { s = (kP3[shape] >> (2u * texel)) & 3u; an1 = kA3a[shape]; an2 = kA3b[shape]; }
+    const uint32_t ne = 2u * ns, e0 = 2u * s, e1 = e0 + 1u;
+    uint32_t c0[4], c1[4];
+#pragma unroll
+    for (uint32_t ch = 0; ch < 3u; ++ch) {
+        c0[ch] = bc7_bits(lo, hi, pos + (ch * ne + e0) * cb, cb);
+        c1[ch] = bc7_bits(lo, hi, pos + (ch * ne + e1) * cb, cb);
+    }
+    pos += 3u * ne * cb;
+    c0[3] = 255u; c1[3] = 255u;
+    if (ab) { c0[3] = bc7_bits(lo, hi, pos + e0 * ab, ab); c1[3] = bc7_bits(lo, hi, pos + e1 * ab, ab); pos += ne * ab; }
+    uint32_t cbits = cb, abits = ab;
+    if (epb) {
+        const uint32_t p0 = bc7_bits(lo, hi, pos + e0, 1), p1 = bc7_bits(lo, hi, pos + e1, 1);
+        pos += ne;
+#pragma unroll
+        for (uint32_t ch = 0; ch < 3u; ++ch) { c0[ch] = (c0[ch] << 1) | p0; c1[ch] = (c1[ch] << 1) | p1; }
+        if (ab) { c0[3] = (c0[3] << 1) | p0; c1[3] = (c1[3] << 1) | p1; abits++; }
+        cbits++;
+    } else if (spb) {
+        const uint32_t p = bc7_bits(lo, hi, pos + s, 1);
+        pos += ns;
+#pragma unroll
+        for (uint32_t ch = 0; ch < 3u; ++ch) { c0[ch] = (c0[ch] << 1) | p; c1[ch] = (c1[ch] << 1) | p; }
+        cbits++;
+    }
+#pragma unroll
+    for (uint32_t ch = 0; ch < 3u; ++ch) {                                 // left-align to 8 bits, replicate the top bits
+        c0[ch] <<= 8u - cbits; c0[ch] |= c0[ch] >> cbits;
+        c1[ch] <<= 8u - cbits; c1[ch] |= c1[ch] >> cbits;
+    }
+    if (ab) { c0[3] <<= 8u - abits; c0[3] |= c0[3] >> abits; c1[3] <<= 8u - abits; c1[3] |= c1[3] >> abits; }
+    // index of this texel: ib bits per texel, one bit less for each subset's anchor texel
+    const uint32_t before = (texel > 0u ? 1u : 0u) + (texel > an1 ? 1u : 0u) + (texel > an2 ? 1u : 0u);
+    const bool isAnchor = texel == 0u || texel == an1 || texel == an2;
+    uint32_t i1 = bc7_bits(lo, hi, pos + texel * ib - before, ib - (isAnchor ? 1u : 0u));
+    pos += 16u * ib - ns;
+    uint32_t ci = i1, cbt = ib, ai = i1, abt = ib;
+    if (ib2) {
+        const uint32_t i2 = bc7_bits(lo, hi, pos + texel * ib2 - (texel > 0u ? 1u : 0u), ib2 - (texel == 0u ? 1u : 0u));
+        ai = i2; abt = ib2;
+        if (isel) { ci = i2; cbt = ib2; ai = i1; abt = ib; }
+    }
+    const uint32_t wc = cbt == 2u ? kW2[ci] : (cbt == 3u ? kW3[ci] : kW4[ci]);
+    const uint32_t wa = abt == 2u ? kW2[ai] : (abt == 3u ? kW3[ai] : kW4[ai]);
+    uint32_t px[4];
+#pragma unroll
+    for (uint32_t ch = 0; ch < 3u; ++ch) px[ch] = ((64u - wc) * c0[ch] + wc * c1[ch] + 32u) >> 6;
+    px[3] = ((64u - wa) * c0[3] + wa * c1[3] + 32u) >> 6;
+    if (rot == 1u) { const uint32_t t = px[3]; px[3] = px[0]; px[0] = t; }
+    else if (rot == 2u) { const uint32_t t = px[3]; px[3] = px[1]; px[1] = t; }
+    else if (rot == 3u) { const uint32_t t = px[3]; px[3] = px[2]; px[2] = t; }
+    return px[0] | (px[1] << 8) | (px[2] << 16) | (px[3] << 24);
+}
+
+// _SplatColor.Load(SplatIndexToPixelIndex(idx)) (GaussianSplatting.hlsl:456-458): the texel as the texture unit returns it,
+// before the chunk de-normalisation
+GS_HD V4 LoadColorTexel(const AssetView& a, uint32_t idx) {
+    uint32_t tx, ty;
+    SplatIndexToPixelIndex(idx, tx, ty);
+    const uint64_t texel = (uint64_t)ty * 2048 + tx;
+    if (a.colorFmt == 0) {
+        const uint8_t* c = a.color + texel * 16;
+        return { u2f(ld32a(c, 0)), u2f(ld32a(c, 4)), u2f(ld32a(c, 8)), u2f(ld32a(c, 12)) };
+    }
+    if (a.colorFmt == 1) {
+        const uint32_t lo = ld32a(a.color, texel * 8), hi = ld32a(a.color, texel * 8 + 4);
+        return { f16tof32(lo), f16tof32(lo >> 16), f16tof32(hi), f16tof32(hi >> 16) };
+    }
+    uint32_t e;
+    if (a.colorFmt == 3) e = DecodeBC7Texel(a.color + ((uint64_t)(ty >> 2) * 512 + (tx >> 2)) * 16, (ty & 3u) * 4u + (tx & 3u));   // RGBA_BC7_UNorm, 512 blocks per row
+    else e = ld32a(a.color, texel * 4);
+    return { (float)(e & 255) * GS_R255, (float)((e >> 8) & 255) * GS_R255, (float)((e >> 16) & 255) * GS_R255, (float)(e >> 24) * GS_R255 };
+}
+
+// splat.sh.col of LoadSplatData: the de-normalised DC colour (GaussianSplatting.hlsl:456-458,590-596), what the debug point
+// shader shows (GaussianDebugRenderPoints.shader:48)
+GS_HD V3 LoadSplatBaseColor(const AssetView& a, uint32_t idx) {
+    V4 col = LoadColorTexel(a, idx);
+    const uint32_t ci = idx >> 8;
+    if (ci < a.chunkCount) {
+        const uint8_t* c = a.chunk + (uint64_t)ci * 64;
+        col.x = lerpf(f16tof32(ld32a(c, 0)), f16tof32(ld32a(c, 0) >> 16), col.x);
+        col.y = lerpf(f16tof32(ld32a(c, 4)), f16tof32(ld32a(c, 4) >> 16), col.y);
+        col.z = lerpf(f16tof32(ld32a(c, 8)), f16tof32(ld32a(c, 8) >> 16), col.z);
+    }
+    return { col.x, col.y, col.z };
+}
+// GaussianDebugRenderPoints.shader:49-54 (_DisplayIndex): a colour that encodes the splat's index
+GS_HD V3 DebugIndexColor(uint32_t idx, uint32_t count) {
+    const float f = (float)idx / (float)count;
+    const float r = f * 100.0f, g = f * 10.0f;
+    return { r - floorf(r), g - floorf(g), f };
+}
+
 // IsSplatCut (SplatUtilities.compute:164-187); pos is the object-space position
 GS_HD bool IsSplatCut(const EditView& e, float px, float py, float pz) {
     bool finalCut = false;
@@ -442,20 +577,7 @@ GS_HD void CalcViewGeom(const AssetView& a, const FrameConsts& P, const EditView
     const V4 q = DecodeRotation(LoadUInt(a.other, otherAddr));
 
     // ---- colour texel
-    uint32_t tx, ty;
-    SplatIndexToPixelIndex(idx, tx, ty);
-    const uint64_t texel = (uint64_t)ty * 2048 + tx;
-    V4 col;
-    if (a.colorFmt == 0) {
-        const uint8_t* c = a.color + texel * 16;
-        col = { u2f(ld32a(c, 0)), u2f(ld32a(c, 4)), u2f(ld32a(c, 8)), u2f(ld32a(c, 12)) };
-    } else if (a.colorFmt == 1) {
-        const uint32_t lo = ld32a(a.color, texel * 8), hi = ld32a(a.color, texel * 8 + 4);
-        col = { f16tof32(lo), f16tof32(lo >> 16), f16tof32(hi), f16tof32(hi >> 16) };
-    } else {
-        const uint32_t e = ld32a(a.color, texel * 4);
-        col = { (float)(e & 255) * GS_R255, (float)((e >> 8) & 255) * GS_R255, (float)((e >> 16) & 255) * GS_R255, (float)(e >> 24) * GS_R255 };
-    }
+    V4 col = LoadColorTexel(a, idx);
 
     if (chunked) {
         col.x = lerpf(f16tof32(ck.w[0]), f16tof32(ck.w[0] >> 16), col.x);

@@ -439,11 +439,16 @@ typedef uint32_t u4v __attribute__((ext_vector_type(4)));
 #ifdef GS_EXP_BLEND_TIMELINE      // experiment build: per-tile start / end (100 MHz wall clock), list length, batches walked
 __device__ unsigned long long g_blend_tl[65536 * 8];
 #endif
-template <int MODE>
+// DEPTH: the target has a depth attachment (gs_target_set_scene_depth): the reference draws the splats with the default
+// ZTest LEqual, ZWrite Off against the camera's depth buffer (RenderGaussianSplats.shader:10; the RT is bound with the
+// current depth, GaussianSplatRenderer.cs:195), and all four vertices of a quad carry the centre's depth (:56-60), so a
+// fragment survives iff the splat's view depth clip.w <= the opaque scene's view depth at that pixel.
+template <int MODE, bool DEPTH>
 __global__ __launch_bounds__(256) void blend_kernel(const uint32_t* __restrict__ pairVals, const uint32_t* __restrict__ tileStart,
                                                     const uint32_t* __restrict__ tileEnd, const uint32_t* __restrict__ tileOrder,
                                                     uint32_t* __restrict__ tileCost, const SplatRec* __restrict__ recs,
-                                                    uint16_t* __restrict__ rt, RasterConsts rc, int dstIsZero) {
+                                                    uint16_t* __restrict__ rt, RasterConsts rc, int dstIsZero,
+                                                    const float* __restrict__ recW, const float* __restrict__ sceneDepth) {
     __shared__ float4 s_a[256];      // cx, cy, u1x, u1y      (u_k = axis_k / |axis_k|^2)
     __shared__ uint4 s_b[256];       // u2x, u2y (float bits), f16 r << 16 | f16 g, f16 b << 16 | f16 a
     __shared__ float4 s_e[256];      // half extents of the footprint's bounding box, pixels; r^2 = ln(255 a) with slack
@@ -476,6 +481,8 @@ __global__ __launch_bounds__(256) void blend_kernel(const uint32_t* __restrict__
     const float qminx = (float)qx0 + 0.5f, qmaxx = (float)qx0 + 7.5f, qminy = (float)qy0 + 0.5f, qmaxy = (float)qy0 + 7.5f;
 
     PixelAcc<MODE> acc;
+    float sceneZ = 0.0f;
+    if (DEPTH) sceneZ = inside ? sceneDepth[(size_t)py * rc.width + (size_t)px] : 0.0f;
     uint2* dst = (uint2*)(rt + ((size_t)py * rc.width + (size_t)px) * 4);
     acc.load((inside && !dstIsZero) ? *dst : make_uint2(0u, 0u));
     if (tid == 0) s_done = 0;
@@ -487,9 +494,12 @@ __global__ __launch_bounds__(256) void blend_kernel(const uint32_t* __restrict__
     // it at the end of the branch, which is exactly the latency this is meant to hide.
     const uint32_t lastPair = end - 1u;
     float4 r0, r1;
+    float rw = 0.0f;                                              // DEPTH: the record's view depth
     {
-        const float4* rp = (const float4*)(recs + pairVals[min(start + (uint32_t)tid, lastPair)]);
+        const uint32_t s0 = pairVals[min(start + (uint32_t)tid, lastPair)];
+        const float4* rp = (const float4*)(recs + s0);
         r0 = rp[0]; r1 = rp[1];                                   // cx cy a1x a1y | a2x a2y c0 c1
+        if (DEPTH) rw = recW[s0];
     }
     uint32_t sidxNext = pairVals[min(start + 256u + (uint32_t)tid, lastPair)];
     for (uint32_t bs = start; bs < end; bs += 256u) {
@@ -511,11 +521,12 @@ __global__ __launch_bounds__(256) void blend_kernel(const uint32_t* __restrict__
             const float exe = rr * sqrtf(gsm::dot2f(r0.z, r1.x, r0.z, r1.x)), eye = rr * sqrtf(gsm::dot2f(r0.w, r1.y, r0.w, r1.y));
             s_a[tid] = make_float4(r0.x, r0.y, r0.z * inv1, r0.w * inv1);
             s_b[tid] = make_uint4(gsm::f2u(r1.x * inv2), gsm::f2u(r1.y * inv2), gsm::f2u(r1.z), gsm::f2u(r1.w));
-            s_e[tid] = make_float4(fminf(exr, exe) + 0.02f, fminf(eyr, eye) + 0.02f, r2, 0.0f);
+            s_e[tid] = make_float4(fminf(exr, exe) + 0.02f, fminf(eyr, eye) + 0.02f, r2, rw);
         }
         {
             const float4* rp = (const float4*)(recs + sidxNext);
             r0 = rp[0]; r1 = rp[1];
+            if (DEPTH) rw = recW[sidxNext];
             sidxNext = pairVals[min(bs + 512u + (uint32_t)tid, lastPair)];
         }
         __syncthreads();
@@ -554,6 +565,7 @@ __global__ __launch_bounds__(256) void blend_kernel(const uint32_t* __restrict__
                     const float alpha = mix_mul_lo_sat_after_trans(B4.w, __expf(power));
 #endif
                     bool live = ((int)(fabsf(q1) <= 2.0f) & (int)(fabsf(q2) <= 2.0f) & (int)(alpha >= 1.0f / 255.0f)) != 0;
+                    if (DEPTH) live = live && (s_e[c + b].w <= sceneZ);                // ZTest LEqual on the quad's (single) depth
                     if (MODE == 1) live = live && !acc.saturated();
                     if (live) acc.blend(B4.z, B4.w, alpha);
                 }
@@ -583,6 +595,53 @@ extern "C" int32_t gs_debug_read_blend_timeline(void* out, size_t bytes) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_blend_tl), bytes) == hipSuccess ? 0 : -2;
 }
 #endif
+
+// RenderMode.DebugPoints / DebugPointIndices (GaussianDebugRenderPoints.shader; GaussianSplatRenderer.cs:126-131,148-161):
+// every splat, in index order (no order buffer), is an opaque screen-space square of _SplatSize pixels around its projected
+// centre, colour = saturate(DC colour) or an index code, drawn with ZWrite On + the default ZTest LEqual.  As compute: the
+// square's pixels race with a 64-bit atomicMin on {view depth, ~index} (nearest wins; at equal depth the LATER instance, as
+// LEqual lets it overwrite), then a second kernel turns the winners into colours and resets the depth words.  Pixel centres
+// are sampled with the top-left rule; a square whose centre depth is outside [near, far] is clipped as a whole.
+__global__ __launch_bounds__(256) void debug_points_kernel(gsm::AssetView a, gsm::FrameConsts P, float halfSize, uint32_t width, uint32_t height,
+                                                           const float* __restrict__ sceneDepth, unsigned long long* __restrict__ zbuf) {
+    const uint32_t idx = blockIdx.x * 256u + threadIdx.x;
+    if (idx >= a.n) return;
+    const gsm::V3 pos = gsm::LoadSplatPos(a, idx);
+    const float wx = gsm::mrow(P.o2w, 0, pos.x, pos.y, pos.z), wy = gsm::mrow(P.o2w, 1, pos.x, pos.y, pos.z), wz = gsm::mrow(P.o2w, 2, pos.x, pos.y, pos.z);
+    const float cxc = gsm::mrow(P.vp, 0, wx, wy, wz), cyc = gsm::mrow(P.vp, 1, wx, wy, wz), w = gsm::mrow(P.vp, 3, wx, wy, wz);
+    if (!(w >= P.nearClip && w <= P.farClip)) return;
+    const float invw = 1.0f / w;
+    const float cx = fmaf(0.5f * (cxc * invw), P.screenW, 0.5f * P.screenW);
+    const float cy = fmaf(-0.5f * (cyc * invw), P.screenH, 0.5f * P.screenH);
+    if (!(gsm::finite32(cx) && gsm::finite32(cy))) return;
+    // pixel (i, j) is covered iff cx - h <= i + 0.5 < cx + h (left / top edges belong to the square)
+    const float x0f = fmaxf(ceilf((cx - halfSize) - 0.5f), 0.0f), x1f = fminf(ceilf((cx + halfSize) - 0.5f) - 1.0f, (float)width - 1.0f);
+    const float y0f = fmaxf(ceilf((cy - halfSize) - 0.5f), 0.0f), y1f = fminf(ceilf((cy + halfSize) - 0.5f) - 1.0f, (float)height - 1.0f);
+    if (!(x0f <= x1f && y0f <= y1f)) return;
+    const unsigned long long key = ((unsigned long long)gsm::f2u(w) << 32) | (unsigned long long)(0xffffffffu - idx);
+    for (int y = (int)y0f; y <= (int)y1f; ++y)
+        for (int x = (int)x0f; x <= (int)x1f; ++x) {
+            const size_t pi = (size_t)y * width + (size_t)x;
+            if (sceneDepth && !(w <= sceneDepth[pi])) continue;
+            atomicMin(&zbuf[pi], key);
+        }
+}
+
+__global__ __launch_bounds__(256) void debug_points_resolve_kernel(gsm::AssetView a, uint32_t numPix, int displayIndex, unsigned long long* __restrict__ zbuf,
+                                                                   uint16_t* __restrict__ rt) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= numPix) return;
+    const unsigned long long key = zbuf[i];
+    if (key == ~0ull) return;                                   // nothing drawn here: the target keeps what it had
+    zbuf[i] = ~0ull;
+    const uint32_t idx = 0xffffffffu - (uint32_t)key;
+    gsm::V3 c = displayIndex ? gsm::DebugIndexColor(idx, a.n) : gsm::LoadSplatBaseColor(a, idx);
+    if (!displayIndex) { c.x = gsm::sat(c.x); c.y = gsm::sat(c.y); c.z = gsm::sat(c.z); }
+    uint2 o;
+    o.x = gsm::f32tof16(c.x) | (gsm::f32tof16(c.y) << 16);
+    o.y = gsm::f32tof16(c.z) | (0x3c00u << 16);                  // frag: half4(color, 1), no blending
+    ((uint2*)rt)[i] = o;
+}
 
 // GaussianComposite.shader:25-39 + "Blend SrcAlpha OneMinusSrcAlpha" over a constant background
 __global__ __launch_bounds__(256) void resolve_kernel(const uint16_t* __restrict__ rt, uint32_t numPix, float bgr, float bgg, float bgb,
@@ -647,10 +706,13 @@ int32_t ensure_arena(gs_renderer* r, uint32_t numTiles) {
 
 } // namespace
 
+ViewOutputs view_outputs(gs_renderer* r) { return ViewOutputs{ r->view, r->recs, r->rects, r->visMask, r->recW }; }
+
 int32_t renderer_alloc_raster(gs_renderer* r) {
     gs_context* ctx = r->ctx;
     r->binParts = div_up(r->n, kBinPart);
     GS_HIP(hipMalloc((void**)&r->recs, (size_t)r->n * sizeof(SplatRec) + 64));
+    GS_HIP(hipMalloc((void**)&r->recW, (size_t)r->n * sizeof(float) + 64));
     GS_HIP(hipMalloc((void**)&r->rects, (size_t)r->n * sizeof(uint2) + 64));
     GS_HIP(hipMemsetAsync(r->rects, 0, (size_t)r->n * sizeof(uint2), ctx->stream));
     GS_HIP(hipMalloc((void**)&r->visMask, ((size_t)r->n + 63) / 64 * 8 + 64));
@@ -673,6 +735,8 @@ int32_t renderer_alloc_raster(gs_renderer* r) {
 void renderer_free_raster(gs_renderer* r) {
     if (r->recs) (void)hipFree(r->recs);
     if (r->rects) (void)hipFree(r->rects);
+    if (r->recW) (void)hipFree(r->recW);
+    r->recW = nullptr;
     if (r->visMask) (void)hipFree(r->visMask);
     if (r->pairKeys) (void)hipFree(r->pairKeys);
     if (r->pairVals) (void)hipFree(r->pairVals);
@@ -737,13 +801,37 @@ int32_t enqueue_draw(gs_renderer* r, const gs_frame_params* p, gs_target* rt) {
     prof_record(r, 5);
     const int dstIsZero = rt->clearPending ? 1 : 0;             // this draw writes every pixel of the target: the clear is folded in
     rt->clearPending = false;
-    if (r->blendMode == 0)
-        hipLaunchKernelGGL(blend_kernel<0>, dim3(numTiles), dim3(256), 0, st, r->pairVals, tileStart, tileEnd, tileOrder, r->tileCost, r->recs, rt->rgba16f, rc, dstIsZero);
-    else
-        hipLaunchKernelGGL(blend_kernel<1>, dim3(numTiles), dim3(256), 0, st, r->pairVals, tileStart, tileEnd, tileOrder, r->tileCost, r->recs, rt->rgba16f, rc, dstIsZero);
+#define GS_LAUNCH_BLEND(M, D) hipLaunchKernelGGL((blend_kernel<M, D>), dim3(numTiles), dim3(256), 0, st, r->pairVals, tileStart, tileEnd, tileOrder, \
+                                             r->tileCost, r->recs, rt->rgba16f, rc, dstIsZero, r->recW, rt->sceneDepth)
+    if (rt->sceneDepth) { if (r->blendMode == 0) GS_LAUNCH_BLEND(0, true); else GS_LAUNCH_BLEND(1, true); }
+    else { if (r->blendMode == 0) GS_LAUNCH_BLEND(0, false); else GS_LAUNCH_BLEND(1, false); }
+#undef GS_LAUNCH_BLEND
     prof_record(r, 6);
     GS_HIP(hipGetLastError());
     r->frameInFlight = true;
+    prof_end_frame(r);
+    return GS_OK;
+}
+
+int32_t enqueue_debug_points(gs_renderer* r, const gs_frame_params* p, gs_target* rt) {
+    gs_context* ctx = r->ctx;
+    hipStream_t st = ctx->stream;
+    GS_TRY(flush_clear(rt));                                    // the squares only touch the pixels they cover
+    const uint32_t numPix = rt->width * rt->height;
+    if (!rt->zbuf) {
+        GS_HIP(hipMalloc((void**)&rt->zbuf, (size_t)numPix * 8));
+        GS_HIP(hipMemsetAsync(rt->zbuf, 0xff, (size_t)numPix * 8, st));      // afterwards the resolve kernel resets what it consumes
+    }
+    gsm::FrameConsts c;
+    flatten_params(p, c);
+    prof_record(r, 3);
+    hipLaunchKernelGGL(debug_points_kernel, dim3(div_up(r->n, 256)), dim3(256), 0, st, r->asset->view, c, 0.5f * r->pointDisplaySize, rt->width, rt->height,
+                       rt->sceneDepth, rt->zbuf);
+    prof_record(r, 5);
+    hipLaunchKernelGGL(debug_points_resolve_kernel, dim3(div_up(numPix, 256)), dim3(256), 0, st, r->asset->view, numPix, r->renderMode == GS_RENDER_DEBUG_POINT_INDICES ? 1 : 0,
+                       rt->zbuf, rt->rgba16f);
+    prof_record(r, 6);
+    GS_HIP(hipGetLastError());
     prof_end_frame(r);
     return GS_OK;
 }

@@ -135,8 +135,10 @@ __global__ __launch_bounds__(1024) void sort_keys_kernel(gsm::AssetView a, float
     constexpr uint32_t ILP = GS_KEYS_ILP;
     const uint32_t chunks = (n + 255u) >> 8;
     const uint32_t sub = threadIdx.x >> 8, t = threadIdx.x & 255u;
-    for (uint32_t c0 = blockIdx.x * (4u * ILP); c0 < chunks; c0 += gridDim.x * (4u * ILP)) {
-        gsm::V3 p[ILP];
+    const uint32_t step = gridDim.x * (4u * ILP);
+    // two-stage software pipeline: the positions of the next ILP chunks are in flight while the keys of the current ones go
+    // through the LDS histograms (the LDS atomic unit and the memory pipe then work at the same time instead of in turns)
+    auto load = [&](uint32_t c0, gsm::V3 (&p)[ILP]) {
 #pragma unroll
         for (uint32_t k = 0; k < ILP; ++k) {
             const uint32_t ci = __builtin_amdgcn_readfirstlane(c0 + k * 4u + sub);       // wave-uniform: 4 waves per chunk
@@ -144,16 +146,27 @@ __global__ __launch_bounds__(1024) void sort_keys_kernel(gsm::AssetView a, float
             p[k] = gsm::V3{0.f, 0.f, 0.f};
             if (idx < n) p[k] = gsm::LoadSplatPosChunk(a, idx, ci);
         }
+    };
+    gsm::V3 cur[ILP], nxt[ILP];
+    uint32_t c0 = blockIdx.x * (4u * ILP);
+    if (c0 < chunks) load(c0, cur);
+    for (; c0 < chunks; c0 += step) {
+        const bool more = c0 + step < chunks;                                            // workgroup-uniform
+        if (more) load(c0 + step, nxt);
 #pragma unroll
         for (uint32_t k = 0; k < ILP; ++k) {
             const uint32_t idx = (c0 + k * 4u + sub) * 256u + t;
             if (idx >= n) continue;
-            const uint32_t key = gsm::SortKeyOf(p[k], m20, m21, m22, m23);
+            const uint32_t key = gsm::SortKeyOf(cur[k], m20, m21, m22, m23);
             keyBySplat[idx] = key;
             lds_hist_add(s_h, key & 255u);
             lds_hist_add(s_h + RADIX, (key >> 8) & 255u);
             lds_hist_add(s_h + 2 * RADIX, (key >> 16) & 255u);
             lds_hist_add(s_h + 3 * RADIX, key >> 24);
+        }
+        if (more) {
+#pragma unroll
+            for (uint32_t k = 0; k < ILP; ++k) cur[k] = nxt[k];
         }
     }
     __syncthreads();
@@ -179,6 +192,9 @@ __device__ unsigned long long g_timeline[16384 * 16];
 #ifndef GS_SORT_LOOKBACK_BATCH
 #define GS_SORT_LOOKBACK_BATCH 16
 #endif
+#ifndef GS_SORT_XCD_BLOCKS
+#define GS_SORT_XCD_BLOCKS 1
+#endif
 #ifndef GS_SORT_MINWAVES
 #define GS_SORT_MINWAVES 6      // <= 80 VGPRs: three 512-thread workgroups per CU (a handful of loop-invariant values spill to scratch)
 #endif
@@ -202,6 +218,9 @@ __global__ __launch_bounds__(THREADS, GS_SORT_MINWAVES) void onesweep_kernel(con
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const uint32_t n = nPtr ? min(*nPtr, nImm) : nImm;
     const uint32_t numParts = (n + PART - 1) / PART;
+    // partitions per XCD block of the GATHER pass: an eighth of the input, at most a look-back group
+    const uint32_t xcdBlock = min((uint32_t)GROUP, max(1u, numParts / 8u));
+    (void)xcdBlock;
 
     // global exclusive digit offsets = exclusive scan of this pass's histogram (raw counts, accumulated by the key
     // generation / binning / histogram kernel): every workgroup scans it for itself instead of a separate 1-workgroup launch
@@ -233,7 +252,22 @@ __global__ __launch_bounds__(THREADS, GS_SORT_MINWAVES) void onesweep_kernel(con
         // a workgroup still only waits on partitions that are running or will run without needing a new slot.
         if (tid == 0) {
             const uint32_t cls = blockIdx.x % TICKET_CLASSES;
-            s_part = __hip_atomic_fetch_add(ticket + cls * 32u, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * TICKET_CLASSES + cls;
+            const uint32_t t = __hip_atomic_fetch_add(ticket + cls * 32u, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            uint32_t p = t * TICKET_CLASSES + cls;
+#if GS_SORT_XCD_BLOCKS
+            if (GATHER) {
+                // The gathered key array does not fit one XCD's L2, but the 16 keys of a 64-byte sector belong to spatial
+                // neighbours (the asset is in Morton order), which are close in the previous depth order too: they are asked for
+                // within a few partitions of each other.  Workgroup b runs on XCD b % 8 (MI355X_MICROARCH.md) = cls % 8, so
+                // instead of dealing partitions round-robin, every XCD takes whole blocks of `xb` consecutive partitions (block
+                // j belongs to XCD j % 8; the two ticket classes of an XCD alternate inside its blocks): the other 15 requests
+                // for a sector then arrive at the L2 that already holds it.  Still monotonic per class, still a bijection.
+                const uint32_t xb = xcdBlock;
+                const uint32_t x = cls & 7u, u = t * 2u + (cls >> 3);       // u-th partition of XCD x
+                p = ((u / xb) * 8u + x) * xb + (u % xb);
+            }
+#endif
+            s_part = p;
         }
         for (int k = tid; k < WAVES * RDX; k += THREADS) s_hist[k] = 0;
         __syncthreads();

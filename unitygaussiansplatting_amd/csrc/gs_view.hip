@@ -48,9 +48,11 @@ constexpr int cmax(int a, int b) { return a > b ? a : b; }
 // waves and whole workgroups drop out), and no view write.  gs_renderer_download_view re-runs the frame's launch with
 // FULL = true on demand, so the parity surface is unchanged.  VALU-bound either way (~1200 instructions per splat FULL).
 template <int SHMODE, bool FULL>
-__global__ __launch_bounds__(256) void calc_view_kernel(gsm::AssetView a, gsm::FrameConsts P, gsm::EditView E, gsm::ViewData* __restrict__ out,
-                                                        SplatRec* __restrict__ recs, uint2* __restrict__ rects,
-                                                        unsigned long long* __restrict__ visMask) {
+__global__ __launch_bounds__(256) void calc_view_kernel(gsm::AssetView a, gsm::FrameConsts P, gsm::EditView E, ViewOutputs O) {
+    gsm::ViewData* __restrict__ out = O.view;
+    SplatRec* __restrict__ recs = O.recs;
+    uint2* __restrict__ rects = O.rects;
+    unsigned long long* __restrict__ visMask = O.visMask;
     constexpr int REC = sh_rec_dwords(SHMODE < 4 ? SHMODE : 3);       // dwords per record
     constexpr int STRIDE = REC | 1;                                    // odd LDS stride
     constexpr int SH_DW = SHMODE < 4 ? 256 * STRIDE : 0;
@@ -157,6 +159,7 @@ __global__ __launch_bounds__(256) void calc_view_kernel(gsm::AssetView a, gsm::F
             uint4* rp = (uint4*)(recs + idx);
             rp[0] = make_uint4(gsm::f2u(fp.cx), gsm::f2u(fp.cy), gsm::f2u(vp.view.axis1[0]), gsm::f2u(vp.view.axis1[1]));
             rp[1] = make_uint4(gsm::f2u(vp.view.axis2[0]), gsm::f2u(vp.view.axis2[1]), vp.view.color[0], vp.view.color[1]);
+            O.recW[idx] = vp.view.pos[3];                       // the depth all four vertices of the quad share (:56-60)
         }
         rects[idx] = rect;
     }
@@ -200,27 +203,26 @@ void flatten_params(const gs_frame_params* p, gsm::FrameConsts& c) {
 
 template <bool FULL>
 static void launch_calc_view(int mode, uint32_t grid, hipStream_t st, const gsm::AssetView& a, const gsm::FrameConsts& c, const gsm::EditView& e,
-                             gsm::ViewData* out, SplatRec* recs, uint2* rects, unsigned long long* visMask) {
+                             const ViewOutputs& o) {
     switch (mode) {
-        case 0: hipLaunchKernelGGL((calc_view_kernel<0, FULL>), dim3(grid), dim3(256), 0, st, a, c, e, out, recs, rects, visMask); break;
-        case 1: hipLaunchKernelGGL((calc_view_kernel<1, FULL>), dim3(grid), dim3(256), 0, st, a, c, e, out, recs, rects, visMask); break;
-        case 2: hipLaunchKernelGGL((calc_view_kernel<2, FULL>), dim3(grid), dim3(256), 0, st, a, c, e, out, recs, rects, visMask); break;
-        case 3: hipLaunchKernelGGL((calc_view_kernel<3, FULL>), dim3(grid), dim3(256), 0, st, a, c, e, out, recs, rects, visMask); break;
-        default: hipLaunchKernelGGL((calc_view_kernel<4, FULL>), dim3(grid), dim3(256), 0, st, a, c, e, out, recs, rects, visMask); break;
+        case 0: hipLaunchKernelGGL((calc_view_kernel<0, FULL>), dim3(grid), dim3(256), 0, st, a, c, e, o); break;
+        case 1: hipLaunchKernelGGL((calc_view_kernel<1, FULL>), dim3(grid), dim3(256), 0, st, a, c, e, o); break;
+        case 2: hipLaunchKernelGGL((calc_view_kernel<2, FULL>), dim3(grid), dim3(256), 0, st, a, c, e, o); break;
+        case 3: hipLaunchKernelGGL((calc_view_kernel<3, FULL>), dim3(grid), dim3(256), 0, st, a, c, e, o); break;
+        default: hipLaunchKernelGGL((calc_view_kernel<4, FULL>), dim3(grid), dim3(256), 0, st, a, c, e, o); break;
     }
 }
 
 // full = true: also evaluate the colour of every splat in front of the camera and write the N x 40 B view buffer
-int32_t enqueue_calc_view(gs_context* ctx, const gsm::AssetView& a, const gs_frame_params* p, const gsm::EditView& e, gsm::ViewData* out,
-                          SplatRec* recs, uint2* rects, unsigned long long* visMask, bool full) {
+int32_t enqueue_calc_view(gs_context* ctx, const gsm::AssetView& a, const gs_frame_params* p, const gsm::EditView& e, const ViewOutputs& out, bool full) {
     gsm::FrameConsts c;
     flatten_params(p, c);
     const uint32_t grid = (a.n + 255u) / 256u;
     // per-splat SH records are staged through LDS (needs the blob 16-byte aligned, which hipMalloc and torch guarantee);
     // Cluster* tables, an unaligned borrowed blob, or SH switched off read straight from the blob
     const int mode = (a.shFmt <= 3 && (((uintptr_t)a.sh) & 15u) == 0 && p->sh_order >= 1) ? (int)a.shFmt : 4;
-    if (full) launch_calc_view<true>(mode, grid, ctx->stream, a, c, e, out, recs, rects, visMask);
-    else launch_calc_view<false>(mode, grid, ctx->stream, a, c, e, out, recs, rects, visMask);
+    if (full) launch_calc_view<true>(mode, grid, ctx->stream, a, c, e, out);
+    else launch_calc_view<false>(mode, grid, ctx->stream, a, c, e, out);
     GS_HIP(hipGetLastError());
     return GS_OK;
 }

@@ -92,6 +92,7 @@ namespace GaussianSplatting.Runtime
         [DllImport(Lib)] public static extern int gs_renderer_download_order(IntPtr renderer, uint[] dst, UIntPtr count);
         [DllImport(Lib)] public static extern int gs_renderer_download_distances(IntPtr renderer, uint[] dst, UIntPtr count);
         [DllImport(Lib)] public static extern int gs_renderer_upload_order(IntPtr renderer, uint[] src, UIntPtr count);
+        [DllImport(Lib)] public static extern int gs_renderer_set_render_mode(IntPtr renderer, int mode, float pointDisplaySize);
         [DllImport(Lib)] public static extern int gs_renderer_download_view(IntPtr renderer, IntPtr dst, UIntPtr bytes);
         [DllImport(Lib)] public static extern int gs_renderer_download_raster_records(IntPtr renderer, IntPtr recs, IntPtr rects, IntPtr visMask);
         [DllImport(Lib)] public static extern int gs_renderer_frame_stats(IntPtr renderer, out FrameStats stats);
@@ -103,6 +104,7 @@ namespace GaussianSplatting.Runtime
         [DllImport(Lib)] public static extern int gs_target_clear(IntPtr target);
         [DllImport(Lib)] public static extern int gs_target_download(IntPtr target, IntPtr dstRgba16f, UIntPtr bytes);
         [DllImport(Lib)] public static extern int gs_target_resolve(IntPtr target, float[] backgroundRgba4, IntPtr dstRgba32f, IntPtr dstRgba8);
+        [DllImport(Lib)] public static extern int gs_target_set_scene_depth(IntPtr target, IntPtr depth, int memoryKind);
         [DllImport(Lib)] public static extern int gs_target_device_ptr(IntPtr target, out IntPtr rgba16fDev, out IntPtr resolvedDev);
         [DllImport(Lib)] public static extern int gs_target_set_profiling(IntPtr target, int enabled);
         [DllImport(Lib)] public static extern int gs_target_resolve_time(IntPtr target, out float meanMs, out int count);

@@ -10,6 +10,7 @@ from __future__ import annotations
 
 import atexit
 import ctypes as C
+import enum
 import weakref
 from typing import List, Optional, Tuple
 
@@ -39,6 +40,14 @@ def _dispose_all_contexts():
             ctx.Dispose()
         except Exception:
             pass
+
+
+class RenderMode(enum.IntEnum):          # GaussianSplatRenderer.RenderMode (:217-223)
+    Splats = 0
+    DebugPoints = 1
+    DebugPointIndices = 2
+    DebugBoxes = 3
+    DebugChunkBounds = 4
 
 
 class GpuContext:
@@ -93,6 +102,15 @@ class RenderTarget:
 
     def Clear(self) -> None:
         check(_lib.lib().gs_target_clear(self._h), "gs_target_clear")
+
+    def SetSceneDepth(self, depth: Optional[np.ndarray]) -> None:
+        """The camera's depth attachment (GaussianSplatRenderer.cs:195): H x W float32 VIEW depths of the opaque scene, or None."""
+        if depth is None:
+            check(_lib.lib().gs_target_set_scene_depth(self._h, None, 0), "gs_target_set_scene_depth")
+            return
+        d = np.ascontiguousarray(depth, np.float32)
+        assert d.shape == (self.height, self.width)
+        check(_lib.lib().gs_target_set_scene_depth(self._h, d.ctypes.data, 0), "gs_target_set_scene_depth")
 
     def Download(self) -> np.ndarray:
         out = np.empty((self.height, self.width, 4), np.uint16)
@@ -181,6 +199,8 @@ class GaussianSplatRenderer:
         self.m_SHOrder = 3
         self.m_SHOnly = False
         self.m_SortNthFrame = 1
+        self.m_RenderMode = RenderMode.Splats                                # :241
+        self.m_PointDisplaySize = 3.0                                        # :242
         self.m_Cutouts: Optional[List[Optional[GaussianCutout]]] = None      # :244
         self.m_FrameCounter = 0
         self.blendMode = 0            # 0 exact (fp16 ROP rounding), 1 fast (fp32 accumulate)
@@ -294,6 +314,7 @@ class GaussianSplatRenderer:
 
     def Draw(self, cam: Camera, rt: RenderTarget) -> None:     # the DrawProcedural of :156-166
         check(_lib.lib().gs_renderer_set_blend_mode(self._r_h, int(self.blendMode)), "gs_renderer_set_blend_mode")
+        check(_lib.lib().gs_renderer_set_render_mode(self._r_h, int(self.m_RenderMode), float(self.m_PointDisplaySize)), "gs_renderer_set_render_mode")
         p = self.FrameParams(cam)
         check(_lib.lib().gs_renderer_draw(self._r_h, C.byref(p), rt._h), "gs_renderer_draw")
 
@@ -387,6 +408,10 @@ class GaussianSplatRenderSystem:
     def __init__(self):
         self.m_Splats: List[GaussianSplatRenderer] = []
         self.m_ActiveSplats: List[GaussianSplatRenderer] = []
+        # A frame whose (tile, splat) pairs overflow the pair buffer drops its farthest pairs; the library notices (and grows
+        # the buffer) within the pipeline depth, but THAT frame is truncated.  With strictPairs (default) OnPreCullCamera reads
+        # the frame statistics (blocking) and renders the frame again after an overflow, so what it returns is always complete.
+        self.strictPairs = True
 
     def RegisterSplat(self, r: GaussianSplatRenderer) -> None:      # :25-36
         if r not in self.m_Splats:
@@ -423,6 +448,22 @@ class GaussianSplatRenderSystem:
             return None
         rt.Clear()
         self.SortAndRenderSplats(cam, rt)
+        if self.strictPairs:
+            overflowed = False
+            for gs in self.m_ActiveSplats:
+                if gs.m_RenderMode != RenderMode.Splats:
+                    continue
+                try:
+                    gs.FrameStats()
+                except GsError as e:
+                    if e.code != GS_ERR_PAIR_OVERFLOW:
+                        raise
+                    overflowed = True                         # the buffer has been grown by the call
+            if overflowed:                                     # same frame again: the order is already sorted, only the draws repeat
+                rt.Clear()
+                for gs in self.m_ActiveSplats:
+                    gs.CalcViewData(cam)
+                    gs.Draw(cam, rt)
         if background is not None:
             return rt.Resolve(background)
         return None
