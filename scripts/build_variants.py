@@ -8,7 +8,7 @@ def one(spec):
     name, _, defs = spec.partition(":")
     out_dir = os.path.join(B.HERE, "variants"); os.makedirs(out_dir, exist_ok=True)
     out = os.path.join(out_dir, name + ".so")
-    cmd = [B.hipcc()] + B.FLAGS + ["-w"] + ["-D" + d for d in defs.split(",") if d] + [os.path.join(B.CSRC, s) for s in B.SOURCES] + ["-ldl", "-o", out]
+    cmd = [B.hipcc()] + B.FLAGS + ["-w"] + ["-D" + d for d in defs.split(",") if d] + [os.path.join(B.CSRC, s) for s in B.SOURCES] + ["-ldl", "-lz", "-o", out]
     r = subprocess.run(cmd, capture_output=True, text=True)
     return name, r.returncode, r.stderr[-2000:] if r.returncode else ""
 with ThreadPoolExecutor(8) as ex:

@@ -110,3 +110,47 @@ def test_native_ply_reader_matches_numpy(tmp_path):
     open(slim, "wb").write(b"\n".join(lines) + b"\nend_header\n" + np.ascontiguousarray(arr[:, keep]).tobytes())
     c, d = creator.ReadPLY(slim), creator.ReadPLYNative(slim)
     assert np.array_equal(c.sh, d.sh) and not d.sh.any() and np.array_equal(c.rot, d.rot) and np.array_equal(d.pos, raw.pos)
+
+
+@pytest.mark.parametrize("sh_level,fract_bits", [(3, 12), (2, 10), (1, 16), (0, 8)])
+def test_spz_reader_native_matches_numpy_and_the_format(tmp_path, sh_level, fract_bits):
+    """SPZFileReader.cs: the native reader (gs_spz_open) == the numpy restatement bit for bit; both recover what WriteSPZ
+    quantised (positions to 2^-fract_bits, log-scales to 1/16, opacities and colours to a byte); the unpacked splats are
+    already linear, so they encode with linearize = 0 -- natively and in numpy to the same bytes."""
+    raw = scenes.make_splats(2_345, 31, 2.0)
+    path = str(tmp_path / "scene.spz")
+    creator.WriteSPZ(path, raw, fract_bits=fract_bits, sh_level=sh_level)
+    a, b = creator.ReadSPZ(path), creator.ReadSPZNative(path)
+    for nm in ("pos", "dc0", "sh", "opacity", "scale", "rot"):
+        assert np.array_equal(getattr(a, nm), getattr(b, nm)), nm
+    lin = creator.LinearizeData(raw)
+    assert np.abs(a.pos - raw.pos).max() <= 0.5 / (1 << fract_bits) + 1e-6
+    assert np.abs(np.log(a.scale) - np.clip(raw.scale, -10.0, 5.9)).max() <= 0.5 / 16 + 1e-4
+    assert np.abs(a.opacity - lin.opacity).max() <= 0.5 / 255 + 1e-6
+    assert np.abs(a.dc0 - np.clip(lin.dc0, 0.5 - 0.5 / 0.15 * 0.2820948, 0.5 + 0.5 / 0.15 * 0.2820948)).max() <= 0.0075
+    k = {0: 0, 1: 3, 2: 8, 3: 15}[sh_level]
+    if sh_level == 3:
+        assert np.abs(a.sh - np.clip(raw.sh, -1.0, 127.0 / 128.0)).max() <= 0.5 / 128 + 1e-6
+    else:
+        assert k == 0 or np.abs(a.sh[:, :k] - raw.sh[:, :k]).max() <= 0.5 / 128 + 1e-6      # (the reference reads on into its neighbours' bytes beyond k)
+    # rotation: the packed smallest-three decodes to the file's quaternion within a byte step
+    _same(creator.CreateAssetFromSplats(a, "Medium", linearize=False), creator.CreateAssetFromSplatsNative(b, "Medium", linearize=False))
+    assert creator.CreateAsset(path, "Medium").splatCount == len(raw)
+    # header rules (:37-47, :72-77)
+    import gzip, struct
+    body = gzip.decompress(open(path, "rb").read())
+    for bad_hdr in (struct.pack("<IIII", 0x12345678, 2, 10, 3), struct.pack("<IIII", creator.SPZ_MAGIC, 3, 10, 3),
+                    struct.pack("<IIII", creator.SPZ_MAGIC, 2, 0, 3), struct.pack("<IIII", creator.SPZ_MAGIC, 2, 10, 4),
+                    struct.pack("<IIII", creator.SPZ_MAGIC, 2, len(raw) + 1, sh_level | (fract_bits << 8))):
+        bad = str(tmp_path / "bad.spz")
+        open(bad, "wb").write(gzip.compress(bad_hdr + body[16:]))
+        with pytest.raises(IOError):
+            creator.ReadSPZ(bad)
+        with pytest.raises(_lib.GsError):
+            creator.ReadSPZNative(bad)
+    notgz = str(tmp_path / "notgz.spz")
+    open(notgz, "wb").write(body)
+    with pytest.raises(IOError):
+        creator.ReadSPZ(notgz)
+    with pytest.raises(_lib.GsError):
+        creator.ReadSPZNative(notgz)

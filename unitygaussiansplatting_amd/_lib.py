@@ -78,6 +78,7 @@ SIGNATURES = {
     "gs_import_encode": (C.c_int32, [C.POINTER(gs_import_input), C.POINTER(gs_import_formats), C.c_void_p * 5, C.c_uint64 * 5,
                                       C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "gs_ply_open": (C.c_int32, [C.c_char_p, _PP, C.POINTER(C.c_uint32)]),
+    "gs_spz_open": (C.c_int32, [C.c_char_p, _PP, C.POINTER(C.c_uint32)]),
     "gs_ply_arrays": (C.c_int32, [_P, C.POINTER(gs_import_input)]),
     "gs_ply_close": (C.c_int32, [_P]),
     "gs_sorter_create": (C.c_int32, [_P, C.c_uint32, _PP]),

@@ -38,7 +38,7 @@ def build_variant(name: str, defines, verbose: bool = False) -> str:
     out_dir = os.path.join(HERE, "variants")
     os.makedirs(out_dir, exist_ok=True)
     out = os.path.join(out_dir, name + ".so")
-    cmd = [hipcc()] + FLAGS + ["-D" + d for d in defines] + [os.path.join(CSRC, s) for s in SOURCES] + ["-ldl", "-o", out]
+    cmd = [hipcc()] + FLAGS + ["-D" + d for d in defines] + [os.path.join(CSRC, s) for s in SOURCES] + ["-ldl", "-lz", "-o", out]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
@@ -48,7 +48,7 @@ def build_variant(name: str, defines, verbose: bool = False) -> str:
 def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not needs_build():
         return LIB
-    cmd = [hipcc()] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-ldl", "-o", LIB]
+    cmd = [hipcc()] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-ldl", "-lz", "-o", LIB]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)

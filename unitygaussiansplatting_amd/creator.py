@@ -506,6 +506,117 @@ def CreateAssetFromSplatsNative(raw: InputSplatData, quality: str = "Medium", *,
     return a
 
 
+# --------------------------------------------------------------------------------------------------
+# SPZ (Niantic / Scaniverse), Editor/Utils/SPZFileReader.cs
+# --------------------------------------------------------------------------------------------------
+SPZ_MAGIC = 0x5053474e
+
+
+def _spz_sh_coeffs(level: int) -> int:
+    return {0: 0, 1: 3, 2: 8, 3: 15}.get(level, 0)
+
+
+def WriteSPZ(path: str, raw: InputSplatData, fract_bits: int = 12, sh_level: int = 3) -> None:
+    """Test-fixture writer: raw (PLY-domain) splats quantised the way the SPZ format stores them (24-bit fixed-point positions,
+    log-scale bytes (s + 10) * 16, sigmoid opacity bytes, colour bytes (dc0 * 0.15 + 0.5) * 255, unit-quaternion xyz bytes with
+    w >= 0, SH bytes sh * 128 + 128), gzip-compressed."""
+    import gzip
+    import struct
+    n = len(raw)
+    k = _spz_sh_coeffs(sh_level)
+    pos = np.clip(np.rint(raw.pos.astype(np.float64) * (1 << fract_bits)), -(1 << 23), (1 << 23) - 1).astype(np.int64) & 0xffffff
+    pos_b = np.stack([(pos >> s) & 0xff for s in (0, 8, 16)], axis=-1).astype(np.uint8).reshape(n, 9)
+    alpha = np.clip(np.rint(255.0 / (1.0 + np.exp(-raw.opacity.astype(np.float64)))), 0, 255).astype(np.uint8)
+    col = np.clip(np.rint((raw.dc0.astype(np.float64) * 0.15 + 0.5) * 255.0), 0, 255).astype(np.uint8)
+    scale = np.clip(np.rint((raw.scale.astype(np.float64) + 10.0) * 16.0), 0, 255).astype(np.uint8)
+    q = raw.rot.astype(np.float64)                                   # (w, x, y, z)
+    q = q / np.linalg.norm(q, axis=1, keepdims=True)
+    q = np.where(q[:, :1] < 0, -q, q)
+    rot = np.clip(np.rint(q[:, 1:4] * 127.5 + 127.5), 0, 255).astype(np.uint8)
+    sh = np.clip(np.rint(raw.sh[:, :k, :].astype(np.float64) * 128.0 + 128.0), 0, 255).astype(np.uint8).reshape(n, k * 3)
+    body = struct.pack("<IIII", SPZ_MAGIC, 2, n, sh_level | (fract_bits << 8)) + pos_b.tobytes() + alpha.tobytes() + col.tobytes() + \
+        scale.tobytes() + rot.tobytes() + sh.tobytes()
+    with open(path, "wb") as f:
+        f.write(gzip.compress(body, compresslevel=1))
+
+
+def ReadSPZ(path: str) -> InputSplatData:
+    """SPZFileReader.ReadFile (:66-139) + UnpackDataJob (:141-205): ALREADY LINEAR splats (use linearize=False)."""
+    import gzip
+    import struct
+    with open(path, "rb") as f:
+        try:
+            data = gzip.decompress(f.read())
+        except Exception as e:
+            raise IOError(f"SPZ {path} read error: not a gzip stream") from e
+    if len(data) < 16:
+        raise IOError(f"SPZ {path} read error, failed to read header")
+    magic, version, n, word = struct.unpack_from("<IIiI", data, 0)
+    if magic != SPZ_MAGIC:
+        raise IOError(f"SPZ {path} read error, header magic unexpected {magic}")
+    if version != 2:
+        raise IOError(f"SPZ {path} read error, header version unexpected {version}")
+    sh_level, fract_bits = word & 0xff, (word >> 8) & 0xff
+    if n < 1 or n > 10_000_000:
+        raise IOError(f"SPZ {path} read error, out of range splat count {n}")
+    if sh_level > 3:
+        raise IOError(f"SPZ {path} read error, out of range SH level {sh_level}")
+    if fract_bits > 24:
+        raise IOError(f"SPZ {path} read error, out of range fractional bits {fract_bits}")
+    k = _spz_sh_coeffs(sh_level)
+    o, parts = 16, []
+    for sz in (n * 9, n, n * 3, n * 3, n * 3, n * 3 * k):
+        parts.append(np.frombuffer(data, np.uint8, count=min(sz, max(0, len(data) - o)), offset=min(o, len(data))))
+        o += sz
+    if len(data) < o:
+        raise IOError(f"SPZ {path} read error, file smaller than it should be")
+    ppos, palpha, pcol, pscale, prot, psh = parts
+    b = ppos.reshape(n, 3, 3).astype(np.int32)
+    fx = b[..., 0] | (b[..., 1] << 8) | (b[..., 2] << 16)
+    fx = np.where(fx & 0x800000, fx - (1 << 24), fx)
+    pos = fx.astype(f32) * f32(1.0 / (1 << fract_bits))
+    scale = np.abs(ExpDet(pscale.reshape(n, 3).astype(f32) / f32(16.0) - f32(10.0))).astype(f32)
+    xyz = prot.reshape(n, 3).astype(f32) * f32(1.0 / 127.5) - f32(1.0)
+    sq = ((xyz[:, 0] * xyz[:, 0] + xyz[:, 1] * xyz[:, 1]) + xyz[:, 2] * xyz[:, 2]).astype(f32)
+    w = np.sqrt(np.maximum(f32(0.0), f32(1.0) - sq)).astype(f32)
+    q = np.concatenate([xyz, w[:, None]], 1).astype(f32)
+    l2 = (((q[:, 0] * q[:, 0] + q[:, 1] * q[:, 1]) + q[:, 2] * q[:, 2]) + q[:, 3] * q[:, 3]).astype(f32)
+    q = (q * (f32(1.0) / np.sqrt(l2).astype(f32))[:, None]).astype(f32)
+    col = ((pcol.reshape(n, 3).astype(f32) / f32(255.0) - f32(0.5)) / f32(0.15)).astype(f32)
+    # UnpackSH reads 15 coefficients from index * shCoeffs * 3 whatever the level (:178-193): for levels < 3 it runs on into the
+    # following splats' bytes (restated as is; bytes past the end of the array read as 128 = 0.0)
+    at = (np.arange(n, dtype=np.int64) * (3 * k))[:, None] + np.arange(45, dtype=np.int64)[None, :]
+    padded = np.concatenate([psh, np.full(45, 128, np.uint8)])
+    shb = padded[np.minimum(at, len(psh) + 44 if len(psh) else 44)] if len(psh) else np.full((n, 45), 128, np.uint8)
+    shb = np.where(at < len(psh), shb, 128)
+    sh = ((shb.astype(f32) - f32(128.0)) / f32(128.0)).reshape(n, 15, 3).astype(f32)
+    return InputSplatData(pos=pos, dc0=SH0ToColor(col), sh=sh, opacity=(palpha.astype(f32) / f32(255.0)).astype(f32), scale=scale,
+                          rot=PackSmallest3Rotation(q))
+
+
+def _ReadNativeHandle(open_fn_name: str, path: str) -> InputSplatData:
+    import ctypes as C
+    from . import _lib
+    from ._abi import gs_import_input
+    l = _lib.lib()
+    h, cnt = C.c_void_p(), C.c_uint32()
+    _lib.check(getattr(l, open_fn_name)(path.encode("utf-8"), C.byref(h), C.byref(cnt)), open_fn_name)
+    try:
+        inp = gs_import_input()
+        _lib.check(l.gs_ply_arrays(h, C.byref(inp)), "gs_ply_arrays")
+        n = cnt.value
+        get = lambda ptr, k: np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_float)), shape=(n * k,)).copy()
+        return InputSplatData(pos=get(inp.pos, 3).reshape(n, 3), dc0=get(inp.dc0, 3).reshape(n, 3), sh=get(inp.sh, 45).reshape(n, 15, 3),
+                              opacity=get(inp.opacity, 1), scale=get(inp.scale, 3).reshape(n, 3), rot=get(inp.rot, 4).reshape(n, 4))
+    finally:
+        l.gs_ply_close(h)
+
+
+def ReadSPZNative(path: str) -> InputSplatData:
+    """ReadSPZ through the native reader (gs_spz_open, csrc/gs_import.cpp)."""
+    return _ReadNativeHandle("gs_spz_open", path)
+
+
 def ReadPLYNative(path: str) -> InputSplatData:
     """ReadPLY through the native reader (gs_ply_open / gs_ply_arrays, csrc/gs_import.cpp); the arrays are copied out."""
     import ctypes as C
@@ -524,6 +635,10 @@ def ReadPLYNative(path: str) -> InputSplatData:
         _lib.lib().gs_ply_close(h)
 
 
-def CreateAsset(ply_path: str, quality: str = "Medium", **kw) -> GaussianSplatAsset:
-    """PLY file -> asset (ReadFile + LinearizeData + CreateAsset)."""
-    return CreateAssetFromSplats(ReadPLY(ply_path), quality, **kw)
+def CreateAsset(path: str, quality: str = "Medium", **kw) -> GaussianSplatAsset:
+    """.ply / .spz file -> asset (GaussianFileReader.ReadFile :45-71 + CreateAsset): PLY data is linearised, SPZ data already is."""
+    if path.lower().endswith(".spz"):
+        return CreateAssetFromSplats(ReadSPZ(path), quality, linearize=False, **kw)
+    if path.lower().endswith(".ply"):
+        return CreateAssetFromSplats(ReadPLY(path), quality, **kw)
+    raise IOError(f"File {path} is not a supported format")

@@ -56,7 +56,6 @@ struct ViewOutputs {
     SplatRec* recs;                 // N x 32 B blend records (visible splats only)
     uint2* rects;                   // N x 8 B tile rectangles
     unsigned long long* visMask;    // 1 bit per splat
-    float* recW;                    // N x 4 B view depth (clip.w) of visible splats: the scene-depth test and the debug point modes
 };
 
 // Onesweep look-back state for one sort (shared by all passes: every pass uses a fresh epoch)
@@ -162,7 +161,7 @@ struct gs_renderer {
     int depthControlIdx = 0;                   // the block the last / current sort uses
     // compositor buffers
     gs::SplatRec* recs = nullptr;           // N x 32 B, indexed by splat (written by calc_view)
-    float* recW = nullptr;                  // N x 4 B: clip.w of the visible splats
+    float* recW = nullptr;                  // N x 4 B: clip.w of the visible splats, filled by the draw only when the target has a depth attachment
     uint2* rects = nullptr;                 // N x 8 B: x = tx0 | ty0 << 16, y = tiles wide | tiles high << 16 (0 = culled)
     unsigned long long* visMask = nullptr;  // ceil(N/64) x 8 B: bit s = splat s reaches at least one tile (written by calc_view)
     // edit state read by calc_view (m_GpuEditDeleted / m_GpuEditCutouts, GaussianSplatRenderer.cs:266,269)

@@ -184,6 +184,42 @@ GS_HD V3 LoadVec(const uint8_t* buf, uint64_t a, uint32_t fmt) {
     return Dec_6_5_5(LoadUShort(buf, a));
 }
 
+// The same values as LoadVec for a compile-time format, with every load unconditional (a load inside a branch is waited for
+// at the end of the branch, which serialises a streaming kernel's loads): unaligned 6- and 2-byte records take the two aligned
+// dwords around them and select (the blobs carry >= 4 readable bytes after the last record).
+template <int FMT> struct RawVec { uint32_t d[FMT == 0 ? 3 : (FMT == 1 ? 2 : 1)]; };
+template <int FMT> GS_HD RawVec<FMT> LoadRawT(const uint8_t* buf, uint64_t a) {            // the loads alone (so that a caller can issue many before it decodes)
+    RawVec<FMT> r;
+    if (FMT == 0) { r.d[0] = ld32a(buf, a); r.d[FMT == 0 ? 1 : 0] = ld32a(buf, a + 4); r.d[FMT == 0 ? 2 : 0] = ld32a(buf, a + 8); return r; }
+    const uint64_t aa = a & ~(uint64_t)3;
+    r.d[0] = ld32a(buf, aa);
+    if (FMT == 1) r.d[FMT == 1 ? 1 : 0] = ld32a(buf, aa + 4);
+    return r;
+}
+template <int FMT> GS_HD V3 DecodeRawT(const RawVec<FMT>& r, uint64_t a) {
+    if (FMT == 0) return { u2f(r.d[0]), u2f(r.d[FMT == 0 ? 1 : 0]), u2f(r.d[FMT == 0 ? 2 : 0]) };
+    if (FMT == 2) return Dec_11_10_11(r.d[0]);
+    const bool odd = (a & 2u) != 0;
+    if (FMT == 3) return Dec_6_5_5(odd ? (r.d[0] >> 16) : (r.d[0] & 0xffffu));
+    const uint32_t d0 = r.d[0], d1 = r.d[FMT == 1 ? 1 : 0];
+    return Dec_16_16_16(odd ? ((d0 >> 16) | (d1 << 16)) : d0, odd ? (d1 >> 16) : (d1 & 0xffffu));
+}
+template <int FMT> GS_HD V3 LoadVecT(const uint8_t* buf, uint64_t a) { return DecodeRawT<FMT>(LoadRawT<FMT>(buf, a), a); }
+template <int FMT> GS_HD uint32_t vecStrideT() { return FMT == 0 ? 12u : (FMT == 1 ? 6u : (FMT == 2 ? 4u : 2u)); }
+// chunk de-normalisation of a decoded position (LoadSplatPos, GaussianSplatting.hlsl:394-421)
+GS_HD V3 ChunkLerpPos(const AssetView& a, V3 p, uint32_t ci) {
+    if (ci < a.chunkCount) {
+        const uint8_t* c = a.chunk + (uint64_t)ci * 64;
+        p.x = lerpf(u2f(ld32a(c, 16)), u2f(ld32a(c, 20)), p.x);
+        p.y = lerpf(u2f(ld32a(c, 24)), u2f(ld32a(c, 28)), p.y);
+        p.z = lerpf(u2f(ld32a(c, 32)), u2f(ld32a(c, 36)), p.z);
+    }
+    return p;
+}
+template <int FMT> GS_HD V3 LoadSplatPosChunkT(const AssetView& a, uint32_t idx, uint32_t ci) {
+    return ChunkLerpPos(a, LoadVecT<FMT>(a.pos, (uint64_t)idx * vecStrideT<FMT>()), ci);
+}
+
 struct ChunkRaw { uint32_t w[16]; };    // colR,colG,colB,colA, posX(2),posY(2),posZ(2), sclX..Z, shR..B
 GS_HD ChunkRaw LoadChunk(const uint8_t* chunk, uint32_t ci) {
     ChunkRaw c;

@@ -26,6 +26,8 @@
 #include <thread>
 #include <vector>
 
+#include <zlib.h>
+
 #include "../../include/gsplat_c.h"
 
 namespace gs {
@@ -60,6 +62,20 @@ template <class F> void parallel_for(size_t n, size_t grain, F f) {
     }
     for (auto& x : th) x.join();
     if (first) std::rethrow_exception(first);
+}
+
+// PackSmallest3Rotation (GaussianUtils.cs:46-76): q = xyzw, unit; out = the three smallest components in 0..1 + index / 3
+inline void pack_smallest3(const float qv[4], float out[4]) {
+    int idx = 0;                                                                            // first max wins
+    float best = std::fabs(qv[0]);
+    for (int c = 1; c < 4; ++c) if (std::fabs(qv[c]) > best) { best = std::fabs(qv[c]); idx = c; }
+    float t[4] = { qv[0], qv[1], qv[2], qv[3] };
+    if (idx == 0) { t[0] = qv[1]; t[1] = qv[2]; t[2] = qv[3]; t[3] = qv[0]; }
+    if (idx == 1) { t[0] = qv[0]; t[1] = qv[2]; t[2] = qv[3]; t[3] = qv[1]; }
+    if (idx == 2) { t[0] = qv[0]; t[1] = qv[1]; t[2] = qv[3]; t[3] = qv[2]; }
+    const float sg = t[3] >= 0.0f ? 1.0f : -1.0f;
+    for (int c = 0; c < 3; ++c) out[c] = ((t[c] * sg) * 1.41421354f) * 0.5f + 0.5f;
+    out[3] = (float)idx / 3.0f;
 }
 
 inline float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
@@ -216,16 +232,7 @@ static int32_t import_encode_impl(const gs_import_input* in, const gs_import_for
             const float* w = in->rot + i * 4;                                               // (w, x, y, z)
             const float len = std::sqrt(((w[0] * w[0] + w[1] * w[1]) + w[2] * w[2]) + w[3] * w[3]);
             const float qv[4] = { w[1] / len, w[2] / len, w[3] / len, w[0] / len };         // normalize(wxyz).yzwx
-            int idx = 0;                                                                    // PackSmallest3Rotation: first max wins
-            float best = std::fabs(qv[0]);
-            for (int c = 1; c < 4; ++c) if (std::fabs(qv[c]) > best) { best = std::fabs(qv[c]); idx = c; }
-            float t[4] = { qv[0], qv[1], qv[2], qv[3] };
-            if (idx == 0) { t[0] = qv[1]; t[1] = qv[2]; t[2] = qv[3]; t[3] = qv[0]; }
-            if (idx == 1) { t[0] = qv[0]; t[1] = qv[2]; t[2] = qv[3]; t[3] = qv[1]; }
-            if (idx == 2) { t[0] = qv[0]; t[1] = qv[1]; t[2] = qv[3]; t[3] = qv[2]; }
-            const float sg = t[3] >= 0.0f ? 1.0f : -1.0f;
-            for (int c = 0; c < 3; ++c) o.rot[c] = ((t[c] * sg) * 1.41421354f) * 0.5f + 0.5f;
-            o.rot[3] = (float)idx / 3.0f;
+            pack_smallest3(qv, o.rot);
         }
     });
 
@@ -432,6 +439,110 @@ static int32_t ply_open_impl(const char* path, gs_ply** out, uint32_t* splat_cou
     *out = p;
     if (splat_count) *splat_count = p->count;
     return GS_OK;
+}
+
+// ---- SPZ input (Niantic / Scaniverse; Editor/Utils/SPZFileReader.cs): a gzip stream of  header(16 B: "NGSP", version 2,
+// numPoints, shLevel | fractBits << 8 | flags << 16)  then, for all points, the arrays  positions (3 x 24-bit fixed point),
+// alphas (u8), colours (3 x u8), scales (3 x u8), rotations (3 x u8), SH (shCoeffs x 3 x u8).  UnpackDataJob (:141-205)
+// turns them into ALREADY LINEAR InputSplatData (scale = |exp(b/16 - 10)|, opacity = b/255, dc0 = SH0ToColor((b/255 - 0.5)/0.15),
+// rot = PackSmallest3Rotation(normalize(xyz, w))), so the handle's arrays go to gs_import_encode with linearize = 0.
+static bool gunzip_file(FILE* f, std::vector<uint8_t>& out, size_t limit) {
+    std::vector<uint8_t> in(1 << 16);
+    z_stream zs;
+    memset(&zs, 0, sizeof(zs));
+    if (inflateInit2(&zs, 16 + MAX_WBITS) != Z_OK) return false;       // gzip wrapper
+    int rc = Z_OK;
+    out.resize(1 << 20);
+    size_t have = 0;
+    while (rc != Z_STREAM_END) {
+        if (zs.avail_in == 0) {
+            zs.avail_in = (uInt)fread(in.data(), 1, in.size(), f);
+            zs.next_in = in.data();
+            if (zs.avail_in == 0) break;
+        }
+        if (have == out.size()) { if (out.size() >= limit) { inflateEnd(&zs); return false; } out.resize(std::min(limit, out.size() * 2)); }
+        zs.next_out = out.data() + have;
+        zs.avail_out = (uInt)std::min<size_t>(out.size() - have, 1u << 30);
+        const size_t before = zs.avail_out;
+        rc = inflate(&zs, Z_NO_FLUSH);
+        have += before - zs.avail_out;
+        if (rc != Z_OK && rc != Z_STREAM_END && rc != Z_BUF_ERROR) { inflateEnd(&zs); return false; }
+    }
+    inflateEnd(&zs);
+    out.resize(have);
+    return true;
+}
+
+static int32_t spz_open_impl(const char* path, gs_ply** out, uint32_t* splat_count) {
+    if (!path || !out) return gs::fail(GS_ERR_INVALID_ARGUMENT, "null argument");
+    *out = nullptr;
+    FILE* f = fopen(path, "rb");
+    if (!f) return gs::fail(GS_ERR_INVALID_ASSET, "SPZ file cannot be opened");
+    std::vector<uint8_t> raw;
+    const bool ok = gunzip_file(f, raw, (size_t)10'000'000 * 64 + 64);
+    fclose(f);
+    if (!ok) return gs::fail(GS_ERR_INVALID_ASSET, "SPZ read error: not a gzip stream");
+    if (raw.size() < 16) return gs::fail(GS_ERR_INVALID_ASSET, "SPZ read error, failed to read header");
+    uint32_t h[4];
+    memcpy(h, raw.data(), 16);
+    if (h[0] != 0x5053474eu) return gs::fail(GS_ERR_INVALID_ASSET, "SPZ read error, header magic unexpected");
+    if (h[1] != 2u) return gs::fail(GS_ERR_INVALID_ASSET, "SPZ read error, header version unexpected");
+    const int64_t n = (int32_t)h[2];
+    const int shLevel = (int)(h[3] & 0xFF), fractBits = (int)((h[3] >> 8) & 0xFF);
+    if (n < 1 || n > 10'000'000) return gs::fail(GS_ERR_INVALID_ASSET, "SPZ read error, out of range splat count");     // 10M hardcoded in SPZ code
+    if (shLevel < 0 || shLevel > 3) return gs::fail(GS_ERR_INVALID_ASSET, "SPZ read error, out of range SH level");
+    if (fractBits < 0 || fractBits > 24) return gs::fail(GS_ERR_INVALID_ASSET, "SPZ read error, out of range fractional bits");
+    const int shCoeffs = shLevel == 1 ? 3 : (shLevel == 2 ? 8 : (shLevel == 3 ? 15 : 0));
+    const size_t N = (size_t)n;
+    const size_t oPos = 16, oAlpha = oPos + N * 9, oCol = oAlpha + N, oScale = oCol + N * 3, oRot = oScale + N * 3, oSh = oRot + N * 3, end = oSh + N * 3 * shCoeffs;
+    if (raw.size() < end) return gs::fail(GS_ERR_INVALID_ASSET, "SPZ read error, file smaller than it should be");
+    gs_ply* p = new (std::nothrow) gs_ply();
+    if (!p) return gs::fail(GS_ERR_OUT_OF_MEMORY, "host allocation");
+    try {
+        p->count = (uint32_t)n;
+        p->pos.resize(N * 3); p->dc0.resize(N * 3); p->sh.assign(N * 45, 0.0f);
+        p->opacity.resize(N); p->scale.resize(N * 3); p->rot.resize(N * 4);
+    } catch (...) { delete p; return gs::fail(GS_ERR_OUT_OF_MEMORY, "host allocation"); }
+    const float fractScale = 1.0f / (float)(1 << fractBits);
+    const uint8_t* d = raw.data();
+    const size_t shLen = N * 3 * shCoeffs;
+    parallel_for(N, 1 << 14, [&](size_t a, size_t b) {
+        for (size_t i = a; i < b; ++i) {
+            for (int c = 0; c < 3; ++c) {
+                const uint8_t* q = d + oPos + (i * 3 + c) * 3;
+                int32_t fx = (int32_t)q[0] | ((int32_t)q[1] << 8) | ((int32_t)q[2] << 16);
+                if (fx & 0x800000) fx |= (int32_t)0xff000000;                      // sign extension
+                p->pos[i * 3 + c] = (float)fx * fractScale;
+                p->scale[i * 3 + c] = std::fabs(exp_det((float)d[oScale + i * 3 + c] / 16.0f - 10.0f));         // LinearScale
+                p->dc0[i * 3 + c] = (((float)d[oCol + i * 3 + c] / 255.0f - 0.5f) / 0.15f) * 0.2820948f + 0.5f;    // SH0ToColor
+            }
+            p->opacity[i] = (float)d[oAlpha + i] / 255.0f;
+            float q4[4];
+            for (int c = 0; c < 3; ++c) q4[c] = (float)d[oRot + i * 3 + c] * (1.0f / 127.5f) - 1.0f;
+            const float sq = (q4[0] * q4[0] + q4[1] * q4[1]) + q4[2] * q4[2];
+            q4[3] = std::sqrt(std::fmax(0.0f, 1.0f - sq));
+            const float inv = 1.0f / std::sqrt(((q4[0] * q4[0] + q4[1] * q4[1]) + q4[2] * q4[2]) + q4[3] * q4[3]);   // math.normalize
+            const float qv[4] = { q4[0] * inv, q4[1] * inv, q4[2] * inv, q4[3] * inv };
+            pack_smallest3(qv, &p->rot[i * 4]);
+            // UnpackSH: the job reads FIFTEEN coefficients starting at index * shCoeffs * 3 whatever the level (:178-193), i.e. for
+            // levels < 3 it runs on into the following splats' bytes; restated as is, with bytes past the array reading as 128 (= 0)
+            const size_t base = i * 3 * (size_t)shCoeffs;
+            for (int k = 0; k < 45; ++k) {
+                const size_t at = base + (size_t)k;
+                const float bv = at < shLen ? (float)d[oSh + at] : 128.0f;
+                p->sh[i * 45 + k] = (bv - 128.0f) / 128.0f;
+            }
+        }
+    });
+    *out = p;
+    if (splat_count) *splat_count = p->count;
+    return GS_OK;
+}
+
+int32_t gs_spz_open(const char* path, gs_ply** out, uint32_t* splat_count) {
+    try { return spz_open_impl(path, out, splat_count); }
+    catch (const std::bad_alloc&) { return gs::fail(GS_ERR_OUT_OF_MEMORY, "host allocation"); }
+    catch (...) { return gs::fail(GS_ERR_INVALID_ASSET, "unexpected failure while reading the SPZ file"); }
 }
 
 int32_t gs_ply_arrays(const gs_ply* ply, gs_import_input* out) {

@@ -596,6 +596,17 @@ extern "C" int32_t gs_debug_read_blend_timeline(void* out, size_t bytes) {
 }
 #endif
 
+// View depth (centerClipPos.w, SplatUtilities.compute:199-200) of every visible splat, for the scene-depth test of the blend:
+// only launched by a draw whose target has a depth attachment, so the default path neither computes nor stores it.  Same
+// operations as CalcViewGeom, hence the same bits as the w the splat was culled and drawn with.
+__global__ __launch_bounds__(256) void splat_depth_kernel(gsm::AssetView a, gsm::FrameConsts P, const uint32_t* __restrict__ visMask32, float* __restrict__ recW) {
+    const uint32_t idx = blockIdx.x * 256u + threadIdx.x;
+    if (idx >= a.n || !((visMask32[idx >> 5] >> (idx & 31u)) & 1u)) return;
+    const gsm::V3 pos = gsm::LoadSplatPosChunk(a, idx, blockIdx.x);
+    const float wx = gsm::mrow(P.o2w, 0, pos.x, pos.y, pos.z), wy = gsm::mrow(P.o2w, 1, pos.x, pos.y, pos.z), wz = gsm::mrow(P.o2w, 2, pos.x, pos.y, pos.z);
+    recW[idx] = gsm::mrow(P.vp, 3, wx, wy, wz);
+}
+
 // RenderMode.DebugPoints / DebugPointIndices (GaussianDebugRenderPoints.shader; GaussianSplatRenderer.cs:126-131,148-161):
 // every splat, in index order (no order buffer), is an opaque screen-space square of _SplatSize pixels around its projected
 // centre, colour = saturate(DC colour) or an index code, drawn with ZWrite On + the default ZTest LEqual.  As compute: the
@@ -706,7 +717,7 @@ int32_t ensure_arena(gs_renderer* r, uint32_t numTiles) {
 
 } // namespace
 
-ViewOutputs view_outputs(gs_renderer* r) { return ViewOutputs{ r->view, r->recs, r->rects, r->visMask, r->recW }; }
+ViewOutputs view_outputs(gs_renderer* r) { return ViewOutputs{ r->view, r->recs, r->rects, r->visMask }; }
 
 int32_t renderer_alloc_raster(gs_renderer* r) {
     gs_context* ctx = r->ctx;
@@ -801,6 +812,11 @@ int32_t enqueue_draw(gs_renderer* r, const gs_frame_params* p, gs_target* rt) {
     prof_record(r, 5);
     const int dstIsZero = rt->clearPending ? 1 : 0;             // this draw writes every pixel of the target: the clear is folded in
     rt->clearPending = false;
+    if (rt->sceneDepth) {
+        gsm::FrameConsts fc;
+        flatten_params(p, fc);
+        hipLaunchKernelGGL(splat_depth_kernel, dim3(div_up(r->n, 256)), dim3(256), 0, st, r->asset->view, fc, (const uint32_t*)r->visMask, r->recW);
+    }
 #define GS_LAUNCH_BLEND(M, D) hipLaunchKernelGGL((blend_kernel<M, D>), dim3(numTiles), dim3(256), 0, st, r->pairVals, tileStart, tileEnd, tileOrder, \
                                              r->tileCost, r->recs, rt->rgba16f, rc, dstIsZero, r->recW, rt->sceneDepth)
     if (rt->sceneDepth) { if (r->blendMode == 0) GS_LAUNCH_BLEND(0, true); else GS_LAUNCH_BLEND(1, true); }

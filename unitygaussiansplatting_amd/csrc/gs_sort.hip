@@ -122,6 +122,7 @@ __global__ __launch_bounds__(256) void histogram_kernel(const uint32_t* __restri
 #ifndef GS_KEYS_ILP
 #define GS_KEYS_ILP 4
 #endif
+template <int POSFMT>
 __global__ __launch_bounds__(1024) void sort_keys_kernel(gsm::AssetView a, float m20, float m21, float m22, float m23,
                                                          uint32_t* __restrict__ keyBySplat, uint32_t* __restrict__ hist, uint32_t n,
                                                          unsigned long long* __restrict__ groupAgg, uint32_t groupAggWords,
@@ -138,16 +139,18 @@ __global__ __launch_bounds__(1024) void sort_keys_kernel(gsm::AssetView a, float
     const uint32_t step = gridDim.x * (4u * ILP);
     // two-stage software pipeline: the positions of the next ILP chunks are in flight while the keys of the current ones go
     // through the LDS histograms (the LDS atomic unit and the memory pipe then work at the same time instead of in turns)
-    auto load = [&](uint32_t c0, gsm::V3 (&p)[ILP]) {
+    // (raw dwords first, decoded only when they are consumed: every load of a stage is issued before anything waits)
+    typedef gsm::RawVec<POSFMT> Raw;
+    auto load = [&](uint32_t c0, Raw (&p)[ILP]) {
 #pragma unroll
         for (uint32_t k = 0; k < ILP; ++k) {
-            const uint32_t ci = __builtin_amdgcn_readfirstlane(c0 + k * 4u + sub);       // wave-uniform: 4 waves per chunk
-            const uint32_t idx = ci * 256u + t;
-            p[k] = gsm::V3{0.f, 0.f, 0.f};
-            if (idx < n) p[k] = gsm::LoadSplatPosChunk(a, idx, ci);
+            // unconditional loads with a clamped index: a load inside a divergent branch is waited for at the end of the branch
+            const uint32_t ci = min(c0 + k * 4u + sub, chunks - 1u);
+            const uint32_t idx = min(ci * 256u + t, n - 1u);
+            p[k] = gsm::LoadRawT<POSFMT>(a.pos, (uint64_t)idx * gsm::vecStrideT<POSFMT>());
         }
     };
-    gsm::V3 cur[ILP], nxt[ILP];
+    Raw cur[ILP], nxt[ILP];
     uint32_t c0 = blockIdx.x * (4u * ILP);
     if (c0 < chunks) load(c0, cur);
     for (; c0 < chunks; c0 += step) {
@@ -155,9 +158,11 @@ __global__ __launch_bounds__(1024) void sort_keys_kernel(gsm::AssetView a, float
         if (more) load(c0 + step, nxt);
 #pragma unroll
         for (uint32_t k = 0; k < ILP; ++k) {
-            const uint32_t idx = (c0 + k * 4u + sub) * 256u + t;
+            const uint32_t ci = __builtin_amdgcn_readfirstlane(c0 + k * 4u + sub);       // wave-uniform: 4 waves per chunk => scalar ChunkInfo loads
+            const uint32_t idx = ci * 256u + t;
             if (idx >= n) continue;
-            const uint32_t key = gsm::SortKeyOf(cur[k], m20, m21, m22, m23);
+            const gsm::V3 pos = gsm::ChunkLerpPos(a, gsm::DecodeRawT<POSFMT>(cur[k], (uint64_t)idx * gsm::vecStrideT<POSFMT>()), ci);
+            const uint32_t key = gsm::SortKeyOf(pos, m20, m21, m22, m23);
             keyBySplat[idx] = key;
             lds_hist_add(s_h, key & 255u);
             lds_hist_add(s_h + RADIX, (key >> 8) & 255u);
@@ -583,8 +588,10 @@ int32_t enqueue_sort_keys(gs_context* ctx, hipStream_t stream, const gsm::AssetV
     // `control` was zeroed by the previous sort's launch of this kernel (or at creation); this launch zeroes `nextControl`
     const uint32_t chunks = div_up(n, 256u);
     const uint32_t grid = max(1u, min(div_up(chunks, 4u * GS_KEYS_ILP), (uint32_t)ctx->cuCount));
-    hipLaunchKernelGGL(sort_keys_kernel, dim3(grid), dim3(1024), 0, stream, a, m[8], m[9], m[10], m[11], keyBySplat,
-                       control->hist, n, st.groupAgg, sort_group_words(n, 4), (uint32_t*)nextControl);
+#define GS_LAUNCH_KEYS(F) hipLaunchKernelGGL(sort_keys_kernel<F>, dim3(grid), dim3(1024), 0, stream, a, m[8], m[9], m[10], m[11], keyBySplat, \
+                                             control->hist, n, st.groupAgg, sort_group_words(n, 4), (uint32_t*)nextControl)
+    switch (a.posFmt) { case 0: GS_LAUNCH_KEYS(0); break; case 1: GS_LAUNCH_KEYS(1); break; case 2: GS_LAUNCH_KEYS(2); break; default: GS_LAUNCH_KEYS(3); break; }
+#undef GS_LAUNCH_KEYS
     GS_HIP(hipGetLastError());
     return GS_OK;
 }

@@ -159,7 +159,6 @@ __global__ __launch_bounds__(256) void calc_view_kernel(gsm::AssetView a, gsm::F
             uint4* rp = (uint4*)(recs + idx);
             rp[0] = make_uint4(gsm::f2u(fp.cx), gsm::f2u(fp.cy), gsm::f2u(vp.view.axis1[0]), gsm::f2u(vp.view.axis1[1]));
             rp[1] = make_uint4(gsm::f2u(vp.view.axis2[0]), gsm::f2u(vp.view.axis2[1]), vp.view.color[0], vp.view.color[1]);
-            O.recW[idx] = vp.view.pos[3];                       // the depth all four vertices of the quad share (:56-60)
         }
         rects[idx] = rect;
     }

@@ -118,6 +118,7 @@ namespace GaussianSplatting.Runtime
         [DllImport(Lib)] public static extern int gs_import_encode(ref ImportInput input, ref ImportFormats formats, IntPtr[] blobs5, ulong[] sizes5, float[] boundsMin3, float[] boundsMax3);
 
         [DllImport(Lib)] public static extern int gs_ply_open([MarshalAs(UnmanagedType.LPStr)] string path, out IntPtr ply, out uint splatCount);
+        [DllImport(Lib)] public static extern int gs_spz_open([MarshalAs(UnmanagedType.LPStr)] string path, out IntPtr ply, out uint splatCount);
         [DllImport(Lib)] public static extern int gs_ply_arrays(IntPtr ply, out ImportInput arrays);
         [DllImport(Lib)] public static extern int gs_ply_close(IntPtr ply);
 
