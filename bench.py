@@ -64,8 +64,8 @@ def stage_bytes(n, P, vis, W, H, asset, passes_pair):
     chunk = 64.0 / 256.0 if asset.chunkCount else 0.0
     b_asset = b_pos + GetOtherSizeNoSHIndex(asset.scaleFormat) + GetColorSize(asset.colorFormat) + sh_item + chunk
     return {
-        "calc_distances": n * (4 + b_pos + chunk + 4),           # prev order in, gathered pos, key out
-        "sort": n * 16 * 4,                                      # 4 Onesweep passes x (key+payload read + write); histogram is fused into calc_distances
+        "calc_distances": n * (b_pos + chunk + 4),               # CSCalcDistances' arithmetic in index order: pos in, key out (+ the digit histograms)
+        "sort": n * 16 * 4,                                      # 4 Onesweep passes x 16 B/key (the first reads prev order + gathered key instead of key + payload)
         # pos/rot/scale/colour/chunk of every splat in, 8-B tile rect + 1 visibility bit out; the SH record is read and the
         # 32-B blend record written only for splats that reach the screen (the 40-B m_GpuView record is materialised on demand)
         "calc_view": n * (b_asset - sh_item + 8 + 0.125) + vis * (sh_item + 32),
@@ -280,11 +280,11 @@ def main():
         # Onesweep launches of a frame (4 depth-sort passes + the pair-sort passes) are one kernel; it is timed on its own
         # by hipEvents recorded around exactly those launches on the context's stream (gs_stage_times.onesweep_*).
         launches = {"onesweep_kernel": 4 + int(stage.onesweep_pair_launches), "blend_kernel": 1, "calc_view_kernel": 1, "bin_emit_kernel": 1,
-                    "calc_distances_kernel": 1}
+                    "sort_keys_kernel": 1}
         ktime = {"onesweep_kernel": stage.onesweep_depth_ms + stage.onesweep_pairs_ms, "blend_kernel": stage.blend_ms,
-                 "calc_view_kernel": stage.calc_view_ms, "bin_emit_kernel": stage.bin_ms, "calc_distances_kernel": stage.calc_distances_ms}
+                 "calc_view_kernel": stage.calc_view_ms, "bin_emit_kernel": stage.bin_ms, "sort_keys_kernel": stage.calc_distances_ms}
         kbytes = {"onesweep_kernel": n * 16 * 4 + P * 16 * passes_pair, "blend_kernel": sb["blend"], "calc_view_kernel": sb["calc_view"],
-                  "bin_emit_kernel": sb["bin"], "calc_distances_kernel": sb["calc_distances"]}
+                  "bin_emit_kernel": sb["bin"], "sort_keys_kernel": sb["calc_distances"]}
         dom = max(ktime, key=lambda k: ktime[k])
         dom_ms = ktime[dom] / launches[dom]
         dom_bytes = kbytes[dom] / launches[dom]

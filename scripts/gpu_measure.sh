@@ -1,0 +1,16 @@
+#!/bin/bash
+# The measurement call of a round (on the GPU box, from the repo root): bench lines of every single-GPU configuration,
+# rocprofv3 kernel stats + PMC traffic passes of the headline bench, SQ counters.  Outputs under gpurun_out/.
+export PYTHONPATH=$PWD
+O=$PWD/gpurun_out; mkdir -p $O
+WHAT="${@:-c2 c3 c5 prof sq c4}"
+for w in $WHAT; do
+case $w in
+c2) timeout 600 python bench.py > $O/bench_c2.json 2> $O/bench_c2.err; tail -c 600 $O/bench_c2.json;;
+c3) timeout 600 python bench.py --config C3 > $O/bench_c3.json 2> $O/bench_c3.err; tail -c 300 $O/bench_c3.json;;
+c4) timeout 900 python bench.py --config C4 --steps 20 > $O/bench_c4.json 2> $O/bench_c4.err; tail -c 300 $O/bench_c4.json;;
+c5) timeout 600 python bench.py --config C5 --steps 20 > $O/bench_c5.json 2> $O/bench_c5.err; tail -c 300 $O/bench_c5.json;;
+prof) bash scripts/profile_round.sh > $O/profile_round.log 2>&1; tail -5 $O/profile_round.log;;
+sq) bash scripts/pmc_sq.sh C2 > $O/pmc_sq.log 2>&1; tail -3 $O/pmc_sq.log;;
+esac
+done

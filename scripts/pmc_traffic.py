@@ -31,14 +31,19 @@ for k in ("calib_write_b32", "calib_write_b128", "calib_scatter_runs32"):
     if k in cw: cal[k] = {"WRITE_SIZE_KiB": sum(cw[k]) / len(cw[k]), "true_over_counter": GIB_KIB / (sum(cw[k]) / len(cw[k]))}
     if k in cf: cal[k]["FETCH_SIZE_KiB_of_a_pure_write"] = sum(cf[k]) / len(cf[k])
 # which calibration applies to which kernel's dominant access width
-READ_CAL = {"onesweep_kernel": "calib_read_b32", "calc_distances_kernel": "calib_read_b32", "bin_emit_kernel": "calib_read_b32",
+READ_CAL = {"onesweep_kernel": "calib_read_b32", "sort_keys_kernel": "calib_read_b32", "splat_depth_kernel": "calib_read_b32", "bin_emit_kernel": "calib_read_b32",
             "tile_ranges_kernel": "calib_read_b32", "calc_view_kernel": "calib_read_b128", "blend_kernel": "calib_read_b128", "resolve_kernel": "calib_read_b128"}
-WRITE_CAL = {"onesweep_kernel": "calib_scatter_runs32", "calc_distances_kernel": "calib_write_b32", "bin_emit_kernel": "calib_write_b32",
+WRITE_CAL = {"onesweep_kernel": "calib_scatter_runs32", "sort_keys_kernel": "calib_write_b32", "bin_emit_kernel": "calib_write_b32",
              "calc_view_kernel": "calib_write_b128", "blend_kernel": "calib_write_b128", "resolve_kernel": "calib_write_b128"}
-bf, bw = counters("pmc_FETCH_SIZE"), counters("pmc_WRITE_SIZE")
+def by_base(c):
+    out = defaultdict(list)
+    for k, v in c.items():
+        out[re.sub(r"<.*", "", k)] += v
+    return out
+bf, bw = by_base(counters("pmc_FETCH_SIZE")), by_base(counters("pmc_WRITE_SIZE"))
 kernels = {}
 for k in sorted(set(bf) | set(bw)):
-    base = re.sub(r"<.*", "", k)
+    base = k
     if not (base.endswith("_kernel")): continue
     rf = cal.get(READ_CAL.get(base, "calib_read_b128"), {}).get("true_over_counter", 2.0)
     wf = cal.get(WRITE_CAL.get(base, "calib_write_b128"), {}).get("true_over_counter", 1.0)
