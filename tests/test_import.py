@@ -71,12 +71,26 @@ def test_native_importer_argument_validation():
     assert lib.gs_import_blob_sizes(1000, C.byref(ok), sizes) == 0
     assert list(sizes) == [4000, 8000, 2048 * 16 * 4, 32000, 4 * 64]
     assert lib.gs_import_blob_sizes(0, C.byref(ok), sizes) == -1
-    assert lib.gs_import_blob_sizes(1000, C.byref(gs_import_formats(2, 2, 3, 3, 1, 1)), sizes) == -3       # BC7
-    assert lib.gs_import_blob_sizes(1000, C.byref(gs_import_formats(2, 2, 2, 8, 1, 1)), sizes) == -3       # Cluster4k
+    assert lib.gs_import_blob_sizes(1000, C.byref(gs_import_formats(2, 2, 3, 3, 1, 1)), sizes) == 0        # BC7: 1 byte per texel
+    assert list(sizes)[2] == 2048 * 16
+    assert lib.gs_import_blob_sizes(1000, C.byref(gs_import_formats(2, 2, 2, 8, 1, 1)), sizes) == -1       # Cluster4k needs > 4096 splats
+    assert lib.gs_import_blob_sizes(5000, C.byref(gs_import_formats(2, 3, 2, 8, 1, 1)), sizes) == 0
+    assert list(sizes)[1] == 5000 * 8 and list(sizes)[3] == 4096 * 96                                      # rot + Norm6 scale + u16 index; fp16 table
     assert lib.gs_import_blob_sizes(1000, C.byref(gs_import_formats(9, 2, 2, 3, 1, 1)), sizes) == -1
     assert lib.gs_import_encode(None, C.byref(ok), (C.c_void_p * 5)(), sizes, None, None) == -1
     with pytest.raises(_lib.GsError):
-        creator.CreateAssetFromSplatsNative(scenes.make_splats(5000, 3, 2.0), "Low")
+        creator.CreateAssetFromSplatsNative(scenes.make_splats(5000, 3, 2.0), "Low")          # Cluster16k with 5000 splats
+
+
+@pytest.mark.parametrize("quality,n", [("VeryLow", 4_500), ("VeryLow", 9_001), ("Low", 17_000)])
+def test_native_importer_matches_numpy_clustered_and_bc7(quality, n):
+    """The VeryLow (BC7 colour + Cluster4k SH + Norm6 scale) and Low (Cluster16k) presets: SH palette, u16 indices and mode-6
+    BC7 blocks byte for byte equal in the two importers (deterministic k-means, fp32 block encoder restated op for op)."""
+    raw = scenes.make_splats(n, 200 + n, 3.0)
+    a, b = creator.CreateAssetFromSplats(raw, quality), creator.CreateAssetFromSplatsNative(raw, quality)
+    _same(a, b)
+    k = A.GetSHCount(a.shFormat, n)
+    assert len(a.shData) == k * 96 and len(np.unique(np.frombuffer(a.otherData[:n * 8], "<u2").reshape(n, 4)[:, 3])) > k // 8
 
 
 def test_native_ply_reader_matches_numpy(tmp_path):

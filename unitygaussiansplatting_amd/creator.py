@@ -311,31 +311,33 @@ def _pad8(b: np.ndarray) -> np.ndarray:
 # --------------------------------------------------------------------------------------------------
 # ClusterSHs (:476-518): K-means over the 45-D SH vectors -> fp16 palette + per-splat index
 # --------------------------------------------------------------------------------------------------
-def ClusterSHs(sh: np.ndarray, count: int, seed: int = 0, iterations: int = 4, sample: int = 200_000):
-    """sh [N,15,3] f32 -> (means [count,45] f32, indices [N] int).  Seeded mini-batch Lloyd iterations on a subsample,
-    then one full assignment pass; distances through |a|^2 + |b|^2 - 2ab (one GEMM per block of splats)."""
+def ClusterSHs(sh: np.ndarray, count: int, iterations: int = 4, sample: int = 200_000):
+    """sh [N,15,3] f32 -> (means [count,45] f32, indices [N] int).  Deterministic (no RNG), so that the native importer
+    (csrc/gs_import.cpp cluster_shs) emits the same palette: seeds and the training subset are stride samples, `iterations`
+    Lloyd steps on the subset (nearest mean by |c|^2 - 2 x.c in float64, first minimum; new mean = float64 sum of its points
+    in point order / count, rounded to fp32; an empty cluster keeps its mean), then one assignment pass over all splats."""
     n = len(sh)
     x = np.ascontiguousarray(sh.reshape(n, 45), f32)
-    rng = np.random.Generator(np.random.PCG64(seed))
-    means = x[rng.choice(n, size=count, replace=False)].copy()
+    means = x[(np.arange(count, dtype=np.int64) * n) // count].copy()
 
     def assign(pts, cen):
         out = np.empty(len(pts), np.int64)
-        c2 = (cen * cen).sum(1)
-        for i in range(0, len(pts), 16384):
-            blk = pts[i:i + 16384]
-            d = c2[None, :] - f32(2.0) * (blk @ cen.T)
-            out[i:i + 16384] = d.argmin(1)
+        c64 = cen.astype(np.float64)
+        c2 = (c64 * c64).sum(1)
+        for i in range(0, len(pts), 8192):
+            blk = pts[i:i + 8192].astype(np.float64)
+            d = c2[None, :] - 2.0 * (blk @ c64.T)
+            out[i:i + 8192] = d.argmin(1)
         return out
 
-    sub = x if n <= sample else x[rng.choice(n, size=sample, replace=False)]
+    sub = x if n <= sample else x[(np.arange(sample, dtype=np.int64) * n) // sample]
     for _ in range(iterations):
         idx = assign(sub, means)
         sums = np.zeros((count, 45), np.float64)
-        np.add.at(sums, idx, sub)
+        np.add.at(sums, idx, sub.astype(np.float64))              # unbuffered: strictly in point order
         cnt = np.bincount(idx, minlength=count)
         nz = cnt > 0
-        means[nz] = (sums[nz] / cnt[nz, None]).astype(f32)
+        means[nz] = (sums[nz] / cnt[nz, None].astype(np.float64)).astype(f32)
     return means, assign(x, means)
 
 
@@ -480,7 +482,7 @@ def CreateAssetFromSplats(raw: InputSplatData, quality: str = "Medium", *, forma
 def CreateAssetFromSplatsNative(raw: InputSplatData, quality: str = "Medium", *, formatPos=None, formatScale=None, formatColor=None,
                                 formatSH=None, name: str = "asset", morton: bool = True, linearize: bool = True) -> GaussianSplatAsset:
     """The same asset through the native importer of libgsplat_hip.so (gs_import_encode, csrc/gs_import.cpp: multi-threaded
-    host C++).  Bit-identical to CreateAssetFromSplats for every format it supports (tests/test_import.py); BC7 / Cluster* raise."""
+    host C++).  Bit-identical to CreateAssetFromSplats for every format and preset (tests/test_import.py), Cluster* palettes and BC7 included."""
     import ctypes as C
     from . import _lib
     from ._abi import gs_import_formats, gs_import_input

@@ -224,7 +224,10 @@ __global__ __launch_bounds__(THREADS, GS_SORT_MINWAVES) void onesweep_kernel(con
     const uint32_t n = nPtr ? min(*nPtr, nImm) : nImm;
     const uint32_t numParts = (n + PART - 1) / PART;
     // partitions per XCD block of the GATHER pass: an eighth of the input, at most a look-back group
-    const uint32_t xcdBlock = min((uint32_t)GROUP, max(1u, numParts / 8u));
+#ifndef GS_SORT_XCD_MAXBLOCK
+#define GS_SORT_XCD_MAXBLOCK 32
+#endif
+    const uint32_t xcdBlock = min((uint32_t)GS_SORT_XCD_MAXBLOCK, max(1u, numParts / 8u));
     (void)xcdBlock;
 
     // global exclusive digit offsets = exclusive scan of this pass's histogram (raw counts, accumulated by the key
