@@ -65,6 +65,9 @@ __device__ __forceinline__ void st16_sc1(uint32_t* p, u32x4 v) {
 // 32-bit element index on a wave-uniform base pointer: lets the compiler use the SGPR-base + 32-bit-VGPR-offset
 // addressing form instead of a 64-bit address per access (arrays are < 4 GB: counts are capped at 2^30)
 __device__ __forceinline__ uint32_t ldg32(const uint32_t* base, uint32_t idx) { return *(const uint32_t*)((const char*)base + (size_t)(idx << 2)); }
+// the random 4-byte gather of the first depth-sort pass: a plain (L1-allocating) load -- the `nt` form, which bypasses the
+// CU's L1, was measured 45 us slower per pass: neighbours of a sector do meet in L1
+__device__ __forceinline__ uint32_t gather32(const uint32_t* base, uint32_t idx) { return ldg32(base, idx); }
 __device__ __forceinline__ void stg32(uint32_t* base, uint32_t idx, uint32_t v) { *(uint32_t*)((char*)base + (size_t)(idx << 2)) = v; }
 
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane) {
@@ -224,10 +227,14 @@ __global__ __launch_bounds__(THREADS, GS_SORT_MINWAVES) void onesweep_kernel(con
     const uint32_t n = nPtr ? min(*nPtr, nImm) : nImm;
     const uint32_t numParts = (n + PART - 1) / PART;
     // partitions per XCD block of the GATHER pass: an eighth of the input, at most a look-back group
+    // partitions per XCD block of the GATHER pass: the input is cut into 8 r equal blocks, r = the fewest rounds for which a
+    // block is no larger than what one XCD runs at once (32 CUs x 3 workgroups), so that every XCD gets the same number of
+    // blocks (measured on C2, 749 partitions: blocks of 94 -> 156 us per depth sort, 32 -> 165, 64 (unbalanced) -> 179)
 #ifndef GS_SORT_XCD_MAXBLOCK
-#define GS_SORT_XCD_MAXBLOCK 32
+#define GS_SORT_XCD_MAXBLOCK 96
 #endif
-    const uint32_t xcdBlock = min((uint32_t)GS_SORT_XCD_MAXBLOCK, max(1u, numParts / 8u));
+    const uint32_t xcdRounds = (numParts + 8u * GS_SORT_XCD_MAXBLOCK - 1u) / (8u * GS_SORT_XCD_MAXBLOCK);
+    const uint32_t xcdBlock = max(1u, (numParts + 8u * max(xcdRounds, 1u) - 1u) / (8u * max(xcdRounds, 1u)));
     (void)xcdBlock;
 
     // global exclusive digit offsets = exclusive scan of this pass's histogram (raw counts, accumulated by the key
@@ -301,12 +308,12 @@ __global__ __launch_bounds__(THREADS, GS_SORT_MINWAVES) void onesweep_kernel(con
 #pragma unroll
                 for (int k = 0; k < KPT; ++k) key[k] = ldg32(vp + k * 64, (uint32_t)lane);
 #pragma unroll
-                for (int k = 0; k < KPT; ++k) key[k] = ldg32(keysIn, key[k]);
+                for (int k = 0; k < KPT; ++k) key[k] = gather32(keysIn, key[k]);
             } else {
 #pragma unroll
                 for (int k = 0; k < KPT; ++k) {
                     const uint32_t gi = waveBase + (uint32_t)k * 64u + lane;
-                    key[k] = (gi < n) ? ldg32(keysIn, ldg32(valsIn, gi)) : 0xffffffffu;
+                    key[k] = (gi < n) ? gather32(keysIn, ldg32(valsIn, gi)) : 0xffffffffu;
                 }
             }
         } else if (full) {
