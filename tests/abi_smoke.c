@@ -34,8 +34,10 @@ int main(void) {
     CHECK(bmin[0] == 0.0f && bmax[0] == 5.99f);
     sizes[3] -= 1;                                              /* a blob that is too small is refused */
     CHECK(gs_import_encode(&in, &fmt, blobs, sizes, bmin, bmax) == GS_ERR_INVALID_ARGUMENT);
-    fmt.color_format = GS_COLOR_BC7;
-    CHECK(gs_import_blob_sizes(N, &fmt, sizes) == GS_ERR_UNSUPPORTED_FORMAT);
+    fmt.color_format = GS_COLOR_BC7;                            /* 1 byte per texel: 2048 x 16 texels for 600 splats */
+    CHECK(gs_import_blob_sizes(N, &fmt, sizes) == GS_OK && sizes[2] == 2048u * 16u);
+    fmt.sh_format = GS_SH_CLUSTER4K;                            /* a 4096-entry SH table needs more than 4096 splats */
+    CHECK(gs_import_blob_sizes(N, &fmt, sizes) == GS_ERR_INVALID_ARGUMENT);
 
     /* with a GPU the asset could now be handed to gs_asset_create; without one the context must fail loudly */
     gs_context* ctx = NULL;
