@@ -185,7 +185,7 @@ struct gs_renderer {
     uint8_t* frameArena = nullptr;          // two copies, used alternately: each draw zeroes the other one for the next
     int arenaIdx = 0;
     size_t frameArenaBytes = 0;             // of one copy
-    size_t offBinStatus = 0, offTileStart = 0, offTileEnd = 0, offTileOrder = 0, offPairControl = 0;
+    size_t offBinStatus = 0, offBinGroupAgg = 0, offBinGroupBase = 0, offTileStart = 0, offTileEnd = 0, offTileOrder = 0, offPairControl = 0;
     uint32_t arenaTiles = 0;                // tiles the arena was sized for
     uint32_t* tileCost = nullptr;           // arenaTiles x u32: 256-record batches each tile walked in the previous draw (scheduling hint)
     uint32_t binParts = 0;

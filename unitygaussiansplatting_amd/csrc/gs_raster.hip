@@ -96,7 +96,7 @@ template <int PASSES>
 __global__ __launch_bounds__(kBinThreads, GS_BIN_MINWAVES) void bin_emit_kernel(const uint2* __restrict__ rects, const uint32_t* __restrict__ visMask32,
                                                                 const uint32_t* __restrict__ order, uint32_t n, uint32_t tilesX,
                                                                 uint32_t* __restrict__ pairKeys, uint32_t* __restrict__ pairVals,
-                                                                uint32_t capacity, BinControl* ctl, unsigned long long* binStatus,
+                                                                uint32_t capacity, BinControl* ctl, unsigned long long* binStatus, unsigned long long* binGroupAgg, unsigned long long* binGroupBase,
                                                                 uint32_t* pairHist, unsigned long long* __restrict__ groupAgg, uint32_t groupAggWords,
                                                                 uint32_t* __restrict__ nextArena, uint32_t nextArenaWords, uint32_t digitBits) {
     constexpr int SUB = 4;                                   // k's per emission batch: 256 positions per wave
@@ -161,38 +161,64 @@ __global__ __launch_bounds__(kBinThreads, GS_BIN_MINWAVES) void bin_emit_kernel(
 #pragma unroll
     for (int j = 0; j < 4; ++j) { const uint32_t t = s_wtot[j]; wbase += (j < w) ? t : 0u; blockTotal += t; }
 
-    // ---- chained scan across partitions: wave 0 publishes the aggregate, then looks back 64 partitions at a time ----
+    // ---- scan across partitions (wave 0).  All partitions of the first round of tickets are resident at once and publish
+    //      their totals at about the same time, so a plain decoupled look-back (64 predecessors per step until an inclusive
+    //      prefix turns up) is a serial chain: the inclusive front advances 64 partitions per step and the 1280th workgroup
+    //      waits ~20 steps.  Two levels instead, with groups of 64 partitions:
+    //        * every partition publishes its total (status word) and adds it to its group's word {members:8 | sum:56};
+    //        * the FIRST partition of group g sums the words of groups 0..g-1 (each complete once its 64 members have added --
+    //          that depends on nobody's look-back) and publishes the group's base;
+    //        * every other partition sums the status words of the earlier partitions of its own group (< 64, one step) and
+    //          adds the group's base.
+    //      (Everybody summing all group words themselves was measured: 1280 waves polling the same ~50 words with agent-scope
+    //      loads serialise on a few L2 lines, 0.10 -> 0.18 ms.)
     if (w == 0) {
-        unsigned long long* my = binStatus + part;
+        const uint32_t grp = part >> 6, grpStart = grp << 6;
         if (lane == 0) {
-            __hip_atomic_store(my, (part == 0 ? BFLAG_INCL : BFLAG_AGG) | (unsigned long long)blockTotal, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(binStatus + part, BFLAG_AGG | (unsigned long long)blockTotal, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(binGroupAgg + grp, (1ull << 56) | (unsigned long long)blockTotal, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             visAcc += s_wvis[0] + s_wvis[1] + s_wvis[2] + s_wvis[3];
         }
         unsigned long long excl = 0;
-        if (part > 0) {
-            int q = (int)part - 1;
-            uint32_t spins = 0;
-            for (;;) {
-                const int idx = q - lane;
-                unsigned long long s = BFLAG_INCL;                    // before partition 0: inclusive prefix 0
-                if (idx >= 0) s = __hip_atomic_load(binStatus + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const unsigned long long incl = __ballot((s & BFLAG_INCL) != 0);
-                const unsigned long long notReady = __ballot((s & (BFLAG_AGG | BFLAG_INCL)) == 0);
-                const int lim = incl ? (__ffsll((long long)incl) - 1) : 63;       // nearest inclusive prefix in the window
-                const unsigned long long need = lim == 63 ? ~0ull : ((2ull << lim) - 1ull);
-                if (notReady & need) {
-                    if (++spins > BIN_SPIN_LIMIT) { if (lane == 0) atomicOr(&ctl->error, 2u); break; }
+        uint32_t spins = 0;
+        bool failed = false;
+        if (part == grpStart) {                                          // ---- first of its group: the base of the group
+            int g = (int)grp - 1;
+            while (g >= 0 && !failed) {
+                const int gi = g - lane;
+                unsigned long long agg = 0ull;
+                if (gi >= 0) agg = __hip_atomic_load(binGroupAgg + gi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (__ballot(gi >= 0 && (agg >> 56) != 64ull)) {         // a member of one of these groups has not published yet
+                    if (++spins > BIN_SPIN_LIMIT) { if (lane == 0) atomicOr(&ctl->error, 2u); failed = true; }
                     __builtin_amdgcn_s_sleep(1);
                     continue;
                 }
-                unsigned long long v = (lane <= lim) ? (s & BVAL_MASK) : 0ull;
+                unsigned long long v = gi >= 0 ? (agg & ((1ull << 56) - 1ull)) : 0ull;
 #pragma unroll
                 for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
                 excl += v;
-                if (incl) break;
-                q -= 64;
+                g -= 64;
             }
-            if (lane == 0) __hip_atomic_store(my, BFLAG_INCL | (excl + blockTotal), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane == 0) __hip_atomic_store(binGroupBase + grp, BFLAG_INCL | excl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {                                                         // ---- the earlier partitions of the own group + the group's base
+            for (;;) {
+                const int idx = (int)part - 1 - lane;
+                const bool mine = idx >= (int)grpStart;
+                unsigned long long s = 0ull;
+                if (mine) s = __hip_atomic_load(binStatus + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                unsigned long long base = 0ull;
+                if (lane == 63) base = __hip_atomic_load(binGroupBase + grp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // lane 63 never has a predecessor (<= 63 of them)
+                if (__ballot((mine && (s & BFLAG_AGG) == 0) || (lane == 63 && (base & BFLAG_INCL) == 0))) {
+                    if (++spins > BIN_SPIN_LIMIT) { if (lane == 0) atomicOr(&ctl->error, 2u); failed = true; break; }
+                    __builtin_amdgcn_s_sleep(1);
+                    continue;
+                }
+                unsigned long long v = mine ? (s & BVAL_MASK) : (lane == 63 ? (base & BVAL_MASK) : 0ull);
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+                excl = v;
+                break;
+            }
         }
         if (lane == 0) {
             s_base = excl;
@@ -699,6 +725,8 @@ int32_t ensure_arena(gs_renderer* r, uint32_t numTiles) {
     off = align_up(sizeof(BinControl), 256);
     r->offPairControl = off; off += align_up(sizeof(SortControl), 256);
     r->offBinStatus = off;   off += align_up((size_t)r->binParts * 8, 256);
+    r->offBinGroupAgg = off; off += align_up((size_t)((r->binParts + 63) / 64) * 8, 256);
+    r->offBinGroupBase = off; off += align_up((size_t)((r->binParts + 63) / 64) * 8, 256);
     r->offTileStart = off;   off += align_up((size_t)numTiles * 4, 256);
     r->offTileEnd = off;     off += align_up((size_t)numTiles * 4, 256);
     r->offTileOrder = off;   off += align_up((size_t)numTiles * 4, 256);
@@ -781,6 +809,8 @@ int32_t enqueue_draw(gs_renderer* r, const gs_frame_params* p, gs_target* rt) {
     BinControl* binCtl = (BinControl*)arena;
     SortControl* pairCtl = (SortControl*)(arena + r->offPairControl);
     unsigned long long* binStatus = (unsigned long long*)(arena + r->offBinStatus);
+    unsigned long long* binGroupAgg = (unsigned long long*)(arena + r->offBinGroupAgg);
+    unsigned long long* binGroupBase = (unsigned long long*)(arena + r->offBinGroupBase);
     uint32_t* tileStart = (uint32_t*)(arena + r->offTileStart);
     uint32_t* tileEnd = (uint32_t*)(arena + r->offTileEnd);
     uint32_t* tileOrder = (uint32_t*)(arena + r->offTileOrder);
@@ -801,7 +831,7 @@ int32_t enqueue_draw(gs_renderer* r, const gs_frame_params* p, gs_target* rt) {
     const uint32_t binCap = max((uint32_t)ctx->cuCount * (uint32_t)GS_BIN_BLOCKS_PER_CU / kBinTicketClasses * kBinTicketClasses, kBinTicketClasses);
     const uint32_t binGrid = min(div_up(r->binParts, kBinTicketClasses) * kBinTicketClasses, binCap);
     hipLaunchKernelGGL(binKernel, dim3(binGrid), dim3(kBinThreads), 0, st, r->rects, (const uint32_t*)r->visMask, r->order, r->n, rc.tilesX, r->pairKeys,
-                       r->pairVals, cap, binCtl, binStatus, pairCtl->hist, r->pairSort.groupAgg, sort_group_words(cap, passes), (uint32_t*)nextArena, (uint32_t)(r->frameArenaBytes / 4), (uint32_t)bits);
+                       r->pairVals, cap, binCtl, binStatus, binGroupAgg, binGroupBase, pairCtl->hist, r->pairSort.groupAgg, sort_group_words(cap, passes), (uint32_t*)nextArena, (uint32_t)(r->frameArenaBytes / 4), (uint32_t)bits);
     prof_record(r, 4);
     GS_TRY(enqueue_sort_passes(ctx, st, r->pairSort, pairCtl, r->pairKeys, r->pairVals, cap, &binCtl->pairCountClamped, passes, 255u, r, 12, bits));
     r->lastPairPasses = (uint32_t)passes;

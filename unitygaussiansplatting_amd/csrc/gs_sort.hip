@@ -597,7 +597,10 @@ int32_t enqueue_sort_keys(gs_context* ctx, hipStream_t stream, const gsm::AssetV
                           SortControl* control, SortControl* nextControl, uint32_t n, SortState& st) {
     // `control` was zeroed by the previous sort's launch of this kernel (or at creation); this launch zeroes `nextControl`
     const uint32_t chunks = div_up(n, 256u);
-    const uint32_t grid = max(1u, min(div_up(chunks, 4u * GS_KEYS_ILP), (uint32_t)ctx->cuCount));
+#ifndef GS_KEYS_WGS_PER_CU
+#define GS_KEYS_WGS_PER_CU 1
+#endif
+    const uint32_t grid = max(1u, min(div_up(chunks, 4u * GS_KEYS_ILP), (uint32_t)ctx->cuCount * GS_KEYS_WGS_PER_CU));
 #define GS_LAUNCH_KEYS(F) hipLaunchKernelGGL(sort_keys_kernel<F>, dim3(grid), dim3(1024), 0, stream, a, m[8], m[9], m[10], m[11], keyBySplat, \
                                              control->hist, n, st.groupAgg, sort_group_words(n, 4), (uint32_t*)nextControl)
     switch (a.posFmt) { case 0: GS_LAUNCH_KEYS(0); break; case 1: GS_LAUNCH_KEYS(1); break; case 2: GS_LAUNCH_KEYS(2); break; default: GS_LAUNCH_KEYS(3); break; }
