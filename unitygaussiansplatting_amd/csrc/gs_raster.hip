@@ -92,6 +92,12 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
 #ifndef GS_BIN_MINWAVES
 #define GS_BIN_MINWAVES 1
 #endif
+#ifdef GS_EXP_BIN_TIMELINE        // experiment build: per-partition phase timestamps (100 MHz wall clock) of the LAST launch
+__device__ unsigned long long g_bin_tl[32768 * 8];
+#define GS_BTL(k) do { if (threadIdx.x == 0 && part < 32768u) g_bin_tl[part * 8u + (k)] = wall_clock64(); } while (0)
+#else
+#define GS_BTL(k) do { } while (0)
+#endif
 template <int PASSES>
 __global__ __launch_bounds__(kBinThreads, GS_BIN_MINWAVES) void bin_emit_kernel(const uint2* __restrict__ rects, const uint32_t* __restrict__ visMask32,
                                                                 const uint32_t* __restrict__ order, uint32_t n, uint32_t tilesX,
@@ -122,6 +128,9 @@ __global__ __launch_bounds__(kBinThreads, GS_BIN_MINWAVES) void bin_emit_kernel(
     // t * classes + c; see the same scheme in gs_sort.hip for why a workgroup still only waits on running partitions.
     for (;;) {
     __syncthreads();                                             // s_part / s_wtot / s_base of the previous partition are no longer read
+#ifdef GS_EXP_BIN_TIMELINE
+    const unsigned long long btl0 = wall_clock64();
+#endif
     if (tid == 0) {
         const uint32_t cls = blockIdx.x % kBinTicketClasses;
         s_part = __hip_atomic_fetch_add(&ctl->tickets[cls * 32u], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * kBinTicketClasses + cls;
@@ -129,6 +138,10 @@ __global__ __launch_bounds__(kBinThreads, GS_BIN_MINWAVES) void bin_emit_kernel(
     __syncthreads();
     const uint32_t part = s_part;
     if (part >= numParts) break;
+#ifdef GS_EXP_BIN_TIMELINE
+    if (tid == 0 && part < 32768u) g_bin_tl[part * 8u + 0] = btl0;
+#endif
+    GS_BTL(1);                                                   // ticket known
     const uint32_t waveBase = part * (uint32_t)kBinPart + (uint32_t)w * (64u * kBinItems);
 
     // ---- per sorted position: gather the splat's tile rectangle (8 B, written by calc_view) ----------------------
@@ -153,6 +166,7 @@ __global__ __launch_bounds__(kBinThreads, GS_BIN_MINWAVES) void bin_emit_kernel(
         mySum += c;
         myVis += c ? 1u : 0u;
     }
+    GS_BTL(2);                                                   // order, visibility bits and rectangles arrived (mySum depends on them)
     const uint32_t waveTotal = wave_sum_u32(mySum);
     const uint32_t waveVis = wave_sum_u32(myVis);
     if (lane == 0) { s_wtot[w] = waveTotal; s_wvis[w] = waveVis; }
@@ -230,7 +244,9 @@ __global__ __launch_bounds__(kBinThreads, GS_BIN_MINWAVES) void bin_emit_kernel(
             }
         }
     }
+    GS_BTL(3);                                                   // wave 0: scan done
     __syncthreads();
+    GS_BTL(4);
     const unsigned long long gbase = s_base + wbase;             // global offset of this wave's first pair
 
     // ---- emit (tile, splat) pairs, 256 positions of this wave at a time (no workgroup barriers below) -------------
@@ -295,6 +311,7 @@ __global__ __launch_bounds__(kBinThreads, GS_BIN_MINWAVES) void bin_emit_kernel(
         __builtin_amdgcn_wave_barrier();
     }
 
+    GS_BTL(5);                                                   // wave 0's emission done
     }   // next partition
 
     // ---- flush the pair-sort digit histograms and the visible count ---------------------------------------------
@@ -304,6 +321,13 @@ __global__ __launch_bounds__(kBinThreads, GS_BIN_MINWAVES) void bin_emit_kernel(
         if (c) atomicAdd(&pairHist[j], c);
     }
 }
+
+#ifdef GS_EXP_BIN_TIMELINE
+extern "C" int32_t gs_debug_read_bin_timeline(void* out, size_t bytes) {
+    (void)hipDeviceSynchronize();
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bin_tl), bytes) == hipSuccess ? 0 : -2;
+}
+#endif
 
 // tile -> [start, end) in the tile-sorted pair array.  Four keys per thread from one 16-byte load (the key buffers are
 // 16-byte aligned and padded by 16 entries), plus the one key before and the one after the quad.
