@@ -35,7 +35,7 @@ typedef enum gs_error {
     GS_OK = 0,
     GS_ERR_INVALID_ARGUMENT = -1,   /* null handle, bad size, bad enum (C#: ArgumentOutOfRangeException, GaussianSplatAsset.cs:47,66) */
     GS_ERR_HIP = -2,                /* a HIP runtime call failed; gs_last_error_string() has the detail */
-    GS_ERR_UNSUPPORTED_FORMAT = -3, /* a format / mode this build does not implement (e.g. the debug box render modes) */
+    GS_ERR_UNSUPPORTED_FORMAT = -3, /* a format this build does not implement (none at present: kept for ABI stability) */
     GS_ERR_OUT_OF_MEMORY = -4,
     GS_ERR_INVALID_ASSET = -5,      /* blob sizes do not match splat_count/formats (C#: HasValidAsset, GaussianSplatRenderer.cs:361-368) */
     GS_ERR_PAIR_OVERFLOW = -6,      /* tile-pair buffer too small for this frame; the renderer grew it -- draw again */
@@ -216,8 +216,11 @@ int32_t gs_renderer_set_deleted_bits(gs_renderer* r, const uint32_t* words, size
 /* m_RenderMode + m_PointDisplaySize (GaussianSplatRenderer.cs:241-242; material choice :126-131).  DebugPoints / DebugPointIndices
  * (GaussianDebugRenderPoints.shader) draw every splat as an opaque screen-space square of `point_display_size` pixels, nearest
  * wins (ZWrite On), colour = saturate(DC colour) or an index code; gs_renderer_draw then neither needs gs_renderer_sort nor
- * gs_renderer_calc_view.  DebugBoxes / DebugChunkBounds (GaussianDebugRenderBoxes.shader) are accepted here and refused by
- * gs_renderer_draw with GS_ERR_UNSUPPORTED_FORMAT (editor visualisations, not built). */
+ * gs_renderer_calc_view.  DebugBoxes (GaussianDebugRenderBoxes.shader) draws one box per splat -- half axes 2 x rotation x scale x
+ * splat_scale, colour saturate(DC colour), alpha saturate(opacity x opacity_scale) -- through the order buffer (so it needs
+ * gs_renderer_sort, not gs_renderer_calc_view), DebugChunkBounds one box per 256-splat chunk (position bounds, palette colour,
+ * alpha 0.1, chunk order); both are blended like the splats and honour the depth attachment.  A box draw overwrites the
+ * per-splat tile rectangles: call gs_renderer_calc_view again before the next Splats draw. */
 int32_t gs_renderer_set_render_mode(gs_renderer* r, int32_t mode, float point_display_size);
 /* 0 (default): "exact" -- accumulate in fp16 (RTNE after every blend, like the RGBA16F ROP).
  * 1: "fast" -- accumulate in fp32, stop a pixel when 1-A < 1/4096. */

@@ -909,6 +909,124 @@ void gso_draw_debug_points(const gs_asset_desc* d, const gs_frame_params* P, int
     }
 }
 
+// RenderMode.DebugBoxes / DebugChunkBounds (GaussianDebugRenderBoxes.shader:37-97; GaussianSplatRenderer.cs:126-131,156-166).
+// vert: a cube [-1,1]^3 per instance.  Splat boxes: instance -> _OrderBuffer[instance]; M = (float3x3)unity_ObjectToWorld *
+// CalcMatrixFromRotationScale(rot, scale * _SplatScale); worldPos = ObjectToWorld(pos) + mul(M, localPos) * 2; colour
+// saturate(col), alpha saturate(opacity * _SplatOpacityScale).  Chunk boxes: corners lerp(posMin, posMax, {0,1}^3) through
+// ObjectToWorld, palette colour, alpha 0.1, instance = chunk index.  frag: (rgb * a, a), Blend OneMinusDstAlpha One, ZWrite Off,
+// ZTest LEqual, Cull Front -- and the cube's 36 indices (GaussianSplatRenderer.cs:410-418) wind its outside faces counter-
+// clockwise, which Unity treats as back faces: the faces turned TOWARDS the camera are the ones drawn (the far ones for a
+// mirrored transform).  The rasteriser's coverage / depth per pixel centre is restated as a ray / box intersection in the box's
+// own space: ray through the pixel centre p(t) = o + t d with d = ax R0 + ay R1 + R2 (R0 = VP row 0 / P00,
+// R1 = VP row 1 / P11, R2 = VP row 3), so that t is the view depth; l(t) = Binv (p(t) - c); slab test against [-1,1]^3.
+struct BoxO { float inv[9], lo[3], r, g, b, a; bool mirrored; int x0, x1, y0, y1; bool ok; };
+
+static float inverse3(const float* b, float* inv) {
+    const float c00 = fmaf(b[4], b[8], -(b[5] * b[7])), c01 = fmaf(b[5], b[6], -(b[3] * b[8])), c02 = fmaf(b[3], b[7], -(b[4] * b[6]));
+    const float det = fmaf(b[2], c02, fmaf(b[1], c01, b[0] * c00));
+    const float r = 1.0f / det;
+    inv[0] = c00 * r; inv[1] = fmaf(b[2], b[7], -(b[1] * b[8])) * r; inv[2] = fmaf(b[1], b[5], -(b[2] * b[4])) * r;
+    inv[3] = c01 * r; inv[4] = fmaf(b[0], b[8], -(b[2] * b[6])) * r; inv[5] = fmaf(b[2], b[3], -(b[0] * b[5])) * r;
+    inv[6] = c02 * r; inv[7] = fmaf(b[1], b[6], -(b[0] * b[7])) * r; inv[8] = fmaf(b[0], b[4], -(b[1] * b[3])) * r;
+    return det;
+}
+
+int32_t gso_draw_debug_boxes(const gs_asset_desc* d, const uint32_t* order, const gs_frame_params* P, int32_t chunks, int32_t mode,
+                             uint16_t* rt, const float* scene_depth) {
+    const Asset a = make_asset(d);
+    const int W = (int)P->screen_w, H = (int)P->screen_h;
+    const float Wf = P->screen_w, Hf = P->screen_h;
+    const uint32_t count = chunks ? a.chunkCount : a.n;
+    if (count == 0) return 0;
+    float R0[3], R1[3], R2[3];
+    for (int k = 0; k < 3; ++k) { R0[k] = P->matrix_vp[k] / P->proj_m00; R1[k] = P->matrix_vp[4 + k] / P->proj_m11; R2[k] = P->matrix_vp[12 + k]; }
+    const float ox = P->cam_pos_world[0], oy = P->cam_pos_world[1], oz = P->cam_pos_world[2];
+    std::vector<BoxO> boxes(count);
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < (int64_t)count; ++i) {
+        BoxO& bx = boxes[i];
+        bx.ok = false;
+        const uint32_t idx = chunks ? (uint32_t)i : order[i];          // draw position i -> instance
+        float c[3], B[9], r, g, b, al;
+        const float* o2w = P->matrix_object_to_world;
+        if (!chunks) {
+            const SplatData sp = LoadSplatData(a, idx);
+            const float sx = sp.scale.x * P->splat_scale, sy = sp.scale.y * P->splat_scale, sz = sp.scale.z * P->splat_scale;
+            for (int k = 0; k < 3; ++k) c[k] = mul_row(o2w, k, sp.pos);
+            const float x = sp.rot.x, y = sp.rot.y, z = sp.rot.z, w = sp.rot.w;
+            const float m1[9] = { fmaf(-2.0f, fmaf(z, z, y * y), 1.0f) * sx, (2.0f * fmaf(-w, z, x * y)) * sy, (2.0f * fmaf(w, y, x * z)) * sz,
+                                  (2.0f * fmaf(w, z, x * y)) * sx, fmaf(-2.0f, fmaf(z, z, x * x), 1.0f) * sy, (2.0f * fmaf(-w, x, y * z)) * sz,
+                                  (2.0f * fmaf(-w, y, x * z)) * sx, (2.0f * fmaf(w, x, y * z)) * sy, fmaf(-2.0f, fmaf(y, y, x * x), 1.0f) * sz };
+            for (int ii = 0; ii < 3; ++ii)
+                for (int j = 0; j < 3; ++j) B[ii * 3 + j] = fmaf(o2w[ii * 4 + 2], m1[6 + j], fmaf(o2w[ii * 4 + 1], m1[3 + j], o2w[ii * 4] * m1[j])) * 2.0f;
+            r = saturatef(sp.col.x); g = saturatef(sp.col.y); b = saturatef(sp.col.z);
+            al = saturatef(sp.opacity * P->opacity_scale);
+        } else {
+            const Chunk ck = load_chunk(a, idx);
+            const float mn[3] = { ck.posX[0], ck.posY[0], ck.posZ[0] }, mx[3] = { ck.posX[1], ck.posY[1], ck.posZ[1] };
+            float mid[3], half[3];
+            for (int k = 0; k < 3; ++k) { mid[k] = (mn[k] + mx[k]) * 0.5f; half[k] = (mx[k] - mn[k]) * 0.5f; }
+            for (int k = 0; k < 3; ++k) c[k] = mul_row(o2w, k, f3{ mid[0], mid[1], mid[2] });
+            for (int ii = 0; ii < 3; ++ii)
+                for (int j = 0; j < 3; ++j) B[ii * 3 + j] = o2w[ii * 4 + j] * half[j];
+            const float t = (float)idx / (float)count;
+            r = fmaf(0.5f, cosf(6.28318f * (t + 0.0f)), 0.5f); g = fmaf(0.5f, cosf(6.28318f * (t + 0.33f)), 0.5f); b = fmaf(0.5f, cosf(6.28318f * (t + 0.67f)), 0.5f);
+            al = 0.1f;
+        }
+        const float det = inverse3(B, bx.inv);
+        bool ok = std::isfinite(det) && det != 0.0f;
+        for (int k = 0; k < 9; ++k) ok = ok && std::isfinite(bx.inv[k]);
+        if (!ok || !(al > 0.0f)) continue;
+        const float dx = ox - c[0], dy = oy - c[1], dz = oz - c[2];
+        for (int k = 0; k < 3; ++k) bx.lo[k] = fmaf(bx.inv[k * 3 + 2], dz, fmaf(bx.inv[k * 3 + 1], dy, bx.inv[k * 3] * dx));
+        bx.r = r; bx.g = g; bx.b = b; bx.a = al; bx.mirrored = det < 0.0f;
+        bx.x0 = 0; bx.y0 = 0; bx.x1 = W - 1; bx.y1 = H - 1;           // every pixel is tested (the GPU's tile rectangle is only a speed-up)
+        bx.ok = true;
+    }
+    int nthreads = 1;
+#ifdef _OPENMP
+    nthreads = omp_get_max_threads();
+#endif
+    const int bands = std::max(1, std::min(H, nthreads * 4));
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int band = 0; band < bands; ++band) {
+        const int yb0 = (int)((int64_t)H * band / bands), yb1 = (int)((int64_t)H * (band + 1) / bands) - 1;
+        for (int py = yb0; py <= yb1; ++py)
+            for (int px = 0; px < W; ++px) {
+                const float ndcx = (((float)px + 0.5f) / Wf) * 2.0f - 1.0f;
+                const float ndcy = 1.0f - (((float)py + 0.5f) / Hf) * 2.0f;
+                const float ax = ndcx / P->proj_m00, ay = ndcy / P->proj_m11;
+                float dir[3];
+                for (int k = 0; k < 3; ++k) dir[k] = fmaf(ay, R1[k], fmaf(ax, R0[k], R2[k]));
+                uint16_t* dst = rt + ((size_t)py * W + px) * 4;
+                float acc[4] = { f16tof32(dst[0]), f16tof32(dst[1]), f16tof32(dst[2]), f16tof32(dst[3]) };
+                const float sceneZ = scene_depth ? scene_depth[(size_t)py * W + px] : 0.0f;
+                for (uint32_t i = 0; i < count; ++i) {
+                    const BoxO& bx = boxes[i];
+                    if (!bx.ok) continue;
+                    float ld[3];
+                    for (int k = 0; k < 3; ++k) ld[k] = fmaf(bx.inv[k * 3 + 2], dir[2], fmaf(bx.inv[k * 3 + 1], dir[1], bx.inv[k * 3] * dir[0]));
+                    float tmin = -3.4028234663852886e38f, tmax = 3.4028234663852886e38f;
+                    for (int k = 0; k < 3; ++k) {
+                        const float t1 = (-1.0f - bx.lo[k]) / ld[k], t2 = (1.0f - bx.lo[k]) / ld[k];
+                        tmin = fmaxf(tmin, fminf(t1, t2));
+                        tmax = fminf(tmax, fmaxf(t1, t2));
+                    }
+                    if (!(tmin <= tmax)) continue;
+                    const float t = bx.mirrored ? tmax : tmin;                     // the face turned towards the camera (far face if mirrored)
+                    if (!(t > 0.0f) || !(t >= P->near_clip && t <= P->far_clip)) continue;
+                    if (scene_depth && !(t <= sceneZ)) continue;
+                    if (mode == 1 && (1.0f - acc[3]) < (1.0f / 4096.0f)) continue;
+                    const float tt = 1.0f - acc[3];
+                    const float src[4] = { bx.r * bx.a, bx.g * bx.a, bx.b * bx.a, bx.a };
+                    for (int ch = 0; ch < 4; ++ch) acc[ch] = mode == 0 ? blend_f16(src[ch], tt, acc[ch]) : fmaf(src[ch], tt, acc[ch]);
+                }
+                for (int ch = 0; ch < 4; ++ch) dst[ch] = f32tof16(acc[ch]);
+            }
+    }
+    return 0;
+}
+
 // GaussianComposite.shader:25-39 with "Blend SrcAlpha OneMinusSrcAlpha" onto a constant background.
 // UnityCG.cginc GammaToLinearSpace: c*(c*(c*0.305306011+0.682171111)+0.012522878).
 void gso_resolve(const uint16_t* rt, uint32_t W, uint32_t H, const float* bg, float* out32f, uint8_t* out8) {

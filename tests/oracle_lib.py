@@ -100,6 +100,16 @@ class Oracle:
         lib().gso_draw_debug_points(C.byref(self.desc), C.byref(params), C.c_int32(int(display_index)), C.c_float(size), _p(rt), _p(sd) if sd is not None else None)
         return rt
 
+    def draw_debug_boxes(self, params: gs_frame_params, chunks: bool, mode: int = 0, rt: np.ndarray | None = None, scene_depth=None):
+        """RenderMode.DebugBoxes (through self.order) / DebugChunkBounds; every pixel tests every box: small scenes only."""
+        W, H = int(params.screen_w), int(params.screen_h)
+        if rt is None:
+            rt = np.zeros((H, W, 4), np.uint16)
+        sd = np.ascontiguousarray(scene_depth, np.float32) if scene_depth is not None else None
+        lib().gso_draw_debug_boxes(C.byref(self.desc), _p(self.order), C.byref(params), C.c_int32(int(chunks)), C.c_int32(mode), _p(rt),
+                                   _p(sd) if sd is not None else None)
+        return rt
+
     def raster_records(self, params: gs_frame_params):
         """prepare() of every splat: (recs N x 8 u32, rects N x 2 u32, vis ceil(N/64) u64), gs_renderer_download_raster_records' layout."""
         recs = np.zeros((self.n, 8), np.uint32)

@@ -96,11 +96,6 @@ def test_gpu_debug_point_modes(gpu_ctx, quality):
         ref = orc.draw_debug_points(P, rm == RenderMode.DebugPointIndices, size, scene_depth=sd)
         assert np.array_equal(img, ref), (rm, size)
         assert (img[..., 3] == 0x3c00).mean() > 0.02
-    from unitygaussiansplatting_amd._lib import GsError
-    r.m_RenderMode = RenderMode.DebugBoxes
-    with pytest.raises(GsError) as e:
-        r.Draw(cam, rt)
-    assert e.value.code == -3
     # back to splats on the same target: the normal path is unaffected
     r.m_RenderMode = RenderMode.Splats
     rt.SetSceneDepth(None)
@@ -108,3 +103,101 @@ def test_gpu_debug_point_modes(gpu_ctx, quality):
     orc.sort(camera.sort_matrix(cam, r.transform.localToWorldMatrix)); orc.calc_view(P)
     assert rt_err(rt.Download(), orc.draw(P, 0)) <= RT_TOL
     r.OnDisable()
+
+
+def _hull_coverage(corners_px, W, H):
+    """float64: which pixel centres lie inside the convex hull of the projected corners, and how far from its boundary."""
+    from scipy.spatial import ConvexHull
+    hull = ConvexHull(corners_px)
+    yy, xx = np.mgrid[0:H, 0:W]
+    pts = np.stack([xx + 0.5, yy + 0.5], -1).reshape(-1, 2).astype(np.float64)
+    d = (hull.equations[:, :2] @ pts.T + hull.equations[:, 2:3]).max(0)          # signed distance to the nearest violated / closest face (<= 0 inside)
+    return (d <= 0).reshape(H, W), np.abs(d).reshape(H, W)
+
+
+def test_oracle_debug_box_is_the_projection_of_the_cube():
+    """One splat box seen from outside: the oracle's ray / box coverage equals the convex hull of the 8 projected corners
+    (independent float64 geometry; pixels within 0.01 px of the outline excluded), its colour is (rgb * a, a), a box behind an
+    occluder at its front face's depth is hidden, and a mirrored object transform (which flips the winding, hence draws the far
+    faces) covers the same pixels."""
+    a = fp32_point_asset([[0.3, -0.2, 0.0]])                        # rotation ~identity, scale 0.05, colour 0.5, opacity 1
+    cam = camera.Camera(position=(0.4, 0.6, 3.0), pixelWidth=160, pixelHeight=120)
+    for scale in ((1.0, 1.0, 1.0), (-1.0, 1.0, 1.0)):
+        tr = camera.Transform(position=(0.1, 0.0, 0.0), rotation=(0.0, 0.259, 0.0, 0.966), scale=scale)
+        P = camera.frame_params(cam, tr, splatScale=2.0)
+        orc = O.Oracle(a)
+        img = O.f16_to_f32(orc.draw_debug_boxes(P, chunks=False))
+        dec = orc.decode_all()[0]
+        pos, rot, sc = dec[0:3].astype(np.float64), dec[3:7].astype(np.float64), dec[7:10].astype(np.float64) * 2.0
+        x, y, z, w = rot
+        R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                      [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                      [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+        o2w = tr.localToWorldMatrix.astype(np.float64)
+        B = 2.0 * o2w[:3, :3] @ (R * sc[None, :])
+        c = o2w[:3, :3] @ pos + o2w[:3, 3]
+        vp = (cam.projectionMatrix.astype(np.float64) @ cam.worldToCameraMatrix.astype(np.float64))
+        corners = []
+        for k in range(8):
+            l = np.array([1.0 if k & 1 else -1.0, 1.0 if k & 2 else -1.0, 1.0 if k & 4 else -1.0])
+            cw = vp @ np.append(c + B @ l, 1.0)
+            corners.append(((0.5 + 0.5 * cw[0] / cw[3]) * 160, (0.5 - 0.5 * cw[1] / cw[3]) * 120))
+        inside, dist = _hull_coverage(np.array(corners), 160, 120)
+        covered = img[..., 3] > 0
+        sure = dist > 0.01
+        assert covered.sum() > 200 and np.array_equal(covered[sure], inside[sure])
+        alpha = np.float32(1.0)
+        assert np.allclose(img[covered], [0.5 * alpha, 0.5 * alpha, 0.5 * alpha, alpha], atol=1e-3)
+        # the drawn face's depth: an occluder just in front of the box hides it, one just behind its far side does not
+        front = float(np.linalg.norm(c - np.asarray(cam.position, np.float64))) - 2.0 * np.linalg.norm(B, 2)
+        hidden = orc.draw_debug_boxes(P, chunks=False, scene_depth=np.full((120, 160), front, np.float32))
+        shown = orc.draw_debug_boxes(P, chunks=False, scene_depth=np.full((120, 160), front + 4.1 * np.linalg.norm(B, 2), np.float32))
+        assert not hidden.any() and np.array_equal(O.f16_to_f32(shown)[..., 3] > 0, covered)
+    # camera INSIDE the box: the faces that would be visible are the culled ones -- nothing is drawn
+    cam_in = camera.Camera(position=(0.31, -0.19, 0.01), target=(0.0, 0.0, -5.0), pixelWidth=64, pixelHeight=48)
+    assert not O.Oracle(a).draw_debug_boxes(camera.frame_params(cam_in, camera.Transform(), splatScale=2.0), chunks=False).any()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("quality", ["Medium", "VeryHigh"])
+def test_gpu_debug_box_modes(gpu_ctx, quality):
+    a = small_asset(4_000, 6, quality)
+    cam = default_camera(W=200, H=128, az=-35.0)
+    orc = O.Oracle(a)
+    depth = np.full((cam.pixelHeight, cam.pixelWidth), np.inf, np.float32)
+    depth[:, :80] = 6.0
+    cases = [(RenderMode.DebugBoxes, camera.Transform(), None, 0), (RenderMode.DebugBoxes, camera.Transform(scale=(-1.0, 1.0, 1.2)), depth, 0),
+             (RenderMode.DebugBoxes, camera.Transform(), None, 1)]
+    if a.chunkData is not None and len(a.chunkData):
+        cases += [(RenderMode.DebugChunkBounds, camera.Transform(position=(0.2, 0.0, 0.0)), None, 0), (RenderMode.DebugChunkBounds, camera.Transform(), depth, 0)]
+    for rm, tr, sd, mode in cases:
+        r = GaussianSplatRenderer(gpu_ctx, a, transform=tr)
+        r.OnEnable()
+        r.m_SplatScale, r.m_OpacityScale, r.blendMode = 1.5, 0.6, mode
+        rt = RenderTarget(gpu_ctx, cam.pixelWidth, cam.pixelHeight)
+        r.m_RenderMode = rm
+        rt.SetSceneDepth(sd)
+        r.SortPoints(cam)                                               # the boxes go through the order buffer; no CalcViewData
+        rt.Clear(); r.Draw(cam, rt)
+        img = rt.Download()
+        orc.reset_order()
+        orc.sort(camera.sort_matrix(cam, tr.localToWorldMatrix))
+        assert np.array_equal(r.DownloadOrder(), orc.order)
+        P = r.FrameParams(cam)
+        ref = orc.draw_debug_boxes(P, chunks=rm == RenderMode.DebugChunkBounds, mode=mode, scene_depth=sd)
+        e = rt_err(img, ref, RT_TOL if mode == 0 else 4e-3)
+        assert e <= (RT_TOL if mode == 0 else 4e-3), (rm, e)
+        assert (O.f16_to_f32(ref)[..., 3] > 0).mean() > 0.05
+        if sd is not None:
+            assert rt_err(img, orc.draw_debug_boxes(P, chunks=rm == RenderMode.DebugChunkBounds, mode=mode)) > 0.01      # the occluder hides something
+        # back to splats with the same renderer: the box draw invalidated the per-splat rectangles, calc_view restores them
+        r.m_RenderMode = RenderMode.Splats
+        rt.SetSceneDepth(None)
+        r.blendMode = 0
+        from unitygaussiansplatting_amd._lib import GsError
+        with pytest.raises(GsError):
+            rt.Clear(); r.Draw(cam, rt)
+        r.CalcViewData(cam); rt.Clear(); r.Draw(cam, rt)
+        orc.calc_view(P)
+        assert rt_err(rt.Download(), orc.draw(P, 0)) <= RT_TOL
+        r.OnDisable(); rt.Dispose()

@@ -349,8 +349,9 @@ int32_t gs_renderer_draw(gs_renderer* r, const gs_frame_params* p, gs_target* rt
     if ((uint32_t)p->screen_w != rt->width || (uint32_t)p->screen_h != rt->height) return fail(GS_ERR_INVALID_ARGUMENT, "screen_w/h do not match the target");
     GS_TRY(bind_device(r->ctx));
     if (r->renderMode == GS_RENDER_DEBUG_POINTS || r->renderMode == GS_RENDER_DEBUG_POINT_INDICES) return enqueue_debug_points(r, p, rt);
-    if (r->renderMode != GS_RENDER_SPLATS) return fail(GS_ERR_UNSUPPORTED_FORMAT, "DebugBoxes / DebugChunkBounds render modes are not built");
     GS_TRY(maybe_grow_pairs(r));
+    if (r->renderMode == GS_RENDER_DEBUG_BOXES) return enqueue_debug_boxes(r, p, rt, false);
+    if (r->renderMode == GS_RENDER_DEBUG_CHUNK_BOUNDS) return enqueue_debug_boxes(r, p, rt, true);
     return enqueue_draw(r, p, rt);
 }
 

@@ -161,6 +161,8 @@ struct gs_renderer {
     int depthControlIdx = 0;                   // the block the last / current sort uses
     // compositor buffers
     gs::SplatRec* recs = nullptr;           // N x 32 B, indexed by splat (written by calc_view)
+    gsm::BoxRec* boxRecs = nullptr;         // N x 64 B, debug box modes only (allocated on first use)
+    uint32_t* chunkOrder = nullptr;         // identity order of the chunks (DebugChunkBounds draws them in index order)
     float* recW = nullptr;                  // N x 4 B: clip.w of the visible splats, filled by the draw only when the target has a depth attachment
     uint2* rects = nullptr;                 // N x 8 B: x = tx0 | ty0 << 16, y = tiles wide | tiles high << 16 (0 = culled)
     unsigned long long* visMask = nullptr;  // ceil(N/64) x 8 B: bit s = splat s reaches at least one tile (written by calc_view)
@@ -240,6 +242,7 @@ int32_t renderer_alloc_raster(gs_renderer* r);
 void renderer_free_raster(gs_renderer* r);
 int32_t enqueue_draw(gs_renderer* r, const gs_frame_params* p, gs_target* rt);
 int32_t enqueue_debug_points(gs_renderer* r, const gs_frame_params* p, gs_target* rt);   // RenderMode.DebugPoints / DebugPointIndices
+int32_t enqueue_debug_boxes(gs_renderer* r, const gs_frame_params* p, gs_target* rt, bool chunks);   // RenderMode.DebugBoxes / DebugChunkBounds
 int32_t enqueue_resolve(gs_target* t, const float bg[4], bool want8);
 int32_t flush_clear(gs_target* t);          // perform a pending gs_target_clear now
 } // namespace gs

@@ -128,6 +128,7 @@ GS_HD uint32_t f32tof16(float f) {     // round to nearest even
 // ---- scalar helpers -----------------------------------------------------------------------------
 GS_HD float lerpf(float a, float b, float t) { return fmaf(t, b - a, a); }
 GS_HD float sat(float x) { return fminf(fmaxf(x, 0.0f), 1.0f); }
+GS_HD bool finite32(float x) { return fabsf(x) <= 3.4028234663852886e38f; }
 GS_HD float sgn(float x) { return (x > 0.0f) ? 1.0f : ((x < 0.0f) ? -1.0f : 0.0f); }
 GS_HD float dot3f(float ax, float ay, float az, float bx, float by, float bz) { return fmaf(az, bz, fmaf(ay, by, ax * bx)); }
 GS_HD float dot2f(float ax, float ay, float bx, float by) { return fmaf(ay, by, ax * bx); }
@@ -496,6 +497,105 @@ GS_HD V3 DebugIndexColor(uint32_t idx, uint32_t count) {
     return { r - floorf(r), g - floorf(g), f };
 }
 
+// ---- debug box modes (GaussianDebugRenderBoxes.shader): every box is an affine image of the cube [-1,1]^3,
+// world = c + B l.  Per pixel the rasteriser's result is restated as a ray / box intersection in the box's own space
+// (l = Binv (p - c)): the ray through the pixel centre is p(t) = o + t d with d scaled so that t IS the view depth, the slab
+// test gives its entry / exit parameters, and the face the rasteriser draws is the entry face for a box whose transform
+// keeps the winding (the cube's triangles are wound so that its outside faces are the back faces: with `Cull Front` the
+// faces turned towards the camera are drawn) and the exit face for a mirrored one.  Depth clipping and the depth test use t.
+struct BoxRec { float inv[9]; float lo[3]; float r, g, b, a; };      // 64 B: Binv rows, Binv (o - c), colour; a < 0 marks a mirrored box (its alpha is |a|)
+
+// inverse of a 3x3 (rows of 3) by cofactors; returns the determinant.  A singular / non-finite box is not drawn.
+GS_HD float Inverse3(const float* b, float* inv) {
+    const float c00 = fmaf(b[4], b[8], -(b[5] * b[7])), c01 = fmaf(b[5], b[6], -(b[3] * b[8])), c02 = fmaf(b[3], b[7], -(b[4] * b[6]));
+    const float det = fmaf(b[2], c02, fmaf(b[1], c01, b[0] * c00));
+    const float r = 1.0f / det;
+    inv[0] = c00 * r; inv[1] = fmaf(b[2], b[7], -(b[1] * b[8])) * r; inv[2] = fmaf(b[1], b[5], -(b[2] * b[4])) * r;
+    inv[3] = c01 * r; inv[4] = fmaf(b[0], b[8], -(b[2] * b[6])) * r; inv[5] = fmaf(b[2], b[3], -(b[0] * b[5])) * r;
+    inv[6] = c02 * r; inv[7] = fmaf(b[1], b[6], -(b[0] * b[7])) * r; inv[8] = fmaf(b[0], b[4], -(b[1] * b[3])) * r;
+    return det;
+}
+
+// per-frame ray set-up from the frame constants: R0 = VP row 0 / P00, R1 = VP row 1 / P11 (the camera's right / up axes in
+// world space), R2 = VP row 3 (its forward axis: clip.w = view depth).  World direction of the ray through pixel centre
+// (px + 0.5, py + 0.5): d = ax R0 + ay R1 + R2, ax = ndc.x / P00, ay = ndc.y / P11 -- so that view depth along the ray = t.
+struct RayConsts { float r0[3], r1[3], r2[3]; float ox, oy, oz; float p00, p11, W, H; };
+GS_HD void RayConstsFromFrame(RayConsts& rc, const float* vp, float p00, float p11, float camx, float camy, float camz, float W, float H) {
+    for (int k = 0; k < 3; ++k) { rc.r0[k] = vp[k] / p00; rc.r1[k] = vp[4 + k] / p11; rc.r2[k] = vp[12 + k]; }
+    rc.ox = camx; rc.oy = camy; rc.oz = camz; rc.p00 = p00; rc.p11 = p11; rc.W = W; rc.H = H;
+}
+GS_HD void PixelRay(const RayConsts& rc, int px, int py, float d[3]) {
+    const float ndcx = (((float)px + 0.5f) / rc.W) * 2.0f - 1.0f;
+    const float ndcy = 1.0f - (((float)py + 0.5f) / rc.H) * 2.0f;
+    const float ax = ndcx / rc.p00, ay = ndcy / rc.p11;
+    for (int k = 0; k < 3; ++k) d[k] = fmaf(ay, rc.r1[k], fmaf(ax, rc.r0[k], rc.r2[k]));
+}
+// view depth of the drawn face of box `inv/lo` along the ray with box-space direction ld, or a negative value if the pixel is
+// not covered.  NaNs (a ray parallel to a slab it starts on) compare false: not covered.
+GS_HD float BoxFaceDepth(const float* lo, const float* ld, bool mirrored) {
+    float tmin = -3.4028234663852886e38f, tmax = 3.4028234663852886e38f;
+    for (int k = 0; k < 3; ++k) {
+        const float t1 = (-1.0f - lo[k]) / ld[k], t2 = (1.0f - lo[k]) / ld[k];
+        tmin = fmaxf(tmin, fminf(t1, t2));
+        tmax = fminf(tmax, fmaxf(t1, t2));
+    }
+    if (!(tmin <= tmax)) return -1.0f;
+    const float t = mirrored ? tmax : tmin;
+    return (t > 0.0f) ? t : -1.0f;
+}
+
+// LoadSplatData's rotation, scale (de-normalised) and opacity (GaussianSplatting.hlsl:428-470,565-603) for the box mode
+GS_HD void LoadSplatRotScaleOpacity(const AssetView& a, uint32_t idx, V4& q, V3& scale, float& opacity) {
+    uint32_t otherStride = 4 + vecStride(a.scaleFmt);
+    if (a.shFmt > 3) otherStride += 2;
+    const uint64_t otherAddr = (uint64_t)idx * otherStride;
+    q = DecodeRotation(LoadUInt(a.other, otherAddr));
+    scale = LoadVec(a.other, otherAddr + 4, a.scaleFmt);
+    V4 col = LoadColorTexel(a, idx);
+    const uint32_t ci = idx >> 8;
+    if (ci < a.chunkCount) {
+        const uint8_t* c = a.chunk + (uint64_t)ci * 64;
+        scale.x = lerpf(f16tof32(ld32a(c, 40)), f16tof32(ld32a(c, 40) >> 16), scale.x);
+        scale.y = lerpf(f16tof32(ld32a(c, 44)), f16tof32(ld32a(c, 44) >> 16), scale.y);
+        scale.z = lerpf(f16tof32(ld32a(c, 48)), f16tof32(ld32a(c, 48) >> 16), scale.z);
+        scale.x *= scale.x; scale.y *= scale.y; scale.z *= scale.z;
+        scale.x *= scale.x; scale.y *= scale.y; scale.z *= scale.z;
+        scale.x *= scale.x; scale.y *= scale.y; scale.z *= scale.z;
+        col.w = InvSquareCentered01(lerpf(f16tof32(ld32a(c, 12)), f16tof32(ld32a(c, 12) >> 16), col.w));
+    }
+    opacity = col.w;
+}
+
+// Builds the record of one box from its centre c and matrix B (world = c + B l, rows of 3); returns false if it cannot be drawn.
+// Also the conservative pixel bounding box of its projection (the whole screen if a corner is not in front of the camera).
+GS_HD bool BuildBox(const float c[3], const float B[9], const RayConsts& rc, const float* vp, float r, float g, float bl, float al,
+                    BoxRec& rec, int& x0, int& x1, int& y0, int& y1) {
+    const float det = Inverse3(B, rec.inv);
+    bool ok = finite32(det) && det != 0.0f;
+    for (int k = 0; k < 9; ++k) ok = ok && finite32(rec.inv[k]);
+    if (!ok || !(al > 0.0f)) return false;
+    const float dx = rc.ox - c[0], dy = rc.oy - c[1], dz = rc.oz - c[2];
+    for (int k = 0; k < 3; ++k) rec.lo[k] = fmaf(rec.inv[k * 3 + 2], dz, fmaf(rec.inv[k * 3 + 1], dy, rec.inv[k * 3] * dx));
+    rec.r = r; rec.g = g; rec.b = bl; rec.a = det < 0.0f ? -al : al;
+    float minx = 3.0e38f, maxx = -3.0e38f, miny = 3.0e38f, maxy = -3.0e38f;
+    bool behind = false;
+    for (int corner = 0; corner < 8; ++corner) {
+        const float lx = (corner & 1) ? 1.0f : -1.0f, ly = (corner & 2) ? 1.0f : -1.0f, lz = (corner & 4) ? 1.0f : -1.0f;
+        const float wx = c[0] + fmaf(B[2], lz, fmaf(B[1], ly, B[0] * lx)), wy = c[1] + fmaf(B[5], lz, fmaf(B[4], ly, B[3] * lx)),
+                    wz = c[2] + fmaf(B[8], lz, fmaf(B[7], ly, B[6] * lx));
+        const float cx = mrow(vp, 0, wx, wy, wz), cy = mrow(vp, 1, wx, wy, wz), cw = mrow(vp, 3, wx, wy, wz);
+        if (!(cw > 1.0e-6f)) { behind = true; continue; }
+        const float sx = fmaf(0.5f * (cx / cw), rc.W, 0.5f * rc.W), sy = fmaf(-0.5f * (cy / cw), rc.H, 0.5f * rc.H);
+        minx = fminf(minx, sx); maxx = fmaxf(maxx, sx); miny = fminf(miny, sy); maxy = fmaxf(maxy, sy);
+    }
+    if (behind || !(finite32(minx) && finite32(maxx) && finite32(miny) && finite32(maxy))) { x0 = 0; y0 = 0; x1 = (int)rc.W - 1; y1 = (int)rc.H - 1; return true; }
+    const float fx0 = fmaxf(floorf(minx) - 1.0f, 0.0f), fx1 = fminf(ceilf(maxx) + 1.0f, rc.W - 1.0f);
+    const float fy0 = fmaxf(floorf(miny) - 1.0f, 0.0f), fy1 = fminf(ceilf(maxy) + 1.0f, rc.H - 1.0f);
+    if (!(fx0 <= fx1 && fy0 <= fy1)) return false;
+    x0 = (int)fx0; x1 = (int)fx1; y0 = (int)fy0; y1 = (int)fy1;
+    return true;
+}
+
 // IsSplatCut (SplatUtilities.compute:164-187); pos is the object-space position
 GS_HD bool IsSplatCut(const EditView& e, float px, float py, float pz) {
     bool finalCut = false;
@@ -755,8 +855,6 @@ GS_HD ViewData CalcViewData(const AssetView& a, const FrameConsts& P, const Edit
 // ---- compositor set-up: which splats are drawn, where, and which 16x16 tiles they can touch -----------
 // Restates the vertex stage of RenderGaussianSplats.shader:35-77 plus the fixed-function clipping it relies
 // on (DESIGN.md "compositor semantics"); must stay in step with prepare() in oracle/gs_oracle.cpp.
-GS_HD bool finite32(float x) { return fabsf(x) <= 3.4028234663852886e38f; }
-
 GS_HD void PixRange(float c, float e, float size, int& lo, int& hi) {
     float flo = ceilf((c - e) - 0.5f), fhi = floorf((c + e) - 0.5f);
     flo = fmaxf(flo, 0.0f); fhi = fminf(fhi, size - 1.0f);

@@ -454,6 +454,8 @@ template <> struct PixelAcc<0> {
         mix_blend4(rg, ba, mix_mul_hi(c0, alpha), mix_mul_lo(c0, alpha), mix_mul_hi(c1, alpha), alpha, t);
 #endif
     }
+    // src = (pr, pg, pb, pa) already premultiplied, fp32 (the box fragment shader's output)
+    __device__ __forceinline__ void blend_src(float pr, float pg, float pb, float pa) { const float t = mix_one_minus_hi(ba); mix_blend4(rg, ba, pr, pg, pb, pa, t); }
     __device__ __forceinline__ bool finished() const { return (ba >> 16) == 0x3c00u; }      // A == 1.0: further blends add exactly 0
     __device__ __forceinline__ bool saturated() const { return false; }
     __device__ __forceinline__ uint2 pack() const { return make_uint2(rg, ba); }
@@ -468,6 +470,7 @@ template <> struct PixelAcc<1> {
         r = fmaf(mix_mul_hi(c0, alpha), t, r); g = fmaf(mix_mul_lo(c0, alpha), t, g); b = fmaf(mix_mul_hi(c1, alpha), t, b);
         a = fmaf(alpha, t, a);
     }
+    __device__ __forceinline__ void blend_src(float pr, float pg, float pb, float pa) { const float t = 1.0f - a; r = fmaf(pr, t, r); g = fmaf(pg, t, g); b = fmaf(pb, t, b); a = fmaf(pa, t, a); }
     __device__ __forceinline__ bool finished() const { return (1.0f - a) < (1.0f / 4096.0f); }
     __device__ __forceinline__ bool saturated() const { return (1.0f - a) < (1.0f / 4096.0f); }
     __device__ __forceinline__ uint2 pack() const {
@@ -658,6 +661,115 @@ __global__ __launch_bounds__(256) void splat_depth_kernel(gsm::AssetView a, gsm:
     recW[idx] = gsm::mrow(P.vp, 3, wx, wy, wz);
 }
 
+// RenderMode.DebugBoxes / DebugChunkBounds (GaussianDebugRenderBoxes.shader; GaussianSplatRenderer.cs:126-131,156-166): one
+// box per splat -- centre = the splat, half axes = 2 * rotation * scale * _SplatScale, colour saturate(col) with alpha
+// saturate(opacity * _SplatOpacityScale), drawn through _OrderBuffer -- or one per chunk (the chunk's position bounds, a
+// palette colour, alpha 0.1, chunk order), blended "OneMinusDstAlpha One" like the splats.  Same pipeline as the splat draw:
+// box_setup writes a 64-byte record + tile rectangle + visibility bit per box, bin_emit / pair sort / tile ranges are shared,
+// blend_box evaluates the ray / box test of gs_device_math.h per pixel.
+template <bool CHUNKS>
+__global__ __launch_bounds__(256) void box_setup_kernel(gsm::AssetView a, gsm::FrameConsts P, gsm::RayConsts ray, uint32_t count, gsm::BoxRec* __restrict__ recs,
+                                                        uint2* __restrict__ rects, unsigned long long* __restrict__ visMask) {
+    const uint32_t idx = blockIdx.x * 256u + threadIdx.x;
+    bool visible = false;
+    uint2 rect = make_uint2(0u, 0u);
+    if (idx < count) {
+        float c[3], B[9], r, g, b, al;
+        if (!CHUNKS) {
+            const gsm::V3 pos = gsm::LoadSplatPos(a, idx);
+            gsm::V4 q; gsm::V3 sc; float opacity;
+            gsm::LoadSplatRotScaleOpacity(a, idx, q, sc, opacity);
+            const float sx = sc.x * P.splatScale, sy = sc.y * P.splatScale, sz = sc.z * P.splatScale;
+            for (int k = 0; k < 3; ++k) c[k] = gsm::mrow(P.o2w, k, pos.x, pos.y, pos.z);
+            const float x = q.x, y = q.y, z = q.z, w = q.w;                           // CalcMatrixFromRotationScale (GaussianSplatting.hlsl:29-46)
+            const float m1[9] = { fmaf(-2.0f, fmaf(z, z, y * y), 1.0f) * sx, (2.0f * fmaf(-w, z, x * y)) * sy, (2.0f * fmaf(w, y, x * z)) * sz,
+                                  (2.0f * fmaf(w, z, x * y)) * sx, fmaf(-2.0f, fmaf(z, z, x * x), 1.0f) * sy, (2.0f * fmaf(-w, x, y * z)) * sz,
+                                  (2.0f * fmaf(-w, y, x * z)) * sx, (2.0f * fmaf(w, x, y * z)) * sy, fmaf(-2.0f, fmaf(y, y, x * x), 1.0f) * sz };
+            for (int i = 0; i < 3; ++i)
+                for (int j = 0; j < 3; ++j) B[i * 3 + j] = gsm::dot3f(P.o2w[i * 4], P.o2w[i * 4 + 1], P.o2w[i * 4 + 2], m1[j], m1[3 + j], m1[6 + j]) * 2.0f;
+            const gsm::V3 col = gsm::LoadSplatBaseColor(a, idx);
+            r = gsm::sat(col.x); g = gsm::sat(col.y); b = gsm::sat(col.z);
+            al = gsm::sat(opacity * P.opacityScale);
+        } else {
+            const uint8_t* ck = a.chunk + (uint64_t)idx * 64;
+            float mid[3], half[3];
+            for (int k = 0; k < 3; ++k) { const float mn = gsm::u2f(gsm::ld32a(ck, 16 + 8 * k)), mx = gsm::u2f(gsm::ld32a(ck, 20 + 8 * k)); mid[k] = (mn + mx) * 0.5f; half[k] = (mx - mn) * 0.5f; }
+            for (int k = 0; k < 3; ++k) c[k] = gsm::mrow(P.o2w, k, mid[0], mid[1], mid[2]);
+            for (int i = 0; i < 3; ++i)
+                for (int j = 0; j < 3; ++j) B[i * 3 + j] = P.o2w[i * 4 + j] * half[j];
+            const float t = (float)idx / (float)count;                                  // palette(t, 0.5, 0.5, 1, (0, 0.33, 0.67))
+            r = fmaf(0.5f, cosf(6.28318f * (t + 0.0f)), 0.5f); g = fmaf(0.5f, cosf(6.28318f * (t + 0.33f)), 0.5f); b = fmaf(0.5f, cosf(6.28318f * (t + 0.67f)), 0.5f);
+            al = 0.1f;
+        }
+        gsm::BoxRec rec;
+        int x0, x1, y0, y1;
+        if (gsm::BuildBox(c, B, ray, P.vp, r, g, b, al, rec, x0, x1, y0, y1)) {
+            visible = true;
+            rect.x = (uint32_t)(x0 >> 4) | ((uint32_t)(y0 >> 4) << 16);
+            rect.y = (uint32_t)((x1 >> 4) - (x0 >> 4) + 1) | ((uint32_t)((y1 >> 4) - (y0 >> 4) + 1) << 16);
+            uint4* rp = (uint4*)(recs + idx);
+            const uint32_t* w32 = (const uint32_t*)&rec;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) rp[k] = make_uint4(w32[4 * k], w32[4 * k + 1], w32[4 * k + 2], w32[4 * k + 3]);
+        }
+        rects[idx] = rect;
+    }
+    const unsigned long long vb = __ballot(visible);
+    if ((threadIdx.x & 63u) == 0u && idx < count) visMask[idx >> 6] = vb;
+}
+
+template <int MODE, bool DEPTH>
+__global__ __launch_bounds__(256) void blend_box_kernel(const uint32_t* __restrict__ pairVals, const uint32_t* __restrict__ tileStart,
+                                                        const uint32_t* __restrict__ tileEnd, const uint32_t* __restrict__ tileOrder,
+                                                        uint32_t* __restrict__ tileCost, const gsm::BoxRec* __restrict__ recs, uint16_t* __restrict__ rt,
+                                                        RasterConsts rc, gsm::RayConsts ray, int dstIsZero, const float* __restrict__ sceneDepth) {
+    __shared__ uint4 s_rec[64 * 4];                               // 64 records of 64 B
+    const int tid = threadIdx.x;
+    const uint32_t tile = tileOrder[blockIdx.x];
+    const uint32_t tx = tile % rc.tilesX, ty = tile / rc.tilesX;
+    const uint32_t start = tileStart[tile], end = tileEnd[tile];
+    const int px = (int)tx * 16 + (tid & 15), py = (int)ty * 16 + (tid >> 4);
+    const bool inside = px < (int)rc.width && py < (int)rc.height;
+    uint2* dst = (uint2*)(rt + ((size_t)py * rc.width + (size_t)px) * 4);
+    if (start >= end) {
+        if (tid == 0) tileCost[tile] = 0;
+        if (dstIsZero && inside) *dst = make_uint2(0u, 0u);
+        return;
+    }
+    PixelAcc<MODE> acc;
+    acc.load((inside && !dstIsZero) ? *dst : make_uint2(0u, 0u));
+    float sceneZ = 0.0f;
+    if (DEPTH) sceneZ = inside ? sceneDepth[(size_t)py * rc.width + (size_t)px] : 0.0f;
+    float d[3];
+    gsm::PixelRay(ray, px, py, d);
+    uint32_t walked = 0;
+    for (uint32_t bs = start; bs < end; bs += 64u) {
+        __syncthreads();
+        const uint32_t cnt = min(64u, end - bs);
+        {   // 256 threads stage 64 records: thread t copies 16 bytes (quarter t & 3 of record t >> 2)
+            const uint32_t rix = (uint32_t)tid >> 2;
+            if (rix < cnt) s_rec[tid] = ((const uint4*)(recs + pairVals[bs + rix]))[tid & 3];
+        }
+        __syncthreads();
+        ++walked;
+        for (uint32_t j = 0; j < cnt; ++j) {
+            const float* R = (const float*)&s_rec[j * 4];        // wave-uniform: LDS broadcast
+            float ld[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) ld[k] = fmaf(R[k * 3 + 2], d[2], fmaf(R[k * 3 + 1], d[1], R[k * 3] * d[0]));
+            const float al = R[15];
+            const float t = gsm::BoxFaceDepth(R + 9, ld, al < 0.0f);
+            bool live = inside && t > 0.0f && t >= rc.nearClip && t <= rc.farClip;
+            if (DEPTH) live = live && (t <= sceneZ);
+            if (MODE == 1) live = live && !acc.saturated();
+            const float a = fabsf(al);
+            if (live) acc.blend_src(R[12] * a, R[13] * a, R[14] * a, a);
+        }
+    }
+    if (inside) *dst = acc.pack();
+    if (tid == 0) tileCost[tile] = walked * 8u;
+}
+
 // RenderMode.DebugPoints / DebugPointIndices (GaussianDebugRenderPoints.shader; GaussianSplatRenderer.cs:126-131,148-161):
 // every splat, in index order (no order buffer), is an opaque screen-space square of _SplatSize pixels around its projected
 // centre, colour = saturate(DC colour) or an index code, drawn with ZWrite On + the default ZTest LEqual.  As compute: the
@@ -800,7 +912,9 @@ void renderer_free_raster(gs_renderer* r) {
     if (r->recs) (void)hipFree(r->recs);
     if (r->rects) (void)hipFree(r->rects);
     if (r->recW) (void)hipFree(r->recW);
-    r->recW = nullptr;
+    if (r->boxRecs) (void)hipFree(r->boxRecs);
+    if (r->chunkOrder) (void)hipFree(r->chunkOrder);
+    r->recW = nullptr; r->boxRecs = nullptr; r->chunkOrder = nullptr;
     if (r->visMask) (void)hipFree(r->visMask);
     if (r->pairKeys) (void)hipFree(r->pairKeys);
     if (r->pairVals) (void)hipFree(r->pairVals);
@@ -812,20 +926,21 @@ void renderer_free_raster(gs_renderer* r) {
     r->recs = nullptr; r->rects = nullptr; r->visMask = nullptr; r->pairKeys = r->pairVals = nullptr; r->frameArena = nullptr; r->hostReport = nullptr; r->hostReportDev = nullptr;
 }
 
-int32_t enqueue_draw(gs_renderer* r, const gs_frame_params* p, gs_target* rt) {
+namespace {
+struct DrawSetup { RasterConsts rc; uint32_t numTiles; uint32_t *tileStart, *tileEnd, *tileOrder; int dstIsZero; };
+
+// The part of a draw that does not depend on what a "fragment" is: (tile, item) pairs of the visible items in `order`
+// (bin_emit), the stable pair sort by tile, tile ranges, tile schedule + the draw's report.
+int32_t bin_and_sort(gs_renderer* r, const gs_frame_params* p, gs_target* rt, const uint32_t* order, uint32_t count, DrawSetup& o) {
     gs_context* ctx = r->ctx;
     hipStream_t st = ctx->stream;
-    RasterConsts rc;
+    RasterConsts& rc = o.rc;
     rc.W = (float)rt->width; rc.H = (float)rt->height; rc.nearClip = p->near_clip; rc.farClip = p->far_clip;
     rc.width = rt->width; rc.height = rt->height;
     rc.tilesX = div_up(rt->width, kTile); rc.tilesY = div_up(rt->height, kTile);
-    const uint32_t numTiles = rc.tilesX * rc.tilesY;
+    const uint32_t numTiles = o.numTiles = rc.tilesX * rc.tilesY;
     if (numTiles > (1u << 24)) return fail(GS_ERR_INVALID_ARGUMENT, "target too large (more than 2^24 tiles)");
-    // the per-splat footprints were computed by calc_view: it must have run with the same screen size and clip planes
-    if (!r->viewValid || r->viewW != rc.W || r->viewH != rc.H || r->viewNear != rc.nearClip || r->viewFar != rc.farClip)
-        return fail(GS_ERR_INVALID_ARGUMENT, "gs_renderer_draw: call gs_renderer_calc_view with the same screen size / clip planes first");
     GS_TRY(ensure_arena(r, numTiles));
-    GS_TRY(join_sort(r));                                       // bin_emit reads order[]
     r->lastTilesX = rc.tilesX; r->lastTilesY = rc.tilesY;
 
     r->arenaIdx ^= 1;
@@ -836,9 +951,9 @@ int32_t enqueue_draw(gs_renderer* r, const gs_frame_params* p, gs_target* rt) {
     unsigned long long* binStatus = (unsigned long long*)(arena + r->offBinStatus);
     unsigned long long* binGroupAgg = (unsigned long long*)(arena + r->offBinGroupAgg);
     unsigned long long* binGroupBase = (unsigned long long*)(arena + r->offBinGroupBase);
-    uint32_t* tileStart = (uint32_t*)(arena + r->offTileStart);
-    uint32_t* tileEnd = (uint32_t*)(arena + r->offTileEnd);
-    uint32_t* tileOrder = (uint32_t*)(arena + r->offTileOrder);
+    o.tileStart = (uint32_t*)(arena + r->offTileStart);
+    o.tileEnd = (uint32_t*)(arena + r->offTileEnd);
+    o.tileOrder = (uint32_t*)(arena + r->offTileOrder);
     const uint32_t cap = (uint32_t)r->pairCapacity;
 
     prof_record(r, 3);
@@ -854,19 +969,35 @@ int32_t enqueue_draw(gs_renderer* r, const gs_frame_params* p, gs_target* rt) {
 #define GS_BIN_BLOCKS_PER_CU 5      // 90 VGPRs at 8 positions per thread: five 256-thread workgroups per CU
 #endif
     const uint32_t binCap = max((uint32_t)ctx->cuCount * (uint32_t)GS_BIN_BLOCKS_PER_CU / kBinTicketClasses * kBinTicketClasses, kBinTicketClasses);
-    const uint32_t binGrid = min(div_up(r->binParts, kBinTicketClasses) * kBinTicketClasses, binCap);
-    hipLaunchKernelGGL(binKernel, dim3(binGrid), dim3(kBinThreads), 0, st, r->rects, (const uint32_t*)r->visMask, r->order, r->n, rc.tilesX, r->pairKeys,
+    const uint32_t binGrid = min(div_up(div_up(count, kBinPart), kBinTicketClasses) * kBinTicketClasses, binCap);
+    hipLaunchKernelGGL(binKernel, dim3(binGrid), dim3(kBinThreads), 0, st, r->rects, (const uint32_t*)r->visMask, order, count, rc.tilesX, r->pairKeys,
                        r->pairVals, cap, binCtl, binStatus, binGroupAgg, binGroupBase, pairCtl->hist, r->pairSort.groupAgg, sort_group_words(cap, passes), (uint32_t*)nextArena, (uint32_t)(r->frameArenaBytes / 4), (uint32_t)bits);
     prof_record(r, 4);
     GS_TRY(enqueue_sort_passes(ctx, st, r->pairSort, pairCtl, r->pairKeys, r->pairVals, cap, &binCtl->pairCountClamped, passes, 255u, r, 12, bits));
     r->lastPairPasses = (uint32_t)passes;
     hipLaunchKernelGGL(tile_ranges_kernel, dim3(max(1u, min(div_up(cap, 1024), (uint32_t)ctx->cuCount * 8u))), dim3(256), 0, st, r->pairKeys,
-                       &binCtl->pairCountClamped, tileStart, tileEnd, numTiles);
-    hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, st, tileStart, tileEnd, r->tileCost, numTiles, tileOrder, binCtl, &pairCtl->error,
+                       &binCtl->pairCountClamped, o.tileStart, o.tileEnd, numTiles);
+    hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, st, o.tileStart, o.tileEnd, r->tileCost, numTiles, o.tileOrder, binCtl, &pairCtl->error,
                        r->hostReportDev);
     prof_record(r, 5);
-    const int dstIsZero = rt->clearPending ? 1 : 0;             // this draw writes every pixel of the target: the clear is folded in
+    o.dstIsZero = rt->clearPending ? 1 : 0;                      // this draw writes every pixel of the target: the clear is folded in
     rt->clearPending = false;
+    return GS_OK;
+}
+} // namespace
+
+int32_t enqueue_draw(gs_renderer* r, const gs_frame_params* p, gs_target* rt) {
+    hipStream_t st = r->ctx->stream;
+    // the per-splat footprints were computed by calc_view: it must have run with the same screen size and clip planes
+    if (!r->viewValid || r->viewW != (float)rt->width || r->viewH != (float)rt->height || r->viewNear != p->near_clip || r->viewFar != p->far_clip)
+        return fail(GS_ERR_INVALID_ARGUMENT, "gs_renderer_draw: call gs_renderer_calc_view with the same screen size / clip planes first");
+    GS_TRY(join_sort(r));                                       // bin_emit reads order[]
+    DrawSetup ds;
+    GS_TRY(bin_and_sort(r, p, rt, r->order, r->n, ds));
+    const RasterConsts& rc = ds.rc;
+    const uint32_t numTiles = ds.numTiles;
+    uint32_t *tileStart = ds.tileStart, *tileEnd = ds.tileEnd, *tileOrder = ds.tileOrder;
+    const int dstIsZero = ds.dstIsZero;
     if (rt->sceneDepth) {
         gsm::FrameConsts fc;
         flatten_params(p, fc);
@@ -877,6 +1008,43 @@ int32_t enqueue_draw(gs_renderer* r, const gs_frame_params* p, gs_target* rt) {
     if (rt->sceneDepth) { if (r->blendMode == 0) GS_LAUNCH_BLEND(0, true); else GS_LAUNCH_BLEND(1, true); }
     else { if (r->blendMode == 0) GS_LAUNCH_BLEND(0, false); else GS_LAUNCH_BLEND(1, false); }
 #undef GS_LAUNCH_BLEND
+    prof_record(r, 6);
+    GS_HIP(hipGetLastError());
+    r->frameInFlight = true;
+    prof_end_frame(r);
+    return GS_OK;
+}
+
+// RenderMode.DebugBoxes (chunks = false: one box per splat, through order[]) / DebugChunkBounds (chunks = true: one per chunk)
+int32_t enqueue_debug_boxes(gs_renderer* r, const gs_frame_params* p, gs_target* rt, bool chunks) {
+    gs_context* ctx = r->ctx;
+    hipStream_t st = ctx->stream;
+    const gsm::AssetView& a = r->asset->view;
+    const uint32_t count = chunks ? a.chunkCount : r->n;
+    if (chunks && count == 0) return GS_OK;                      // m_GpuChunksValid == false: instanceCount = 0 (GaussianSplatRenderer.cs:161-162)
+    if (chunks && (uint64_t)count * 256u < (uint64_t)r->n) return fail(GS_ERR_INVALID_ASSET, "chunk blob smaller than the splat count");
+    if (!r->boxRecs) GS_HIP(hipMalloc((void**)&r->boxRecs, (size_t)r->n * sizeof(gsm::BoxRec) + 64));
+    if (chunks && !r->chunkOrder) {
+        GS_HIP(hipMalloc((void**)&r->chunkOrder, ((size_t)count + 16) * 4));
+        GS_TRY(enqueue_set_indices(ctx, r->chunkOrder, count));
+    }
+    if (!chunks) GS_TRY(join_sort(r));
+    gsm::FrameConsts fc;
+    flatten_params(p, fc);
+    gsm::RayConsts ray;
+    gsm::RayConstsFromFrame(ray, p->matrix_vp, p->proj_m00, p->proj_m11, p->cam_pos_world[0], p->cam_pos_world[1], p->cam_pos_world[2], (float)rt->width, (float)rt->height);
+    prof_record(r, 7);
+    if (chunks) hipLaunchKernelGGL(box_setup_kernel<true>, dim3(div_up(count, 256)), dim3(256), 0, st, a, fc, ray, count, r->boxRecs, r->rects, r->visMask);
+    else hipLaunchKernelGGL(box_setup_kernel<false>, dim3(div_up(count, 256)), dim3(256), 0, st, a, fc, ray, count, r->boxRecs, r->rects, r->visMask);
+    prof_record(r, 8);
+    r->viewValid = false;                                        // rects / visibility bits now describe the boxes: a splat draw needs calc_view again
+    DrawSetup ds;
+    GS_TRY(bin_and_sort(r, p, rt, chunks ? r->chunkOrder : r->order, count, ds));
+#define GS_LAUNCH_BOX(M, D) hipLaunchKernelGGL((blend_box_kernel<M, D>), dim3(ds.numTiles), dim3(256), 0, st, r->pairVals, ds.tileStart, ds.tileEnd, ds.tileOrder, \
+                                           r->tileCost, r->boxRecs, rt->rgba16f, ds.rc, ray, ds.dstIsZero, rt->sceneDepth)
+    if (rt->sceneDepth) { if (r->blendMode == 0) GS_LAUNCH_BOX(0, true); else GS_LAUNCH_BOX(1, true); }
+    else { if (r->blendMode == 0) GS_LAUNCH_BOX(0, false); else GS_LAUNCH_BOX(1, false); }
+#undef GS_LAUNCH_BOX
     prof_record(r, 6);
     GS_HIP(hipGetLastError());
     r->frameInFlight = true;
