@@ -19,6 +19,12 @@ variants)
     [ -e "$v" ] || continue
     GSPLAT_LIB=$PWD/$v timeout 200 python scripts/bench_stages.py C2 30 2>&1 | tail -1 | tee -a $O/variants.log
   done;;
+overlap)
+  : > $O/overlap.log
+  for cfgk in C2 C3; do for e in "GSPLAT_OVERLAP=0" "GSPLAT_OVERLAP=1" "GSPLAT_OVERLAP=0" "GSPLAT_OVERLAP=1"; do
+    echo -n "$cfgk $e  " | tee -a $O/overlap.log
+    env $e GS_NOPROF=1 timeout 300 python scripts/bench_stages.py $cfgk 100 2>&1 | tail -1 | tee -a $O/overlap.log
+  done; done;;
 prof)
   (cd /tmp && export TMPDIR=/tmp && rm -rf $O/prof && mkdir -p $O/prof && R=$GRAFT_REPO_ROOT && \
    timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof/stats -- python $R/bench.py --steps 20 --warmup 5 --cpu-baseline off > $O/prof/bench_stats.json 2> $O/prof/bench_stats.err)

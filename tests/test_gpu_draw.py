@@ -9,7 +9,7 @@ import pytest
 
 import oracle_lib as O
 from common import RT_TOL, default_camera, diff_pixels, psnr8, rt_err, small_asset
-from unitygaussiansplatting_amd import camera
+from unitygaussiansplatting_amd import camera, creator, scenes
 from unitygaussiansplatting_amd._lib import GsError
 from unitygaussiansplatting_amd.renderer import GaussianSplatRenderer, GaussianSplatRenderSystem, RenderTarget
 
@@ -195,6 +195,39 @@ def test_overlapped_sort_queue_gives_identical_frames(gpu_ctx):
     gpu_ctx.SetOverlap(False)
     for x, y in zip(frames[False], frames[True]):
         assert np.array_equal(x, y)
+
+
+def test_overlapped_sort_with_frames_in_flight(gpu_ctx):
+    """The pipelined form of the overlap: K frames are recorded back to back without a host sync, so frame k+1's depth sort
+    (second queue, released by frame k's bin_emit through evOrderFree) runs beside frame k's pair sort / blend / resolve and
+    frame k+1's calc_view.  Every frame goes to its own target; all targets, the final order / keys and P must equal the
+    serial run's bit for bit -- a sort that overwrote order[] under a bin_emit still reading it, or a calc_view that
+    overtook a blend, would show here.  1.5 M splats so that the kernels are long enough to overlap for real."""
+    a = creator.CreateAssetFromSplatsNative(scenes.make_splats(1_500_000, 11, 3.0), "Medium", name="inflight")
+    K = 6
+    results = {}
+    for overlap in (False, True):
+        gpu_ctx.SetOverlap(overlap)
+        r = GaussianSplatRenderer(gpu_ctx, a)
+        r.OnEnable()
+        rts = [RenderTarget(gpu_ctx, 960, 540) for _ in range(K)]
+        cams = [default_camera(W=960, H=540, az=10.0 + 40.0 * f) for f in range(K)]
+        prepared = [(r.SortMatrix(c), r.FrameParams(c)) for c in cams]
+        for rep in range(2):                                   # the first round sizes the pair buffer
+            for f in range(K):
+                m16, p = prepared[f]
+                r.SortPointsPrepared(m16); r.CalcViewDataPrepared(p); rts[f].Clear(); r.DrawPrepared(p, rts[f]); rts[f].ResolveAsync((0, 0, 0, 1))
+            st = r.FrameStats()
+            if rep == 0:
+                r.ReservePairs(int(st.tile_pairs * 2) + (1 << 20))
+        results[overlap] = [t.Download().copy() for t in rts] + [r.DownloadOrder().copy(), r.DownloadDistances().copy(), st.tile_pairs]
+        r.OnDisable()
+        for t in rts:
+            t.Dispose()
+    gpu_ctx.SetOverlap(False)
+    for x, y in zip(results[False], results[True]):
+        assert np.array_equal(x, y)
+    assert np.abs(results[True][0].view(np.float16).astype(np.float32)).sum() > 0
 
 
 def test_profiling_ring_reports_stage_and_frame_times(gpu_ctx):

@@ -38,6 +38,10 @@ int32_t join_sort(gs_renderer* r) {
     r->sortPending = false;
     return GS_OK;
 }
+int32_t mark_order_use(gs_renderer* r) {
+    if (r->ctx->overlap) GS_HIP(hipEventRecord(r->evOrderFree, r->ctx->stream));
+    return GS_OK;
+}
 void prof_end_frame(gs_renderer* r) {
     if (!r->profiling || !r->ev) return;
     r->profCompleted++;
@@ -94,9 +98,12 @@ int32_t gs_context_create(int32_t device, void* hip_stream, gs_context** out) {
         ctx->ownStream = true;
     }
     if (hipStreamCreateWithFlags(&ctx->aux, hipStreamNonBlocking) != hipSuccess) { gs_context_destroy(ctx); return fail(GS_ERR_HIP, "hipStreamCreate (aux)"); }
-    // Measured on MI355X (C2): forking the sort does not shorten the frame -- calc_view and the sort's key gather compete
-    // for the same memory system (0.995 ms overlapped vs 0.962 ms serial) -- so the default is off; GSPLAT_OVERLAP=1 or
-    // gs_context_set_overlap(ctx, 1) turns it on.
+    // Measured on MI355X: running the depth sort on the second queue does not shorten the frame -- neither beside
+    // calc_view only (round 1: 0.995 ms overlapped vs 0.962 serial at C2) nor in the pipelined form, beside the previous
+    // frame's pair sort / blend / resolve and this frame's calc_view (round 2: 0.679 vs 0.663 ms at C2, 0.981 vs 0.956 at C3;
+    // smaller persistent sort grids and a lower / higher queue priority move it by < 1 %, profiles/r02_variants.txt).  Every
+    // kernel of the frame already fills the wave slots of the chip, so two queues share them instead of adding to them.
+    // The default is therefore off; GSPLAT_OVERLAP=1 or gs_context_set_overlap(ctx, 1) turns it on.
     const char* ov = getenv("GSPLAT_OVERLAP");
     ctx->overlap = ov && ov[0] == '1';
     *out = ctx;
@@ -125,6 +132,7 @@ int32_t gs_context_set_overlap(gs_context* ctx, int32_t enabled) {
     if (!ctx) return fail(GS_ERR_INVALID_ARGUMENT, "ctx is null");
     GS_TRY(bind_device(ctx));
     GS_HIP(hipStreamSynchronize(ctx->aux));
+    GS_HIP(hipStreamSynchronize(ctx->stream));                  // no order[] use of the main queue is outstanding when the mode changes
     ctx->overlap = enabled != 0;
     return GS_OK;
 }
@@ -243,12 +251,13 @@ int32_t gs_renderer_create(gs_context* ctx, gs_asset* asset, gs_renderer** out) 
     chk(hipMalloc((void**)&r->order, ((size_t)r->n + 16) * 4), "alloc order");
     chk(hipMalloc((void**)&r->depthControl, 2 * sizeof(SortControl)), "alloc sort control");
     if (rc == GS_OK) chk(hipMemsetAsync(r->depthControl, 0, 2 * sizeof(SortControl), ctx->stream), "clear sort control");
-    chk(hipEventCreateWithFlags(&r->evFork, hipEventDisableTiming), "create event");
+    chk(hipEventCreateWithFlags(&r->evOrderFree, hipEventDisableTiming), "create event");
     chk(hipEventCreateWithFlags(&r->evSortDone, hipEventDisableTiming), "create event");
     if (rc == GS_OK) rc = sort_state_create(ctx, r->depthSort, r->n);
     if (rc == GS_OK) rc = renderer_alloc_raster(r);
     if (rc == GS_OK) rc = enqueue_set_indices(ctx, r->order, r->n);
     if (rc == GS_OK) chk(hipMemsetAsync(r->view, 0, (size_t)r->n * sizeof(gsm::ViewData), ctx->stream), "clear view");
+    if (rc == GS_OK) rc = mark_order_use(r);                    // the first sort (second queue) waits for these initialisations
     if (rc != GS_OK) { gs_renderer_destroy(r); return rc; }
     *out = r;
     return GS_OK;
@@ -259,7 +268,7 @@ int32_t gs_renderer_destroy(gs_renderer* r) {
     (void)hipSetDevice(r->ctx->device);
     (void)hipStreamSynchronize(r->ctx->aux);
     (void)hipStreamSynchronize(r->ctx->stream);
-    if (r->evFork) (void)hipEventDestroy(r->evFork);
+    if (r->evOrderFree) (void)hipEventDestroy(r->evOrderFree);
     if (r->evSortDone) (void)hipEventDestroy(r->evSortDone);
     if (r->view) (void)hipFree(r->view);
     if (r->keyBySplat) (void)hipFree(r->keyBySplat);
@@ -281,7 +290,8 @@ int32_t gs_renderer_reset_order(gs_renderer* r) {
     if (!r) return fail(GS_ERR_INVALID_ARGUMENT, "renderer is null");
     GS_TRY(bind_device(r->ctx));
     GS_TRY(join_sort(r));
-    return enqueue_set_indices(r->ctx, r->order, r->n);
+    GS_TRY(enqueue_set_indices(r->ctx, r->order, r->n));
+    return mark_order_use(r);
 }
 
 static void rec_ev(gs_renderer* r, int k) { gs::prof_record(r, k); }
@@ -290,13 +300,17 @@ int32_t gs_renderer_sort(gs_renderer* r, const float m[16]) {
     if (!r || !m) return fail(GS_ERR_INVALID_ARGUMENT, "null argument");
     gs_context* ctx = r->ctx;
     GS_TRY(bind_device(ctx));
-    // SortPoints and CalcViewData are independent (the C# merely records them one after the other, :120-126): with
-    // overlap on, the sort is forked onto the context's second queue here and joined by the first consumer of order[]
-    // (gs_renderer_draw, or any readback), so it runs concurrently with gs_renderer_calc_view.
-    // Only the four Onesweep passes are forked: they are latency-bound with little VALU work and co-run with the VALU-bound
-    // calc_view; the key generation stays on the main stream.
-    GS_TRY(join_sort(r));
+    // SortPoints depends on nothing else the frame computes (the C# merely records it before CalcViewData, :120-126), and
+    // nothing but the draw's bin_emit reads its result.  With overlap on, the whole sort (keys + the four Onesweep passes)
+    // runs on the context's second queue: it starts as soon as the main queue is done with order[] (evOrderFree: the
+    // previous draw's bin_emit), i.e. beside the previous frame's pair sort / blend / resolve and this frame's calc_view
+    // -- latency-bound kernels with little VALU work next to the VALU-bound ones -- and is joined by the first consumer of
+    // order[] (gs_renderer_draw, or any readback).  The second queue is in-order, so consecutive sorts serialise there.
     hipStream_t st = ctx->stream;
+    if (ctx->overlap) {
+        st = ctx->aux;
+        GS_HIP(hipStreamWaitEvent(st, r->evOrderFree, 0));
+    }
     gs::prof_record(r, 0, st);
     r->depthControlIdx ^= 1;
     SortControl* control = r->depthControl + r->depthControlIdx;
@@ -304,15 +318,10 @@ int32_t gs_renderer_sort(gs_renderer* r, const float m[16]) {
     // (_SplatSortKeys, SplatUtilities.compute:76) is the first Onesweep pass's key load
     GS_TRY(enqueue_sort_keys(ctx, st, r->asset->view, m, r->keyBySplat, control, r->depthControl + (r->depthControlIdx ^ 1), r->n, r->depthSort));
     gs::prof_record(r, 1, st);
-    if (ctx->overlap) {
-        GS_HIP(hipEventRecord(r->evFork, ctx->stream));          // after the keys, and after everything that still reads order[]
-        GS_HIP(hipStreamWaitEvent(ctx->aux, r->evFork, 0));
-        st = ctx->aux;
-    }
     GS_TRY(enqueue_sort_passes(ctx, st, r->depthSort, control, r->distances, r->order, r->n, nullptr, 4, 255u, r, 10, 8, r->keyBySplat));
     gs::prof_record(r, 2, st);
     if (ctx->overlap) {
-        GS_HIP(hipEventRecord(r->evSortDone, ctx->aux));
+        GS_HIP(hipEventRecord(r->evSortDone, st));
         r->sortPending = true;
     }
     return GS_OK;

@@ -202,7 +202,8 @@ struct gs_renderer {
     // host copy of last frame's control (pinned), read lazily
     gs::FrameReport* hostReport = nullptr;  // pinned + mapped: written by the last small kernel of a draw (no copy launch)
     gs::FrameReport* hostReportDev = nullptr;   // its device-side address
-    hipEvent_t evFork = nullptr, evSortDone = nullptr;   // main -> aux fork, aux -> main join (timing disabled)
+    hipEvent_t evSortDone = nullptr;        // aux -> main join (timing disabled)
+    hipEvent_t evOrderFree = nullptr;       // main -> aux fork: the last operation of the main queue that reads or writes order[]
     bool sortPending = false;               // a sort on ctx->aux has not been joined into ctx->stream yet
     uint32_t lastTilesX = 0, lastTilesY = 0, lastPairPasses = 0;
     bool frameInFlight = false;
@@ -212,6 +213,7 @@ struct gs_renderer {
 namespace gs {
 void prof_record(gs_renderer* r, int k, hipStream_t st = nullptr);   // gs_api.hip: record event k of the current profiling slot (on st, default ctx->stream)
 int32_t join_sort(gs_renderer* r);          // make ctx->stream wait for a sort still running on ctx->aux
+int32_t mark_order_use(gs_renderer* r);     // the main queue has just been given work that reads / writes order[]: the next sort waits for it
 void prof_end_frame(gs_renderer* r);
 // sort entry points (gs_sort.hip)
 int32_t sort_state_create(gs_context* ctx, SortState& st, uint32_t maxCount);

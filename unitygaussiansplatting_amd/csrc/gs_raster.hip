@@ -972,6 +972,7 @@ int32_t bin_and_sort(gs_renderer* r, const gs_frame_params* p, gs_target* rt, co
     const uint32_t binGrid = min(div_up(div_up(count, kBinPart), kBinTicketClasses) * kBinTicketClasses, binCap);
     hipLaunchKernelGGL(binKernel, dim3(binGrid), dim3(kBinThreads), 0, st, r->rects, (const uint32_t*)r->visMask, order, count, rc.tilesX, r->pairKeys,
                        r->pairVals, cap, binCtl, binStatus, binGroupAgg, binGroupBase, pairCtl->hist, r->pairSort.groupAgg, sort_group_words(cap, passes), (uint32_t*)nextArena, (uint32_t)(r->frameArenaBytes / 4), (uint32_t)bits);
+    GS_TRY(mark_order_use(r));                                  // the next frame's depth sort may overwrite order[] from here on
     prof_record(r, 4);
     GS_TRY(enqueue_sort_passes(ctx, st, r->pairSort, pairCtl, r->pairKeys, r->pairVals, cap, &binCtl->pairCountClamped, passes, 255u, r, 12, bits));
     r->lastPairPasses = (uint32_t)passes;
