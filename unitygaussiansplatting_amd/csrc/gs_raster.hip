@@ -35,13 +35,32 @@ constexpr uint32_t BIN_SPIN_LIMIT = 1u << 24;
 // broadcast lane `b` (wave-uniform) of x to every lane through v_readlane_b32: the result is a scalar operand
 __device__ __forceinline__ float rl(float x, int b) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), b)); }
 
-__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, int lane) {
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t t = __shfl_up(v, o, 64);
-        if (lane >= o) v += t;
-    }
+// inclusive sum-scan over the 64 lanes in 6 DPP steps (v_add_u32 with a DPP source; lanes without a source add 0)
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v) {
+#define GS_DPP(x, ctrl, rowmask) (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(x), ctrl, rowmask, 0xf, false)
+    v += GS_DPP(v, 0x111, 0xf);             // row_shr:1
+    v += GS_DPP(v, 0x112, 0xf);             // row_shr:2
+    v += GS_DPP(v, 0x114, 0xf);             // row_shr:4
+    v += GS_DPP(v, 0x118, 0xf);             // row_shr:8
+    v += GS_DPP(v, 0x142, 0xa);             // row_bcast:15 -> rows 1 and 3
+    v += GS_DPP(v, 0x143, 0xc);             // row_bcast:31 -> rows 2 and 3
+#undef GS_DPP
     return v;
+}
+
+// o / w and o % w for the slot o of a tile rectangle w tiles wide (o < w * h <= 2^24 tiles, w < 2^16).  A u32 division
+// compiles to ~22 VALU instructions, six of them quarter-rate 32-bit multiplies, and this runs once per emitted pair:
+// instead, the fp32 reciprocal estimate (v_rcp_f32, 1 ulp) gives floor(o / w) +- 1 while o < 2^20 (relative error of
+// the product <= 2^-21.9, so the estimate is within 0.27 of the true quotient), and one correction step in either
+// direction with 24-bit multiplies makes it exact.  Larger rectangles (a splat covering more than a million tiles) take
+// the integer division.
+__device__ __forceinline__ void slot_to_xy(uint32_t o, uint32_t w, uint32_t& ty, uint32_t& tx) {
+    if (__builtin_expect(__ballot(o >= (1u << 20)) != 0ull, 0)) { ty = o / w; tx = o - ty * w; return; }
+    const uint32_t q = (uint32_t)((float)o * __builtin_amdgcn_rcpf((float)w));
+    const int r = (int)o - (int)__umul24(q, w);
+    const int lo = r < 0 ? 1 : 0, hi = r >= (int)w ? 1 : 0;      // at most one of them (selects, no branches)
+    ty = q - (uint32_t)lo + (uint32_t)hi;
+    tx = (uint32_t)(r + (lo ? (int)w : 0) - (hi ? (int)w : 0));
 }
 
 // LDS histogram add for one digit of the pair key.  Lanes of a wave that hit the same bin would serialise inside the
@@ -76,9 +95,7 @@ __device__ __forceinline__ uint32_t wave_incl_max_scan_dpp(uint32_t v) {
 }
 
 __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += (uint32_t)__shfl_xor((int)v, o, 64);
-    return v;
+    return (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan_u32(v), 63);
 }
 
 // Binning: one workgroup per partition of kBinPart consecutive SORTED positions (front to back), handed out by ticket.
@@ -248,7 +265,14 @@ __global__ __launch_bounds__(kBinThreads, GS_BIN_MINWAVES) void bin_emit_kernel(
     GS_BTL(3);                                                   // wave 0: scan done
     __syncthreads();
     GS_BTL(4);
-    const unsigned long long gbase = s_base + wbase;             // global offset of this wave's first pair
+    // global offset of this wave's first pair: wave-uniform, so the pair arrays are addressed as scalar base + 32-bit slot
+    // and the capacity test is a 32-bit compare against the number of this wave's slots that fit
+    const unsigned long long gbaseV = s_base + wbase;
+    const unsigned long long gbase = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(gbaseV >> 32)) << 32) |
+                                     (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)gbaseV);
+    const unsigned long long roomAll = gbase < (unsigned long long)capacity ? (unsigned long long)capacity - gbase : 0ull;
+    uint32_t* __restrict__ pk = pairKeys + (roomAll ? gbase : 0ull);
+    uint32_t* __restrict__ pv = pairVals + (roomAll ? gbase : 0ull);
 
     // ---- emit (tile, splat) pairs, 256 positions of this wave at a time (no workgroup barriers below) -------------
     uint32_t* offs = s_off[w];
@@ -265,7 +289,7 @@ __global__ __launch_bounds__(kBinThreads, GS_BIN_MINWAVES) void bin_emit_kernel(
         for (int kk = 0; kk < SUB; ++kk) {
             const int k = sb * SUB + kk;
             const uint32_t c = (rc[k].y & 0xffffu) * (rc[k].y >> 16);
-            const uint32_t incl = wave_incl_scan_u32(c, lane);
+            const uint32_t incl = wave_incl_scan_u32(c);
             offsR[kk] = run + incl - c; cntR[kk] = c;
             offs[kk * 64 + lane] = run + incl - c;
             sids[kk * 64 + lane] = sid[k];
@@ -276,7 +300,7 @@ __global__ __launch_bounds__(kBinThreads, GS_BIN_MINWAVES) void bin_emit_kernel(
         uint32_t carry = 0;                                      // owner (+1) of the slot before j0 (wave-uniform)
         for (uint32_t j0 = subStart; j0 < run; j0 += 64u) {       // wave-uniform trip count
             const uint32_t j = j0 + (uint32_t)lane;
-            const bool act = j < run;
+            const uint32_t room = (uint32_t)(roomAll < (unsigned long long)run ? roomAll : (unsigned long long)run);
             // Which position owns output slot j?  Every non-empty position whose first slot falls into this batch of 64
             // drops its index (+1) at that slot; an inclusive max-scan over the lanes (positions ascend with the slots)
             // carries it forward, `carry` across batches.  One LDS write/read pair and 6 DPP steps instead of an 8-step
@@ -297,13 +321,14 @@ __global__ __launch_bounds__(kBinThreads, GS_BIN_MINWAVES) void bin_emit_kernel(
             const uint2 r = rcts[e];
             const uint32_t s = sids[e];
             const uint32_t tw = max(r.y & 0xffffu, 1u);
-            const uint32_t ty = o / tw, tx = o - ty * tw;
-            const uint32_t tile = ((r.x >> 16) + ty) * tilesX + (r.x & 0xffffu) + tx;
-            const unsigned long long gi = gbase + (unsigned long long)j;
-            const bool wr = act && gi < (unsigned long long)capacity;
+            uint32_t ty, tx;
+            slot_to_xy(o, tw, ty, tx);
+            const uint32_t tile = __umul24((r.x >> 16) + ty, tilesX) + (r.x & 0xffffu) + tx;      // rows, columns < 2^16
+            const bool wr = j < room;                            // room <= run - of the wave's slots, those below the capacity
             if (wr) {
-                pairKeys[gi] = tile;
-                pairVals[gi] = s;                                // payload = splat index: the blend kernel reads rec[splat]
+                const uint32_t boff = j << 2;                    // j < capacity <= 2^30: scalar base + 32-bit byte offset
+                *(uint32_t*)((uint8_t*)pk + boff) = tile;
+                *(uint32_t*)((uint8_t*)pv + boff) = s;           // payload = splat index: the blend kernel reads rec[splat]
                 atomicAdd(&s_hist[tile & digitMask], 1u);        // neighbouring slots are neighbouring tiles: distinct bins
             }
             if (PASSES >= 2) hist_add_aggregated(s_hist + 256, (tile >> digitBits) & digitMask, wr);
