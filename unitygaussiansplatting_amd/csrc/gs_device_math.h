@@ -896,18 +896,19 @@ struct SplatFootprint {
 GS_HD bool PrepareSplat(const ViewData& v, float W, float H, float nearClip, float farClip, SplatFootprint& fp) {
     fp.tx0 = 1; fp.tx1 = 0; fp.ty0 = 1; fp.ty1 = 0; fp.cx = 0.0f; fp.cy = 0.0f;
     const float w = v.pos[3];
-    if (!(w > 0.0f)) return false;
-    if (!(w >= nearClip && w <= farClip)) return false;
-    if (!(finite32(v.axis1[0]) && finite32(v.axis1[1]) && finite32(v.axis2[0]) && finite32(v.axis2[1]))) return false;
     const float a = f16tof32(v.color[1]);
-    if (!(a >= 1.0f / 255.0f)) return false;
+    // the rejections are evaluated as ONE predicate (bitwise &: no short-circuit): a chain of early returns compiles to
+    // nested divergent branches that each re-materialise the "culled" outputs
+    const int drawable = (int)(w > 0.0f) & (int)(w >= nearClip) & (int)(w <= farClip) & (int)finite32(v.axis1[0]) & (int)finite32(v.axis1[1]) &
+                         (int)finite32(v.axis2[0]) & (int)finite32(v.axis2[1]) & (int)(a >= 1.0f / 255.0f);
+    if (!drawable) return false;
     const float invw = 1.0f / w;
-    fp.cx = fmaf(0.5f * (v.pos[0] * invw), W, 0.5f * W);
-    fp.cy = fmaf(-0.5f * (v.pos[1] * invw), H, 0.5f * H);
-    if (!(finite32(fp.cx) && finite32(fp.cy))) return false;
+    const float cx = fmaf(0.5f * (v.pos[0] * invw), W, 0.5f * W);
+    const float cy = fmaf(-0.5f * (v.pos[1] * invw), H, 0.5f * H);
     const float a1x = v.axis1[0], a1y = v.axis1[1], a2x = v.axis2[0], a2y = v.axis2[1];
     const float inv1 = 1.0f / dot2f(a1x, a1y, a1x, a1y), inv2 = 1.0f / dot2f(a2x, a2y, a2x, a2y);
-    if (!(finite32(inv1) && finite32(inv2))) return false;
+    fp.cx = cx; fp.cy = cy;                                         // (only read when the splat turns out visible)
+    if (!((int)finite32(cx) & (int)finite32(cy) & (int)finite32(inv1) & (int)finite32(inv2))) return false;
     const float exr = 2.0f * (fabsf(a1x) + fabsf(a2x)), eyr = 2.0f * (fabsf(a1y) + fabsf(a2y));
     const float slack = 0.01f;
     int x0, x1, y0, y1;
