@@ -183,13 +183,17 @@ struct gs_renderer {
     uint32_t* pairVals = nullptr;           // sorted positions
     gs::SortState pairSort;
     uint64_t pairCapacity = 0;
-    // per-frame zero arena: [BinControl | SortControl(pair) | binStatus | tileStart | tileEnd | tileOrder]
+    // per-frame zero arena: [BinControl | SortControl(pair) | binStatus | tileStart | tileEnd]
     uint8_t* frameArena = nullptr;          // two copies, used alternately: each draw zeroes the other one for the next
     int arenaIdx = 0;
     size_t frameArenaBytes = 0;             // of one copy
-    size_t offBinStatus = 0, offBinGroupAgg = 0, offBinGroupBase = 0, offTileStart = 0, offTileEnd = 0, offTileOrder = 0, offPairControl = 0;
+    size_t offBinStatus = 0, offBinGroupAgg = 0, offBinGroupBase = 0, offTileStart = 0, offTileEnd = 0, offPairControl = 0;
     uint32_t arenaTiles = 0;                // tiles the arena was sized for
-    uint32_t* tileCost = nullptr;           // arenaTiles x u32: 256-record batches each tile walked in the previous draw (scheduling hint)
+    uint32_t* tileCost = nullptr;           // 2 x arenaTiles x u32: batches each tile walked -- a draw writes copy costIdx and reads (for scheduling) the other
+    int costIdx = 0;
+    uint32_t* tileOrderBuf = nullptr;       // 2 x arenaTiles x u32: the blend's tile schedule; a draw consumes copy orderIdx and produces the other for the next one
+    int orderIdx = 0;
+    uint32_t orderTiles[2] = {0, 0};        // tile count each copy is a valid permutation for (0 = none)
     uint32_t binParts = 0;
     int blendMode = 0;
     int renderMode = 0;                     // gs_render_mode (GaussianSplatRenderer.RenderMode, :126-131)

@@ -10,8 +10,9 @@
 //                  look-back) so pairs are emitted in i order.  Persistent grid, ticketed partitions.
 //   2. pair sort:  STABLE Onesweep sort of the pairs by tile id only (2 passes for <= 65536 tiles): every
 //                  tile's list is then already depth ordered -- no per-tile depth sort.
-//   3. ranges:     tile -> [start, end) in the sorted pair array; order: tiles by descending cost (previous frame's).
-//   4. blend:      one 256-thread workgroup per tile, one pixel per lane, each wave owns an 8x8 quadrant.
+//   3. ranges:     tile -> [start, end) in the sorted pair array.
+//   4. blend:      one 256-thread workgroup per tile, one pixel per lane, each wave owns an 8x8 quadrant; tiles are
+//                  scheduled by descending cost -- the schedule of draw k+1 is computed by workgroup 0 of draw k's blend.
 //                  The tile's list is streamed in batches of 256 records staged in LDS (software-pipelined loads); each
 //                  wave culls the batch against its quadrant (bounding box + separating-axis test) with a ballot and walks
 //                  only the survivors, reading the record with wave-uniform LDS loads, blending front-to-back in registers.
@@ -355,18 +356,20 @@ extern "C" int32_t gs_debug_read_bin_timeline(void* out, size_t bytes) {
 }
 #endif
 
-// tile -> [start, end) in the tile-sorted pair array.  Four keys per thread from one 16-byte load (the key buffers are
-// 16-byte aligned and padded by 16 entries), plus the one key before and the one after the quad.
+// tile -> [start, end) in the tile-sorted pair array (both zero in the fresh arena: a tile nothing lands on stays empty).
+// Eight keys per thread from two 16-byte loads (the key buffers are 16-byte aligned and padded by 16 entries), plus the one
+// key before and the one after them.
 __global__ __launch_bounds__(256) void tile_ranges_kernel(const uint32_t* __restrict__ pairKeys, const uint32_t* nPtr,
                                                           uint32_t* __restrict__ tileStart, uint32_t* __restrict__ tileEnd, uint32_t numTiles) {
     const uint32_t n = *nPtr;
-    const uint32_t quads = (n + 3u) >> 2;
-    for (uint32_t q = blockIdx.x * 256u + threadIdx.x; q < quads; q += gridDim.x * 256u) {
-        const uint32_t j0 = q << 2;
-        const uint4 k4 = ((const uint4*)pairKeys)[q];
-        const uint32_t k[6] = { j0 ? pairKeys[j0 - 1u] : 0xffffffffu, k4.x, k4.y, k4.z, k4.w, (j0 + 4u < n) ? pairKeys[j0 + 4u] : 0xffffffffu };
+    const uint32_t octs = (n + 7u) >> 3;
+    for (uint32_t q = blockIdx.x * 256u + threadIdx.x; q < octs; q += gridDim.x * 256u) {
+        const uint32_t j0 = q << 3;
+        const uint4 ka = ((const uint4*)pairKeys)[2u * q], kb = ((const uint4*)pairKeys)[2u * q + 1u];
+        const uint32_t k[10] = { j0 ? pairKeys[j0 - 1u] : 0xffffffffu, ka.x, ka.y, ka.z, ka.w, kb.x, kb.y, kb.z, kb.w,
+                                 (j0 + 8u < n) ? pairKeys[j0 + 8u] : 0xffffffffu };
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
+        for (int c = 0; c < 8; ++c) {
             const uint32_t j = j0 + (uint32_t)c;
             if (j >= n) break;
             const uint32_t t = k[c + 1];
@@ -377,27 +380,30 @@ __global__ __launch_bounds__(256) void tile_ranges_kernel(const uint32_t* __rest
     }
 }
 
+// The draw's report, straight into the host's mapped memory (visible to it once the stream is idle) -- written before the
+// blend's tiles run, so that an overflowing scene is noticed within the pipeline depth.
+__device__ __forceinline__ void write_report(const BinControl* binCtl, const uint32_t* pairSortError, FrameReport* report) {
+    report->pairCount = binCtl->pairCount; report->binError = binCtl->error; report->visible = binCtl->visible;
+    report->pairSortError = *pairSortError;
+}
+
+// Scheduling order of the blend's workgroups: tiles by descending expected cost (the hardware hands out workgroups in
+// blockIdx order), a counting sort over 256 cost buckets by one workgroup.  The cost is a hint, never a result: the
+// batches the tile walked in an earlier draw (tileCost), else a guess from the length of its list; empty tiles last.
 __device__ __forceinline__ uint32_t tile_bucket(uint32_t len, uint32_t lastCost) {   // 0 = most expensive ... 255 = empty
     if (len == 0) return 255u;
     // 32 x the batches walked in the previous frame; no history: a third of a long list at most
     const uint32_t pred = lastCost ? lastCost : min((len + 255u) >> 8, 12u) * 32u;
     return 254u - min(pred, 254u);
 }
-__global__ __launch_bounds__(1024) void tile_order_kernel(const uint32_t* __restrict__ tileStart, const uint32_t* __restrict__ tileEnd,
-                                                          const uint32_t* __restrict__ tileCost, uint32_t numTiles, uint32_t* __restrict__ tileOrder,
-                                                          const BinControl* __restrict__ binCtl, const uint32_t* __restrict__ pairSortError,
-                                                          FrameReport* __restrict__ report) {
-    __shared__ uint32_t s_cnt[256], s_off[256], s_w[4];
+// s_cnt, s_off: 256 words each, s_w: 4 words of LDS; called by every thread of a workgroup of `nthreads` >= 256 threads
+__device__ __forceinline__ void tile_order_body(const uint32_t* __restrict__ tileStart, const uint32_t* __restrict__ tileEnd,
+                                                const uint32_t* tileCost, uint32_t numTiles, uint32_t* __restrict__ tileOrder,
+                                                uint32_t* s_cnt, uint32_t* s_off, uint32_t* s_w, uint32_t nthreads) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    if (tid == 0) {     // the draw's report, straight into the host's mapped memory (visible to it once the stream is idle)
-        report->pairCount = binCtl->pairCount; report->binError = binCtl->error; report->visible = binCtl->visible;
-        report->pairSortError = *pairSortError;
-    }
     if (tid < 256) s_cnt[tid] = 0;
     __syncthreads();
-    for (uint32_t t = tid; t < numTiles; t += 1024u) {
-        atomicAdd(&s_cnt[tile_bucket(tileEnd[t] - tileStart[t], tileCost[t])], 1u);
-    }
+    for (uint32_t t = tid; t < numTiles; t += nthreads) atomicAdd(&s_cnt[tile_bucket(tileEnd[t] - tileStart[t], tileCost[t])], 1u);
     __syncthreads();
     uint32_t v = 0, incl = 0;
     if (tid < 256) {
@@ -414,9 +420,17 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(const uint32_t* __rest
         s_off[tid] = base + incl - v;
     }
     __syncthreads();
-    for (uint32_t t = tid; t < numTiles; t += 1024u) {
-        tileOrder[atomicAdd(&s_off[tile_bucket(tileEnd[t] - tileStart[t], tileCost[t])], 1u)] = t;
-    }
+    // (both sweeps must see the same cost of a tile, or a bucket would overflow: tileCost is the buffer of an EARLIER draw,
+    // which nobody writes while this runs -- the draw in flight writes the other one)
+    for (uint32_t t = tid; t < numTiles; t += nthreads) tileOrder[atomicAdd(&s_off[tile_bucket(tileEnd[t] - tileStart[t], tileCost[t])], 1u)] = t;
+}
+__global__ __launch_bounds__(1024) void tile_order_kernel(const uint32_t* __restrict__ tileStart, const uint32_t* __restrict__ tileEnd,
+                                                          const uint32_t* __restrict__ tileCost, uint32_t numTiles, uint32_t* __restrict__ tileOrder,
+                                                          const BinControl* __restrict__ binCtl, const uint32_t* __restrict__ pairSortError,
+                                                          FrameReport* __restrict__ report) {
+    __shared__ uint32_t s_cnt[256], s_off[256], s_w[4];
+    if (threadIdx.x == 0) write_report(binCtl, pairSortError, report);
+    tile_order_body(tileStart, tileEnd, tileCost, numTiles, tileOrder, s_cnt, s_off, s_w, 1024u);
 }
 
 // gfx950 mixed-precision FMA (v_fma_mix*): fp32 fma whose sources may be fp16 halves of a register and whose result
@@ -527,14 +541,26 @@ __global__ __launch_bounds__(256) void blend_kernel(const uint32_t* __restrict__
                                                     const uint32_t* __restrict__ tileEnd, const uint32_t* __restrict__ tileOrder,
                                                     uint32_t* __restrict__ tileCost, const SplatRec* __restrict__ recs,
                                                     uint16_t* __restrict__ rt, RasterConsts rc, int dstIsZero,
-                                                    const float* __restrict__ recW, const float* __restrict__ sceneDepth) {
+                                                    const float* __restrict__ recW, const float* __restrict__ sceneDepth,
+                                                    const uint32_t* __restrict__ prevCost, uint32_t* __restrict__ nextOrder, uint32_t numTiles,
+                                                    const BinControl* __restrict__ binCtl, const uint32_t* __restrict__ pairSortError,
+                                                    FrameReport* __restrict__ report) {
     __shared__ float4 s_a[256];      // cx, cy, u1x, u1y      (u_k = axis_k / |axis_k|^2)
     __shared__ uint4 s_b[256];       // u2x, u2y (float bits), f16 r << 16 | f16 g, f16 b << 16 | f16 a
     __shared__ float4 s_e[256];      // half extents of the footprint's bounding box, pixels; r^2 = ln(255 a) with slack
     __shared__ int s_done;
 
+    // Workgroup 0 is not a tile: it computes the NEXT draw's scheduling order (tile_order_body) from the costs of the previous
+    // draw and this draw's list lengths, while the other workgroups blend -- the one-workgroup tile_order kernel (9 us of
+    // latency between the pair sort and the blend) then only runs when there is no order for this tile count yet.
+    if (blockIdx.x == 0) {
+        uint32_t* sc = (uint32_t*)s_a;
+        if (threadIdx.x == 0) write_report(binCtl, pairSortError, report);
+        tile_order_body(tileStart, tileEnd, prevCost, numTiles, nextOrder, sc, sc + 256, sc + 512, 256u);
+        return;
+    }
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const uint32_t tile = tileOrder[blockIdx.x];
+    const uint32_t tile = tileOrder[blockIdx.x - 1u];
     const uint32_t tx = tile % rc.tilesX, ty = tile / rc.tilesX;
     const uint32_t start = tileStart[tile], end = tileEnd[tile];
 #ifdef GS_EXP_BLEND_TIMELINE
@@ -891,17 +917,20 @@ int32_t ensure_arena(gs_renderer* r, uint32_t numTiles) {
     r->offBinGroupBase = off; off += align_up((size_t)((r->binParts + 63) / 64) * 8, 256);
     r->offTileStart = off;   off += align_up((size_t)numTiles * 4, 256);
     r->offTileEnd = off;     off += align_up((size_t)numTiles * 4, 256);
-    r->offTileOrder = off;   off += align_up((size_t)numTiles * 4, 256);
     off = align_up(off, 256);
     r->frameArenaBytes = off;
     r->arenaTiles = numTiles;
     GS_HIP(hipMalloc((void**)&r->frameArena, 2 * off));
     GS_HIP(hipMemsetAsync(r->frameArena, 0, 2 * off, r->ctx->stream));
     r->arenaIdx = 0;
+    // persist across frames (not part of the zeroed arena): the scheduling hints and the schedule itself, two copies each
     if (r->tileCost) (void)hipFree(r->tileCost);
-    r->tileCost = nullptr;
-    GS_HIP(hipMalloc((void**)&r->tileCost, (size_t)numTiles * 4));                      // persists across frames (not part of the zeroed arena)
-    GS_HIP(hipMemsetAsync(r->tileCost, 0, (size_t)numTiles * 4, r->ctx->stream));
+    if (r->tileOrderBuf) (void)hipFree(r->tileOrderBuf);
+    r->tileCost = nullptr; r->tileOrderBuf = nullptr;
+    GS_HIP(hipMalloc((void**)&r->tileCost, (size_t)2 * numTiles * 4));
+    GS_HIP(hipMemsetAsync(r->tileCost, 0, (size_t)2 * numTiles * 4, r->ctx->stream));
+    GS_HIP(hipMalloc((void**)&r->tileOrderBuf, (size_t)2 * numTiles * 4));
+    r->costIdx = 0; r->orderIdx = 0; r->orderTiles[0] = r->orderTiles[1] = 0;
     return GS_OK;
 }
 
@@ -946,17 +975,19 @@ void renderer_free_raster(gs_renderer* r) {
     sort_state_destroy(r->pairSort);
     if (r->frameArena) (void)hipFree(r->frameArena);
     if (r->tileCost) (void)hipFree(r->tileCost);
-    r->tileCost = nullptr;
+    if (r->tileOrderBuf) (void)hipFree(r->tileOrderBuf);
+    r->tileCost = nullptr; r->tileOrderBuf = nullptr;
     if (r->hostReport) (void)hipHostFree(r->hostReport);
     r->recs = nullptr; r->rects = nullptr; r->visMask = nullptr; r->pairKeys = r->pairVals = nullptr; r->frameArena = nullptr; r->hostReport = nullptr; r->hostReportDev = nullptr;
 }
 
 namespace {
-struct DrawSetup { RasterConsts rc; uint32_t numTiles; uint32_t *tileStart, *tileEnd, *tileOrder; int dstIsZero; };
+struct DrawSetup { RasterConsts rc; uint32_t numTiles; uint32_t *tileStart, *tileEnd, *tileOrder, *nextOrder, *costWrite; const uint32_t* costRead;
+                   const BinControl* binCtl; const uint32_t* pairSortError; int dstIsZero; };
 
 // The part of a draw that does not depend on what a "fragment" is: (tile, item) pairs of the visible items in `order`
 // (bin_emit), the stable pair sort by tile, tile ranges, tile schedule + the draw's report.
-int32_t bin_and_sort(gs_renderer* r, const gs_frame_params* p, gs_target* rt, const uint32_t* order, uint32_t count, DrawSetup& o) {
+int32_t bin_and_sort(gs_renderer* r, const gs_frame_params* p, gs_target* rt, const uint32_t* order, uint32_t count, DrawSetup& o, bool forceOrderKernel) {
     gs_context* ctx = r->ctx;
     hipStream_t st = ctx->stream;
     RasterConsts& rc = o.rc;
@@ -978,7 +1009,11 @@ int32_t bin_and_sort(gs_renderer* r, const gs_frame_params* p, gs_target* rt, co
     unsigned long long* binGroupBase = (unsigned long long*)(arena + r->offBinGroupBase);
     o.tileStart = (uint32_t*)(arena + r->offTileStart);
     o.tileEnd = (uint32_t*)(arena + r->offTileEnd);
-    o.tileOrder = (uint32_t*)(arena + r->offTileOrder);
+    o.tileOrder = r->tileOrderBuf + (size_t)r->orderIdx * r->arenaTiles;
+    o.nextOrder = r->tileOrderBuf + (size_t)(r->orderIdx ^ 1) * r->arenaTiles;
+    o.costWrite = r->tileCost + (size_t)r->costIdx * r->arenaTiles;          // this draw's blend writes it ...
+    o.costRead = r->tileCost + (size_t)(r->costIdx ^ 1) * r->arenaTiles;      // ... and schedules by what the previous draw wrote
+    r->costIdx ^= 1;
     const uint32_t cap = (uint32_t)r->pairCapacity;
 
     prof_record(r, 3);
@@ -1000,11 +1035,17 @@ int32_t bin_and_sort(gs_renderer* r, const gs_frame_params* p, gs_target* rt, co
     GS_TRY(mark_order_use(r));                                  // the next frame's depth sort may overwrite order[] from here on
     prof_record(r, 4);
     GS_TRY(enqueue_sort_passes(ctx, st, r->pairSort, pairCtl, r->pairKeys, r->pairVals, cap, &binCtl->pairCountClamped, passes, 255u, r, 12, bits));
-    r->lastPairPasses = (uint32_t)passes;
-    hipLaunchKernelGGL(tile_ranges_kernel, dim3(max(1u, min(div_up(cap, 1024), (uint32_t)ctx->cuCount * 8u))), dim3(256), 0, st, r->pairKeys,
+    hipLaunchKernelGGL(tile_ranges_kernel, dim3(max(1u, min(div_up(cap, 2048), (uint32_t)ctx->cuCount * 8u))), dim3(256), 0, st, r->pairKeys,
                        &binCtl->pairCountClamped, o.tileStart, o.tileEnd, numTiles);
-    hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, st, o.tileStart, o.tileEnd, r->tileCost, numTiles, o.tileOrder, binCtl, &pairCtl->error,
-                       r->hostReportDev);
+    r->lastPairPasses = (uint32_t)passes;
+    o.binCtl = binCtl; o.pairSortError = &pairCtl->error;
+    // the tile schedule: normally left behind by the previous draw's blend (its workgroup 0); computed here only when there is
+    // none for this tile count (first draw, another target size) or the caller's blend does not produce one
+    if (forceOrderKernel || r->orderTiles[r->orderIdx] != numTiles) {
+        hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, st, o.tileStart, o.tileEnd, o.costRead, numTiles, o.tileOrder, binCtl, &pairCtl->error,
+                           r->hostReportDev);
+        r->orderTiles[r->orderIdx] = numTiles;
+    }
     prof_record(r, 5);
     o.dstIsZero = rt->clearPending ? 1 : 0;                      // this draw writes every pixel of the target: the clear is folded in
     rt->clearPending = false;
@@ -1019,7 +1060,7 @@ int32_t enqueue_draw(gs_renderer* r, const gs_frame_params* p, gs_target* rt) {
         return fail(GS_ERR_INVALID_ARGUMENT, "gs_renderer_draw: call gs_renderer_calc_view with the same screen size / clip planes first");
     GS_TRY(join_sort(r));                                       // bin_emit reads order[]
     DrawSetup ds;
-    GS_TRY(bin_and_sort(r, p, rt, r->order, r->n, ds));
+    GS_TRY(bin_and_sort(r, p, rt, r->order, r->n, ds, false));
     const RasterConsts& rc = ds.rc;
     const uint32_t numTiles = ds.numTiles;
     uint32_t *tileStart = ds.tileStart, *tileEnd = ds.tileEnd, *tileOrder = ds.tileOrder;
@@ -1029,11 +1070,14 @@ int32_t enqueue_draw(gs_renderer* r, const gs_frame_params* p, gs_target* rt) {
         flatten_params(p, fc);
         hipLaunchKernelGGL(splat_depth_kernel, dim3(div_up(r->n, 256)), dim3(256), 0, st, r->asset->view, fc, (const uint32_t*)r->visMask, r->recW);
     }
-#define GS_LAUNCH_BLEND(M, D) hipLaunchKernelGGL((blend_kernel<M, D>), dim3(numTiles), dim3(256), 0, st, r->pairVals, tileStart, tileEnd, tileOrder, \
-                                             r->tileCost, r->recs, rt->rgba16f, rc, dstIsZero, r->recW, rt->sceneDepth)
+#define GS_LAUNCH_BLEND(M, D) hipLaunchKernelGGL((blend_kernel<M, D>), dim3(numTiles + 1u), dim3(256), 0, st, r->pairVals, tileStart, tileEnd, tileOrder, \
+                                             ds.costWrite, r->recs, rt->rgba16f, rc, dstIsZero, r->recW, rt->sceneDepth, ds.costRead, ds.nextOrder, numTiles, \
+                                             ds.binCtl, ds.pairSortError, r->hostReportDev)
     if (rt->sceneDepth) { if (r->blendMode == 0) GS_LAUNCH_BLEND(0, true); else GS_LAUNCH_BLEND(1, true); }
     else { if (r->blendMode == 0) GS_LAUNCH_BLEND(0, false); else GS_LAUNCH_BLEND(1, false); }
 #undef GS_LAUNCH_BLEND
+    r->orderIdx ^= 1;                                            // workgroup 0 of the blend has left the next draw's schedule in the other copy
+    r->orderTiles[r->orderIdx] = numTiles;
     prof_record(r, 6);
     GS_HIP(hipGetLastError());
     r->frameInFlight = true;
@@ -1065,9 +1109,9 @@ int32_t enqueue_debug_boxes(gs_renderer* r, const gs_frame_params* p, gs_target*
     prof_record(r, 8);
     r->viewValid = false;                                        // rects / visibility bits now describe the boxes: a splat draw needs calc_view again
     DrawSetup ds;
-    GS_TRY(bin_and_sort(r, p, rt, chunks ? r->chunkOrder : r->order, count, ds));
+    GS_TRY(bin_and_sort(r, p, rt, chunks ? r->chunkOrder : r->order, count, ds, true));   // the box blend leaves no schedule (nor report): tile_order_kernel does both
 #define GS_LAUNCH_BOX(M, D) hipLaunchKernelGGL((blend_box_kernel<M, D>), dim3(ds.numTiles), dim3(256), 0, st, r->pairVals, ds.tileStart, ds.tileEnd, ds.tileOrder, \
-                                           r->tileCost, r->boxRecs, rt->rgba16f, ds.rc, ray, ds.dstIsZero, rt->sceneDepth)
+                                           ds.costWrite, r->boxRecs, rt->rgba16f, ds.rc, ray, ds.dstIsZero, rt->sceneDepth)
     if (rt->sceneDepth) { if (r->blendMode == 0) GS_LAUNCH_BOX(0, true); else GS_LAUNCH_BOX(1, true); }
     else { if (r->blendMode == 0) GS_LAUNCH_BOX(0, false); else GS_LAUNCH_BOX(1, false); }
 #undef GS_LAUNCH_BOX
