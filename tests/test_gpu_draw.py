@@ -230,6 +230,34 @@ def test_overlapped_sort_with_frames_in_flight(gpu_ctx):
     assert np.abs(results[True][0].view(np.float16).astype(np.float32)).sum() > 0
 
 
+def test_tile_schedule_survives_changing_targets(gpu_ctx):
+    """The blend's tile schedule for draw k+1 is produced by draw k (workgroup 0 of its blend) and is only valid for the same
+    tile count; a renderer that alternates between targets of different sizes (and between splat and debug-box draws, whose
+    blend produces no schedule) must fall back to the schedule kernel and still draw every tile exactly once: every frame
+    equals the frame a fresh renderer draws."""
+    a = small_asset(60_000, 9, "Medium")
+    sizes = [(640, 360), (320, 200), (640, 360), (640, 360), (1280, 720), (320, 200), (320, 200)]
+    def fresh(W, H, az):
+        r = GaussianSplatRenderer(gpu_ctx, a); r.OnEnable()
+        rt = RenderTarget(gpu_ctx, W, H)
+        cam = default_camera(W=W, H=H, az=az)
+        r.SortPoints(cam); r.CalcViewData(cam); rt.Clear(); r.Draw(cam, rt)
+        img = rt.Download().copy()
+        r.OnDisable(); rt.Dispose()
+        return img
+    r = GaussianSplatRenderer(gpu_ctx, a); r.OnEnable()
+    rts = {}
+    for f, (W, H) in enumerate(sizes):
+        rt = rts.setdefault((W, H), RenderTarget(gpu_ctx, W, H))
+        cam = default_camera(W=W, H=H, az=20.0 + 15.0 * f)
+        r.ResetOrder()                                          # same starting order as the fresh renderer (ties)
+        r.SortPoints(cam); r.CalcViewData(cam); rt.Clear(); r.Draw(cam, rt)
+        assert np.array_equal(rt.Download(), fresh(W, H, 20.0 + 15.0 * f)), f"frame {f} ({W}x{H})"
+    r.OnDisable()
+    for rt in rts.values():
+        rt.Dispose()
+
+
 def test_profiling_ring_reports_stage_and_frame_times(gpu_ctx):
     """gs_renderer_set_profiling + gs_renderer_frame_times / gs_renderer_stage_times: one GPU duration per profiled frame,
     stage means that add up to about a frame, and the ring resets after stage_times."""
