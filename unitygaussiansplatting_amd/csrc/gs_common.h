@@ -191,9 +191,8 @@ struct gs_renderer {
     uint32_t arenaTiles = 0;                // tiles the arena was sized for
     uint32_t* tileCost = nullptr;           // 2 x arenaTiles x u32: batches each tile walked -- a draw writes copy costIdx and reads (for scheduling) the other
     int costIdx = 0;
-    uint32_t* tileOrderBuf = nullptr;       // 2 x arenaTiles x u32: the blend's tile schedule; a draw consumes copy orderIdx and produces the other for the next one
-    int orderIdx = 0;
-    uint32_t orderTiles[2] = {0, 0};        // tile count each copy is a valid permutation for (0 = none)
+    uint32_t costTiles[2] = {0, 0};         // tile count of the draw that wrote each copy (0 = none): a schedule can be made from it for the same count only
+    uint32_t* tileOrderBuf = nullptr;       // arenaTiles x u32: the blend's tile schedule of the draw in flight
     uint32_t binParts = 0;
     int blendMode = 0;
     int renderMode = 0;                     // gs_render_mode (GaussianSplatRenderer.RenderMode, :126-131)

@@ -12,7 +12,7 @@
 //                  tile's list is then already depth ordered -- no per-tile depth sort.
 //   3. ranges:     tile -> [start, end) in the sorted pair array.
 //   4. blend:      one 256-thread workgroup per tile, one pixel per lane, each wave owns an 8x8 quadrant; tiles are
-//                  scheduled by descending cost -- the schedule of draw k+1 is computed by workgroup 0 of draw k's blend.
+//                  scheduled by descending cost (the schedule is made by an extra workgroup of bin_emit meanwhile).
 //                  The tile's list is streamed in batches of 256 records staged in LDS (software-pipelined loads); each
 //                  wave culls the batch against its quadrant (bounding box + separating-axis test) with a ballot and walks
 //                  only the survivors, reading the record with wave-uniform LDS loads, blending front-to-back in registers.
@@ -99,6 +99,85 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
     return (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan_u32(v), 63);
 }
 
+// The draw's report, straight into the host's mapped memory (visible to it once the stream is idle) -- written before the
+// blend's tiles run, so that an overflowing scene is noticed within the pipeline depth.
+__device__ __forceinline__ void write_report(const BinControl* binCtl, const uint32_t* pairSortError, FrameReport* report) {
+    report->pairCount = binCtl->pairCount; report->binError = binCtl->error; report->visible = binCtl->visible;
+    report->pairSortError = *pairSortError;
+}
+
+// Scheduling order of the blend's workgroups: tiles by descending expected cost (the hardware hands out workgroups in
+// blockIdx order), a counting sort over 256 cost buckets by one workgroup.  The cost is a hint, never a result: the
+// batches the tile walked in an earlier draw (tileCost), else a guess from the length of its list; empty tiles last.
+__device__ __forceinline__ uint32_t tile_bucket(uint32_t len, uint32_t lastCost) {   // 0 = most expensive ... 255 = empty
+    if (len == 0) return 255u;
+    // 32 x the batches walked in the previous frame; no history: a third of a long list at most
+    const uint32_t pred = lastCost ? lastCost : min((len + 255u) >> 8, 12u) * 32u;
+    return 254u - min(pred, 254u);
+}
+// The cost hint of tile t is one or two draws old and the image moves (5 px per frame on the C2 orbit): the prediction is the
+// maximum over the tile and its 8 neighbours, which keeps a heavy tile early when its content has moved next door
+// (scheduling a light tile too early costs nothing; a heavy one too late costs the tail of the launch).
+__device__ __forceinline__ uint32_t tile_cost_dilated(const uint32_t* tileCost, uint32_t t, uint32_t tilesX, uint32_t numTiles) {
+    const uint32_t x = t % tilesX;
+    uint32_t c = 0;
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy) {
+        const int64_t row = (int64_t)t + (int64_t)dy * (int64_t)tilesX;
+        if (row < 0 || row >= (int64_t)numTiles) continue;
+        const uint32_t r = (uint32_t)row;
+        c = max(c, tileCost[r]);
+        if (x > 0u) c = max(c, tileCost[r - 1u]);
+        if (x + 1u < tilesX && r + 1u < numTiles) c = max(c, tileCost[r + 1u]);
+    }
+    return c;
+}
+// s_cnt, s_off: 256 words each, s_w: 4 words of LDS; called by every thread of a workgroup of `nthreads` >= 256 threads.
+// tileStart == null: the list lengths of the draw are not known yet (the schedule is made while the draw's pairs are still
+// being emitted): cost hint only, a tile without one counts as cheap.
+__device__ __forceinline__ void tile_order_body(const uint32_t* __restrict__ tileStart, const uint32_t* __restrict__ tileEnd,
+                                                const uint32_t* tileCost, uint32_t numTiles, uint32_t tilesX, uint32_t* __restrict__ tileOrder,
+                                                uint32_t* s_cnt, uint32_t* s_off, uint32_t* s_w, uint32_t nthreads) {
+    auto bucket = [&](uint32_t t) -> uint32_t {
+        const uint32_t c = tile_cost_dilated(tileCost, t, tilesX, numTiles);
+        if (tileStart) return tile_bucket(tileEnd[t] - tileStart[t], c);
+        return 254u - min(c, 254u);
+    };
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    if (tid < 256) s_cnt[tid] = 0;
+    __syncthreads();
+    for (uint32_t t = tid; t < numTiles; t += nthreads)
+        atomicAdd(&s_cnt[bucket(t)], 1u);
+    __syncthreads();
+    uint32_t v = 0, incl = 0;
+    if (tid < 256) {
+        v = s_cnt[tid];
+        incl = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t u = __shfl_up(incl, o, 64); if (lane >= o) incl += u; }
+        if (lane == 63) s_w[w] = incl;
+    }
+    __syncthreads();
+    if (tid < 256) {
+        uint32_t base = 0;
+        for (int k = 0; k < w; ++k) base += s_w[k];
+        s_off[tid] = base + incl - v;
+    }
+    __syncthreads();
+    // (both sweeps must see the same cost of a tile, or a bucket would overflow: tileCost is the buffer of an EARLIER draw,
+    // which nobody writes while this runs -- the draw in flight writes the other one)
+    for (uint32_t t = tid; t < numTiles; t += nthreads)
+        tileOrder[atomicAdd(&s_off[bucket(t)], 1u)] = t;
+}
+__global__ __launch_bounds__(1024) void tile_order_kernel(const uint32_t* __restrict__ tileStart, const uint32_t* __restrict__ tileEnd,
+                                                          const uint32_t* __restrict__ tileCost, uint32_t numTiles, uint32_t tilesX, uint32_t* __restrict__ tileOrder,
+                                                          const BinControl* __restrict__ binCtl, const uint32_t* __restrict__ pairSortError,
+                                                          FrameReport* __restrict__ report) {
+    __shared__ uint32_t s_cnt[256], s_off[256], s_w[4];
+    if (threadIdx.x == 0) write_report(binCtl, pairSortError, report);
+    tile_order_body(tileStart, tileEnd, tileCost, numTiles, tilesX, tileOrder, s_cnt, s_off, s_w, 1024u);
+}
+
 // Binning: one workgroup per partition of kBinPart consecutive SORTED positions (front to back), handed out by ticket.
 // Wave w owns positions [w*1024, (w+1)*1024) of the partition, item (k, lane) = position k*64 + lane, so every load of
 // order[] is a coalesced 256-B row.  Pair offsets = exclusive scan of the per-position tile counts in position order:
@@ -122,7 +201,8 @@ __global__ __launch_bounds__(kBinThreads, GS_BIN_MINWAVES) void bin_emit_kernel(
                                                                 uint32_t* __restrict__ pairKeys, uint32_t* __restrict__ pairVals,
                                                                 uint32_t capacity, BinControl* ctl, unsigned long long* binStatus, unsigned long long* binGroupAgg, unsigned long long* binGroupBase,
                                                                 uint32_t* pairHist, unsigned long long* __restrict__ groupAgg, uint32_t groupAggWords,
-                                                                uint32_t* __restrict__ nextArena, uint32_t nextArenaWords, uint32_t digitBits) {
+                                                                uint32_t* __restrict__ nextArena, uint32_t nextArenaWords, uint32_t digitBits,
+                                                                const uint32_t* __restrict__ schedCost, uint32_t schedTiles, uint32_t* __restrict__ schedOut) {
     constexpr int SUB = 4;                                   // k's per emission batch: 256 positions per wave
     __shared__ uint32_t s_hist[3 * 256];
     __shared__ uint32_t s_wtot[4], s_wvis[4];
@@ -134,10 +214,22 @@ __global__ __launch_bounds__(kBinThreads, GS_BIN_MINWAVES) void bin_emit_kernel(
     __shared__ uint32_t s_mark[4][64];
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    // One extra workgroup (the last) is not a binning workgroup: it makes the blend's tile schedule of THIS draw from the costs
+    // the previous draw left (tile_order_body, cost hint only) while the others bin -- this kernel is latency-bound with idle
+    // issue slots, and the one-workgroup schedule kernel (9 us of pure latency between the pair sort and the blend) then only
+    // runs when there is no cost history for the tile count.
+    // It is workgroup 0 -- dispatched first, beside the others; as the last one it would only get a slot of the persistent grid
+    // when the binning is over (measured: +11 us).
+    const uint32_t binBlocks = gridDim.x - (schedOut ? 1u : 0u);
+    if (schedOut && blockIdx.x == 0u) {
+        tile_order_body(nullptr, nullptr, schedCost, schedTiles, tilesX, schedOut, s_hist, s_hist + 256, s_hist + 512, (uint32_t)kBinThreads);
+        return;
+    }
+    const uint32_t bid = blockIdx.x - (schedOut ? 1u : 0u);      // index among the binning workgroups
     for (int j = tid; j < 3 * 256; j += kBinThreads) s_hist[j] = 0;
-    for (uint32_t j = blockIdx.x * (uint32_t)kBinThreads + (uint32_t)tid; j < groupAggWords; j += gridDim.x * (uint32_t)kBinThreads) groupAgg[j] = 0ull;   // for the pair sort's look-back
+    for (uint32_t j = bid * (uint32_t)kBinThreads + (uint32_t)tid; j < groupAggWords; j += binBlocks * (uint32_t)kBinThreads) groupAgg[j] = 0ull;   // for the pair sort's look-back
     // the zero-initialised per-draw arena of the NEXT draw (the two copies alternate: no memset launch per draw)
-    for (uint32_t j = blockIdx.x * (uint32_t)kBinThreads + (uint32_t)tid; j < nextArenaWords; j += gridDim.x * (uint32_t)kBinThreads) nextArena[j] = 0u;
+    for (uint32_t j = bid * (uint32_t)kBinThreads + (uint32_t)tid; j < nextArenaWords; j += binBlocks * (uint32_t)kBinThreads) nextArena[j] = 0u;
     const uint32_t numParts = (n + kBinPart - 1) / kBinPart;
     const uint32_t digitMask = (1u << digitBits) - 1u;          // the pair sort's digit width (6..8 bits by tile count)
     uint32_t visAcc = 0;                                         // thread 0: visible splats of this workgroup's partitions
@@ -150,7 +242,7 @@ __global__ __launch_bounds__(kBinThreads, GS_BIN_MINWAVES) void bin_emit_kernel(
     const unsigned long long btl0 = wall_clock64();
 #endif
     if (tid == 0) {
-        const uint32_t cls = blockIdx.x % kBinTicketClasses;
+        const uint32_t cls = bid % kBinTicketClasses;
         const uint32_t t = __hip_atomic_fetch_add(&ctl->tickets[cls * 32u], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         s_part = t * kBinTicketClasses + cls;     // (XCD blocks as in the sort's gather pass were measured here too: 0.133 vs 0.102 ms -- the scan then waits on blocks other XCDs have not reached)
     }
@@ -380,59 +472,6 @@ __global__ __launch_bounds__(256) void tile_ranges_kernel(const uint32_t* __rest
     }
 }
 
-// The draw's report, straight into the host's mapped memory (visible to it once the stream is idle) -- written before the
-// blend's tiles run, so that an overflowing scene is noticed within the pipeline depth.
-__device__ __forceinline__ void write_report(const BinControl* binCtl, const uint32_t* pairSortError, FrameReport* report) {
-    report->pairCount = binCtl->pairCount; report->binError = binCtl->error; report->visible = binCtl->visible;
-    report->pairSortError = *pairSortError;
-}
-
-// Scheduling order of the blend's workgroups: tiles by descending expected cost (the hardware hands out workgroups in
-// blockIdx order), a counting sort over 256 cost buckets by one workgroup.  The cost is a hint, never a result: the
-// batches the tile walked in an earlier draw (tileCost), else a guess from the length of its list; empty tiles last.
-__device__ __forceinline__ uint32_t tile_bucket(uint32_t len, uint32_t lastCost) {   // 0 = most expensive ... 255 = empty
-    if (len == 0) return 255u;
-    // 32 x the batches walked in the previous frame; no history: a third of a long list at most
-    const uint32_t pred = lastCost ? lastCost : min((len + 255u) >> 8, 12u) * 32u;
-    return 254u - min(pred, 254u);
-}
-// s_cnt, s_off: 256 words each, s_w: 4 words of LDS; called by every thread of a workgroup of `nthreads` >= 256 threads
-__device__ __forceinline__ void tile_order_body(const uint32_t* __restrict__ tileStart, const uint32_t* __restrict__ tileEnd,
-                                                const uint32_t* tileCost, uint32_t numTiles, uint32_t* __restrict__ tileOrder,
-                                                uint32_t* s_cnt, uint32_t* s_off, uint32_t* s_w, uint32_t nthreads) {
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    if (tid < 256) s_cnt[tid] = 0;
-    __syncthreads();
-    for (uint32_t t = tid; t < numTiles; t += nthreads) atomicAdd(&s_cnt[tile_bucket(tileEnd[t] - tileStart[t], tileCost[t])], 1u);
-    __syncthreads();
-    uint32_t v = 0, incl = 0;
-    if (tid < 256) {
-        v = s_cnt[tid];
-        incl = v;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { const uint32_t u = __shfl_up(incl, o, 64); if (lane >= o) incl += u; }
-        if (lane == 63) s_w[w] = incl;
-    }
-    __syncthreads();
-    if (tid < 256) {
-        uint32_t base = 0;
-        for (int k = 0; k < w; ++k) base += s_w[k];
-        s_off[tid] = base + incl - v;
-    }
-    __syncthreads();
-    // (both sweeps must see the same cost of a tile, or a bucket would overflow: tileCost is the buffer of an EARLIER draw,
-    // which nobody writes while this runs -- the draw in flight writes the other one)
-    for (uint32_t t = tid; t < numTiles; t += nthreads) tileOrder[atomicAdd(&s_off[tile_bucket(tileEnd[t] - tileStart[t], tileCost[t])], 1u)] = t;
-}
-__global__ __launch_bounds__(1024) void tile_order_kernel(const uint32_t* __restrict__ tileStart, const uint32_t* __restrict__ tileEnd,
-                                                          const uint32_t* __restrict__ tileCost, uint32_t numTiles, uint32_t* __restrict__ tileOrder,
-                                                          const BinControl* __restrict__ binCtl, const uint32_t* __restrict__ pairSortError,
-                                                          FrameReport* __restrict__ report) {
-    __shared__ uint32_t s_cnt[256], s_off[256], s_w[4];
-    if (threadIdx.x == 0) write_report(binCtl, pairSortError, report);
-    tile_order_body(tileStart, tileEnd, tileCost, numTiles, tileOrder, s_cnt, s_off, s_w, 1024u);
-}
-
 // gfx950 mixed-precision FMA (v_fma_mix*): fp32 fma whose sources may be fp16 halves of a register and whose result
 // is either fp32 or RTNE-rounded into one fp16 half of the destination (the other half is preserved).  LLVM selects the
 // same instructions for  (half)fmaf(a, b, (float)h)  (so their semantics are fp32-fma-then-round), but only when its
@@ -542,7 +581,6 @@ __global__ __launch_bounds__(256) void blend_kernel(const uint32_t* __restrict__
                                                     uint32_t* __restrict__ tileCost, const SplatRec* __restrict__ recs,
                                                     uint16_t* __restrict__ rt, RasterConsts rc, int dstIsZero,
                                                     const float* __restrict__ recW, const float* __restrict__ sceneDepth,
-                                                    const uint32_t* __restrict__ prevCost, uint32_t* __restrict__ nextOrder, uint32_t numTiles,
                                                     const BinControl* __restrict__ binCtl, const uint32_t* __restrict__ pairSortError,
                                                     FrameReport* __restrict__ report) {
     __shared__ float4 s_a[256];      // cx, cy, u1x, u1y      (u_k = axis_k / |axis_k|^2)
@@ -550,17 +588,9 @@ __global__ __launch_bounds__(256) void blend_kernel(const uint32_t* __restrict__
     __shared__ float4 s_e[256];      // half extents of the footprint's bounding box, pixels; r^2 = ln(255 a) with slack
     __shared__ int s_done;
 
-    // Workgroup 0 is not a tile: it computes the NEXT draw's scheduling order (tile_order_body) from the costs of the previous
-    // draw and this draw's list lengths, while the other workgroups blend -- the one-workgroup tile_order kernel (9 us of
-    // latency between the pair sort and the blend) then only runs when there is no order for this tile count yet.
-    if (blockIdx.x == 0) {
-        uint32_t* sc = (uint32_t*)s_a;
-        if (threadIdx.x == 0) write_report(binCtl, pairSortError, report);
-        tile_order_body(tileStart, tileEnd, prevCost, numTiles, nextOrder, sc, sc + 256, sc + 512, 256u);
-        return;
-    }
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const uint32_t tile = tileOrder[blockIdx.x - 1u];
+    if (blockIdx.x == 0 && tid == 0) write_report(binCtl, pairSortError, report);      // the first workgroup to run: before any tile is blended
+    const uint32_t tile = tileOrder[blockIdx.x];
     const uint32_t tx = tile % rc.tilesX, ty = tile / rc.tilesX;
     const uint32_t start = tileStart[tile], end = tileEnd[tile];
 #ifdef GS_EXP_BLEND_TIMELINE
@@ -929,8 +959,8 @@ int32_t ensure_arena(gs_renderer* r, uint32_t numTiles) {
     r->tileCost = nullptr; r->tileOrderBuf = nullptr;
     GS_HIP(hipMalloc((void**)&r->tileCost, (size_t)2 * numTiles * 4));
     GS_HIP(hipMemsetAsync(r->tileCost, 0, (size_t)2 * numTiles * 4, r->ctx->stream));
-    GS_HIP(hipMalloc((void**)&r->tileOrderBuf, (size_t)2 * numTiles * 4));
-    r->costIdx = 0; r->orderIdx = 0; r->orderTiles[0] = r->orderTiles[1] = 0;
+    GS_HIP(hipMalloc((void**)&r->tileOrderBuf, (size_t)numTiles * 4));
+    r->costIdx = 0; r->costTiles[0] = r->costTiles[1] = 0;
     return GS_OK;
 }
 
@@ -982,7 +1012,7 @@ void renderer_free_raster(gs_renderer* r) {
 }
 
 namespace {
-struct DrawSetup { RasterConsts rc; uint32_t numTiles; uint32_t *tileStart, *tileEnd, *tileOrder, *nextOrder, *costWrite; const uint32_t* costRead;
+struct DrawSetup { RasterConsts rc; uint32_t numTiles; uint32_t *tileStart, *tileEnd, *tileOrder, *costWrite; const uint32_t* costRead;
                    const BinControl* binCtl; const uint32_t* pairSortError; int dstIsZero; };
 
 // The part of a draw that does not depend on what a "fragment" is: (tile, item) pairs of the visible items in `order`
@@ -1009,10 +1039,11 @@ int32_t bin_and_sort(gs_renderer* r, const gs_frame_params* p, gs_target* rt, co
     unsigned long long* binGroupBase = (unsigned long long*)(arena + r->offBinGroupBase);
     o.tileStart = (uint32_t*)(arena + r->offTileStart);
     o.tileEnd = (uint32_t*)(arena + r->offTileEnd);
-    o.tileOrder = r->tileOrderBuf + (size_t)r->orderIdx * r->arenaTiles;
-    o.nextOrder = r->tileOrderBuf + (size_t)(r->orderIdx ^ 1) * r->arenaTiles;
+    o.tileOrder = r->tileOrderBuf;
     o.costWrite = r->tileCost + (size_t)r->costIdx * r->arenaTiles;          // this draw's blend writes it ...
-    o.costRead = r->tileCost + (size_t)(r->costIdx ^ 1) * r->arenaTiles;      // ... and schedules by what the previous draw wrote
+    o.costRead = r->tileCost + (size_t)(r->costIdx ^ 1) * r->arenaTiles;      // ... and is scheduled by what the previous draw wrote
+    const bool haveCosts = r->costTiles[r->costIdx ^ 1] == numTiles;          // (a hint from another tile grid is no hint)
+    r->costTiles[r->costIdx] = numTiles;
     r->costIdx ^= 1;
     const uint32_t cap = (uint32_t)r->pairCapacity;
 
@@ -1030,8 +1061,10 @@ int32_t bin_and_sort(gs_renderer* r, const gs_frame_params* p, gs_target* rt, co
 #endif
     const uint32_t binCap = max((uint32_t)ctx->cuCount * (uint32_t)GS_BIN_BLOCKS_PER_CU / kBinTicketClasses * kBinTicketClasses, kBinTicketClasses);
     const uint32_t binGrid = min(div_up(div_up(count, kBinPart), kBinTicketClasses) * kBinTicketClasses, binCap);
-    hipLaunchKernelGGL(binKernel, dim3(binGrid), dim3(kBinThreads), 0, st, r->rects, (const uint32_t*)r->visMask, order, count, rc.tilesX, r->pairKeys,
-                       r->pairVals, cap, binCtl, binStatus, binGroupAgg, binGroupBase, pairCtl->hist, r->pairSort.groupAgg, sort_group_words(cap, passes), (uint32_t*)nextArena, (uint32_t)(r->frameArenaBytes / 4), (uint32_t)bits);
+    const bool schedInBin = haveCosts && !forceOrderKernel;     // one extra workgroup makes the blend's tile schedule meanwhile
+    hipLaunchKernelGGL(binKernel, dim3(binGrid + (schedInBin ? 1u : 0u)), dim3(kBinThreads), 0, st, r->rects, (const uint32_t*)r->visMask, order, count, rc.tilesX, r->pairKeys,
+                       r->pairVals, cap, binCtl, binStatus, binGroupAgg, binGroupBase, pairCtl->hist, r->pairSort.groupAgg, sort_group_words(cap, passes), (uint32_t*)nextArena, (uint32_t)(r->frameArenaBytes / 4), (uint32_t)bits,
+                       o.costRead, numTiles, schedInBin ? o.tileOrder : (uint32_t*)nullptr);
     GS_TRY(mark_order_use(r));                                  // the next frame's depth sort may overwrite order[] from here on
     prof_record(r, 4);
     GS_TRY(enqueue_sort_passes(ctx, st, r->pairSort, pairCtl, r->pairKeys, r->pairVals, cap, &binCtl->pairCountClamped, passes, 255u, r, 12, bits));
@@ -1039,13 +1072,11 @@ int32_t bin_and_sort(gs_renderer* r, const gs_frame_params* p, gs_target* rt, co
                        &binCtl->pairCountClamped, o.tileStart, o.tileEnd, numTiles);
     r->lastPairPasses = (uint32_t)passes;
     o.binCtl = binCtl; o.pairSortError = &pairCtl->error;
-    // the tile schedule: normally left behind by the previous draw's blend (its workgroup 0); computed here only when there is
-    // none for this tile count (first draw, another target size) or the caller's blend does not produce one
-    if (forceOrderKernel || r->orderTiles[r->orderIdx] != numTiles) {
-        hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, st, o.tileStart, o.tileEnd, o.costRead, numTiles, o.tileOrder, binCtl, &pairCtl->error,
+    // the tile schedule: normally made by the extra workgroup of this draw's bin_emit; a kernel of its own (which also knows the
+    // list lengths) only when there is no cost history for this tile grid (first draw, another target size) or the caller asks
+    if (!schedInBin)
+        hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, st, o.tileStart, o.tileEnd, o.costRead, numTiles, rc.tilesX, o.tileOrder, binCtl, &pairCtl->error,
                            r->hostReportDev);
-        r->orderTiles[r->orderIdx] = numTiles;
-    }
     prof_record(r, 5);
     o.dstIsZero = rt->clearPending ? 1 : 0;                      // this draw writes every pixel of the target: the clear is folded in
     rt->clearPending = false;
@@ -1070,14 +1101,12 @@ int32_t enqueue_draw(gs_renderer* r, const gs_frame_params* p, gs_target* rt) {
         flatten_params(p, fc);
         hipLaunchKernelGGL(splat_depth_kernel, dim3(div_up(r->n, 256)), dim3(256), 0, st, r->asset->view, fc, (const uint32_t*)r->visMask, r->recW);
     }
-#define GS_LAUNCH_BLEND(M, D) hipLaunchKernelGGL((blend_kernel<M, D>), dim3(numTiles + 1u), dim3(256), 0, st, r->pairVals, tileStart, tileEnd, tileOrder, \
-                                             ds.costWrite, r->recs, rt->rgba16f, rc, dstIsZero, r->recW, rt->sceneDepth, ds.costRead, ds.nextOrder, numTiles, \
+#define GS_LAUNCH_BLEND(M, D) hipLaunchKernelGGL((blend_kernel<M, D>), dim3(numTiles), dim3(256), 0, st, r->pairVals, tileStart, tileEnd, tileOrder, \
+                                             ds.costWrite, r->recs, rt->rgba16f, rc, dstIsZero, r->recW, rt->sceneDepth, \
                                              ds.binCtl, ds.pairSortError, r->hostReportDev)
     if (rt->sceneDepth) { if (r->blendMode == 0) GS_LAUNCH_BLEND(0, true); else GS_LAUNCH_BLEND(1, true); }
     else { if (r->blendMode == 0) GS_LAUNCH_BLEND(0, false); else GS_LAUNCH_BLEND(1, false); }
 #undef GS_LAUNCH_BLEND
-    r->orderIdx ^= 1;                                            // workgroup 0 of the blend has left the next draw's schedule in the other copy
-    r->orderTiles[r->orderIdx] = numTiles;
     prof_record(r, 6);
     GS_HIP(hipGetLastError());
     r->frameInFlight = true;
@@ -1109,7 +1138,7 @@ int32_t enqueue_debug_boxes(gs_renderer* r, const gs_frame_params* p, gs_target*
     prof_record(r, 8);
     r->viewValid = false;                                        // rects / visibility bits now describe the boxes: a splat draw needs calc_view again
     DrawSetup ds;
-    GS_TRY(bin_and_sort(r, p, rt, chunks ? r->chunkOrder : r->order, count, ds, true));   // the box blend leaves no schedule (nor report): tile_order_kernel does both
+    GS_TRY(bin_and_sort(r, p, rt, chunks ? r->chunkOrder : r->order, count, ds, true));   // the box blend writes no report: tile_order_kernel does
 #define GS_LAUNCH_BOX(M, D) hipLaunchKernelGGL((blend_box_kernel<M, D>), dim3(ds.numTiles), dim3(256), 0, st, r->pairVals, ds.tileStart, ds.tileEnd, ds.tileOrder, \
                                            ds.costWrite, r->boxRecs, rt->rgba16f, ds.rc, ray, ds.dstIsZero, rt->sceneDepth)
     if (rt->sceneDepth) { if (r->blendMode == 0) GS_LAUNCH_BOX(0, true); else GS_LAUNCH_BOX(1, true); }
