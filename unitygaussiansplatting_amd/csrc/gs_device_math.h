@@ -170,6 +170,25 @@ GS_HD uint32_t LoadUShort(const uint8_t* p, uint64_t a) {
 
 struct V3 { float x, y, z; };
 struct V4 { float x, y, z, w; };
+// (r, g) of a colour as a 2-vector: on the device its fp32 multiplies / fmas are ONE packed instruction (v_pk_mul_f32 /
+// v_pk_fma_f32 run two IEEE operations per issue slot on gfx950) -- same results as the scalar forms, element by element.
+#if defined(__clang__)
+typedef float F2 __attribute__((ext_vector_type(2)));
+#else       // a host compiler without vector extensions (the header is also compiled by g++ in tests): the same arithmetic, element by element
+struct F2 { float x, y; };
+inline F2 operator*(F2 a, F2 b) { return F2{ a.x * b.x, a.y * b.y }; }
+inline F2 operator-(F2 a, F2 b) { return F2{ a.x - b.x, a.y - b.y }; }
+inline F2 operator-(F2 a) { return F2{ -a.x, -a.y }; }
+inline F2& operator+=(F2& a, F2 b) { a.x += b.x; a.y += b.y; return a; }
+#endif
+struct RGB { F2 rg; float b; };
+GS_HD F2 fma2(F2 a, F2 b, F2 c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_elementwise_fma(a, b, c);
+#else
+    return F2{ fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y) };
+#endif
+}
 
 GS_HD V3 Dec_6_5_5(uint32_t e) { return { (float)(e & 63) * GS_R63, (float)((e >> 6) & 31) * GS_R31, (float)((e >> 11) & 31) * GS_R31 }; }
 GS_HD V3 Dec_5_6_5(uint32_t e) { return { (float)(e & 31) * GS_R31, (float)((e >> 5) & 63) * GS_R63, (float)((e >> 11) & 31) * GS_R31 }; }
@@ -293,6 +312,16 @@ GS_HD V3 LoadSH(const uint8_t* sp, uint32_t shFormat, int k) {
     return { f16tof32(LoadUShort(sp, (uint64_t)(k - 1) * 6)), f16tof32(LoadUShort(sp, (uint64_t)(k - 1) * 6 + 2)), f16tof32(LoadUShort(sp, (uint64_t)(k - 1) * 6 + 4)) };
 }
 
+// the same coefficient as (rg, b); the 5.6.5 decode's multiplies are packed
+GS_HD RGB LoadSHrgb(const uint8_t* sp, uint32_t shFormat, int k) {
+    if (shFormat == 3) {
+        const uint32_t e = LoadUShort(sp, (uint64_t)(k - 1) * 2);
+        return { F2{ (float)(e & 31), (float)((e >> 5) & 63) } * F2{ GS_R31, GS_R63 }, (float)((e >> 11) & 31) * GS_R31 };
+    }
+    const V3 v = LoadSH(sp, shFormat, k);
+    return { F2{ v.x, v.y }, v.z };
+}
+
 GS_HD uint32_t shStrideOf(uint32_t shFormat) { return shFormat == 0 ? 192u : (shFormat == 2 ? 60u : (shFormat == 3 ? 32u : 96u)); }
 
 #define GS_SH_C1 0.4886025f
@@ -303,6 +332,7 @@ struct SHFromBlob {
     const uint8_t* sp; uint32_t fmt;
     GS_HD void begin(const uint8_t* p, uint32_t f) { sp = p; fmt = f; }
     GS_HD V3 load(int k) const { return LoadSH(sp, fmt, k); }
+    GS_HD RGB load_rgb(int k) const { return LoadSHrgb(sp, fmt, k); }
 };
 
 // Whole-chunk cull (per-frame path only).  A chunk's 256 splats lie in the box [posMin, posMax] of its ChunkInfo and are no
@@ -783,22 +813,29 @@ GS_HD void CalcViewColor(const AssetView& a, const FrameConsts& P, uint32_t idx,
     const float dx = -ox, dy = -oy, dz = -oz;
 
     const bool onlySH = P.shOnly != 0;
-    float r = onlySH ? 0.5f : col.x, g = onlySH ? 0.5f : col.y, b = onlySH ? 0.5f : col.z;
+    // (r, g) travel as a 2-vector (packed fp32 instructions on the device), b alone; every channel sees exactly the
+    // operations of ShadeSH in the same order
+    F2 rg = onlySH ? F2{ 0.5f, 0.5f } : F2{ col.x, col.y };
+    float b = onlySH ? 0.5f : col.z;
     if (P.shOrder >= 1) {
         uint32_t shIndex = idx;
         if (a.shFmt > 3) shIndex = LoadUShort(a.other, vp.otherEnd - 2);
         shsrc.begin(a.sh + (uint64_t)shIndex * shStrideOf(a.shFmt), a.shFmt);
-        auto SHK = [&](int k) -> V3 {
-            V3 s = shsrc.load(k);
-            if (shLerp) { s.x = lerpf(shMin.x, shMax.x, s.x); s.y = lerpf(shMin.y, shMax.y, s.y); s.z = lerpf(shMin.z, shMax.z, s.z); }
+        const F2 minRG = { shMin.x, shMin.y }, dRG = F2{ shMax.x, shMax.y } - minRG;      // lerp(a, b, t) = fma(t, b - a, a)
+        const float minB = shMin.z, dB = shMax.z - shMin.z;
+        auto SHK = [&](int k) -> RGB {
+            RGB s = shsrc.load_rgb(k);
+            if (shLerp) { s.rg = fma2(s.rg, dRG, minRG); s.b = fmaf(s.b, dB, minB); }
             return s;
         };
+        auto MUL = [](float w, const RGB& s) -> RGB { return { F2{ w, w } * s.rg, w * s.b }; };
+        auto FMA = [](float w, const RGB& s, const RGB& acc) -> RGB { return { fma2(F2{ w, w }, s.rg, acc.rg), fmaf(w, s.b, acc.b) }; };
         {   // degree 1: res += C1 * (-sh1*y + sh2*z - sh3*x)
-            const V3 s1v = SHK(1), s2v = SHK(2), s3v = SHK(3);
-            float tr = (-s1v.x) * dy, tg = (-s1v.y) * dy, tb = (-s1v.z) * dy;
-            tr = fmaf(s2v.x, dz, tr); tg = fmaf(s2v.y, dz, tg); tb = fmaf(s2v.z, dz, tb);
-            tr = fmaf(-s3v.x, dx, tr); tg = fmaf(-s3v.y, dx, tg); tb = fmaf(-s3v.z, dx, tb);
-            r = fmaf(GS_SH_C1, tr, r); g = fmaf(GS_SH_C1, tg, g); b = fmaf(GS_SH_C1, tb, b);
+            const RGB s1v = SHK(1), s2v = SHK(2), s3v = SHK(3);
+            RGB t = MUL(dy, RGB{ -s1v.rg, -s1v.b });
+            t = FMA(dz, s2v, t);
+            t = FMA(dx, RGB{ -s3v.rg, -s3v.b }, t);
+            rg = fma2(F2{ GS_SH_C1, GS_SH_C1 }, t.rg, rg); b = fmaf(GS_SH_C1, t.b, b);
         }
         if (P.shOrder >= 2) {
             const float xx = dx * dx, yy = dy * dy, zz = dz * dz;
@@ -806,13 +843,12 @@ GS_HD void CalcViewColor(const AssetView& a, const FrameConsts& P, uint32_t idx,
             {
                 const float b4 = 1.0925484f * xy, b5 = -1.0925484f * yz, b6 = 0.3153916f * (fmaf(2.0f, zz, -xx) - yy),
                             b7 = -1.0925484f * xz, b8 = 0.5462742f * (xx - yy);
-                V3 s = SHK(4);
-                float ar = b4 * s.x, ag = b4 * s.y, ab = b4 * s.z;
-                s = SHK(5); ar = fmaf(b5, s.x, ar); ag = fmaf(b5, s.y, ag); ab = fmaf(b5, s.z, ab);
-                s = SHK(6); ar = fmaf(b6, s.x, ar); ag = fmaf(b6, s.y, ag); ab = fmaf(b6, s.z, ab);
-                s = SHK(7); ar = fmaf(b7, s.x, ar); ag = fmaf(b7, s.y, ag); ab = fmaf(b7, s.z, ab);
-                s = SHK(8); ar = fmaf(b8, s.x, ar); ag = fmaf(b8, s.y, ag); ab = fmaf(b8, s.z, ab);
-                r += ar; g += ag; b += ab;
+                RGB acc = MUL(b4, SHK(4));
+                acc = FMA(b5, SHK(5), acc);
+                acc = FMA(b6, SHK(6), acc);
+                acc = FMA(b7, SHK(7), acc);
+                acc = FMA(b8, SHK(8), acc);
+                rg += acc.rg; b += acc.b;
             }
             if (P.shOrder >= 3) {
                 const float b9 = (-0.5900436f * dy) * fmaf(3.0f, xx, -yy);
@@ -822,18 +858,18 @@ GS_HD void CalcViewColor(const AssetView& a, const FrameConsts& P, uint32_t idx,
                 const float b13 = (-0.4570458f * dx) * (fmaf(4.0f, zz, -xx) - yy);
                 const float b14 = (1.4453057f * dz) * (xx - yy);
                 const float b15 = (-0.5900436f * dx) * fmaf(-3.0f, yy, xx);
-                V3 s = SHK(9);
-                float ar = b9 * s.x, ag = b9 * s.y, ab = b9 * s.z;
-                s = SHK(10); ar = fmaf(b10, s.x, ar); ag = fmaf(b10, s.y, ag); ab = fmaf(b10, s.z, ab);
-                s = SHK(11); ar = fmaf(b11, s.x, ar); ag = fmaf(b11, s.y, ag); ab = fmaf(b11, s.z, ab);
-                s = SHK(12); ar = fmaf(b12, s.x, ar); ag = fmaf(b12, s.y, ag); ab = fmaf(b12, s.z, ab);
-                s = SHK(13); ar = fmaf(b13, s.x, ar); ag = fmaf(b13, s.y, ag); ab = fmaf(b13, s.z, ab);
-                s = SHK(14); ar = fmaf(b14, s.x, ar); ag = fmaf(b14, s.y, ag); ab = fmaf(b14, s.z, ab);
-                s = SHK(15); ar = fmaf(b15, s.x, ar); ag = fmaf(b15, s.y, ag); ab = fmaf(b15, s.z, ab);
-                r += ar; g += ag; b += ab;
+                RGB acc = MUL(b9, SHK(9));
+                acc = FMA(b10, SHK(10), acc);
+                acc = FMA(b11, SHK(11), acc);
+                acc = FMA(b12, SHK(12), acc);
+                acc = FMA(b13, SHK(13), acc);
+                acc = FMA(b14, SHK(14), acc);
+                acc = FMA(b15, SHK(15), acc);
+                rg += acc.rg; b += acc.b;
             }
         }
     }
+    float r = rg.x, g = rg.y;
     r = fmaxf(r, 0.0f); g = fmaxf(g, 0.0f); b = fmaxf(b, 0.0f);
     view.color[0] = (f32tof16(r) << 16) | f32tof16(g);
     view.color[1] = (f32tof16(b) << 16) | (view.color[1] & 0xffffu);

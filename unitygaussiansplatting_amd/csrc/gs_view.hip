@@ -28,6 +28,14 @@ template <int FMT> struct SHFromLds {
         if (FMT == 3) return gsm::Dec_5_6_5(half_at(k - 1));
         return { gsm::f16tof32(half_at((k - 1) * 3)), gsm::f16tof32(half_at((k - 1) * 3 + 1)), gsm::f16tof32(half_at((k - 1) * 3 + 2)) };
     }
+    __device__ __forceinline__ gsm::RGB load_rgb(int k) const {
+        if (FMT == 3) {                                          // 5.6.5: the two decode multiplies of (r, g) as one packed instruction
+            const uint32_t e = half_at(k - 1);
+            return { gsm::F2{ (float)(e & 31), (float)((e >> 5) & 63) } * gsm::F2{ GS_R31, GS_R63 }, (float)((e >> 11) & 31) * GS_R31 };
+        }
+        const gsm::V3 v = load(k);
+        return { gsm::F2{ v.x, v.y }, v.z };
+    }
 };
 
 constexpr int sh_rec_dwords(int fmt) { return fmt == 0 ? 48 : (fmt == 1 ? 24 : (fmt == 2 ? 15 : 8)); }
