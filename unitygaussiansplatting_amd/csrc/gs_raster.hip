@@ -119,18 +119,19 @@ __device__ __forceinline__ uint32_t tile_bucket(uint32_t len, uint32_t lastCost)
 // maximum over the tile and its 8 neighbours, which keeps a heavy tile early when its content has moved next door
 // (scheduling a light tile too early costs nothing; a heavy one too late costs the tail of the launch).
 __device__ __forceinline__ uint32_t tile_cost_dilated(const uint32_t* tileCost, uint32_t t, uint32_t tilesX, uint32_t numTiles) {
-    const uint32_t x = t % tilesX;
-    uint32_t c = 0;
+    // nine UNCONDITIONAL loads (neighbour coordinates clamped to the grid: a duplicate changes no maximum) -- a load inside a
+    // branch makes the compiler wait for it there, i.e. nine dependent round trips per tile instead of one
+    const uint32_t tilesY = numTiles / tilesX;                  // the grid is exactly tilesX x tilesY
+    const uint32_t y = t / tilesX, x = t - y * tilesX;
+    const uint32_t x0 = x > 0u ? x - 1u : 0u, x1 = min(x + 1u, tilesX - 1u);
+    const uint32_t y0 = y > 0u ? y - 1u : 0u, y1 = min(y + 1u, tilesY - 1u);
+    const uint32_t r0 = y0 * tilesX, r1 = y * tilesX, r2 = y1 * tilesX;
+    const uint32_t c[9] = { tileCost[r0 + x0], tileCost[r0 + x], tileCost[r0 + x1], tileCost[r1 + x0], tileCost[r1 + x], tileCost[r1 + x1],
+                            tileCost[r2 + x0], tileCost[r2 + x], tileCost[r2 + x1] };
+    uint32_t m = c[0];
 #pragma unroll
-    for (int dy = -1; dy <= 1; ++dy) {
-        const int64_t row = (int64_t)t + (int64_t)dy * (int64_t)tilesX;
-        if (row < 0 || row >= (int64_t)numTiles) continue;
-        const uint32_t r = (uint32_t)row;
-        c = max(c, tileCost[r]);
-        if (x > 0u) c = max(c, tileCost[r - 1u]);
-        if (x + 1u < tilesX && r + 1u < numTiles) c = max(c, tileCost[r + 1u]);
-    }
-    return c;
+    for (int i = 1; i < 9; ++i) m = max(m, c[i]);
+    return m;
 }
 // s_cnt, s_off: 256 words each, s_w: 4 words of LDS; called by every thread of a workgroup of `nthreads` >= 256 threads.
 // tileStart == null: the list lengths of the draw are not known yet (the schedule is made while the draw's pairs are still
@@ -146,8 +147,15 @@ __device__ __forceinline__ void tile_order_body(const uint32_t* __restrict__ til
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     if (tid < 256) s_cnt[tid] = 0;
     __syncthreads();
-    for (uint32_t t = tid; t < numTiles; t += nthreads)
-        atomicAdd(&s_cnt[bucket(t)], 1u);
+    // four tiles per thread and step: their 36 cost loads are in flight together (the workgroup shares a kernel with the
+    // binning; one tile at a time it took longer than the binning itself at 1080p: 8,160 tiles, 64 dependent round trips)
+    for (uint32_t t0 = tid; t0 < numTiles; t0 += 4u * nthreads) {
+        uint32_t bk[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { const uint32_t t = t0 + (uint32_t)i * nthreads; bk[i] = t < numTiles ? bucket(t) : 0xffffffffu; }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) if (bk[i] != 0xffffffffu) atomicAdd(&s_cnt[bk[i]], 1u);
+    }
     __syncthreads();
     uint32_t v = 0, incl = 0;
     if (tid < 256) {
@@ -166,8 +174,13 @@ __device__ __forceinline__ void tile_order_body(const uint32_t* __restrict__ til
     __syncthreads();
     // (both sweeps must see the same cost of a tile, or a bucket would overflow: tileCost is the buffer of an EARLIER draw,
     // which nobody writes while this runs -- the draw in flight writes the other one)
-    for (uint32_t t = tid; t < numTiles; t += nthreads)
-        tileOrder[atomicAdd(&s_off[bucket(t)], 1u)] = t;
+    for (uint32_t t0 = tid; t0 < numTiles; t0 += 4u * nthreads) {
+        uint32_t bk[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { const uint32_t t = t0 + (uint32_t)i * nthreads; bk[i] = t < numTiles ? bucket(t) : 0xffffffffu; }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) if (bk[i] != 0xffffffffu) tileOrder[atomicAdd(&s_off[bk[i]], 1u)] = t0 + (uint32_t)i * nthreads;
+    }
 }
 __global__ __launch_bounds__(1024) void tile_order_kernel(const uint32_t* __restrict__ tileStart, const uint32_t* __restrict__ tileEnd,
                                                           const uint32_t* __restrict__ tileCost, uint32_t numTiles, uint32_t tilesX, uint32_t* __restrict__ tileOrder,
@@ -583,8 +596,8 @@ __global__ __launch_bounds__(256) void blend_kernel(const uint32_t* __restrict__
                                                     const float* __restrict__ recW, const float* __restrict__ sceneDepth,
                                                     const BinControl* __restrict__ binCtl, const uint32_t* __restrict__ pairSortError,
                                                     FrameReport* __restrict__ report) {
-    __shared__ float4 s_a[256];      // cx, cy, u1x, u1y      (u_k = axis_k / |axis_k|^2)
-    __shared__ uint4 s_b[256];       // u2x, u2y (float bits), f16 r << 16 | f16 g, f16 b << 16 | f16 a
+    __shared__ float4 s_a[256];      // cx, cy, u1x, u2x      (u_k = axis_k / |axis_k|^2; the x's and the y's of the two axes side by side:
+    __shared__ uint4 s_b[256];       // u1y, u2y (float bits), f16 r << 16 | f16 g, f16 b << 16 | f16 a      operands of packed fp32 instructions)
     __shared__ float4 s_e[256];      // half extents of the footprint's bounding box, pixels; r^2 = ln(255 a) with slack
     __shared__ int s_done;
 
@@ -613,6 +626,7 @@ __global__ __launch_bounds__(256) void blend_kernel(const uint32_t* __restrict__
     const int px = qx0 + (lane & 7), py = qy0 + (lane >> 3);
     const bool inside = px < (int)rc.width && py < (int)rc.height;
     const float fx = (float)px + 0.5f, fy = (float)py + 0.5f;
+    const gsm::F2 fxy = { fx, fy };
     const float qminx = (float)qx0 + 0.5f, qmaxx = (float)qx0 + 7.5f, qminy = (float)qy0 + 0.5f, qmaxy = (float)qy0 + 7.5f;
 
     PixelAcc<MODE> acc;
@@ -654,8 +668,8 @@ __global__ __launch_bounds__(256) void blend_kernel(const uint32_t* __restrict__
             const float r2 = fmaf(gsm::LogDet(255.0f * ca), 1.0001f, 1.0e-3f);
             const float rr = sqrtf(fmaxf(r2, 0.0f));
             const float exe = rr * sqrtf(gsm::dot2f(r0.z, r1.x, r0.z, r1.x)), eye = rr * sqrtf(gsm::dot2f(r0.w, r1.y, r0.w, r1.y));
-            s_a[tid] = make_float4(r0.x, r0.y, r0.z * inv1, r0.w * inv1);
-            s_b[tid] = make_uint4(gsm::f2u(r1.x * inv2), gsm::f2u(r1.y * inv2), gsm::f2u(r1.z), gsm::f2u(r1.w));
+            s_a[tid] = make_float4(r0.x, r0.y, r0.z * inv1, r1.x * inv2);
+            s_b[tid] = make_uint4(gsm::f2u(r0.w * inv1), gsm::f2u(r1.y * inv2), gsm::f2u(r1.z), gsm::f2u(r1.w));
             s_e[tid] = make_float4(fminf(exr, exe) + 0.02f, fminf(eyr, eye) + 0.02f, r2, rw);
         }
         {
@@ -678,7 +692,7 @@ __global__ __launch_bounds__(256) void blend_kernel(const uint32_t* __restrict__
                     hit = (ra.x + re.x >= qminx) && (ra.x - re.x <= qmaxx) && (ra.y + re.y >= qminy) && (ra.y - re.y <= qmaxy);
                     // oriented test: 30 % of the bounding-box survivors cannot put a live fragment on this 8x8 quadrant
                     const uint4 rb = s_b[j];
-                    hit = hit && gsm::BlockMayTouch((float)qx0 + 4.0f, (float)qy0 + 4.0f, 3.5f, ra.x, ra.y, ra.z, ra.w, gsm::u2f(rb.x), gsm::u2f(rb.y), re.z);
+                    hit = hit && gsm::BlockMayTouch((float)qx0 + 4.0f, (float)qy0 + 4.0f, 3.5f, ra.x, ra.y, ra.z, gsm::u2f(rb.x), ra.w, gsm::u2f(rb.y), re.z);
                 }
                 unsigned long long mask = __ballot(hit);
 #ifdef GS_EXP_BLEND_TIMELINE
@@ -690,9 +704,11 @@ __global__ __launch_bounds__(256) void blend_kernel(const uint32_t* __restrict__
                     const float4 A4 = s_a[c + b];                      // wave-uniform address: LDS broadcast
                     u4v B4 = *(const u4v*)&s_b[c + b];
                     asm volatile("" : "+v"(B4));                       // keep it ONE ds_read_b128 (no piece sunk into the branch)
-                    const float dx = fx - A4.x, dy = fy - A4.y;
-                    const float q1 = fmaf(dy, A4.w, dx * A4.z);
-                    const float q2 = fmaf(dy, gsm::u2f(B4.y), dx * gsm::u2f(B4.x));
+                    // q_k = dx u_kx + dy u_ky for both axes at once: three packed fp32 instructions (v_pk_add / v_pk_mul / v_pk_fma)
+                    // instead of six scalar ones, element by element the same operations
+                    const gsm::F2 d = fxy - gsm::F2{ A4.x, A4.y };
+                    const gsm::F2 q = gsm::fma2(gsm::F2{ d.y, d.y }, gsm::F2{ gsm::u2f(B4.x), gsm::u2f(B4.y) }, gsm::F2{ d.x, d.x } * gsm::F2{ A4.z, A4.w });
+                    const float q1 = q.x, q2 = q.y;
                     const float power = -fmaf(q2, q2, q1 * q1);
 #ifdef GS_BLEND_PLAIN
                     const float alpha = gsm::sat(__expf(power) * half_lo(B4.w));
