@@ -144,16 +144,26 @@ __global__ __launch_bounds__(1024) void sort_keys_kernel(gsm::AssetView a, float
     // through the LDS histograms (the LDS atomic unit and the memory pipe then work at the same time instead of in turns)
     // (raw dwords first, decoded only when they are consumed: every load of a stage is issued before anything waits)
     typedef gsm::RawVec<POSFMT> Raw;
-    auto load = [&](uint32_t c0, Raw (&p)[ILP]) {
+    // The chunk's position bounds (ChunkInfo.posX/Y/Z: 24 bytes at +16) travel through the same pipeline as the positions, as
+    // VECTOR loads of a wave-uniform address.  As scalar loads issued where they are used they were the kernel's critical path:
+    // one exposed ~1 us round trip per chunk, four per iteration (the position loads were prefetched, these were not).
+    struct Staged { Raw raw; uint4 bx; uint2 bz; };              // bx = posX.min, posX.max, posY.min, posY.max; bz = posZ.min, posZ.max
+    const bool chunked = a.chunkCount != 0u;
+    const uint8_t* cbase = chunked ? a.chunk : (const uint8_t*)keyBySplat;            // (no chunks: any readable 64 bytes, never used)
+    const uint32_t lastChunk = chunked ? a.chunkCount - 1u : 0u;
+    auto load = [&](uint32_t c0, Staged (&p)[ILP]) {
 #pragma unroll
         for (uint32_t k = 0; k < ILP; ++k) {
             // unconditional loads with a clamped index: a load inside a divergent branch is waited for at the end of the branch
             const uint32_t ci = min(c0 + k * 4u + sub, chunks - 1u);
             const uint32_t idx = min(ci * 256u + t, n - 1u);
-            p[k] = gsm::LoadRawT<POSFMT>(a.pos, (uint64_t)idx * gsm::vecStrideT<POSFMT>());
+            p[k].raw = gsm::LoadRawT<POSFMT>(a.pos, (uint64_t)idx * gsm::vecStrideT<POSFMT>());
+            const uint8_t* c = cbase + (size_t)min(ci, lastChunk) * 64u;
+            p[k].bx = *(const uint4*)(c + 16);
+            p[k].bz = *(const uint2*)(c + 32);
         }
     };
-    Raw cur[ILP], nxt[ILP];
+    Staged cur[ILP], nxt[ILP];
     uint32_t c0 = blockIdx.x * (4u * ILP);
     if (c0 < chunks) load(c0, cur);
     for (; c0 < chunks; c0 += step) {
@@ -161,10 +171,15 @@ __global__ __launch_bounds__(1024) void sort_keys_kernel(gsm::AssetView a, float
         if (more) load(c0 + step, nxt);
 #pragma unroll
         for (uint32_t k = 0; k < ILP; ++k) {
-            const uint32_t ci = __builtin_amdgcn_readfirstlane(c0 + k * 4u + sub);       // wave-uniform: 4 waves per chunk => scalar ChunkInfo loads
+            const uint32_t ci = c0 + k * 4u + sub;
             const uint32_t idx = ci * 256u + t;
             if (idx >= n) continue;
-            const gsm::V3 pos = gsm::ChunkLerpPos(a, gsm::DecodeRawT<POSFMT>(cur[k], (uint64_t)idx * gsm::vecStrideT<POSFMT>()), ci);
+            gsm::V3 pos = gsm::DecodeRawT<POSFMT>(cur[k].raw, (uint64_t)idx * gsm::vecStrideT<POSFMT>());
+            if (chunked && ci <= lastChunk) {                    // LoadSplatPos' chunk de-normalisation (ChunkLerpPos), same expressions
+                pos.x = gsm::lerpf(gsm::u2f(cur[k].bx.x), gsm::u2f(cur[k].bx.y), pos.x);
+                pos.y = gsm::lerpf(gsm::u2f(cur[k].bx.z), gsm::u2f(cur[k].bx.w), pos.y);
+                pos.z = gsm::lerpf(gsm::u2f(cur[k].bz.x), gsm::u2f(cur[k].bz.y), pos.z);
+            }
             const uint32_t key = gsm::SortKeyOf(pos, m20, m21, m22, m23);
             keyBySplat[idx] = key;
             lds_hist_add(s_h, key & 255u);
