@@ -79,7 +79,7 @@ struct SortControl {
     uint32_t pad[3];
 };
 
-// What the host wants to know about a finished draw: stored by tile_order_kernel straight into mapped pinned host memory
+// What the host wants to know about a finished draw: stored by the blend's first workgroup (or tile_order_kernel) straight into mapped pinned host memory
 struct FrameReport {
     unsigned long long pairCount;
     uint32_t binError, pairSortError, visible, pad;

@@ -732,7 +732,7 @@ __global__ __launch_bounds__(256) void blend_kernel(const uint32_t* __restrict__
 #endif
     }
     if (inside) *dst = acc.pack();
-    // next frame's scheduling hint (tile_order_kernel): batches walked.  (The measured duration of the tile was tried as the
+    // next frame's scheduling hint (tile_order_body): batches walked.  (The measured duration of the tile was tried as the
     // cost and schedules slightly worse, 0.189 vs 0.185 ms: it depends on who the tile shared its SIMDs with.)
     if (threadIdx.x == 0) tileCost[tile] = batchesWalked * 32u;
 #ifdef GS_EXP_BLEND_TIMELINE
