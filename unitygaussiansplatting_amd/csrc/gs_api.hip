@@ -342,7 +342,7 @@ int32_t gs_renderer_calc_view(gs_renderer* r, const gs_frame_params* p) {
 }
 
 // Grow the pair buffers before they overflow again.  The report of a draw is stored by the first workgroup of its blend straight
-// into mapped pinned host memory (before the blend even starts), so whatever it holds is the most recent draw that got
+// into mapped pinned host memory (before any tile is blended), so whatever it holds is the most recent draw that got
 // that far -- also in a pipelined loop in which the host runs ahead and the stream is never idle.  An overflowing scene is
 // therefore noticed within the pipeline depth, not only when the caller polls gs_renderer_frame_stats.
 static int32_t maybe_grow_pairs(gs_renderer* r) {
