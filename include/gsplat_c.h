@@ -73,7 +73,11 @@ typedef struct gs_asset_desc {
     uint32_t color_format;    /* gs_color_format  */
     uint32_t sh_format;       /* gs_sh_format     */
     uint32_t memory_kind;     /* 0: pointers are host memory, copied.  1: pointers are device memory on the
-                                 context's GPU, BORROWED (must outlive the asset; e.g. buffers filled by an RCCL broadcast) */
+                                 context's GPU, BORROWED (must outlive the asset; e.g. buffers filled by an RCCL broadcast):
+                                 every blob base 16-byte aligned (the kernels use 16-byte vector loads; hipMalloc gives 256)
+                                 and pos / other / sh declared with >= 4 readable bytes after their last record (the
+                                 2-byte-aligned dword stitching of the decoder may touch the next dword; owned uploads
+                                 are padded by the library).  Violations: GS_ERR_INVALID_ARGUMENT / GS_ERR_INVALID_ASSET. */
     const void* pos_data;    uint64_t pos_size;
     const void* other_data;  uint64_t other_size;
     const void* color_data;  uint64_t color_size;
@@ -146,11 +150,12 @@ const char* gs_last_error_string(void);          /* thread-local detail of the l
 int32_t gs_context_create(int32_t device, void* hip_stream, gs_context** out);
 int32_t gs_context_destroy(gs_context* ctx);
 int32_t gs_context_synchronize(gs_context* ctx);
-/* The depth sort of a frame does not depend on CalcViewData.  With overlap on, gs_renderer_sort is enqueued on a second
- * in-order queue owned by the context, forked from the context's stream and joined to it by the first consumer of the
- * order (gs_renderer_draw or a readback), so sort and view data run concurrently on the GPU.  Results are identical
- * either way.  Default OFF: on MI355X the two stages compete for the memory system and the frame is not shorter
- * (DESIGN.md).  Blocks until the second queue is idle. */
+/* The depth sort of a frame depends on nothing else the frame computes, and only the draw's binning reads its result.
+ * With overlap on, gs_renderer_sort (keys + the four passes) is enqueued on a second in-order queue owned by the context:
+ * it is released by the previous draw's binning (the last reader of the order on the main queue) and joined by the next
+ * consumer of the order (gs_renderer_draw or a readback), so with frames in flight it runs beside the previous draw's
+ * blend / resolve and this frame's gs_renderer_calc_view.  Results are identical either way.  Default OFF: on MI355X every
+ * kernel of the frame already fills the chip and the frame is not shorter.  Blocks until both queues are idle. */
 int32_t gs_context_set_overlap(gs_context* ctx, int32_t enabled);
 int32_t gs_context_device_info(gs_context* ctx, char* name_out, size_t name_cap, int32_t* cu_count, uint64_t* hbm_bytes);
 

@@ -169,10 +169,11 @@ int32_t gs_asset_create(gs_context* ctx, const gs_asset_desc* d, gs_asset** out)
     for (int k = 0; k < 4; ++k)
         if (have[k] < need[k]) { set_error_detail("blob %d too small: %llu < %llu", k, (unsigned long long)have[k], (unsigned long long)need[k]); return GS_ERR_INVALID_ASSET; }
     if (d->memory_kind == 1) {
-        // borrowed device blobs: the decoders read aligned dwords (4-byte aligned bases) and the 2-byte-aligned dword stitching
-        // of LoadUInt / LoadUShort may touch the dword after the last record (owned uploads are padded by 16 bytes)
+        // borrowed device blobs: the kernels use 16-byte vector loads on the blobs (SH staging, chunk bounds) and aligned dword
+        // loads everywhere else, and the 2-byte-aligned dword stitching of LoadUInt / LoadUShort may touch the dword after
+        // the last record (owned uploads are padded by 16 bytes)
         for (int k = 0; k < 5; ++k)
-            if (src[k] && (((uintptr_t)src[k]) & 3u)) return fail(GS_ERR_INVALID_ARGUMENT, "borrowed blobs must be 4-byte aligned");
+            if (src[k] && (((uintptr_t)src[k]) & 15u)) return fail(GS_ERR_INVALID_ARGUMENT, "borrowed blobs must be 16-byte aligned");
         for (int k : {0, 1, 3})
             if (have[k] < need[k] + 4) { set_error_detail("borrowed blob %d needs 4 readable bytes after its last record (declare size >= %llu)", k, (unsigned long long)(need[k] + 4)); return GS_ERR_INVALID_ASSET; }
     }
