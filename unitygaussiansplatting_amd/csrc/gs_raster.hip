@@ -194,11 +194,11 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(const uint32_t* __rest
 // Binning: one workgroup per partition of kBinPart consecutive SORTED positions (front to back), handed out by ticket.
 // Wave w owns positions [w*1024, (w+1)*1024) of the partition, item (k, lane) = position k*64 + lane, so every load of
 // order[] is a coalesced 256-B row.  Pair offsets = exclusive scan of the per-position tile counts in position order:
-// inside the wave by DPP scans, across waves through LDS, across partitions by a single-pass chained scan whose
-// look-back is done 64 predecessors at a time by wave 0.  Emission is output-centric: the wave's pairs of 256 positions
-// are produced 64 consecutive output slots at a time, each lane finding its source position by a binary search over
-// the 256 exclusive offsets in LDS -- global stores of pairs are therefore fully coalesced whatever the footprints
-// are (a splat covering the whole screen is just a long run), and no lane idles behind a neighbour's big splat.
+// inside the wave by DPP scans, across waves through LDS, across partitions by a two-level scan (group aggregates + the
+// status words of the own group, see below) done by wave 0.  Emission is output-centric: the wave's pairs of 256 positions
+// are produced 64 consecutive output slots at a time, each lane finding its source position from marks dropped at the
+// first slot of every position and a DPP max-scan -- global stores of pairs are therefore fully coalesced whatever the
+// footprints are (a splat covering the whole screen is just a long run), and no lane idles behind a neighbour's big splat.
 #ifndef GS_BIN_MINWAVES
 #define GS_BIN_MINWAVES 1
 #endif
