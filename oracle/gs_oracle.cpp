@@ -445,6 +445,8 @@ bool IsSplatCut(const gs_cutout* cutouts, uint32_t count, f3 pos) {
     return finalCut;
 }
 
+thread_local float* g_stage = nullptr;   // gso_cov_stages: where CalcViewDataOne drops its intermediate covariance stages
+
 // SplatUtilities.compute:189-252 CSCalcViewData for one splat
 ViewData CalcViewDataOne(const Asset& a, const gs_frame_params& P, uint32_t idx, const gs_cutout* cutouts = nullptr, uint32_t cutoutCount = 0,
                          const uint32_t* deletedBits = nullptr) {
@@ -466,10 +468,12 @@ ViewData CalcViewDataOne(const Asset& a, const gs_frame_params& P, uint32_t idx,
 
     // CalcMatrixFromRotationScale (GaussianSplatting.hlsl:29-46): mul(mr, diag(scale))
     const float x = splat.rot.x, y = splat.rot.y, z = splat.rot.z, w = splat.rot.w;
+    // (contraction as oracle/_ref's fused build of :40-44 evaluates it: the first product of a sum is the fused one; x*x takes the
+    //  fusion in the [1][1] and [2][2] entries, which leaves the [0][0] sum plain)
     float mr[3][3] = {
-        { fmaf(-2.0f, fmaf(z, z, y * y), 1.0f), 2.0f * fmaf(-w, z, x * y),            2.0f * fmaf(w, y, x * z) },
-        { 2.0f * fmaf(w, z, x * y),            fmaf(-2.0f, fmaf(z, z, x * x), 1.0f), 2.0f * fmaf(-w, x, y * z) },
-        { 2.0f * fmaf(-w, y, x * z),           2.0f * fmaf(w, x, y * z),            fmaf(-2.0f, fmaf(y, y, x * x), 1.0f) } };
+        { fmaf(-2.0f, y * y + z * z, 1.0f),      2.0f * fmaf(x, y, -(w * z)),          2.0f * fmaf(x, z, w * y) },
+        { 2.0f * fmaf(x, y, w * z),            fmaf(-2.0f, fmaf(x, x, z * z), 1.0f), 2.0f * fmaf(y, z, -(w * x)) },
+        { 2.0f * fmaf(x, z, -(w * y)),         2.0f * fmaf(y, z, w * x),            fmaf(-2.0f, fmaf(x, x, y * y), 1.0f) } };
     float M[3][3];
     for (int i = 0; i < 3; ++i) { M[i][0] = mr[i][0] * splat.scale.x; M[i][1] = mr[i][1] * splat.scale.y; M[i][2] = mr[i][2] * splat.scale.z; }
     // CalcCovariance3D (:48-53): sig = M * M^T, 6 unique
@@ -478,18 +482,24 @@ ViewData CalcViewDataOne(const Asset& a, const gs_frame_params& P, uint32_t idx,
     const float c00 = sig(0, 0) * splatScale2, c01 = sig(0, 1) * splatScale2, c02 = sig(0, 2) * splatScale2;
     const float c11 = sig(1, 1) * splatScale2, c12 = sig(1, 2) * splatScale2, c22 = sig(2, 2) * splatScale2;
 
+    if (g_stage) { for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) g_stage[i * 3 + j] = M[i][j];
+                   g_stage[9] = c00; g_stage[10] = c01; g_stage[11] = c02; g_stage[12] = c11; g_stage[13] = c12; g_stage[14] = c22; }
+
     // CalcCovariance2D (:56-90)
     f3 viewPos = { mul_row(P.matrix_mv, 0, splat.pos), mul_row(P.matrix_mv, 1, splat.pos), mul_row(P.matrix_mv, 2, splat.pos) };
     const float aspect = P.proj_m00 / P.proj_m11;
     const float tanFovX = 1.0f / P.proj_m00;
     const float tanFovY = 1.0f / (P.proj_m11 * aspect);
     const float limX = 1.3f * tanFovX, limY = 1.3f * tanFovY;
-    viewPos.x = fminf(fmaxf(viewPos.x / viewPos.z, -limX), limX) * viewPos.z;
-    viewPos.y = fminf(fmaxf(viewPos.y / viewPos.z, -limY), limY) * viewPos.z;
+    // the divisions by viewPos.z (:67-68,73-74) share one reciprocal and 1 / z^2 = rz * rz: what oracle/_ref's fused build (and a
+    // shader compiler's rcp) makes of them
+    const float rz = 1.0f / viewPos.z;
+    viewPos.x = fminf(fmaxf(viewPos.x * rz, -limX), limX) * viewPos.z;
+    viewPos.y = fminf(fmaxf(viewPos.y * rz, -limY), limY) * viewPos.z;
     const float focal = P.screen_w * P.proj_m00 / 2.0f;
-    const float zz2 = viewPos.z * viewPos.z;
-    const float J00 = focal / viewPos.z, J02 = -(focal * viewPos.x) / zz2;
-    const float J11 = focal / viewPos.z, J12 = -(focal * viewPos.y) / zz2;
+    const float rzz = rz * rz;
+    const float J00 = focal * rz, J02 = -(focal * viewPos.x) * rzz;
+    const float J11 = focal * rz, J12 = -(focal * viewPos.y) * rzz;
     const float* W = P.matrix_mv;
     // T = J * W (rows 0,1; J's zero entries dropped)
     float T[2][3];
@@ -520,6 +530,8 @@ ViewData CalcViewDataOne(const Asset& a, const gs_frame_params& P, uint32_t idx,
     const float s1 = fminf(sqrtf(2.0f * lambda1), maxSize), s2 = fminf(sqrtf(2.0f * lambda2), maxSize);
     view.axis1[0] = s1 * dvx;  view.axis1[1] = s1 * dvy;
     view.axis2[0] = s2 * dvy;  view.axis2[1] = s2 * (-dvx);
+    if (g_stage) { g_stage[15] = cov00; g_stage[16] = cov01; g_stage[17] = cov11;
+                   g_stage[18] = view.axis1[0]; g_stage[19] = view.axis1[1]; g_stage[20] = view.axis2[0]; g_stage[21] = view.axis2[1]; }
 
     // view direction + SH (SplatUtilities.compute:241-248)
     const f3 worldViewDir = { P.cam_pos_world[0] - centerWorldPos.x, P.cam_pos_world[1] - centerWorldPos.y, P.cam_pos_world[2] - centerWorldPos.z };
@@ -724,6 +736,13 @@ void gso_calc_view_ex(const gs_asset_desc* d, const gs_frame_params* P, const gs
 #pragma omp parallel for schedule(static)
     for (int64_t i = 0; i < (int64_t)a.n; ++i) out[i] = CalcViewDataOne(a, *P, (uint32_t)i, cutouts, cutout_count, deleted_bits);
 }
+// the covariance path's intermediate stages of one splat (layout of oracle/ref_build's gsr_cs_cov_stages)
+void gso_cov_stages(const gs_asset_desc* d, const gs_frame_params* P, uint32_t idx, float* out22) {
+    const Asset a = make_asset(d);
+    g_stage = out22;
+    (void)CalcViewDataOne(a, *P, idx);
+    g_stage = nullptr;
+}
 void gso_calc_view(const gs_asset_desc* d, const gs_frame_params* P, void* view_out) { gso_calc_view_ex(d, P, nullptr, 0, nullptr, view_out); }
 
 // prepare() of every splat in index order, in the layout of gs_renderer_download_raster_records (include/gsplat_c.h):
@@ -749,6 +768,18 @@ void gso_raster_records(const void* view_in, uint32_t n, const gs_frame_params* 
         }
         vis[wd] = bits;
     }
+}
+
+// RenderGaussianSplats.shader:79-108 frag() for an unselected splat, exposed for tests/test_ref_parity.py: q = the interpolated
+// i.pos, col = i.col (rgb, opacity).  Returns 1 for a discarded fragment, else out4 = (rgb * alpha, alpha).
+int32_t gso_fragment(const float* q, const float* col, float* out4) {
+    const float power = -fmaf(q[1], q[1], q[0] * q[0]);
+    float alpha = exp_canon(power);
+    alpha = saturatef(alpha * col[3]);
+    out4[0] = out4[1] = out4[2] = out4[3] = 0.0f;
+    if (alpha < 1.0f / 255.0f) return 1;
+    out4[0] = col[0] * alpha; out4[1] = col[1] * alpha; out4[2] = col[2] * alpha; out4[3] = alpha;
+    return 0;
 }
 
 // The DrawProcedural of GaussianSplatRenderer.cs:156-166 with RenderGaussianSplats.shader, executed splat by

@@ -1,0 +1,133 @@
+"""ctypes binding of oracle/_ref/libgs_ref_*.so: the reference's OWN shader text (GaussianSplatting.hlsl,
+SplatUtilities.compute:37-252, RenderGaussianSplats.shader, GaussianComposite.shader) compiled for the host by
+oracle/ref_build (gen_ref.py + hlsl_compat.h).  Test infrastructure: only tests/ may load it, and only to check the oracle.
+
+Three builds of the same text (oracle/Makefile `ref`):  strict (separately rounded IEEE operations),  fused (intrinsics as
+mad chains + host-compiler contraction, g++),  fused_clang (the same with clang's contraction choices)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from unitygaussiansplatting_amd import asset as A
+from unitygaussiansplatting_amd import bc7
+from unitygaussiansplatting_amd._abi import VIEW_DTYPE, gs_frame_params, make_asset_desc
+
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_DIR = os.path.join(_ROOT, "oracle", "_ref")
+REFERENCE = "/root/reference"
+BUILDS = ("strict", "fused", "fused_clang")
+
+
+def build() -> None:
+    """(Re)build oracle/_ref when the reference tree is here; the prebuilt libraries travel to machines without it."""
+    if os.path.isdir(os.path.join(REFERENCE, "package", "Shaders")):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(_ROOT, "oracle"), "ref"], stdout=subprocess.DEVNULL)
+
+
+_libs: dict = {}
+
+
+def lib(which: str):
+    if which not in _libs:
+        build()
+        path = os.path.join(_DIR, f"libgs_ref_{which}.so")
+        if not os.path.exists(path):
+            if which == "fused_clang":
+                pytest.skip("no clang++ on the machine that built oracle/_ref")
+            if not os.path.isdir(REFERENCE):
+                pytest.skip("oracle/_ref was not built and there is no reference tree to build it from")
+            raise FileNotFoundError(path)
+        L = C.CDLL(path)
+        L.gsr_cs_sortable_uint.restype = C.c_uint32
+        L.gsr_cs_sortable_uint.argtypes = [C.c_float]
+        L.gsr_cs_encode_morton.restype = C.c_uint32
+        L.gsr_cs_encode_quat_norm10.restype = C.c_uint32
+        _libs[which] = L
+    return _libs[which]
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def flipped(P: gs_frame_params) -> gs_frame_params:
+    """The matrices Unity binds when it renders into a texture on D3D / Vulkan / Metal (GL.GetGPUProjectionMatrix(proj, true)):
+    projection row 1 negated, so clip.y points down and the D3D viewport stores the picture bottom row first."""
+    F = gs_frame_params.from_buffer_copy(bytes(P))
+    for k in range(4):
+        F.matrix_vp[4 + k] = -P.matrix_vp[4 + k]
+    F.proj_m11 = -P.proj_m11
+    return F
+
+
+class Ref:
+    """The reference kernels bound to one asset (SetAssetDataOnCS)."""
+
+    def __init__(self, asset, which: str):
+        self.L = lib(which)
+        self.which = which
+        self.n = asset.splatCount
+        self._keep = []
+        a = asset
+        if a.colorFormat == A.ColorFormat.BC7:            # the texture unit decodes BC7; hand the texels over as R8G8B8A8
+            h = len(a.colorData) // (2048 // 4 * 16) * 4
+            rgba = bc7.decode_texture(a.colorData, 2048, h)
+            a = A.GaussianSplatAsset(splatCount=a.splatCount, posFormat=a.posFormat, scaleFormat=a.scaleFormat, colorFormat=A.ColorFormat.Norm8x4,
+                                     shFormat=a.shFormat, posData=a.posData, otherData=a.otherData, colorData=rgba.reshape(-1), shData=a.shData,
+                                     chunkData=a.chunkData, name=a.name)
+        self.desc = make_asset_desc(a, self._keep)
+        self.order = np.arange(self.n, dtype=np.uint32)
+        self.keys = np.zeros(self.n, np.uint32)
+        self.view = np.zeros(self.n, VIEW_DTYPE)
+
+    def bind(self):
+        assert self.L.gsr_cs_bind_asset(C.byref(self.desc)) == 0
+
+    def set_indices(self):
+        self.L.gsr_cs_set_indices(_p(self.order), C.c_uint32(self.n))
+
+    def calc_distances(self, matrix_sort):
+        self.bind()
+        m = np.ascontiguousarray(matrix_sort, np.float32).reshape(16)
+        self.L.gsr_cs_calc_distances(_p(self.order), _p(m), _p(self.keys), C.c_uint32(self.n))
+        return self.keys
+
+    def decode_all(self):
+        self.bind()
+        out = np.zeros((self.n, 59), np.float32)
+        self.L.gsr_cs_decode_all(_p(out), C.c_uint32(self.n))
+        return out
+
+    def calc_view(self, P: gs_frame_params, cutouts=None, cutout_count: int = 0, deleted_bits=None):
+        self.bind()
+        db = np.ascontiguousarray(deleted_bits, np.uint32) if deleted_bits is not None else None
+        self.L.gsr_cs_set_frame(C.byref(P), cutouts if cutout_count else None, C.c_uint32(cutout_count),
+                                _p(db) if db is not None else None, C.c_uint64(db.nbytes if db is not None else 0))
+        self.L.gsr_cs_calc_view(_p(self.view), C.c_uint32(self.n))
+        return self.view
+
+    def draw(self, W: int, H: int, near: float, far: float, rt=None):
+        """DrawProcedural of self.view through self.order under the D3D rules of oracle/ref_build/ref_render.cpp."""
+        self.L.gsr_rs_bind(_p(self.view), _p(self.order), C.c_uint32(self.n), C.c_float(W), C.c_float(H))
+        if rt is None:
+            rt = np.zeros((H, W, 4), np.uint16)
+        self.L.gsr_rs_draw(_p(rt), C.c_uint32(W), C.c_uint32(H), C.c_float(near), C.c_float(far))
+        return rt
+
+
+def fragment(which: str, q, col):
+    out = np.zeros(4, np.float32)
+    d = lib(which).gsr_rs_frag(_p(np.asarray(q, np.float32)), _p(np.asarray(col, np.float32)), _p(out))
+    return int(d), out
+
+
+def resolve(which: str, rt: np.ndarray, bg):
+    H, W, _ = rt.shape
+    out = np.zeros((H, W, 4), np.float32)
+    lib(which).gsr_comp_resolve(_p(np.ascontiguousarray(rt)), C.c_uint32(W), C.c_uint32(H), _p(np.asarray(bg, np.float32)), _p(out))
+    return out

@@ -68,6 +68,8 @@ def test_product_code_never_references_the_oracle():
                 txt = open(os.path.join(dp, f), errors="replace").read()
                 # comments may cite the oracle; code may not bind it: its symbols (gso_*), its library, its binding module
                 assert "gso_" not in txt and "oracle_lib" not in txt and "libgs_oracle" not in txt, f
+                # ... nor oracle/_ref, the reference's own shader text compiled for the host (symbols gsr_*, tests/ref_lib.py)
+                assert "gsr_" not in txt and "ref_lib" not in txt and "libgs_ref" not in txt and "hlsl_compat" not in txt, f
                 assert not re.search(r'#include\s*"[^"]*oracle', txt), f
 
 

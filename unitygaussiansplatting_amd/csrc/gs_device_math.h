@@ -713,11 +713,14 @@ GS_HD void CalcViewGeom(const AssetView& a, const FrameConsts& P, const EditView
     float vx = mrow(P.mv, 0, pos.x, pos.y, pos.z), vy = mrow(P.mv, 1, pos.x, pos.y, pos.z);
     const float vz = mrow(P.mv, 2, pos.x, pos.y, pos.z);
     const float limX = P.limX, limY = P.limY, focal = P.focal;
-    vx = fminf(fmaxf(vx / vz, -limX), limX) * vz;
-    vy = fminf(fmaxf(vy / vz, -limY), limY) * vz;
-    const float zz2 = vz * vz;
-    const float J00 = focal / vz, J02 = -(focal * vx) / zz2;
-    const float J11 = J00, J12 = -(focal * vy) / zz2;
+    // the four divisions by viewPos.z and the two by its square share ONE reciprocal: rz = 1 / z, 1 / z^2 = rz * rz -- what a
+    // shader compiler makes of them, and bit for bit what oracle/_ref's fused build of the reference text computes
+    const float rz = 1.0f / vz;
+    vx = fminf(fmaxf(vx * rz, -limX), limX) * vz;
+    vy = fminf(fmaxf(vy * rz, -limY), limY) * vz;
+    const float rzz = rz * rz;
+    const float J00 = focal * rz, J02 = -(focal * vx) * rzz;
+    const float J11 = J00, J12 = -(focal * vy) * rzz;
     const float T00 = fmaf(J02, P.mv[8], J00 * P.mv[0]), T01 = fmaf(J02, P.mv[9], J00 * P.mv[1]), T02 = fmaf(J02, P.mv[10], J00 * P.mv[2]);
     const float T10 = fmaf(J12, P.mv[8], J11 * P.mv[4]), T11 = fmaf(J12, P.mv[9], J11 * P.mv[5]), T12 = fmaf(J12, P.mv[10], J11 * P.mv[6]);
 
@@ -759,9 +762,11 @@ GS_HD void CalcViewGeom(const AssetView& a, const FrameConsts& P, const EditView
 
     // ---- CalcMatrixFromRotationScale + CalcCovariance3D
     const float x = q.x, y = q.y, z = q.z, w = q.w;
-    const float r00 = fmaf(-2.0f, fmaf(z, z, y * y), 1.0f), r01 = 2.0f * fmaf(-w, z, x * y), r02 = 2.0f * fmaf(w, y, x * z);
-    const float r10 = 2.0f * fmaf(w, z, x * y), r11 = fmaf(-2.0f, fmaf(z, z, x * x), 1.0f), r12 = 2.0f * fmaf(-w, x, y * z);
-    const float r20 = 2.0f * fmaf(-w, y, x * z), r21 = 2.0f * fmaf(w, x, y * z), r22 = fmaf(-2.0f, fmaf(y, y, x * x), 1.0f);
+    // contraction of the nine entries = oracle/_ref's fused build (g++ -ffp-contract=fast of GaussianSplatting.hlsl:40-44): the
+    // first product of every sum / difference is the fused one; x*x takes the fusion in r11 and r22, which leaves r00's sum plain
+    const float r00 = fmaf(-2.0f, y * y + z * z, 1.0f), r01 = 2.0f * fmaf(x, y, -(w * z)), r02 = 2.0f * fmaf(x, z, w * y);
+    const float r10 = 2.0f * fmaf(x, y, w * z), r11 = fmaf(-2.0f, fmaf(x, x, z * z), 1.0f), r12 = 2.0f * fmaf(y, z, -(w * x));
+    const float r20 = 2.0f * fmaf(x, z, -(w * y)), r21 = 2.0f * fmaf(y, z, w * x), r22 = fmaf(-2.0f, fmaf(x, x, y * y), 1.0f);
     const float m00 = r00 * scale.x, m01 = r01 * scale.y, m02 = r02 * scale.z;
     const float m10 = r10 * scale.x, m11 = r11 * scale.y, m12 = r12 * scale.z;
     const float m20 = r20 * scale.x, m21 = r21 * scale.y, m22 = r22 * scale.z;
