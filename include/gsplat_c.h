@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GS_ABI_VERSION 4
+#define GS_ABI_VERSION 5
 
 typedef enum gs_error {
     GS_OK = 0,
@@ -185,6 +185,9 @@ int32_t gs_comm_info(const gs_comm* comm, int32_t* nranks, int32_t* rank);
 /* On `root`: asset_on_root = the asset to replicate (of the comm's context), *out = the same handle.  Elsewhere:
  * asset_on_root is ignored, *out = a new asset owning device copies of the blobs (destroy it with gs_asset_destroy).  Blocks. */
 int32_t gs_asset_broadcast(gs_comm* comm, gs_asset* asset_on_root, int32_t root, gs_asset** out);
+/* Single-process hosts (one gs_context per GPU, as a Unity player would hold them): a replica of `src` owned by `dst_ctx`, blobs
+ * moved by a peer device copy -- the receive half of gs_asset_broadcast without a communicator.  Blocks. */
+int32_t gs_asset_replicate(gs_context* dst_ctx, const gs_asset* src, gs_asset** out);
 
 /* ---- renderer (per GaussianSplatRenderer component) ---------------------------------------------- */
 /* allocates m_GpuView (N x 40 B), m_GpuSortDistances, m_GpuSortKeys, the sorter's SupportResources and the
@@ -291,7 +294,7 @@ typedef struct gs_import_formats {
                                (dc0 = colour, opacity in 0..1, scale linear, rot = packed smallest-3 + index/3) */
     uint32_t morton;        /* 1: reorder by the 63-bit Morton code of the position (GaussianSplatAssetCreator.cs:362-429) */
 } gs_import_formats;
-/* byte sizes of the pos, other, color, sh, chunk blobs (chunk = 0 for an all-fp32 asset); BC7 and Cluster* are GS_ERR_UNSUPPORTED_FORMAT */
+/* byte sizes of the pos, other, color, sh, chunk blobs (chunk = 0 for an all-fp32 asset; every format incl. BC7 and Cluster*) */
 int32_t gs_import_blob_sizes(uint32_t splat_count, const gs_import_formats* formats, uint64_t sizes[5]);
 /* encodes into caller-owned host buffers of at least those sizes (blobs[4] may be NULL when sizes[4] == 0);
  * bounds_min/max (may be NULL) receive the position bounds (GaussianSplatAsset.boundsMin/Max). */

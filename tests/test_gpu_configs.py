@@ -5,6 +5,7 @@
   C2  bicycle-sized 6,131,954 / 1200x797 / Medium: the whole frame against the oracle (keys, order, view, per-frame
       raster records, P, visible, RGBA16F target)
   C3  garden-sized 5,834,784 / 1920x1080 / VeryHigh fp32 at FULL size
+  C5  the C2 asset from 8 cameras (azimuth k * 45 deg) at 1920x1080, every view the whole frame
   C4  synthetic 50 M / 3840x2160 / Medium: keys / order / view bit-exact, P and visible equal, the target compared on a
       512x512 window (the oracle composites only that crop) -- the only configuration with > 2^32-byte blobs,
       6,104 sort partitions and 32,400 tiles
@@ -97,11 +98,25 @@ def test_c1_ply_to_pixels(gpu_ctx, tmp_path):
     assert out["visible"] > 10_000
 
 
-def test_c2_full_frame(gpu_ctx):
+@pytest.fixture(scope="module")
+def c2_asset():
     cfg = scenes.CONFIGS["C2"]
-    a = creator.CreateAssetFromSplatsNative(scenes.make_config_splats(cfg), cfg.quality, name="C2")
-    assert a.splatCount == 6_131_954
-    full_frame_vs_oracle(gpu_ctx, a, cfg, azimuths=(0.0, 33.0))
+    return creator.CreateAssetFromSplatsNative(scenes.make_config_splats(cfg), cfg.quality, name="C2")
+
+
+def test_c2_full_frame(gpu_ctx, c2_asset):
+    cfg = scenes.CONFIGS["C2"]
+    assert c2_asset.splatCount == 6_131_954
+    full_frame_vs_oracle(gpu_ctx, c2_asset, cfg, azimuths=(0.0, 33.0))
+
+
+def test_c5_views(gpu_ctx, c2_asset):
+    """BASELINE.json config 5: the C2 asset from the 8 cameras of the orbit (azimuth k * 45 deg) at 1920x1080 -- here all on one GPU,
+    every view the whole frame against the oracle (keys, order, view + raster records, P, visible, target)."""
+    cfg = scenes.CONFIGS["C5"]
+    assert (cfg.width, cfg.height) == (1920, 1080) and cfg.n == c2_asset.splatCount
+    out = full_frame_vs_oracle(gpu_ctx, c2_asset, cfg, azimuths=tuple(45.0 * k for k in range(8)))
+    assert out["visible"] > 1_000_000
 
 
 def test_c3_full_size(gpu_ctx):

@@ -135,3 +135,72 @@ def test_rccl_asset_broadcast_single_rank(gpu_ctx):
     bad = C.c_void_p()
     uid = (C.c_uint8 * 128).from_buffer_copy(parallel.Comm.UniqueId())
     assert _lib.lib().gs_comm_create(gpu_ctx._h, 2, 5, uid, C.byref(bad)) == -1                  # rank out of range
+
+
+@pytest.mark.gpu
+def test_asset_replica_through_the_receive_half_of_the_broadcast(gpu_ctx):
+    """gs_asset_replicate = the non-root branch of gs_asset_broadcast (header -> padded allocations -> blobs -> view) with a
+    device copy in place of ncclBroadcast: the replica (on a second context of the same GPU) renders the same frame, owns its
+    blobs (the source can be destroyed first) and reports the source's description."""
+    import ctypes as C
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from common import default_camera, small_asset
+    from unitygaussiansplatting_amd import _lib
+    from unitygaussiansplatting_amd._lib import check
+    from unitygaussiansplatting_amd.renderer import GaussianSplatRenderer, GpuContext, RenderTarget
+    l = _lib.lib()
+    cam = default_camera()
+    for quality in ("Medium", "VeryHigh"):                       # with and without a chunk blob
+        a = small_asset(20000, 5, quality)
+        r0 = GaussianSplatRenderer(gpu_ctx, a)
+        r0.CreateResourcesForAsset()
+        rt = RenderTarget(gpu_ctx, cam.pixelWidth, cam.pixelHeight)
+        r0.SortPoints(cam); r0.CalcViewData(cam); rt.Clear(); r0.Draw(cam, rt)
+        want, want_order = rt.Download(), r0.DownloadOrder()
+        ctx2 = GpuContext(0)
+        rep = C.c_void_p()
+        check(l.gs_asset_replicate(ctx2._h, r0._asset_h, C.byref(rep)), "gs_asset_replicate")
+        i0, i1 = (C.c_uint32 * 6)(), (C.c_uint32 * 6)()
+        check(l.gs_asset_info(r0._asset_h, i0), "info"); check(l.gs_asset_info(rep, i1), "info")
+        assert list(i0) == list(i1)
+        r0.DisposeResourcesForAsset(); rt.Dispose()              # the replica does not borrow from the source
+        r1 = GaussianSplatRenderer(ctx2, a)
+        r1._asset_h = rep
+        check(l.gs_renderer_create(ctx2._h, rep, C.byref(r1._r_h)), "gs_renderer_create")
+        r1.m_SplatCount = a.splatCount
+        r1.m_PrevAsset, r1.m_PrevHash = a, a.dataHash
+        rt2 = RenderTarget(ctx2, cam.pixelWidth, cam.pixelHeight)
+        r1.SortPoints(cam); r1.CalcViewData(cam); rt2.Clear(); r1.Draw(cam, rt2)
+        assert np.array_equal(rt2.Download(), want) and np.array_equal(r1.DownloadOrder(), want_order)
+        r1.DisposeResourcesForAsset(); rt2.Dispose()
+    bad = C.c_void_p()
+    assert l.gs_asset_replicate(None, None, C.byref(bad)) == -1
+
+
+@pytest.mark.gpu
+def test_torch_transport_at_world_one_adopts_borrowed_blobs(gpu_ctx):
+    """The documented second transport (torch.distributed tensors adopted without a copy, memory_kind = 1) at world = 1 on the GPU:
+    broadcast_asset + attach_device_asset give the frame of a plain upload (the borrowed-blob size rule of gs_asset_create
+    used to reject exactly these tensors)."""
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from common import default_camera, small_asset
+    from unitygaussiansplatting_amd import parallel
+    from unitygaussiansplatting_amd.renderer import GaussianSplatRenderer, RenderTarget
+    cam = default_camera()
+    for quality in ("Medium", "VeryHigh", "Low"):
+        a = small_asset(20000, 5, quality)
+        frames = []
+        for borrowed in (False, True):
+            r = GaussianSplatRenderer(gpu_ctx, a)
+            if borrowed:
+                meta, blobs = parallel.broadcast_asset(a, torch, None, 0, 1, torch.device("cuda:0"))
+                torch.cuda.synchronize()
+                parallel.attach_device_asset(r, meta, blobs)
+            else:
+                r.CreateResourcesForAsset()
+            rt = RenderTarget(gpu_ctx, cam.pixelWidth, cam.pixelHeight)
+            r.SortPoints(cam); r.CalcViewData(cam); rt.Clear(); r.Draw(cam, rt)
+            frames.append(rt.Download())
+            r.DisposeResourcesForAsset(); rt.Dispose()
+        assert np.array_equal(frames[0], frames[1]), quality

@@ -43,6 +43,7 @@ SIGNATURES = {
     "gs_comm_destroy": (C.c_int32, [_P]),
     "gs_comm_info": (C.c_int32, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "gs_asset_broadcast": (C.c_int32, [_P, _P, C.c_int32, _PP]),
+    "gs_asset_replicate": (C.c_int32, [_P, _P, _PP]),
     "gs_renderer_create": (C.c_int32, [_P, _P, _PP]),
     "gs_renderer_destroy": (C.c_int32, [_P]),
     "gs_renderer_reset_order": (C.c_int32, [_P]),

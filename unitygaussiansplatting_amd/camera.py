@@ -10,7 +10,7 @@ from __future__ import annotations
 
 import math
 from dataclasses import dataclass, field
-from typing import Sequence
+from typing import Optional, Sequence
 
 import numpy as np
 
@@ -54,9 +54,28 @@ class Transform:
         return np.linalg.inv(self.localToWorldMatrix.astype(np.float64)).astype(f32)
 
 
+def quat_mul(a: Sequence[float], b: Sequence[float]) -> np.ndarray:
+    """Quaternion product a * b (xyzw), i.e. the rotation b followed by a."""
+    ax, ay, az, aw = [float(v) for v in a]
+    bx, by, bz, bw = [float(v) for v in b]
+    return np.array([aw * bx + ax * bw + ay * bz - az * by, aw * by - ax * bz + ay * bw + az * bx,
+                     aw * bz + ax * by - ay * bx + az * bw, aw * bw - ax * bx - ay * by - az * bz], np.float64)
+
+
+def look_rotation(forward: Sequence[float], up: Sequence[float]) -> np.ndarray:
+    """Quaternion.LookRotation as a 3x3 matrix whose columns are the rotated X, Y, Z axes: Z along `forward`,
+    X along cross(up, forward), Y = cross(Z, X)."""
+    z = np.asarray(forward, np.float64); z = z / np.linalg.norm(z)
+    x = np.cross(np.asarray(up, np.float64), z); x = x / np.linalg.norm(x)
+    y = np.cross(z, x)
+    return np.stack([x, y, z], axis=1)
+
+
 @dataclass
 class Camera:
-    """Perspective camera.  `LookAt` builds the pose; Unity's camera-space looks down -Z in worldToCameraMatrix."""
+    """Perspective camera.  `LookAt` builds the pose; Unity's camera-space looks down -Z in worldToCameraMatrix.
+    With `rotation` set (3x3, columns = the transform's right / up / forward axes in Unity's convention, e.g. from
+    GaussianSplatRenderer.ActivateCamera) the pose is the Unity transform (position, rotation) and target / up are ignored."""
     position: Sequence[float] = (0.0, 0.0, 6.0)
     target: Sequence[float] = (0.0, 0.0, 0.0)
     up: Sequence[float] = (0.0, 1.0, 0.0)
@@ -65,6 +84,7 @@ class Camera:
     pixelHeight: int = 360
     nearClipPlane: float = 0.3
     farClipPlane: float = 1000.0
+    rotation: Optional[np.ndarray] = None
 
     @property
     def aspect(self) -> float:
@@ -73,6 +93,14 @@ class Camera:
     @property
     def worldToCameraMatrix(self) -> np.ndarray:
         eye = np.asarray(self.position, np.float64)
+        if self.rotation is not None:
+            # Camera.worldToCameraMatrix = scale(1, 1, -1) * transform.worldToLocalMatrix (the camera looks down -Z, OpenGL style)
+            R = np.asarray(self.rotation, np.float64)
+            m = np.eye(4)
+            m[:3, :3] = R.T
+            m[:3, 3] = -R.T @ eye
+            m[2, :] *= -1.0
+            return m.astype(f32)
         fwd = np.asarray(self.target, np.float64) - eye
         fwd /= np.linalg.norm(fwd)
         right = np.cross(fwd, np.asarray(self.up, np.float64))

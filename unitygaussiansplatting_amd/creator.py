@@ -637,10 +637,50 @@ def ReadPLYNative(path: str) -> InputSplatData:
         _lib.lib().gs_ply_close(h)
 
 
+kCamerasJson = "cameras.json"
+
+
+def LoadJsonCamerasFile(curPath: str, doImport: bool = True):
+    """GaussianSplatAssetCreator.cs:1068-1118: look for cameras.json in the input file's directory and its ancestors; every entry's
+    `rotation` is a VIEW matrix whose columns are the camera's axes (axisx = column 0 ...), the y and z axes are negated, and the
+    field of view is the constant 25 the reference stores (its "@TODO": callers set the real one, GaussianSplatValidator.cs:56-58)."""
+    import json
+    import os
+    from .asset import CameraInfo
+    if not doImport:
+        return None
+    while True:
+        d = os.path.dirname(curPath)
+        if not d or not os.path.isdir(d):
+            return None
+        camerasPath = os.path.join(d, kCamerasJson)
+        if os.path.isfile(camerasPath):
+            break
+        if d == curPath:
+            return None
+        curPath = d
+    with open(camerasPath) as f:
+        jsonCameras = json.load(f)
+    if not jsonCameras:
+        return None
+    result = []
+    for jc in jsonCameras:
+        rot = jc["rotation"]
+        col = lambda k: np.array([rot[0][k], rot[1][k], rot[2][k]], np.float32)
+        axisx, axisy, axisz = col(0), col(1) * np.float32(-1), col(2) * np.float32(-1)
+        result.append(CameraInfo(pos=tuple(float(v) for v in jc["position"][:3]), axisX=tuple(float(v) for v in axisx),
+                                 axisY=tuple(float(v) for v in axisy), axisZ=tuple(float(v) for v in axisz), fov=25.0))
+    return result
+
+
 def CreateAsset(path: str, quality: str = "Medium", **kw) -> GaussianSplatAsset:
     """.ply / .spz file -> asset (GaussianFileReader.ReadFile :45-71 + CreateAsset): PLY data is linearised, SPZ data already is."""
+    importCameras = kw.pop("importCameras", True)
     if path.lower().endswith(".spz"):
-        return CreateAssetFromSplats(ReadSPZ(path), quality, linearize=False, **kw)
-    if path.lower().endswith(".ply"):
-        return CreateAssetFromSplats(ReadPLY(path), quality, **kw)
-    raise IOError(f"File {path} is not a supported format")
+        a = CreateAssetFromSplats(ReadSPZ(path), quality, linearize=False, **kw)
+    elif path.lower().endswith(".ply"):
+        a = CreateAssetFromSplats(ReadPLY(path), quality, **kw)
+    else:
+        raise IOError(f"File {path} is not a supported format")
+    a.cameras = LoadJsonCamerasFile(path, importCameras) or []           # GaussianSplatAssetCreator.cs:274
+    return a

@@ -349,7 +349,9 @@ int32_t gs_renderer_calc_view(gs_renderer* r, const gs_frame_params* p) {
 static int32_t maybe_grow_pairs(gs_renderer* r) {
     if (!r->frameInFlight) return GS_OK;
     const unsigned long long seen = *(volatile unsigned long long*)&r->hostReport->pairCount;
-    if (seen > r->pairCapacity) return gs_renderer_reserve_pairs(r, seen + seen / 4);
+    // at the 2^30 ceiling there is nothing to grow: the draw goes ahead truncated (gs_renderer_frame_stats reports the frame), so
+    // that a later frame that fits renders normally and rewrites the report
+    if (seen > r->pairCapacity && r->pairCapacity < kSortMaxCount) return gs_renderer_reserve_pairs(r, seen + seen / 4);
     return GS_OK;
 }
 
@@ -560,9 +562,9 @@ int32_t gs_renderer_frame_stats(gs_renderer* r, gs_frame_stats* out) {
     if (out->sort_error) return fail(GS_ERR_SORT_TIMEOUT, "a bounded look-back spin expired");
     if (r->frameInFlight && out->tile_pairs > r->pairCapacity) {
         const unsigned long long want = out->tile_pairs + out->tile_pairs / 4;
-        GS_TRY(gs_renderer_reserve_pairs(r, want));
+        r->frameInFlight = false;                                    // reported once, whatever the growth below does
+        GS_TRY(gs_renderer_reserve_pairs(r, want));                  // (at the 2^30 ceiling this is the GS_ERR_PAIR_OVERFLOW itself)
         out->pair_capacity = r->pairCapacity;
-        r->frameInFlight = false;
         return fail(GS_ERR_PAIR_OVERFLOW, "tile-pair buffer overflowed this frame; it has been grown, render again");
     }
     return GS_OK;

@@ -27,6 +27,7 @@ struct Rccl {
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
     bool ok = false;
 };
@@ -46,8 +47,9 @@ Rccl& rccl() {
         x.CommInitRank = (decltype(x.CommInitRank))dlsym(x.handle, "ncclCommInitRank");
         x.CommDestroy = (decltype(x.CommDestroy))dlsym(x.handle, "ncclCommDestroy");
         x.Broadcast = (decltype(x.Broadcast))dlsym(x.handle, "ncclBroadcast");
+        x.AllReduce = (decltype(x.AllReduce))dlsym(x.handle, "ncclAllReduce");
         x.GetErrorString = (decltype(x.GetErrorString))dlsym(x.handle, "ncclGetErrorString");
-        x.ok = x.GetUniqueId && x.CommInitRank && x.CommDestroy && x.Broadcast && x.GetErrorString;
+        x.ok = x.GetUniqueId && x.CommInitRank && x.CommDestroy && x.Broadcast && x.AllReduce && x.GetErrorString;
         return x;
     }();
     return r;
@@ -70,6 +72,43 @@ int32_t fail_nccl(ncclResult_t e, const char* what) {
     } while (0)
 
 constexpr uint64_t kHeaderMagic = 0x3154414c50534753ull;        // "GSSPLAT1"
+constexpr int kHeaderWords = 16;
+
+// ---- the two halves of a replication, shared by gs_asset_broadcast (blobs moved by ncclBroadcast) and gs_asset_replicate
+// (blobs moved by a device copy): what the SENDER says about its asset, and how a RECEIVER turns that into an asset of its own.
+void pack_header(const gs_asset* a, uint64_t h[kHeaderWords]) {
+    memset(h, 0, kHeaderWords * sizeof(uint64_t));
+    const gsm::AssetView& v = a->view;
+    h[0] = kHeaderMagic; h[1] = v.n; h[2] = v.posFmt; h[3] = v.scaleFmt; h[4] = v.colorFmt; h[5] = v.shFmt; h[6] = v.chunkCount;
+    for (int k = 0; k < 5; ++k) h[7 + k] = a->blobs[k] ? a->sizes[k] : 0;
+}
+
+bool header_ok(const uint64_t h[kHeaderWords]) { return h[0] == kHeaderMagic && h[1] != 0; }
+
+// allocates the receiver's padded blobs (nothing is committed to *out unless every allocation succeeded)
+int32_t receive_alloc(gs_context* ctx, const uint64_t h[kHeaderWords], gs_asset** out) {
+    *out = nullptr;
+    gs_asset* a = new (std::nothrow) gs_asset();
+    if (!a) return gs::fail(GS_ERR_OUT_OF_MEMORY, "host allocation");
+    a->ctx = ctx; a->owned = true;
+    for (int k = 0; k < 5; ++k) {
+        a->sizes[k] = h[7 + k];
+        if (!a->sizes[k]) continue;
+        hipError_t e = hipMalloc(&a->blobs[k], a->sizes[k] + 16);           // + the decoders' tail pad, as gs_asset_create
+        if (e == hipSuccess) e = hipMemsetAsync((uint8_t*)a->blobs[k] + a->sizes[k], 0, 16, ctx->stream);
+        if (e != hipSuccess) { gs_asset_destroy(a); return gs::fail_hip(e, "asset replica: allocate blob", __FILE__, __LINE__); }
+    }
+    *out = a;
+    return GS_OK;
+}
+
+// the blobs have arrived: describe them
+void receive_finish(gs_asset* a, const uint64_t h[kHeaderWords]) {
+    a->view.pos = (const uint8_t*)a->blobs[0]; a->view.other = (const uint8_t*)a->blobs[1]; a->view.color = (const uint8_t*)a->blobs[2];
+    a->view.sh = (const uint8_t*)a->blobs[3]; a->view.chunk = (const uint8_t*)a->blobs[4];
+    a->view.n = (uint32_t)h[1]; a->view.posFmt = (uint32_t)h[2]; a->view.scaleFmt = (uint32_t)h[3];
+    a->view.colorFmt = (uint32_t)h[4]; a->view.shFmt = (uint32_t)h[5]; a->view.chunkCount = (uint32_t)h[6];
+}
 
 } // namespace
 
@@ -131,47 +170,48 @@ int32_t gs_comm_info(const gs_comm* c, int32_t* nranks, int32_t* rank) {
 // Collective over `comm`.  On `root`, `asset_on_root` is the asset to replicate (created on the comm's context) and *out
 // receives the same handle; on every other rank `asset_on_root` is ignored and *out receives a new asset that owns
 // device copies of the five blobs.  Blocks until the blobs have arrived (a load-time operation).
+// Every rank leaves through the same door: after the header every rank contributes a status word (its argument check on the
+// root, its allocations elsewhere) to one ncclAllReduce(min), so that a rank that cannot take part makes ALL ranks return
+// GS_ERR_COMM together instead of leaving the others parked in a broadcast.
 int32_t gs_asset_broadcast(gs_comm* c, gs_asset* asset_on_root, int32_t root, gs_asset** out) {
     if (!c || !out) return fail(GS_ERR_INVALID_ARGUMENT, "null argument");
     *out = nullptr;
     if (root < 0 || root >= c->nranks) return fail(GS_ERR_INVALID_ARGUMENT, "root out of range");
     const bool isRoot = c->rank == root;
-    if (isRoot && (!asset_on_root || asset_on_root->ctx != c->ctx)) return fail(GS_ERR_INVALID_ARGUMENT, "the root must pass an asset of the comm's context");
     gs_context* ctx = c->ctx;
     GS_HIP(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
+    // a root without a usable asset still enters the collectives (with a header nobody accepts) so that nobody hangs
+    const bool rootArgOk = !isRoot || (asset_on_root && asset_on_root->ctx == c->ctx);
 
     // ---- header: formats, count, blob sizes
-    uint64_t h[16] = {0};
+    uint64_t h[kHeaderWords] = {0};
     if (isRoot) {
-        const gsm::AssetView& v = asset_on_root->view;
-        h[0] = kHeaderMagic; h[1] = v.n; h[2] = v.posFmt; h[3] = v.scaleFmt; h[4] = v.colorFmt; h[5] = v.shFmt; h[6] = v.chunkCount;
-        for (int k = 0; k < 5; ++k) h[7 + k] = asset_on_root->blobs[k] ? asset_on_root->sizes[k] : 0;
+        if (rootArgOk) pack_header(asset_on_root, h);
         GS_HIP(hipMemcpyAsync(c->headerDev, h, sizeof(h), hipMemcpyHostToDevice, st));
     }
     GS_NCCL(rccl().Broadcast(c->headerDev, c->headerDev, sizeof(h), ncclUint8, root, c->comm, st));
     GS_HIP(hipMemcpyAsync(h, c->headerDev, sizeof(h), hipMemcpyDeviceToHost, st));
     GS_HIP(hipStreamSynchronize(st));
-    if (h[0] != kHeaderMagic || h[1] == 0) return fail(GS_ERR_COMM, "asset broadcast: bad header received");
 
+    // ---- this rank's half, then the status exchange
     gs_asset* a = asset_on_root;
-    if (!isRoot) {
-        a = new (std::nothrow) gs_asset();
-        if (!a) return fail(GS_ERR_OUT_OF_MEMORY, "host allocation");
-        a->ctx = ctx; a->owned = true;
-        for (int k = 0; k < 5; ++k) {
-            a->sizes[k] = h[7 + k];
-            if (!a->sizes[k]) continue;
-            hipError_t e = hipMalloc(&a->blobs[k], a->sizes[k] + 16);           // + the decoders' tail pad, as gs_asset_create
-            if (e == hipSuccess) e = hipMemsetAsync((uint8_t*)a->blobs[k] + a->sizes[k], 0, 16, st);
-            if (e != hipSuccess) {
-                // every rank must still take part in the remaining broadcasts or the others would hang: receive into nothing is
-                // not possible, so fail loudly on this rank only after draining what can be drained
-                gs_asset_destroy(a);
-                return fail_hip(e, "asset broadcast: allocate blob", __FILE__, __LINE__);
-            }
-        }
+    int32_t mine = GS_OK;
+    if (!header_ok(h)) mine = isRoot ? fail(GS_ERR_INVALID_ARGUMENT, "the root must pass an asset of the comm's context") : fail(GS_ERR_COMM, "asset broadcast: bad header received");
+    else if (!isRoot) mine = receive_alloc(ctx, h, &a);
+    int32_t* statusDev = (int32_t*)(c->headerDev + kHeaderWords - 1);             // last header word: scratch for the status
+    GS_HIP(hipMemcpyAsync(statusDev, &mine, sizeof(int32_t), hipMemcpyHostToDevice, st));
+    GS_NCCL(rccl().AllReduce(statusDev, statusDev, 1, ncclInt32, ncclMin, c->comm, st));
+    int32_t all = GS_OK;
+    GS_HIP(hipMemcpyAsync(&all, statusDev, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    GS_HIP(hipStreamSynchronize(st));
+    if (all != GS_OK) {
+        if (!isRoot && mine == GS_OK) gs_asset_destroy(a);
+        if (mine != GS_OK) return mine;                                             // the detail of this rank's own failure stands
+        gs::set_error_detail("asset broadcast: another rank could not take part (its error %d)", all);
+        return GS_ERR_COMM;
     }
+
     // ---- the blobs, one broadcast each (in place on the root)
     for (int k = 0; k < 5; ++k) {
         if (!h[7 + k]) continue;
@@ -179,12 +219,32 @@ int32_t gs_asset_broadcast(gs_comm* c, gs_asset* asset_on_root, int32_t root, gs
         if (e != ncclSuccess) { if (!isRoot) gs_asset_destroy(a); return fail_nccl(e, "ncclBroadcast(blob)"); }
     }
     { hipError_t e = hipStreamSynchronize(st); if (e != hipSuccess) { if (!isRoot) gs_asset_destroy(a); return fail_hip(e, "asset broadcast sync", __FILE__, __LINE__); } }
-    if (!isRoot) {
-        a->view.pos = (const uint8_t*)a->blobs[0]; a->view.other = (const uint8_t*)a->blobs[1]; a->view.color = (const uint8_t*)a->blobs[2];
-        a->view.sh = (const uint8_t*)a->blobs[3]; a->view.chunk = (const uint8_t*)a->blobs[4];
-        a->view.n = (uint32_t)h[1]; a->view.posFmt = (uint32_t)h[2]; a->view.scaleFmt = (uint32_t)h[3];
-        a->view.colorFmt = (uint32_t)h[4]; a->view.shFmt = (uint32_t)h[5]; a->view.chunkCount = (uint32_t)h[6];
+    if (!isRoot) receive_finish(a, h);
+    *out = a;
+    return GS_OK;
+}
+
+// A replica of `src` on `dst_ctx` (the same or another GPU of this process): the receive half of gs_asset_broadcast --
+// header, padded allocations, blob copies, view -- with a device copy in place of ncclBroadcast.  A single-process host that
+// drives several GPUs (one gs_context each, as a Unity player would) replicates its asset with this instead of a communicator.
+int32_t gs_asset_replicate(gs_context* dst_ctx, const gs_asset* src, gs_asset** out) {
+    if (!dst_ctx || !src || !out) return fail(GS_ERR_INVALID_ARGUMENT, "null argument");
+    *out = nullptr;
+    uint64_t h[kHeaderWords];
+    pack_header(src, h);
+    if (!header_ok(h)) return fail(GS_ERR_INVALID_ASSET, "source asset is empty");
+    GS_HIP(hipSetDevice(src->ctx->device));
+    GS_HIP(hipStreamSynchronize(src->ctx->stream));                                // uploads of the source have landed
+    GS_HIP(hipSetDevice(dst_ctx->device));
+    gs_asset* a = nullptr;
+    GS_TRY(receive_alloc(dst_ctx, h, &a));
+    for (int k = 0; k < 5; ++k) {
+        if (!h[7 + k]) continue;
+        const hipError_t e = hipMemcpyPeerAsync(a->blobs[k], dst_ctx->device, src->blobs[k], src->ctx->device, (size_t)h[7 + k], dst_ctx->stream);
+        if (e != hipSuccess) { gs_asset_destroy(a); return fail_hip(e, "asset replica: copy blob", __FILE__, __LINE__); }
     }
+    { const hipError_t e = hipStreamSynchronize(dst_ctx->stream); if (e != hipSuccess) { gs_asset_destroy(a); return fail_hip(e, "asset replica sync", __FILE__, __LINE__); } }
+    receive_finish(a, h);
     *out = a;
     return GS_OK;
 }

@@ -28,9 +28,6 @@ int32_t fail_hip(hipError_t e, const char* what, const char* file, int line);
     } while (0)
 
 constexpr int kTile = 16;                 // compositor tile edge, pixels
-constexpr int kSortThreads = 256;
-constexpr int kSortKPT = 16;              // keys per thread
-constexpr int kSortPart = kSortThreads * kSortKPT;   // 4096 keys per partition
 constexpr int kBinThreads = 256;
 #ifndef GS_BIN_ITEMS
 #define GS_BIN_ITEMS 8       // 2048 positions per partition: ~3 rounds of partitions over the persistent grid balance better than 1.5 (measured)

@@ -15,7 +15,7 @@ namespace GaussianSplatting.Runtime
     {
         const string Lib = "gsplat_hip";
 
-        public enum Error { Ok = 0, InvalidArgument = -1, Hip = -2, UnsupportedFormat = -3, OutOfMemory = -4, InvalidAsset = -5, PairOverflow = -6, SortTimeout = -7, NoDevice = -8 }
+        public enum Error { Ok = 0, InvalidArgument = -1, Hip = -2, UnsupportedFormat = -3, OutOfMemory = -4, InvalidAsset = -5, PairOverflow = -6, SortTimeout = -7, NoDevice = -8, Comm = -9 }
 
         [StructLayout(LayoutKind.Sequential)]
         public struct AssetDesc
@@ -72,6 +72,7 @@ namespace GaussianSplatting.Runtime
         [DllImport(Lib)] public static extern int gs_comm_destroy(IntPtr comm);
         [DllImport(Lib)] public static extern int gs_comm_info(IntPtr comm, out int nranks, out int rank);
         [DllImport(Lib)] public static extern int gs_asset_broadcast(IntPtr comm, IntPtr assetOnRoot, int root, out IntPtr asset);
+        [DllImport(Lib)] public static extern int gs_asset_replicate(IntPtr dstContext, IntPtr srcAsset, out IntPtr asset);
 
         [DllImport(Lib)] public static extern int gs_renderer_create(IntPtr ctx, IntPtr asset, out IntPtr renderer);
         [DllImport(Lib)] public static extern int gs_renderer_destroy(IntPtr renderer);

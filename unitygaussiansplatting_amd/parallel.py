@@ -51,12 +51,20 @@ class Comm:
         from ._lib import check
         l = _lib.lib()
         src = C.c_void_p()
+        root_error = None
         if self.rank == root:
-            keep: list = []
-            desc = make_asset_desc(renderer.m_Asset, keep)
-            check(l.gs_asset_create(self.ctx._h, C.byref(desc), C.byref(src)), "gs_asset_create")
+            try:
+                keep: list = []
+                desc = make_asset_desc(renderer.m_Asset, keep)
+                check(l.gs_asset_create(self.ctx._h, C.byref(desc), C.byref(src)), "gs_asset_create")
+            except Exception as e:            # still enter the collective (with no asset): every rank then fails together instead of
+                root_error = e                # waiting for a header that never comes
+                src = C.c_void_p()
         out = C.c_void_p()
-        check(l.gs_asset_broadcast(self._h, src, root, C.byref(out)), "gs_asset_broadcast")
+        rc = l.gs_asset_broadcast(self._h, src, root, C.byref(out))
+        if root_error is not None:
+            raise root_error
+        check(rc, "gs_asset_broadcast")
         renderer._asset_h = out
         info = (C.c_uint32 * 6)()
         check(l.gs_asset_info(out, info), "gs_asset_info")
@@ -145,7 +153,10 @@ def attach_device_asset(renderer, meta: dict, blobs) -> None:
     d.memory_kind = 1
     for nm, t, sz in zip(("pos", "other", "color", "sh", "chunk"), blobs, meta["sizes"]):
         setattr(d, nm + "_data", None if t is None else t.data_ptr())
-        setattr(d, nm + "_size", 0 if t is None else sz)
+        # pos / other / sh: a borrowed blob must DECLARE the readable bytes behind its last record (gs_asset_create checks for >= 4);
+        # broadcast_asset's tensors carry 16 bytes of zero padding for exactly that
+        pad = 16 if nm in ("pos", "other", "sh") and t is not None and int(t.numel()) >= sz + 16 else 0
+        setattr(d, nm + "_size", 0 if t is None else sz + pad)
     renderer._device_blobs = blobs            # keep the tensors alive as long as the renderer
     check(_lib.lib().gs_asset_create(renderer.ctx._h, C.byref(d), C.byref(renderer._asset_h)), "gs_asset_create")
     check(_lib.lib().gs_renderer_create(renderer.ctx._h, renderer._asset_h, C.byref(renderer._r_h)), "gs_renderer_create")

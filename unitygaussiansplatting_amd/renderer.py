@@ -281,6 +281,19 @@ class GaussianSplatRenderer:
             self.DisposeResourcesForAsset()
             self.CreateResourcesForAsset()
 
+    def ActivateCamera(self, index: int, mainCam: Camera) -> None:     # :660-680
+        """Pose `mainCam` as camera `index` of the asset's cameras.json: parented to this renderer's transform with
+        localPosition = cam.pos and localRotation = LookRotation(cam.axisZ, cam.axisY), then unparented keeping its world pose
+        (world position through the full localToWorld matrix, world rotation = transform.rotation * localRotation), scale one."""
+        from .camera import look_rotation, quat_to_mat3
+        if mainCam is None or self.m_Asset is None or not self.m_Asset.cameras:
+            return
+        ci = self.m_Asset.cameras[index]
+        o2w = self.transform.localToWorldMatrix.astype(np.float64)
+        pos = o2w @ np.array([ci.pos[0], ci.pos[1], ci.pos[2], 1.0])
+        mainCam.position = tuple(float(v) for v in pos[:3])
+        mainCam.rotation = quat_to_mat3(self.transform.rotation) @ look_rotation(ci.axisZ, ci.axisY)
+
     # -- per frame ------------------------------------------------------------------------------------------
     def FrameParams(self, cam: Camera) -> gs_frame_params:
         return frame_params(cam, self.transform, self.m_SplatScale, self.m_OpacityScale, self.m_SHOrder, self.m_SHOnly)
@@ -409,9 +422,10 @@ class GaussianSplatRenderSystem:
         self.m_Splats: List[GaussianSplatRenderer] = []
         self.m_ActiveSplats: List[GaussianSplatRenderer] = []
         # A frame whose (tile, splat) pairs overflow the pair buffer drops its farthest pairs; the library notices (and grows
-        # the buffer) within the pipeline depth, but THAT frame is truncated.  With strictPairs (default) OnPreCullCamera reads
-        # the frame statistics (blocking) and renders the frame again after an overflow, so what it returns is always complete.
-        self.strictPairs = True
+        # the buffer) within the pipeline depth, but THAT frame is truncated.  With strictPairs OnPreCullCamera reads the frame
+        # statistics (BLOCKING: it serialises host and GPU) and renders the frame again after an overflow, so what it returns is
+        # always complete.  Off by default: a render loop keeps the GPU queue full and a scene's first frames grow the buffer.
+        self.strictPairs = False
 
     def RegisterSplat(self, r: GaussianSplatRenderer) -> None:      # :25-36
         if r not in self.m_Splats:
