@@ -589,6 +589,33 @@ inline float exp_canon(float x) {
     return (float)std::exp2((double)y);
 }
 
+// The discard decision of frag() (RenderGaussianSplats.shader:100), made identical on the CPU and the GPU: when the alpha comes
+// out within 8 ulps of 1/255 it is recomputed from an exp2 built from fp32 operations only and the decision is taken on that
+// (gs_device_math.h: Exp2Det / DecideAlpha, restated here; tests/test_host_math.py keeps the two in step).  Outside the window
+// this is exactly saturate(exp(power) * a) >= 1/255.
+constexpr uint32_t kAlphaThresholdBits = 0x3B808081u, kAlphaWindow = 16u, kAlphaWindowLo = kAlphaThresholdBits - kAlphaWindow / 2u;
+inline float exp2_det(float y) {
+    const float n = rintf(y);
+    const float f = y - n;
+    float p = 1.525273380405984e-05f;
+    p = fmaf(p, f, 1.5403530393381608e-04f);
+    p = fmaf(p, f, 1.3333558146428443e-03f);
+    p = fmaf(p, f, 9.618129107628477e-03f);
+    p = fmaf(p, f, 5.550410866482158e-02f);
+    p = fmaf(p, f, 2.402265069591007e-01f);
+    p = fmaf(p, f, 6.931471805599453e-01f);
+    p = fmaf(p, f, 1.0f);
+    return ldexpf(p, (int)n);
+}
+inline float fragment_alpha(float power, float a, bool windowed, bool& live) {
+    const float y = power * 1.44269504088896340736f;
+    float alpha = saturatef((float)std::exp2((double)y) * a);
+    uint32_t bits; std::memcpy(&bits, &alpha, 4);
+    if (windowed && bits - kAlphaWindowLo < kAlphaWindow) alpha = saturatef(exp2_det(y) * a);
+    live = alpha >= 1.0f / 255.0f;
+    return alpha;
+}
+
 // Shared definition of "is this splat drawn at all, and where": see DESIGN.md "compositor semantics".
 Prepared prepare(const ViewData& v, const gs_frame_params& P) {
     Prepared p; std::memset(&p, 0, sizeof(p));
@@ -772,14 +799,24 @@ void gso_raster_records(const void* view_in, uint32_t n, const gs_frame_params* 
 
 // RenderGaussianSplats.shader:79-108 frag() for an unselected splat, exposed for tests/test_ref_parity.py: q = the interpolated
 // i.pos, col = i.col (rgb, opacity).  Returns 1 for a discarded fragment, else out4 = (rgb * alpha, alpha).
-int32_t gso_fragment(const float* q, const float* col, float* out4) {
+// windowed = 0: the canonical arithmetic alone (what oracle/_ref's fused build computes); 1: with the deterministic decision inside
+// the 16-ulp window around 1/255, as gso_draw and the HIP blend evaluate it.
+int32_t gso_fragment(const float* q, const float* col, float* out4, int32_t windowed) {
     const float power = -fmaf(q[1], q[1], q[0] * q[0]);
-    float alpha = exp_canon(power);
-    alpha = saturatef(alpha * col[3]);
+    bool live;
+    const float alpha = fragment_alpha(power, col[3], windowed != 0, live);
     out4[0] = out4[1] = out4[2] = out4[3] = 0.0f;
-    if (alpha < 1.0f / 255.0f) return 1;
+    if (!live) return 1;
     out4[0] = col[0] * alpha; out4[1] = col[1] * alpha; out4[2] = col[2] * alpha; out4[3] = alpha;
     return 0;
+}
+
+// the native (un-windowed) alpha and y = power * log2(e) of a fragment, for tests/test_host_math.py
+float gso_fragment_native(const float* q, float a, float* y_out) {
+    const float power = -fmaf(q[1], q[1], q[0] * q[0]);
+    *y_out = power * 1.44269504088896340736f;
+    bool live;
+    return fragment_alpha(power, a, false, live);
 }
 
 // The DrawProcedural of GaussianSplatRenderer.cs:156-166 with RenderGaussianSplats.shader, executed splat by
@@ -867,9 +904,9 @@ static int32_t draw_impl(const ViewData* view, const uint32_t* order, uint32_t n
                     float* d = row + (size_t)px * 4;
                     if (mode == 1 && (1.0f - d[3]) < (1.0f / 4096.0f)) continue; // fast mode: pixel finished
                     const float power = -fmaf(q2, q2, q1 * q1);                 // frag: -dot(i.pos, i.pos)
-                    float alpha = exp_canon(power);
-                    alpha = saturatef(alpha * p.a);
-                    if (alpha < 1.0f / 255.0f) continue;                        // discard
+                    bool live;
+                    const float alpha = fragment_alpha(power, p.a, true, live);  // saturate(exp(power) * a), discard below 1/255
+                    if (!live) continue;                                         // discard
                     const float t = 1.0f - d[3];                                 // OneMinusDstAlpha
                     const float sr = p.r * alpha, sg = p.g * alpha, sb = p.b * alpha;   // fragment output (fp32): rgb*alpha, alpha
                     if (mode == 0) {        // exact: one RTNE to the fp16 storage format per blend

@@ -43,8 +43,6 @@ def views_equal(got: np.ndarray, want: np.ndarray) -> bool:
 
 
 RT_TOL = 2.0 ** -9
-RT_FLIP_TOL = 2.0 ** -7          # a fragment kept on one side and discarded on the other (see rt_err)
-RT_FLIP_FRACTION = 1.0e-4        # of the pixels
 
 
 def rt_diff(img: np.ndarray, ref: np.ndarray) -> np.ndarray:
@@ -54,19 +52,10 @@ def rt_diff(img: np.ndarray, ref: np.ndarray) -> np.ndarray:
 
 
 def rt_err(img: np.ndarray, ref: np.ndarray, tol: float = RT_TOL) -> float:
-    """Parity metric of the RGBA16F target.  Per pixel and channel e = |a - b| / max(1, |b|): the
-    accumulator is fp16, a value c in [2^k, 2^(k+1)) has an ulp of 2^(k-10) and premultiplied splat colours are not clamped
+    """Parity metric of the RGBA16F target: the largest e = |a - b| / max(1, |b|) over all pixels and channels.
+    The accumulator is fp16, a value c in [2^k, 2^(k+1)) has an ulp of 2^(k-10) and premultiplied splat colours are not clamped
     to 1, so the bound scales with the value (2^-9 = two fp16 ulps of any c in [0.5, 1), at most two of every larger c).
-
-    One effect is NOT a rounding effect and gets its own allowance: the fragment shader discards alpha < 1/255
-    (RenderGaussianSplats.shader:100), and the only operation that is not bit-identical on both sides is exp (<= 1 ulp of the
-    GPU's exp2 unit).  A fragment whose alpha lies within that ulp of 1/255 is kept on one side and discarded on the other --
-    a difference of up to colour * (1 - A) / 255 at that pixel, for a few fragments out of ~10^8 per frame.  So: every pixel
-    within RT_FLIP_TOL, and all but RT_FLIP_FRACTION of the pixels (+2) within `tol`.  Returns the value to compare with
-    `tol`: the largest e after setting aside the allowed outliers (inf if the allowance itself is violated)."""
-    e = rt_diff(img, ref).max(axis=-1).reshape(-1)
-    over = e > tol
-    allowed = int(RT_FLIP_FRACTION * e.size) + 2
-    if int(over.sum()) > allowed or float(e.max()) > RT_FLIP_TOL:
-        return float(e.max())
-    return float(e[~over].max()) if (~over).any() else 0.0
+    No outlier allowance: the one effect that used to need one -- a fragment kept on one side and discarded on the other because
+    the GPU's exp2 unit and the oracle's exp2 differ by an ulp at alpha = 1/255 -- is gone since both sides take that decision
+    on the same deterministic exp2 (gs_device_math.h DecideAlpha / the oracle's fragment_alpha)."""
+    return float(rt_diff(img, ref).max())

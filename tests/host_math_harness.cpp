@@ -53,6 +53,9 @@ int32_t hm_block_may_touch(float bcx, float bcy, float half, float cx, float cy,
     return gsm::BlockMayTouch(bcx, bcy, half, cx, cy, u1x, u1y, u2x, u2y, r2) ? 1 : 0;
 }
 float hm_log_det(float x) { return gsm::LogDet(x); }
+float hm_exp2_det(float y) { return gsm::Exp2Det(y); }
+// the header's discard decision given a native alpha; returns the alpha, *live_out = kept
+float hm_decide_alpha(float alphaNative, float y, float a, int32_t* live_out) { bool live; const float r = gsm::DecideAlpha(alphaNative, y, a, live); *live_out = live ? 1 : 0; return r; }
 // early-cull property: out[i] = {culled by CalcViewGeom(allowCull), tiles of the full path's footprint}
 void hm_cull_check(const gs_asset_desc* d, const gs_frame_params* p, uint32_t* out) {
     const gsm::AssetView a = mk(d); const gsm::FrameConsts c = fl(p);

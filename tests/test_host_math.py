@@ -221,3 +221,44 @@ def test_chunk_cull_never_drops_a_drawable_splat(hm):
     P.matrix_vp[12:16] = [0.0, 0.0, 0.0, 1.0]
     cc = np.zeros(nch, np.uint8)
     assert hm.hm_chunk_cull(C.byref(orc.desc), C.byref(P), cc.ctypes.data_as(C.c_void_p)) == 0 and not cc.any()
+
+
+def test_discard_decision_is_identical_whatever_the_exp2_unit_rounds(hm):
+    """The fragment's alpha near 1/255: the header's DecideAlpha (what the blend kernel runs) fed with the correctly rounded native
+    alpha AND with that alpha +-1 ulp (any exp2 unit within 1 ulp) takes the oracle's decision every time, and inside the window the
+    alpha is the oracle's bit for bit; Exp2Det is within 1 ulp of 2^y and identical on both sides by construction (fp32 operations)."""
+    import ctypes as C
+    hm.hm_exp2_det.restype = C.c_float; hm.hm_exp2_det.argtypes = [C.c_float]
+    hm.hm_decide_alpha.restype = C.c_float; hm.hm_decide_alpha.argtypes = [C.c_float, C.c_float, C.c_float, C.POINTER(C.c_int32)]
+    rng = np.random.default_rng(4)
+    ys = rng.uniform(-30.0, 0.0, 4000).astype(np.float32)
+    got = np.array([hm.hm_exp2_det(C.c_float(float(y))) for y in ys], np.float32)
+    want = np.exp2(ys.astype(np.float64))
+    assert (np.abs(got.astype(np.float64) - want) / want).max() < 1.2e-7
+    L = O.lib()
+    out = np.zeros(4, np.float32)
+    T = np.float32(1.0) / np.float32(255.0)
+    n_in_window = 0
+    for _ in range(6000):
+        q = rng.uniform(-2.0, 2.0, 2).astype(np.float32)
+        power = np.float32(-(np.float32(q[1] * q[1]) + np.float32(q[0]) * np.float32(q[0])))          # not the fused form: only used to aim near the threshold
+        a = np.float32(min(1.0, float(np.exp(-float(power))) / 255.0 * (1.0 + rng.uniform(-2e-6, 2e-6))))
+        col = np.array([0.3, 0.5, 0.7, a], np.float32)
+        dead = L.gso_fragment(q.ctypes.data_as(C.c_void_p), col.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), C.c_int32(1))
+        # the oracle's own native alpha and y (canonical forms), then the header's decision with the native alpha nudged by -1, 0, +1 ulp
+        L.gso_fragment_native.restype = C.c_float
+        y = C.c_float()
+        native = np.float32(L.gso_fragment_native(q.ctypes.data_as(C.c_void_p), C.c_float(float(a)), C.byref(y)))
+        for nudge in (-1, 0, 1):
+            an = np.uint32(int(native.view(np.uint32)) + nudge).view(np.float32) if native > 0 else native
+            live = C.c_int32()
+            alpha = np.float32(hm.hm_decide_alpha(C.c_float(float(an)), y, C.c_float(float(a)), C.byref(live)))
+            assert (live.value == 0) == bool(dead), (q, a, nudge)
+            u, u0 = int(an.view(np.uint32)) - 0x3B808079, int(native.view(np.uint32)) - 0x3B808079
+            if 0 <= u < 16 and 0 <= u0 < 16:                  # both sides inside the window: the same deterministic alpha
+                n_in_window += 1
+                if not dead:
+                    assert alpha.view(np.uint32) == out[3].view(np.uint32)
+            elif not dead:                                     # one side at the window's edge: a few ulps apart, same decision (above)
+                assert abs(int(alpha.view(np.uint32)) - int(out[3].view(np.uint32))) <= 4
+    assert n_in_window > 500

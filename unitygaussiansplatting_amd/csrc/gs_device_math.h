@@ -903,6 +903,43 @@ GS_HD void PixRange(float c, float e, float size, int& lo, int& hi) {
     lo = (int)flo; hi = (int)fhi;
 }
 
+// ---- the fragment's discard decision, made identical on the CPU and the GPU ---------------------------------------
+// frag() discards alpha < 1/255 (RenderGaussianSplats.shader:100).  alpha = saturate(exp(power) * a) goes through the one
+// operation of the frame that is not bit-identical on both sides (the GPU's exp2 unit vs a correctly rounded exp2, <= 1 ulp),
+// so a fragment whose alpha lands within that ulp of 1/255 would be kept on one side and discarded on the other.  Instead,
+// when alpha comes out within kAlphaWindow / 2 ulps of 1/255 (about 10^-6 of the fragments) BOTH sides recompute it from
+// Exp2Det, an exp2 made of fp32 operations only (the same bits everywhere), and decide on that.  Outside the window the native
+// alpha is at least 8 ulps away from the threshold: no 1-ulp difference can change the decision.
+constexpr uint32_t kAlphaThresholdBits = 0x3B808081u;                  // 1.0f / 255.0f
+constexpr uint32_t kAlphaWindow = 16u;                                 // [1/255 - 8 ulp, 1/255 + 8 ulp)
+constexpr uint32_t kAlphaWindowLo = kAlphaThresholdBits - kAlphaWindow / 2u;
+// 2^y for y in (-126, 0]: n = rint(y), 2^(y - n) by the degree-7 Taylor polynomial of 2^f on [-0.5, 0.5] (|error| < 1 ulp), exact scaling
+GS_HD float Exp2Det(float y) {
+    const float n = rintf(y);
+    const float f = y - n;
+    float p = 1.525273380405984e-05f;
+    p = fmaf(p, f, 1.5403530393381608e-04f);
+    p = fmaf(p, f, 1.3333558146428443e-03f);
+    p = fmaf(p, f, 9.618129107628477e-03f);
+    p = fmaf(p, f, 5.550410866482158e-02f);
+    p = fmaf(p, f, 2.402265069591007e-01f);
+    p = fmaf(p, f, 6.931471805599453e-01f);
+    p = fmaf(p, f, 1.0f);
+    return ldexpf(p, (int)n);
+}
+// alpha of a fragment given the native alpha (= saturate(exp2(y) * a) with whatever exp2 the machine has), y = power * log2(e)
+// and the splat's opacity a: returns the alpha to blend with, `live` = the fragment is not discarded.
+GS_HD float DecideAlpha(float alphaNative, float y, float a, bool& live) {
+    const uint32_t u = f2u(alphaNative) - kAlphaWindowLo;
+    if (u < kAlphaWindow) {
+        const float ad = fminf(fmaxf(Exp2Det(y) * a, 0.0f), 1.0f);
+        live = ad >= u2f(kAlphaThresholdBits);
+        return ad;
+    }
+    live = (int32_t)u >= (int32_t)kAlphaWindow;
+    return alphaNative;
+}
+
 // ln(x) for a positive normal x from fp32 operations only (bit manipulation, one division, explicit fmaf): the same bits
 // on the host and on the device, unlike logf().  |error| < 1e-6 (atanh series of the mantissa reduced to [0.707, 1.414)).
 GS_HD float LogDet(float x) {

@@ -623,7 +623,13 @@ __global__ __launch_bounds__(256) void blend_kernel(const uint32_t* __restrict__
     uint32_t batchesWalked = 0;
 
     const int qx0 = (int)tx * 16 + (w & 1) * 8, qy0 = (int)ty * 16 + (w >> 1) * 8;
+#if GS_BLEND_GROUPS
+    // every 16-lane group of the wave is one 4x4 pixel block of the quadrant and walks its OWN survivor list (below)
+    const int grp = lane >> 4;
+    const int px = qx0 + (grp & 1) * 4 + (lane & 3), py = qy0 + (grp >> 1) * 4 + ((lane >> 2) & 3);
+#else
     const int px = qx0 + (lane & 7), py = qy0 + (lane >> 3);
+#endif
     const bool inside = px < (int)rc.width && py < (int)rc.height;
     const float fx = (float)px + 0.5f, fy = (float)py + 0.5f;
     const gsm::F2 fxy = { fx, fy };
@@ -694,6 +700,59 @@ __global__ __launch_bounds__(256) void blend_kernel(const uint32_t* __restrict__
                     const uint4 rb = s_b[j];
                     hit = hit && gsm::BlockMayTouch((float)qx0 + 4.0f, (float)qy0 + 4.0f, 3.5f, ra.x, ra.y, ra.z, gsm::u2f(rb.x), ra.w, gsm::u2f(rb.y), re.z);
                 }
+#if GS_BLEND_GROUPS
+                // 4x4 blocks: a survivor of the quadrant's (oriented) test is handed only to the blocks its bounding box reaches.  The
+                // groups then walk their own lists side by side: a splat that covers one block costs one group one iteration instead
+                // of the whole wave one, and the wave's trip count is the LONGEST of four short lists, not their union.
+                bool h0 = false, h1 = false, h2 = false, h3 = false;
+                if (hit) {
+                    const float4 ra = s_a[j];
+                    const float4 re = s_e[j];
+                    const bool xl = ra.x - re.x <= qminx + 3.0f, xr = ra.x + re.x >= qminx + 4.0f;
+                    const bool yt = ra.y - re.y <= qminy + 3.0f, yb = ra.y + re.y >= qminy + 4.0f;
+                    h0 = xl && yt; h1 = xr && yt; h2 = xl && yb; h3 = xr && yb;
+                }
+                const unsigned long long M0 = __ballot(h0), M1 = __ballot(h1), M2 = __ballot(h2), M3 = __ballot(h3);
+#ifdef GS_EXP_BLEND_TIMELINE
+                tlSurv += (uint32_t)__popcll(M0 | M1 | M2 | M3);
+#endif
+                const unsigned long long mine = grp == 0 ? M0 : (grp == 1 ? M1 : (grp == 2 ? M2 : M3));
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    uint32_t m32 = half ? (uint32_t)(mine >> 32) : (uint32_t)mine;
+                    if (!((half ? ((M0 | M1 | M2 | M3) >> 32) : (M0 | M1 | M2 | M3)) & 0xffffffffull)) continue;     // wave-uniform
+                    while (__any(m32 != 0u)) {
+                        const bool has = m32 != 0u;
+                        const uint32_t b = has ? (uint32_t)(__ffs((int)m32) - 1) : 0u;
+                        m32 &= m32 - 1u;
+                        const uint32_t ridx = c + (uint32_t)half * 32u + b;
+                        const float4 A4 = s_a[ridx];                       // one address per 16-lane group
+                        u4v B4 = *(const u4v*)&s_b[ridx];
+                        asm volatile("" : "+v"(B4));
+                        const gsm::F2 d = fxy - gsm::F2{ A4.x, A4.y };
+                        const gsm::F2 q = gsm::fma2(gsm::F2{ d.y, d.y }, gsm::F2{ gsm::u2f(B4.x), gsm::u2f(B4.y) }, gsm::F2{ d.x, d.x } * gsm::F2{ A4.z, A4.w });
+                        const float q1 = q.x, q2 = q.y;
+                        const float power = -fmaf(q2, q2, q1 * q1);
+                        const float y2 = power * 1.44269504088896340736f;
+                        float alpha = mix_mul_lo_sat_after_trans(B4.w, __builtin_amdgcn_exp2f(y2));
+                        const int inQuad = (int)has & (int)(fabsf(q1) <= 2.0f) & (int)(fabsf(q2) <= 2.0f);
+                        bool live;
+                        if (MODE == 0) {
+                            const uint32_t u = gsm::f2u(alpha) - gsm::kAlphaWindowLo;
+                            live = (inQuad & (int)((int32_t)u >= (int32_t)gsm::kAlphaWindow)) != 0;
+                            const bool nearT = (inQuad & (int)(u < gsm::kAlphaWindow)) != 0;
+                            if (__builtin_expect(__any(nearT), 0)) {
+                                if (nearT) alpha = gsm::DecideAlpha(alpha, y2, half_lo(B4.w), live);
+                            }
+                        } else {
+                            live = (inQuad & (int)(alpha >= 1.0f / 255.0f)) != 0;
+                        }
+                        if (DEPTH) live = live && (s_e[ridx].w <= sceneZ);
+                        if (MODE == 1) live = live && !acc.saturated();
+                        if (live) acc.blend(B4.z, B4.w, alpha);
+                    }
+                }
+#else
                 unsigned long long mask = __ballot(hit);
 #ifdef GS_EXP_BLEND_TIMELINE
                 tlSurv += (uint32_t)__popcll(mask);
@@ -710,16 +769,36 @@ __global__ __launch_bounds__(256) void blend_kernel(const uint32_t* __restrict__
                     const gsm::F2 q = gsm::fma2(gsm::F2{ d.y, d.y }, gsm::F2{ gsm::u2f(B4.x), gsm::u2f(B4.y) }, gsm::F2{ d.x, d.x } * gsm::F2{ A4.z, A4.w });
                     const float q1 = q.x, q2 = q.y;
                     const float power = -fmaf(q2, q2, q1 * q1);
+                    const float y2 = power * 1.44269504088896340736f;                // exp(x) = exp2(x * log2 e), DESIGN.md section 5 #6
 #ifdef GS_BLEND_PLAIN
-                    const float alpha = gsm::sat(__expf(power) * half_lo(B4.w));
+                    float alpha = gsm::sat(__builtin_amdgcn_exp2f(y2) * half_lo(B4.w));
 #else
-                    const float alpha = mix_mul_lo_sat_after_trans(B4.w, __expf(power));
+                    float alpha = mix_mul_lo_sat_after_trans(B4.w, __builtin_amdgcn_exp2f(y2));
 #endif
-                    bool live = ((int)(fabsf(q1) <= 2.0f) & (int)(fabsf(q2) <= 2.0f) & (int)(alpha >= 1.0f / 255.0f)) != 0;
+                    const int inQuad = (int)(fabsf(q1) <= 2.0f) & (int)(fabsf(q2) <= 2.0f);
+                    bool live;
+#ifdef GS_EXP_NO_ALPHA_WINDOW            // A/B only: the round-2 decision (native alpha against 1/255), to price the window test
+                    if (false) {
+#else
+                    if (MODE == 0) {
+#endif
+                        // discard decision identical to the oracle's (gsm::DecideAlpha): outside a 16-ulp window around 1/255 the native
+                        // alpha decides (one integer subtract + one signed compare); inside it -- ~1e-6 of the fragments, a wave-rare
+                        // branch -- the alpha is recomputed from the deterministic exp2
+                        const uint32_t u = gsm::f2u(alpha) - gsm::kAlphaWindowLo;
+                        live = (inQuad & (int)((int32_t)u >= (int32_t)gsm::kAlphaWindow)) != 0;
+                        const bool nearT = (inQuad & (int)(u < gsm::kAlphaWindow)) != 0;
+                        if (__builtin_expect(__any(nearT), 0)) {
+                            if (nearT) alpha = gsm::DecideAlpha(alpha, y2, half_lo(B4.w), live);
+                        }
+                    } else {
+                        live = (inQuad & (int)(alpha >= 1.0f / 255.0f)) != 0;
+                    }
                     if (DEPTH) live = live && (s_e[c + b].w <= sceneZ);                // ZTest LEqual on the quad's (single) depth
                     if (MODE == 1) live = live && !acc.saturated();
                     if (live) acc.blend(B4.z, B4.w, alpha);
                 }
+#endif
                 if (__all(!inside || acc.finished())) {
                     waveDone = true;
                     if (lane == 0) atomicAdd(&s_done, 1);
