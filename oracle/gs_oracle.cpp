@@ -4,12 +4,17 @@
 // load this library, and only as the checker / reported CPU baseline.  The product path
 // (unitygaussiansplatting_amd + libgsplat_hip.so) never links, imports or falls back to it.
 //
-// *** PARITY UNPINNED. ***  The reference (aras-p/UnityGaussianSplatting) is HLSL + Unity C#; it cannot be
-// built or run in this environment (no dxc / Unity / dotnet) and it ships no unit tests or golden vectors for
-// this path other than full-scene PNGs of INRIA models that are not available offline.
-// This file is therefore a line-by-line restatement of the shader source, with the places where HLSL leaves
-// evaluation order / precision to the GPU compiler pinned to the canonical forms listed in DESIGN.md
-// ("canonical arithmetic").  The HIP kernels use the same canonical forms, so most outputs compare bit-exact.
+// *** PARITY PINNED TO THE REFERENCE'S OWN SHADER TEXT (round 3). ***  The reference (aras-p/UnityGaussianSplatting) is HLSL +
+// Unity C#; Unity / dxc / dotnet do not exist here and it ships no unit tests or golden vectors for this path other than
+// full-scene PNGs of INRIA models that are not available offline.  But the shader maths is
+// dependency-free: oracle/ref_build/ compiles the TEXT of GaussianSplatting.hlsl, SplatUtilities.compute:37-252, the vertex +
+// fragment shader of RenderGaussianSplats.shader and the fragment shader of GaussianComposite.shader, read from /root/reference
+// at build time, as C++ (oracle/_ref/libgs_ref_{strict,fused,fused_clang}.so; `make -C oracle ref`), and
+// tests/test_ref_parity.py holds this file against it: the canonical arithmetic below IS the "fused"
+// build of that text bit for bit -- sort keys, every field of LoadSplatData in every format, the whole 40-byte view record,
+// the fragment's alpha and discard -- and whole frames rasterised through the reference's vert + frag match within the
+// framebuffer bar.  What remains outside the reference tree (Unity's GammaToLinearSpace, the fixed-function raster / blend
+// rules, f16 conversion) is restated in oracle/ref_build and listed in DESIGN.md.
 //
 // Each function cites the reference lines it restates (paths relative to /root/reference/package/).
 //

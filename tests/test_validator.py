@@ -45,27 +45,38 @@ def test_cameras_json_import_follows_the_reference(tmp_path):
 
 
 def test_activate_camera_is_the_unity_transform():
-    """ActivateCamera (GaussianSplatRenderer.cs:660-680) against a float64 restatement: world position through the renderer's
-    localToWorld (mirror scale included), world rotation = renderer rotation * LookRotation(axisZ, axisY); the resulting
-    worldToCameraMatrix maps the camera's own forward axis to -Z and is a rigid transform."""
+    """ActivateCamera (GaussianSplatRenderer.cs:660-680): world position through the renderer's localToWorld (mirror scale included),
+    world rotation = parent rotation * (local rotation conjugated by the signs of the parent's scale).  Checked from the outside:
+    a cameras.json camera that looks at the object-space origin (COLMAP axes: x right, y down, z forward) must, under the sample
+    scene's mirrored transform, see the object's origin at the image centre, a point to ITS right on the right and a point ABOVE
+    it (COLMAP -y) on top -- i.e. the picture the trainer's camera saw, not its mirror image."""
     from unitygaussiansplatting_amd.asset import CameraInfo
     from unitygaussiansplatting_amd.renderer import GaussianSplatRenderer
+    import json as _json
     a = small_asset(500, 3, "Medium")
-    a.cameras = [CameraInfo(pos=(0.5, -1.0, 2.0), axisX=(1, 0, 0), axisY=(0.0, 0.9, 0.2), axisZ=(0.1, -0.2, 1.0), fov=25.0)]
+    jc = colmap_cameras(3)[1]
+    R = np.asarray(jc["rotation"], np.float64)                           # columns: camera x (right), y (down), z (forward) in object space
+    a.cameras = [CameraInfo(pos=tuple(jc["position"]), axisX=tuple(R[:, 0]), axisY=tuple(-R[:, 1]), axisZ=tuple(-R[:, 2]), fov=25.0)]
     tr = camera.Transform(position=(0.3, 0.2, -0.1), rotation=V.SCENE_ROTATION, scale=V.SCENE_SCALE)
     r = GaussianSplatRenderer.__new__(GaussianSplatRenderer)
     r.m_Asset, r.transform = a, tr
     cam = camera.Camera(pixelWidth=64, pixelHeight=48)
     GaussianSplatRenderer.ActivateCamera(r, 0, cam)
-    want_pos = tr.localToWorldMatrix.astype(np.float64) @ np.array([0.5, -1.0, 2.0, 1.0])
-    assert np.allclose(cam.position, want_pos[:3], atol=1e-6)
-    Rw = camera.quat_to_mat3(tr.rotation) @ camera.look_rotation((0.1, -0.2, 1.0), (0.0, 0.9, 0.2))
+    o2w = tr.localToWorldMatrix.astype(np.float64)
+    assert np.allclose(cam.position, (o2w @ np.append(jc["position"], 1.0))[:3], atol=1e-6)
+    Rw = np.asarray(cam.rotation)
     assert np.allclose(Rw.T @ Rw, np.eye(3), atol=1e-6) and np.linalg.det(Rw) > 0
-    V2C = cam.worldToCameraMatrix.astype(np.float64)
-    p = np.append(np.asarray(cam.position) + 3.0 * Rw[:, 2], 1.0)              # 3 units along the camera's forward axis
-    assert np.allclose(V2C @ p, [0, 0, -3, 1], atol=1e-5)
-    p = np.append(np.asarray(cam.position) + Rw[:, 0] + 2.0 * Rw[:, 1], 1.0)   # its right and up axes
-    assert np.allclose(V2C @ p, [1, 2, 0, 1], atol=1e-5)
+    VP = (cam.projectionMatrix.astype(np.float64) @ cam.worldToCameraMatrix.astype(np.float64))
+
+    def ndc(p_obj):
+        c = VP @ (o2w @ np.append(p_obj, 1.0))
+        return c[:2] / c[3], c[3]
+    centre, w = ndc(np.zeros(3))
+    assert w > 0 and np.allclose(centre, 0.0, atol=1e-5)                   # looks at the origin, which is in front
+    right, _ = ndc(0.2 * R[:, 0])
+    above, _ = ndc(-0.2 * R[:, 1])
+    assert right[0] > 0.01 and abs(right[1]) < 1e-5                        # the camera's right is the picture's right (clip x grows to the right)
+    assert above[1] > 0.01 and abs(above[0]) < 1e-5                        # COLMAP -y is up (clip y grows upwards)
 
 
 def test_diff_images_metric_is_the_validators():

@@ -319,7 +319,11 @@ int32_t gs_renderer_sort(gs_renderer* r, const float m[16]) {
     // (_SplatSortKeys, SplatUtilities.compute:76) is the first Onesweep pass's key load
     GS_TRY(enqueue_sort_keys(ctx, st, r->asset->view, m, r->keyBySplat, control, r->depthControl + (r->depthControlIdx ^ 1), r->n, r->depthSort));
     gs::prof_record(r, 1, st);
-    GS_TRY(enqueue_sort_passes(ctx, st, r->depthSort, control, r->distances, r->order, r->n, nullptr, 4, 255u, r, 10, 8, r->keyBySplat));
+    #ifndef GS_SORT_SKIP_LAST_KEYS
+#define GS_SORT_SKIP_LAST_KEYS 1     // the last depth pass writes only the order: nothing on the frame's path reads the sorted keys
+#endif
+    GS_TRY(enqueue_sort_passes(ctx, st, r->depthSort, control, r->distances, r->order, r->n, nullptr, 4, 255u, r, 10, 8, r->keyBySplat, GS_SORT_SKIP_LAST_KEYS != 0));
+    r->distancesStale = GS_SORT_SKIP_LAST_KEYS != 0;
     gs::prof_record(r, 2, st);
     if (ctx->overlap) {
         GS_HIP(hipEventRecord(r->evSortDone, st));
@@ -508,6 +512,11 @@ int32_t gs_renderer_download_order(gs_renderer* r, uint32_t* out, size_t count) 
 int32_t gs_renderer_download_distances(gs_renderer* r, uint32_t* out, size_t count) {
     if (!r || !out || count > r->n) return fail(GS_ERR_INVALID_ARGUMENT, "bad argument");
     GS_TRY(join_sort(r));
+    if (r->distancesStale) {         // m_GpuSortDistances after the sort = the sorted keys (GpuSorting.cs:142-198): materialised on demand
+        GS_TRY(bind_device(r->ctx));
+        GS_TRY(enqueue_gather_keys(r->ctx, r->keyBySplat, r->order, r->distances, r->n));
+        r->distancesStale = false;
+    }
     return download(r->ctx, out, r->distances, count * 4);
 }
 int32_t gs_renderer_upload_order(gs_renderer* r, const uint32_t* in, size_t count) {

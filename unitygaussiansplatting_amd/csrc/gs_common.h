@@ -204,6 +204,7 @@ struct gs_renderer {
     gs::FrameReport* hostReportDev = nullptr;   // its device-side address
     hipEvent_t evSortDone = nullptr;        // aux -> main join (timing disabled)
     hipEvent_t evOrderFree = nullptr;       // main -> aux fork: the last operation of the main queue that reads or writes order[]
+    bool distancesStale = false;      // the last depth pass skipped the sorted-key write: gs_renderer_download_distances gathers them
     bool sortPending = false;               // a sort on ctx->aux has not been joined into ctx->stream yet
     uint32_t lastTilesX = 0, lastTilesY = 0, lastPairPasses = 0;
     bool frameInFlight = false;
@@ -232,7 +233,8 @@ int32_t enqueue_histogram(gs_context* ctx, hipStream_t st, const uint32_t* keys,
 // gatherKeys != null (8-bit passes, an even number of them): the first pass reads its keys as gatherKeys[vals[i]].
 int32_t enqueue_sort_passes(gs_context* ctx, hipStream_t stream, SortState& st, SortControl* control, uint32_t* keys, uint32_t* vals,
                             uint32_t nUpper, const uint32_t* nPtr, int passes, uint32_t lastMask = 255u,
-                            gs_renderer* profR = nullptr, int evFirst = -1, int bitsPerPass = 8, const uint32_t* gatherKeys = nullptr);
+                            gs_renderer* profR = nullptr, int evFirst = -1, int bitsPerPass = 8, const uint32_t* gatherKeys = nullptr, bool skipLastKeys = false);
+int32_t enqueue_gather_keys(gs_context* ctx, const uint32_t* keyBySplat, const uint32_t* order, uint32_t* out, uint32_t n);
 constexpr uint32_t kSortMaxCount = 1u << 30;   // 32-bit byte offsets inside the sort kernels
 int32_t enqueue_set_indices(gs_context* ctx, uint32_t* order, uint32_t n);
 // view (gs_view.hip)

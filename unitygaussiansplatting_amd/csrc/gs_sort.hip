@@ -540,7 +540,7 @@ __global__ __launch_bounds__(THREADS, GS_SORT_MINWAVES) void onesweep_kernel(con
             if (j < valid) {
                 const uint32_t kk = s_buf[j];
                 const uint32_t d = (kk >> shift) & digitMask;
-                stg32(keysOut, s_gbase[d] + j, kk);
+                if (keysOut) stg32(keysOut, s_gbase[d] + j, kk);       // (null: the last pass of a depth sort whose sorted keys nobody reads)
                 dpack[k >> 2] |= d << (8 * (k & 3));
             }
         }
@@ -600,6 +600,16 @@ void sort_state_destroy(SortState& st) {
     st = SortState();
 }
 
+namespace { __global__ __launch_bounds__(256) void gather_keys_kernel(const uint32_t* __restrict__ keyBySplat, const uint32_t* __restrict__ order, uint32_t* __restrict__ out, uint32_t n) {
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) out[i] = keyBySplat[order[i]];
+} }
+// sorted keys on demand (distances[i] = key of the splat at sorted position i): the depth sort itself only delivers the order
+int32_t enqueue_gather_keys(gs_context* ctx, const uint32_t* keyBySplat, const uint32_t* order, uint32_t* out, uint32_t n) {
+    hipLaunchKernelGGL(gather_keys_kernel, dim3(max(1u, min(div_up(n, 256), (uint32_t)ctx->cuCount * 8u))), dim3(256), 0, ctx->stream, keyBySplat, order, out, n);
+    GS_HIP(hipGetLastError());
+    return GS_OK;
+}
+
 int32_t enqueue_set_indices(gs_context* ctx, uint32_t* order, uint32_t n) {
     hipLaunchKernelGGL(set_indices_kernel, dim3(div_up(n, 1024)), dim3(1024), 0, ctx->stream, order, n);
     GS_HIP(hipGetLastError());
@@ -634,7 +644,8 @@ int32_t enqueue_histogram(gs_context* ctx, hipStream_t stream, const uint32_t* k
 }
 
 int32_t enqueue_sort_passes(gs_context* ctx, hipStream_t stream, SortState& st, SortControl* control, uint32_t* keys, uint32_t* vals, uint32_t nUpper,
-                            const uint32_t* nPtr, int passes, uint32_t lastMask, gs_renderer* profR, int evFirst, int bits, const uint32_t* gatherKeys) {
+                            const uint32_t* nPtr, int passes, uint32_t lastMask, gs_renderer* profR, int evFirst, int bits, const uint32_t* gatherKeys,
+                            bool skipLastKeys) {
     if (passes < 1 || passes > 4) return fail(GS_ERR_INVALID_ARGUMENT, "sort passes");
     if (bits < 6 || bits > 8 || (gatherKeys && bits != 8)) return fail(GS_ERR_INVALID_ARGUMENT, "sort digit width");
     if (nUpper > st.maxCount) return fail(GS_ERR_INVALID_ARGUMENT, "sort count exceeds sorter capacity");
@@ -660,8 +671,9 @@ int32_t enqueue_sort_passes(gs_context* ctx, hipStream_t stream, SortState& st, 
         unsigned long long* agg = st.groupAgg + (size_t)p * groups * RADIX;
         const uint32_t mask = p == passes - 1 ? (lastMask & fullMask) : fullMask;
         const uint32_t shift = (uint32_t)(bits * p);
+        uint32_t* kdst = (skipLastKeys && p == passes - 1) ? (uint32_t*)nullptr : kd;      // the payload (order) is all the caller wants
 #define GS_LAUNCH_ONESWEEP(B, G, KIN) \
-        hipLaunchKernelGGL((onesweep_kernel<B, G>), dim3(grid), dim3(THREADS), 0, stream, KIN, vs, kd, vd, hist, st.status, agg, st.groupIncl, \
+        hipLaunchKernelGGL((onesweep_kernel<B, G>), dim3(grid), dim3(THREADS), 0, stream, KIN, vs, kdst, vd, hist, st.status, agg, st.groupIncl, \
                            control->tickets[p], &control->error, nUpper, nPtr, shift, epoch, mask)
         if (p == 0 && gatherKeys) GS_LAUNCH_ONESWEEP(8, true, gatherKeys);
         else if (bits == 8) GS_LAUNCH_ONESWEEP(8, false, ks);

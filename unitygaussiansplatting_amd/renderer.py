@@ -283,8 +283,11 @@ class GaussianSplatRenderer:
 
     def ActivateCamera(self, index: int, mainCam: Camera) -> None:     # :660-680
         """Pose `mainCam` as camera `index` of the asset's cameras.json: parented to this renderer's transform with
-        localPosition = cam.pos and localRotation = LookRotation(cam.axisZ, cam.axisY), then unparented keeping its world pose
-        (world position through the full localToWorld matrix, world rotation = transform.rotation * localRotation), scale one."""
+        localPosition = cam.pos and localRotation = LookRotation(cam.axisZ, cam.axisY), then unparented keeping its world pose,
+        scale one.  World position = localToWorld * pos.  World rotation is Unity's Transform.rotation of a child: parent.rotation *
+        ScaleMulQuat(parent.localScale, localRotation) -- the local rotation conjugated by the SIGNS of the parent's scale, which
+        is what makes the importer's negated y / z camera axes come out looking at the scene under the sample scene's mirrored
+        (scale z = -1) splat object (GSTestScene.unity:363-365)."""
         from .camera import look_rotation, quat_to_mat3
         if mainCam is None or self.m_Asset is None or not self.m_Asset.cameras:
             return
@@ -292,7 +295,8 @@ class GaussianSplatRenderer:
         o2w = self.transform.localToWorldMatrix.astype(np.float64)
         pos = o2w @ np.array([ci.pos[0], ci.pos[1], ci.pos[2], 1.0])
         mainCam.position = tuple(float(v) for v in pos[:3])
-        mainCam.rotation = quat_to_mat3(self.transform.rotation) @ look_rotation(ci.axisZ, ci.axisY)
+        sgn = np.diag(np.sign(np.asarray(self.transform.scale, np.float64)))
+        mainCam.rotation = quat_to_mat3(self.transform.rotation) @ (sgn @ look_rotation(ci.axisZ, ci.axisY) @ sgn)
 
     # -- per frame ------------------------------------------------------------------------------------------
     def FrameParams(self, cam: Camera) -> gs_frame_params:
