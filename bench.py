@@ -297,7 +297,8 @@ def main():
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                if tj.get("config") == args.config and dom in tj.get("kernels", {}):
+                tj = tj.get("configs", {}).get(args.config, tj if tj.get("config") == args.config else {})
+                if dom in tj.get("kernels", {}):
                     traffic = tj["kernels"][dom]["hbm_bytes_per_launch"]
             except Exception:
                 traffic = None

@@ -6,9 +6,10 @@ Usage: python scripts/pmc_traffic.py <tag> [config]"""
 import csv, glob, json, os, re, sys
 from collections import defaultdict
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-P = os.path.join(ROOT, "gpurun_out", "prof")
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 config = sys.argv[2] if len(sys.argv) > 2 else "C2"
+P = os.path.join(ROOT, "gpurun_out", "prof_" + config)
+if not os.path.isdir(P): P = os.path.join(ROOT, "gpurun_out", "prof")
 
 def short(name):
     name = name.replace("(anonymous namespace)::", "").replace("void ", "")
@@ -53,9 +54,19 @@ for k in sorted(set(bf) | set(bw)):
                      "read_factor": round(rf, 3), "write_factor": round(wf, 3),
                      "hbm_bytes_per_launch": int((f_kib * rf + w_kib * wf) * 1024)}
 os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
-json.dump({"config": config, "source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on `bench.py --steps 20 --warmup 5`, {tag}",
-           "units": "counters are KiB; true bytes = counter * factor * 1024, factors calibrated on 1-GiB kernels of the same access width in the same session",
-           "calibration": cal, "kernels": kernels}, open(os.path.join(ROOT, "profiles", "hbm_traffic.json"), "w"), indent=1)
+tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+entry = {"config": config, "source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on `bench.py --config {config} --warmup 5`, {tag}",
+         "units": "counters are KiB; true bytes = counter * factor * 1024, factors calibrated on 1-GiB kernels of the same access width in the same session",
+         "calibration": cal, "kernels": kernels}
+allcfg = {}
+if os.path.exists(tpath):
+    try:
+        old = json.load(open(tpath))
+        allcfg = old.get("configs", {}) if "configs" in old else ({old["config"]: old} if "config" in old else {})
+    except Exception:
+        allcfg = {}
+allcfg[config] = entry
+json.dump({"configs": allcfg}, open(tpath, "w"), indent=1)
 
 # ---- kernel time summary
 rows = []

@@ -1,11 +1,12 @@
 #!/bin/bash
 # (remove the local gpurun_out/prof first: gpurun MERGES what the box wrote into it)
 # On the GPU box: kernel-trace stats of the default bench, then separate PMC passes (FETCH_SIZE, WRITE_SIZE) for the bench
-# and for the calibration probe.  Outputs under gpurun_out/prof/.
+# and for the calibration probe.  Usage: profile_round.sh [C2|C4|...] [steps].  Outputs under gpurun_out/prof_<config>/.
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof; rm -rf $O; mkdir -p $O
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof_${1:-C2}; rm -rf $O; mkdir -p $O
 export PYTHONPATH=$R
-BENCH="python $R/bench.py --steps 20 --warmup 5 --cpu-baseline off"
+CFG=${1:-C2}; STEPS=${2:-20}
+BENCH="python $R/bench.py --config $CFG --steps $STEPS --warmup 5 --cpu-baseline off"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- $BENCH > $O/bench_stats.json 2> $O/bench_stats.err
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_$c -- $BENCH > $O/bench_$c.json 2> $O/bench_$c.err

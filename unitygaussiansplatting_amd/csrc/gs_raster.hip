@@ -200,7 +200,7 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(const uint32_t* __rest
 // first slot of every position and a DPP max-scan -- global stores of pairs are therefore fully coalesced whatever the
 // footprints are (a splat covering the whole screen is just a long run), and no lane idles behind a neighbour's big splat.
 #ifndef GS_BIN_MINWAVES
-#define GS_BIN_MINWAVES 5      // <= 96 VGPRs (three dwords of the prefetched partition spill): five 256-thread workgroups per CU
+#define GS_BIN_MINWAVES 1
 #endif
 #ifdef GS_EXP_BIN_TIMELINE        // experiment build: per-partition phase timestamps (100 MHz wall clock) of the LAST launch
 __device__ unsigned long long g_bin_tl[32768 * 8];
@@ -249,92 +249,55 @@ __global__ __launch_bounds__(kBinThreads, GS_BIN_MINWAVES) void bin_emit_kernel(
     // Persistent grid, partitions drawn from kBinTicketClasses counters in separate 128-B lines (one counter would
     // serialise ~1500 same-address atomics, 12 ns each, at the start of the kernel): ticket t of class c = partition
     // t * classes + c; see the same scheme in gs_sort.hip for why a workgroup still only waits on running partitions.
-#ifndef GS_BIN_PIPE
-#define GS_BIN_PIPE 1
-#endif
-    auto draw_ticket = [&]() {                                   // tid 0 only
-        const uint32_t cls = bid % kBinTicketClasses;
-        const uint32_t t = __hip_atomic_fetch_add(&ctl->tickets[cls * 32u], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return t * kBinTicketClasses + cls;       // (XCD blocks as in the sort's gather pass were measured here too: 0.133 vs 0.102 ms -- the scan then waits on blocks other XCDs have not reached)
-    };
-    // The three dependent loads of a partition -- order[i] -> visibility word of that splat -> its 8-byte rectangle -- are what a
-    // partition's time is made of (a dependent chain of ~4 us, twice per workgroup and frame).  They are software-pipelined
-    // across partitions: the chain of partition k+1 is issued piecewise while partition k publishes its total, waits for the
-    // scan and emits its pairs, one link per phase, so that every link has a whole phase to arrive.
-    // (1 bit per splat first -- a 0.8 MB array for 6.1 M splats, it stays in L2 -- so that only the splats that reach a tile
-    // pay for the random 8-byte gather of their rectangle; lanes without one read element 0, a broadcast.)
-    auto load_order = [&](uint32_t p, uint32_t (&sidv)[kBinItems]) {
-        const uint32_t wb = p * (uint32_t)kBinPart + (uint32_t)w * (64u * kBinItems);
-#pragma unroll
-        for (int k = 0; k < kBinItems; ++k) {
-            const uint32_t i = wb + (uint32_t)k * 64u + (uint32_t)lane;
-            sidv[k] = order[min(i, n - 1u)];                     // unconditional (a load inside a divergent branch is waited for at its end)
-            if (i >= n) sidv[k] = 0xffffffffu;
-        }
-    };
-    auto load_vis = [&](const uint32_t (&sidv)[kBinItems], uint32_t& visBits) {     // bit k of visBits = position k is visible
-        uint32_t wv[kBinItems];
-#pragma unroll
-        for (int k = 0; k < kBinItems; ++k) wv[k] = visMask32[(sidv[k] != 0xffffffffu ? sidv[k] : 0u) >> 5];
-        visBits = 0u;
-#pragma unroll
-        for (int k = 0; k < kBinItems; ++k) visBits |= ((sidv[k] != 0xffffffffu) ? ((wv[k] >> (sidv[k] & 31u)) & 1u) : 0u) << k;
-    };
-    auto load_rect = [&](const uint32_t (&sidv)[kBinItems], uint32_t visBits, uint2 (&rcv)[kBinItems]) {
-#pragma unroll
-        for (int k = 0; k < kBinItems; ++k) {
-            const bool v = (visBits >> k) & 1u;
-            const uint2 rv = rects[v ? sidv[k] : 0u];
-            rcv[k] = v ? rv : make_uint2(0u, 0u);
-        }
-    };
-    // wave sums of the per-position tile counts of the partition held in (sidv, rcv) -> s_wtot / s_wvis
-    auto count_cur = [&](const uint2 (&rcv)[kBinItems]) {
-        uint32_t mySum = 0, myVis = 0;
-#pragma unroll
-        for (int k = 0; k < kBinItems; ++k) {
-            const uint32_t c = (rcv[k].y & 0xffffu) * (rcv[k].y >> 16);
-            mySum += c;
-            myVis += c ? 1u : 0u;
-        }
-        const uint32_t waveTotal = wave_sum_u32(mySum), waveVis = wave_sum_u32(myVis);
-        if (lane == 0) { s_wtot[w] = waveTotal; s_wvis[w] = waveVis; }
-    };
-    // a partition's total goes out (status word + its group's aggregate) as soon as it is known -- a whole emission before
-    // the partition's own look-back needs its predecessors': the scan across partitions never waits on anybody's emission
-    auto publish = [&](uint32_t p, uint32_t total) {             // one lane
-        __hip_atomic_store(binStatus + p, BFLAG_AGG | (unsigned long long)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_fetch_add(binGroupAgg + (p >> 6), (1ull << 56) | (unsigned long long)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        visAcc += s_wvis[0] + s_wvis[1] + s_wvis[2] + s_wvis[3];
-    };
-    uint32_t sid[kBinItems], sidN[kBinItems], visN = 0u;
-    uint2 rc[kBinItems], rcN[kBinItems];
-    if (tid == 0) s_part = draw_ticket();
-    __syncthreads();
-    uint32_t part = s_part;
-    uint32_t wbase = 0, blockTotal = 0;
-    if (part < numParts) {                                       // prologue: the first partition's chain is exposed (once per workgroup)
-        load_order(part, sid); load_vis(sid, visN); load_rect(sid, visN, rc);
-        count_cur(rc);
-    }
-    __syncthreads();                                             // (s_part has been read by everyone)
-    if (part < numParts) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { const uint32_t t = s_wtot[j]; wbase += (j < w) ? t : 0u; blockTotal += t; }
-        if (tid == 0) { publish(part, blockTotal); s_part = draw_ticket(); }        // + the ticket of the partition after this one
-    }
     for (;;) {
-    if (part >= numParts) break;
+    __syncthreads();                                             // s_part / s_wtot / s_base of the previous partition are no longer read
 #ifdef GS_EXP_BIN_TIMELINE
     const unsigned long long btl0 = wall_clock64();
+#endif
+    if (tid == 0) {
+        const uint32_t cls = bid % kBinTicketClasses;
+        const uint32_t t = __hip_atomic_fetch_add(&ctl->tickets[cls * 32u], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_part = t * kBinTicketClasses + cls;     // (XCD blocks as in the sort's gather pass were measured here too: 0.133 vs 0.102 ms -- the scan then waits on blocks other XCDs have not reached)
+    }
+    __syncthreads();
+    const uint32_t part = s_part;
+    if (part >= numParts) break;
+#ifdef GS_EXP_BIN_TIMELINE
     if (tid == 0 && part < 32768u) g_bin_tl[part * 8u + 0] = btl0;
 #endif
-    __syncthreads();                                             // s_part = the next ticket; s_wtot / s_wvis of `part` consumed
-    const uint32_t partNext = s_part;
-    const bool haveNext = partNext < numParts;                   // workgroup-uniform
-    if (haveNext) load_order(partNext, sidN);                    // link 1 of the next partition: in flight during the look-back
-    GS_BTL(1);
-    GS_BTL(2);
+    GS_BTL(1);                                                   // ticket known
+    const uint32_t waveBase = part * (uint32_t)kBinPart + (uint32_t)w * (64u * kBinItems);
+
+    // ---- per sorted position: gather the splat's tile rectangle (8 B, written by calc_view) ----------------------
+    uint32_t sid[kBinItems];
+    uint2 rc[kBinItems];
+#pragma unroll
+    for (int k = 0; k < kBinItems; ++k) {
+        const uint32_t i = waveBase + (uint32_t)k * 64u + (uint32_t)lane;
+        sid[k] = (i < n) ? order[i] : 0xffffffffu;
+    }
+    // 1 bit per splat first (a 0.8 MB array for 6.1 M splats: it stays in L2), so that only the splats that reach a tile
+    // pay for the random 8-byte gather of their rectangle from the N x 8 B array
+    uint32_t visw[kBinItems];
+#pragma unroll
+    for (int k = 0; k < kBinItems; ++k) visw[k] = (sid[k] != 0xffffffffu) ? visMask32[sid[k] >> 5] : 0u;
+    uint32_t mySum = 0, myVis = 0;
+#pragma unroll
+    for (int k = 0; k < kBinItems; ++k) {
+        rc[k] = make_uint2(0u, 0u);
+        if ((visw[k] >> (sid[k] & 31u)) & 1u) rc[k] = rects[sid[k]];
+        const uint32_t c = (rc[k].y & 0xffffu) * (rc[k].y >> 16);
+        mySum += c;
+        myVis += c ? 1u : 0u;
+    }
+    GS_BTL(2);                                                   // order, visibility bits and rectangles arrived (mySum depends on them)
+    const uint32_t waveTotal = wave_sum_u32(mySum);
+    const uint32_t waveVis = wave_sum_u32(myVis);
+    if (lane == 0) { s_wtot[w] = waveTotal; s_wvis[w] = waveVis; }
+    __syncthreads();
+    uint32_t wbase = 0, blockTotal = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const uint32_t t = s_wtot[j]; wbase += (j < w) ? t : 0u; blockTotal += t; }
 
     // ---- scan across partitions (wave 0).  All partitions of the first round of tickets are resident at once and publish
     //      their totals at about the same time, so a plain decoupled look-back (64 predecessors per step until an inclusive
@@ -348,7 +311,12 @@ __global__ __launch_bounds__(kBinThreads, GS_BIN_MINWAVES) void bin_emit_kernel(
     //      (Everybody summing all group words themselves was measured: 1280 waves polling the same ~50 words with agent-scope
     //      loads serialise on a few L2 lines, 0.10 -> 0.18 ms.)
     if (w == 0) {
-        const uint32_t grp = part >> 6, grpStart = grp << 6;     // (this partition's total was published a partition ago)
+        const uint32_t grp = part >> 6, grpStart = grp << 6;
+        if (lane == 0) {
+            __hip_atomic_store(binStatus + part, BFLAG_AGG | (unsigned long long)blockTotal, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(binGroupAgg + grp, (1ull << 56) | (unsigned long long)blockTotal, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            visAcc += s_wvis[0] + s_wvis[1] + s_wvis[2] + s_wvis[3];
+        }
         unsigned long long excl = 0;
         uint32_t spins = 0;
         bool failed = false;
@@ -402,7 +370,6 @@ __global__ __launch_bounds__(kBinThreads, GS_BIN_MINWAVES) void bin_emit_kernel(
     }
     GS_BTL(3);                                                   // wave 0: scan done
     __syncthreads();
-    if (haveNext) load_vis(sidN, visN);                          // link 2: in flight during the first half of the emission
     GS_BTL(4);
     // global offset of this wave's first pair: wave-uniform, so the pair arrays are addressed as scalar base + 32-bit slot
     // and the capacity test is a 32-bit compare against the number of this wave's slots that fit
@@ -422,7 +389,6 @@ __global__ __launch_bounds__(kBinThreads, GS_BIN_MINWAVES) void bin_emit_kernel(
     uint32_t run = 0;                                            // wave-local exclusive offset, wave-uniform
 #pragma unroll
     for (int sb = 0; sb < kBinItems / SUB; ++sb) {
-        if (sb == kBinItems / SUB - 1 && haveNext) load_rect(sidN, visN, rcN);      // link 3: in flight during the last part of the emission
         const uint32_t subStart = run;
         uint32_t offsR[SUB], cntR[SUB];
 #pragma unroll
@@ -478,25 +444,9 @@ __global__ __launch_bounds__(kBinThreads, GS_BIN_MINWAVES) void bin_emit_kernel(
     }
 
     GS_BTL(5);                                                   // wave 0's emission done
-    // ---- the next partition becomes the current one: count it and publish its total right away
-    __syncthreads();                                             // s_part / s_wtot of this iteration are no longer read
-    if (haveNext) {
-#pragma unroll
-        for (int k = 0; k < kBinItems; ++k) { sid[k] = sidN[k]; rc[k] = rcN[k]; }
-        count_cur(rc);
-    }
-    __syncthreads();
-    wbase = 0; blockTotal = 0;
-    if (haveNext) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { const uint32_t t = s_wtot[j]; wbase += (j < w) ? t : 0u; blockTotal += t; }
-        if (tid == 0) { publish(partNext, blockTotal); s_part = draw_ticket(); }
-    }
-    part = partNext;
     }   // next partition
 
     // ---- flush the pair-sort digit histograms and the visible count ---------------------------------------------
-    __syncthreads();                                             // every wave's emission (LDS histogram adds) is finished
     if (tid == 0 && visAcc) atomicAdd(&ctl->visible, visAcc);
     for (int j = tid; j < PASSES * 256; j += kBinThreads) {
         const uint32_t c = s_hist[j];
@@ -750,7 +700,7 @@ __global__ __launch_bounds__(256) void blend_kernel(const uint32_t* __restrict__
 #endif
                 while (mask) {
                     const int b = __ffsll((long long)mask) - 1;
-#if GS_BLEND_LOOP2
+#if !defined(GS_BLEND_LOOP1)
                     mask &= ~(1ull << b);                              // one s_bitset0_b64 instead of a 64-bit subtract + and
 #else
                     mask &= mask - 1ull;
@@ -770,7 +720,7 @@ __global__ __launch_bounds__(256) void blend_kernel(const uint32_t* __restrict__
 #else
                     float alpha = mix_mul_lo_sat_after_trans(B4.w, __builtin_amdgcn_exp2f(y2));
 #endif
-#if GS_BLEND_LOOP2
+#if !defined(GS_BLEND_LOOP1)
                     const int inQuad = (int)(fmaxf(fabsf(q1), fabsf(q2)) <= 2.0f);     // one v_max with |.| modifiers + one compare (NaN q: not inside, as before)
 #else
                     const int inQuad = (int)(fabsf(q1) <= 2.0f) & (int)(fabsf(q2) <= 2.0f);
