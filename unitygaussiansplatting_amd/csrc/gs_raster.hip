@@ -221,9 +221,7 @@ __global__ __launch_bounds__(kBinThreads, GS_BIN_MINWAVES) void bin_emit_kernel(
     __shared__ uint32_t s_wtot[4], s_wvis[4];
     __shared__ uint32_t s_part;
     __shared__ unsigned long long s_base;
-    __shared__ uint32_t s_off[4][SUB * 64];
-    __shared__ uint32_t s_sid[4][SUB * 64];
-    __shared__ uint2 s_rect[4][SUB * 64];
+    __shared__ uint4 s_rec[4][SUB * 64];                     // per staged position: first output slot, splat index, tile rectangle (one 16-byte LDS access each way)
     __shared__ uint32_t s_mark[4][64];
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -381,9 +379,7 @@ __global__ __launch_bounds__(kBinThreads, GS_BIN_MINWAVES) void bin_emit_kernel(
     uint32_t* __restrict__ pv = pairVals + (roomAll ? gbase : 0ull);
 
     // ---- emit (tile, splat) pairs, 256 positions of this wave at a time (no workgroup barriers below) -------------
-    uint32_t* offs = s_off[w];
-    uint32_t* sids = s_sid[w];
-    uint2* rcts = s_rect[w];
+    uint4* recsL = s_rec[w];
     uint32_t* mark = s_mark[w];
     mark[lane] = 0u;
     uint32_t run = 0;                                            // wave-local exclusive offset, wave-uniform
@@ -397,9 +393,7 @@ __global__ __launch_bounds__(kBinThreads, GS_BIN_MINWAVES) void bin_emit_kernel(
             const uint32_t c = (rc[k].y & 0xffffu) * (rc[k].y >> 16);
             const uint32_t incl = wave_incl_scan_u32(c);
             offsR[kk] = run + incl - c; cntR[kk] = c;
-            offs[kk * 64 + lane] = run + incl - c;
-            sids[kk * 64 + lane] = sid[k];
-            rcts[kk * 64 + lane] = rc[k];
+            recsL[kk * 64 + lane] = make_uint4(run + incl - c, sid[k], rc[k].x, rc[k].y);
             run += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
         }
         __builtin_amdgcn_wave_barrier();
@@ -423,9 +417,10 @@ __global__ __launch_bounds__(kBinThreads, GS_BIN_MINWAVES) void bin_emit_kernel(
             const uint32_t e1 = max(wave_incl_max_scan_dpp(m), carry);
             carry = (uint32_t)__builtin_amdgcn_readlane((int)e1, 63);
             const uint32_t e = max(e1, 1u) - 1u;
-            const uint32_t o = j - offs[e];
-            const uint2 r = rcts[e];
-            const uint32_t s = sids[e];
+            const uint4 rec4 = recsL[e];
+            const uint32_t o = j - rec4.x;
+            const uint2 r = make_uint2(rec4.z, rec4.w);
+            const uint32_t s = rec4.y;
             const uint32_t tw = max(r.y & 0xffffu, 1u);
             uint32_t ty, tx;
             slot_to_xy(o, tw, ty, tx);
