@@ -88,6 +88,15 @@ with open(outp, "w") as o:
     o.write("\n# HBM traffic per launch from the PMC passes (profiles/hbm_traffic.json)\n")
     for k, v in kernels.items():
         o.write(f"{k:34s} fetch {v['FETCH_SIZE_KiB_per_launch']:>11.1f} KiB x{v['read_factor']:<5}  write {v['WRITE_SIZE_KiB_per_launch']:>11.1f} KiB x{v['write_factor']:<5} -> {v['hbm_bytes_per_launch']/1e6:9.1f} MB\n")
+    o.write("\n# the same per template instantiation (onesweep: <8, true> = the depth sort's gather pass, <8, false> = its other passes, <6|7, false> = pair sort)\n")
+    ff, fw = counters("pmc_FETCH_SIZE"), counters("pmc_WRITE_SIZE")
+    for k in sorted(set(ff) | set(fw)):
+        if "<" not in k: continue
+        base = re.sub(r"<.*", "", k)
+        rf = cal.get(READ_CAL.get(base, "calib_read_b128"), {}).get("true_over_counter", 2.0)
+        wf = cal.get(WRITE_CAL.get(base, "calib_write_b128"), {}).get("true_over_counter", 1.0)
+        f_kib = sum(ff.get(k, [0])) / max(1, len(ff.get(k, [0]))); w_kib = sum(fw.get(k, [0])) / max(1, len(fw.get(k, [0])))
+        o.write(f"{k[:34]:34s} fetch {f_kib:>11.1f} KiB  write {w_kib:>11.1f} KiB -> {(f_kib * rf + w_kib * wf) * 1024 / 1e6:9.1f} MB  ({len(ff.get(k, []))} launches)\n")
     o.write("\n# calibration (1 GiB each)\n")
     for k, v in cal.items(): o.write(f"{k:26s} {v}\n")
 print(open(outp).read())
