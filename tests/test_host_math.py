@@ -262,3 +262,18 @@ def test_discard_decision_is_identical_whatever_the_exp2_unit_rounds(hm):
             elif not dead:                                     # one side at the window's edge: a few ulps apart, same decision (above)
                 assert abs(int(alpha.view(np.uint32)) - int(out[3].view(np.uint32))) <= 4
     assert n_in_window > 500
+
+
+def test_axis_length_guard_equals_the_division_it_replaces():
+    """PrepareSplat's `1 / |axis|^2 is finite` as an integer range test on the bits of d = |axis|^2 (gs_device_math.h): equal to the
+    IEEE division for every class of d a sum of two squares can take -- zero, denormals around 2^-128 (where 1/d starts to
+    overflow), normals, +inf, NaN."""
+    edge = np.array([0x00000000, 0x00000001, 0x001fffff, 0x00200000, 0x00200001, 0x00200002, 0x007fffff, 0x00800000, 0x3f800000,
+                     0x7f7fffff, 0x7f800000, 0x7f800001, 0x7fc00000, 0x7fffffff], np.uint32)
+    rnd = np.random.default_rng(2).integers(0, 0x7fffffff, 200000, dtype=np.uint64).astype(np.uint32)
+    bits = np.concatenate([edge, rnd, np.arange(0x001ffff0, 0x00200010, dtype=np.uint32)])
+    d = bits.view(np.float32)
+    with np.errstate(divide="ignore", over="ignore", invalid="ignore"):
+        want = np.isfinite(np.float32(1.0) / d)
+    got = (bits - np.uint32(0x00200001)) <= np.uint32(0x7f800000 - 0x00200001)
+    assert np.array_equal(got, want)
