@@ -662,13 +662,19 @@ struct ViewPartial {
     bool culled;                // allowCull only: the splat cannot reach the screen and the geometry was not finished
 };
 
-GS_HD void CalcViewGeom(const AssetView& a, const FrameConsts& P, const EditView& E, uint32_t idx, ViewPartial& vp, bool allowCull = false) {
+// outputsOnlyIfDrawn: the caller reads vp (beyond front / culled) only for a splat that passes PrepareSplat -- the per-frame kernel --
+// so the record is not zero-filled first (a dozen register moves at every divergent exit of a VALU-bound kernel).
+GS_HD void CalcViewGeom(const AssetView& a, const FrameConsts& P, const EditView& E, uint32_t idx, ViewPartial& vp, bool allowCull = false,
+                        bool outputsOnlyIfDrawn = false) {
     ViewData& view = vp.view;
-    view.pos[0] = view.pos[1] = view.pos[2] = view.pos[3] = 0.0f;
-    view.axis1[0] = view.axis1[1] = view.axis2[0] = view.axis2[1] = 0.0f;
-    view.color[0] = view.color[1] = 0u;
-    vp.front = false; vp.culled = false; vp.shLerp = false; vp.otherEnd = 0u;
-    vp.shMin = { 0, 0, 0 }; vp.shMax = { 0, 0, 0 }; vp.col = { 0, 0, 0, 0 };
+    if (!outputsOnlyIfDrawn) {
+        view.pos[0] = view.pos[1] = view.pos[2] = view.pos[3] = 0.0f;
+        view.axis1[0] = view.axis1[1] = view.axis2[0] = view.axis2[1] = 0.0f;
+        view.color[0] = view.color[1] = 0u;
+        vp.shLerp = false; vp.otherEnd = 0u;
+        vp.shMin = { 0, 0, 0 }; vp.shMax = { 0, 0, 0 }; vp.col = { 0, 0, 0, 0 };
+    }
+    vp.front = false; vp.culled = false;
 
     // ---- LoadSplatData: position first (needed for the early out)
     V3 pos = LoadVec(a.pos, (uint64_t)idx * vecStride(a.posFmt), a.posFmt);
@@ -735,7 +741,12 @@ GS_HD void CalcViewGeom(const AssetView& a, const FrameConsts& P, const EditView
         const float smax = fmaxf(fmaxf(fabsf(scale.x), fabsf(scale.y)), fabsf(scale.z));
         const float t2 = dot3f(T00, T01, T02, T00, T01, T02) + dot3f(T10, T11, T12, T10, T11, T12);
         const float lam = fmaf(t2 * (1.1f * ss2), smax * smax, 0.6f);
+        // (a bound with 5 % + 2 px of slack: the GPU's 1-ulp v_sqrt_f32 does, without the ~10-instruction correctly-rounded fix-up)
+#if defined(__HIP_DEVICE_COMPILE__)
+        const float rad = fmaf(4.0f * 1.05f, __builtin_amdgcn_sqrtf(2.0f * lam), 2.0f);
+#else
         const float rad = fmaf(4.0f * 1.05f, sqrtf(2.0f * lam), 2.0f);
+#endif
         const float invw = 1.0f / w;
         const float cx = fmaf(0.5f * (view.pos[0] * invw), P.screenW, 0.5f * P.screenW);
         const float cy = fmaf(-0.5f * (view.pos[1] * invw), P.screenH, 0.5f * P.screenH);

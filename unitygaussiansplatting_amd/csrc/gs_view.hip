@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256) void calc_view_kernel(gsm::AssetView a, gsm::F
         }
         if (threadIdx.x == 0) s_any = 0;
         if (idx < a.n) {
-            gsm::CalcViewGeom(a, P, E, idx, vp, true);             // early out for splats that cannot reach the screen
+            gsm::CalcViewGeom(a, P, E, idx, vp, true, true);       // early out for splats that cannot reach the screen; vp only read if drawn
             const bool ok = vp.front && !vp.culled && gsm::PrepareSplat(vp.view, P.screenW, P.screenH, P.nearClip, P.farClip, fp);
             visible = ok && fp.tx0 <= fp.tx1;
         }
