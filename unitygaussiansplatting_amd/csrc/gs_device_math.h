@@ -23,6 +23,10 @@
 #define GS_HD inline
 #endif
 
+#ifndef GS_CULL_EXTENT
+#define GS_CULL_EXTENT 2.8285f     // 2 sqrt(2), rounded up: see the early cull in CalcViewGeom
+#endif
+
 namespace gsm {
 
 struct AssetView {              // device (or, in the host test, host) pointers to the five blobs
@@ -338,17 +342,17 @@ struct SHFromBlob {
 // Whole-chunk cull (per-frame path only).  A chunk's 256 splats lie in the box [posMin, posMax] of its ChunkInfo and are no
 // larger than its scale maximum, so if all 8 corners of the box are on the outer side of one frustum plane -- pushed out
 // by a bound on the footprint radius -- no splat of the chunk can be drawn and its workgroup stops before decoding anything.
-// Footprint half extent <= 4 sqrt(2 lambda1), lambda1 <= (|T0|^2 + |T1|^2) 1.1 s^2 smax^2 + 0.6 (as in CalcViewGeom's early cull),
+// Footprint half extent <= 2 sqrt(2) sqrt(2 lambda1), lambda1 <= (|T0|^2 + |T1|^2) 1.1 s^2 smax^2 + 0.6 (as in CalcViewGeom's early cull),
 // |T0|^2 + |T1|^2 <= (focal / w)^2 G with G = 2 (|mv0|^2 + |mv1|^2 + (limX^2 + limY^2) |mv2|^2)  =>  half extent <=
-// K focal smax / w + 4.4 px with K = 4 sqrt(2.2 G s^2).  "Right of the screen" (cx - extent > W) becomes the LINEAR test
-// x - w (1 + 13.2 / W) - (2 K focal / W) smax > 0 on clip coordinates (slack: K is taken 5 % larger, 6.6 px instead of 4.9);
+// K focal smax / w + 3.1 px with K = 2 sqrt(2) sqrt(2.2 G s^2).  "Right of the screen" (cx - extent > W) becomes the LINEAR test
+// x - w (1 + 13.2 / W) - (2 K focal / W) smax > 0 on clip coordinates (slack: K is taken 5 % larger, 6.6 px instead of 3.1);
 // likewise left / top / bottom; the depth planes are the rasteriser's own centre-depth rule.  Needs clip.w = |view z|
 // (a perspective projection whose last row is (0, 0, -1, 0)); the host checks that and switches the cull off otherwise.
 GS_HD void FrameConstsChunkCull(FrameConsts& c) {
     const float g0 = dot3f(c.mv[0], c.mv[1], c.mv[2], c.mv[0], c.mv[1], c.mv[2]), g1 = dot3f(c.mv[4], c.mv[5], c.mv[6], c.mv[4], c.mv[5], c.mv[6]);
     const float g2 = dot3f(c.mv[8], c.mv[9], c.mv[10], c.mv[8], c.mv[9], c.mv[10]);
     const float G = 2.0f * (g0 + g1 + (c.limX * c.limX + c.limY * c.limY) * g2);
-    const float K = 4.2f * sqrtf(2.2f * G * (c.splatScale * c.splatScale));
+    const float K = (GS_CULL_EXTENT * 1.05f) * sqrtf(2.2f * G * (c.splatScale * c.splatScale));
     c.cullKx = 2.0f * K * c.focal / c.screenW;
     c.cullKy = 2.0f * K * c.focal / c.screenH;
     c.cullMx = 1.0f + 13.2f / c.screenW;
@@ -731,8 +735,9 @@ GS_HD void CalcViewGeom(const AssetView& a, const FrameConsts& P, const EditView
     const float T10 = fmaf(J12, P.mv[8], J11 * P.mv[4]), T11 = fmaf(J12, P.mv[9], J11 * P.mv[5]), T12 = fmaf(J12, P.mv[10], J11 * P.mv[6]);
 
     // ---- early cull (only for callers that do not need the record of a splat that cannot be drawn).  Exactly as
-    // PrepareSplat: centre depth outside [near, far] => clipped.  Conservatively: the quad's half extent is at most
-    // 2 (|axis1| + |axis2|) <= 4 sqrt(2 lambda1), and lambda1 <= trace(cov2d) <= (|T0|^2 + |T1|^2) lambda_max(Sigma) + 0.6 with
+    // PrepareSplat: centre depth outside [near, far] => clipped.  Conservatively: the quad's half extent along x is
+    // 2 (|axis1.x| + |axis2.x|) <= 2 sqrt(2) sqrt(axis1.x^2 + axis2.x^2) (Cauchy-Schwarz) <= 2 sqrt(2) sqrt(2 lambda1) (the axes are
+    // orthogonal, |axis_k|^2 = 2 lambda_k <= 2 lambda1), the same along y, and lambda1 <= trace(cov2d) <= (|T0|^2 + |T1|^2) lambda_max(Sigma) + 0.6 with
     // lambda_max(Sigma) <= splatScale^2 |R|^2 max(scale)^2  (|R|^2 <= 1.1 for a 10.10.10.2 quaternion); a centre farther than
     // that (+5 %, + 2 px) outside the screen cannot put a fragment on it.  NaNs compare false and take the full path.
     if (allowCull) {
@@ -743,9 +748,9 @@ GS_HD void CalcViewGeom(const AssetView& a, const FrameConsts& P, const EditView
         const float lam = fmaf(t2 * (1.1f * ss2), smax * smax, 0.6f);
         // (a bound with 5 % + 2 px of slack: the GPU's 1-ulp v_sqrt_f32 does, without the ~10-instruction correctly-rounded fix-up)
 #if defined(__HIP_DEVICE_COMPILE__)
-        const float rad = fmaf(4.0f * 1.05f, __builtin_amdgcn_sqrtf(2.0f * lam), 2.0f);
+        const float rad = fmaf(GS_CULL_EXTENT * 1.05f, __builtin_amdgcn_sqrtf(2.0f * lam), 2.0f);
 #else
-        const float rad = fmaf(4.0f * 1.05f, sqrtf(2.0f * lam), 2.0f);
+        const float rad = fmaf(GS_CULL_EXTENT * 1.05f, sqrtf(2.0f * lam), 2.0f);
 #endif
         const float invw = 1.0f / w;
         const float cx = fmaf(0.5f * (view.pos[0] * invw), P.screenW, 0.5f * P.screenW);

@@ -209,7 +209,7 @@ __device__ unsigned long long g_bin_tl[32768 * 8];
 #define GS_BTL(k) do { } while (0)
 #endif
 template <int PASSES>
-__global__ __launch_bounds__(kBinThreads, GS_BIN_MINWAVES) void bin_emit_kernel(const uint2* __restrict__ rects, const uint32_t* __restrict__ visMask32,
+__global__ __launch_bounds__(kBinThreads, GS_BIN_MINWAVES) void bin_emit_kernel(const uint2* __restrict__ rects, const uint8_t* __restrict__ wgVis,
                                                                 const uint32_t* __restrict__ order, uint32_t n, uint32_t tilesX,
                                                                 uint32_t* __restrict__ pairKeys, uint32_t* __restrict__ pairVals,
                                                                 uint32_t capacity, BinControl* ctl, unsigned long long* binStatus, unsigned long long* binGroupAgg, unsigned long long* binGroupBase,
@@ -274,16 +274,19 @@ __global__ __launch_bounds__(kBinThreads, GS_BIN_MINWAVES) void bin_emit_kernel(
         const uint32_t i = waveBase + (uint32_t)k * 64u + (uint32_t)lane;
         sid[k] = (i < n) ? order[i] : 0xffffffffu;
     }
-    // 1 bit per splat first (a 0.8 MB array for 6.1 M splats: it stays in L2), so that only the splats that reach a tile
-    // pay for the random 8-byte gather of their rectangle from the N x 8 B array
+    // 1 byte per WAVE of calc_view first (96 KB for 6.1 M splats, cache resident), so that only positions
+    // whose 64 index neighbours hold a visible splat pay for the random 8-byte gather of their rectangle from the N x 8 B array
+    // (a culled splat beside visible ones has a zero rectangle there).  Visibility is coherent in index = Morton order -- 59 % of
+    // C2's waves hold no visible splat, the others are 89 % full -- so this is 2.5 M rectangle requests per frame instead of
+    // 6.1 M gathers of a per-splat visibility word + 2.3 M rectangles; this kernel is bound by the L2 request rate.
     uint32_t visw[kBinItems];
 #pragma unroll
-    for (int k = 0; k < kBinItems; ++k) visw[k] = (sid[k] != 0xffffffffu) ? visMask32[sid[k] >> 5] : 0u;
+    for (int k = 0; k < kBinItems; ++k) visw[k] = (sid[k] != 0xffffffffu) ? (uint32_t)wgVis[sid[k] >> 6] : 0u;
     uint32_t mySum = 0, myVis = 0;
 #pragma unroll
     for (int k = 0; k < kBinItems; ++k) {
         rc[k] = make_uint2(0u, 0u);
-        if ((visw[k] >> (sid[k] & 31u)) & 1u) rc[k] = rects[sid[k]];
+        if (visw[k]) rc[k] = rects[sid[k]];
         const uint32_t c = (rc[k].y & 0xffffu) * (rc[k].y >> 16);
         mySum += c;
         myVis += c ? 1u : 0u;
@@ -789,7 +792,7 @@ __global__ __launch_bounds__(256) void splat_depth_kernel(gsm::AssetView a, gsm:
 // blend_box evaluates the ray / box test of gs_device_math.h per pixel.
 template <bool CHUNKS>
 __global__ __launch_bounds__(256) void box_setup_kernel(gsm::AssetView a, gsm::FrameConsts P, gsm::RayConsts ray, uint32_t count, gsm::BoxRec* __restrict__ recs,
-                                                        uint2* __restrict__ rects, unsigned long long* __restrict__ visMask) {
+                                                        uint2* __restrict__ rects, unsigned long long* __restrict__ visMask, uint8_t* __restrict__ wgVis) {
     const uint32_t idx = blockIdx.x * 256u + threadIdx.x;
     bool visible = false;
     uint2 rect = make_uint2(0u, 0u);
@@ -836,6 +839,7 @@ __global__ __launch_bounds__(256) void box_setup_kernel(gsm::AssetView a, gsm::F
     }
     const unsigned long long vb = __ballot(visible);
     if ((threadIdx.x & 63u) == 0u && idx < count) visMask[idx >> 6] = vb;
+    if ((threadIdx.x & 63u) == 0u && idx < count) wgVis[idx >> 6] = vb != 0ull ? 1u : 0u;
 }
 
 template <int MODE, bool DEPTH>
@@ -1014,8 +1018,8 @@ int32_t renderer_alloc_raster(gs_renderer* r) {
     GS_HIP(hipMalloc((void**)&r->recW, (size_t)r->n * sizeof(float) + 64));
     GS_HIP(hipMalloc((void**)&r->rects, (size_t)r->n * sizeof(uint2) + 64));
     GS_HIP(hipMemsetAsync(r->rects, 0, (size_t)r->n * sizeof(uint2), ctx->stream));
-    GS_HIP(hipMalloc((void**)&r->visMask, ((size_t)r->n + 63) / 64 * 8 + 64));
-    GS_HIP(hipMemsetAsync(r->visMask, 0, ((size_t)r->n + 63) / 64 * 8, ctx->stream));
+    GS_HIP(hipMalloc((void**)&r->visMask, vis_alloc_bytes(r->n)));
+    GS_HIP(hipMemsetAsync(r->visMask, 0, vis_alloc_bytes(r->n), ctx->stream));
     if (r->pairCapacity == 0) {
         unsigned long long cap = (unsigned long long)r->n * 8ull;
         if (cap < (1ull << 22)) cap = 1ull << 22;
@@ -1101,7 +1105,7 @@ int32_t bin_and_sort(gs_renderer* r, const gs_frame_params* p, gs_target* rt, co
     const uint32_t binCap = max((uint32_t)ctx->cuCount * (uint32_t)GS_BIN_BLOCKS_PER_CU / kBinTicketClasses * kBinTicketClasses, kBinTicketClasses);
     const uint32_t binGrid = min(div_up(div_up(count, kBinPart), kBinTicketClasses) * kBinTicketClasses, binCap);
     const bool schedInBin = haveCosts && !forceOrderKernel;     // one extra workgroup makes the blend's tile schedule meanwhile
-    hipLaunchKernelGGL(binKernel, dim3(binGrid + (schedInBin ? 1u : 0u)), dim3(kBinThreads), 0, st, r->rects, (const uint32_t*)r->visMask, order, count, rc.tilesX, r->pairKeys,
+    hipLaunchKernelGGL(binKernel, dim3(binGrid + (schedInBin ? 1u : 0u)), dim3(kBinThreads), 0, st, r->rects, wg_vis_of(r->visMask, r->n), order, count, rc.tilesX, r->pairKeys,
                        r->pairVals, cap, binCtl, binStatus, binGroupAgg, binGroupBase, pairCtl->hist, r->pairSort.groupAgg, sort_group_words(cap, passes), (uint32_t*)nextArena, (uint32_t)(r->frameArenaBytes / 4), (uint32_t)bits,
                        o.costRead, numTiles, schedInBin ? o.tileOrder : (uint32_t*)nullptr);
     GS_TRY(mark_order_use(r));                                  // the next frame's depth sort may overwrite order[] from here on
@@ -1172,8 +1176,8 @@ int32_t enqueue_debug_boxes(gs_renderer* r, const gs_frame_params* p, gs_target*
     gsm::RayConsts ray;
     gsm::RayConstsFromFrame(ray, p->matrix_vp, p->proj_m00, p->proj_m11, p->cam_pos_world[0], p->cam_pos_world[1], p->cam_pos_world[2], (float)rt->width, (float)rt->height);
     prof_record(r, 7);
-    if (chunks) hipLaunchKernelGGL(box_setup_kernel<true>, dim3(div_up(count, 256)), dim3(256), 0, st, a, fc, ray, count, r->boxRecs, r->rects, r->visMask);
-    else hipLaunchKernelGGL(box_setup_kernel<false>, dim3(div_up(count, 256)), dim3(256), 0, st, a, fc, ray, count, r->boxRecs, r->rects, r->visMask);
+    if (chunks) hipLaunchKernelGGL(box_setup_kernel<true>, dim3(div_up(count, 256)), dim3(256), 0, st, a, fc, ray, count, r->boxRecs, r->rects, r->visMask, wg_vis_of(r->visMask, r->n));
+    else hipLaunchKernelGGL(box_setup_kernel<false>, dim3(div_up(count, 256)), dim3(256), 0, st, a, fc, ray, count, r->boxRecs, r->rects, r->visMask, wg_vis_of(r->visMask, r->n));
     prof_record(r, 8);
     r->viewValid = false;                                        // rects / visibility bits now describe the boxes: a splat draw needs calc_view again
     DrawSetup ds;
