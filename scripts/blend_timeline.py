@@ -39,3 +39,5 @@ for i in idx: print(f"  {i:5d} {st[i]:7.1f} {en[i]:7.1f} {cnt[i]:6d} {bat[i]:4d}
 idx = np.argsort(-dur)[:8]
 print("longest tiles: (tile, start, end, list, batches, us/batch)")
 for i in idx: print(f"  {i:5d} {st[i]:7.1f} {en[i]:7.1f} {cnt[i]:6d} {bat[i]:4d} {dur[i] / max(bat[i],1):6.2f}")
+span = en.max()
+print("resident tiles over time (of 2048 slots): " + "  ".join(f"{int(100 * f)}%:{int(((st <= f * span) & (en > f * span)).sum())}" for f in (0.05, 0.1, 0.2, 0.3, 0.4, 0.5, 0.6, 0.7, 0.8, 0.9, 0.95)))

@@ -602,6 +602,11 @@ __global__ __launch_bounds__(256) void blend_kernel(const uint32_t* __restrict__
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     if (blockIdx.x == 0 && tid == 0) write_report(binCtl, pairSortError, report);      // the first workgroup to run: before any tile is blended
     const uint32_t tile = tileOrder[blockIdx.x];
+    // tiles are dispatched heaviest first (tileOrder); the heaviest also get the higher issue priority on their SIMD, so that the longest
+    // survivor chains -- the launch lasts as long as they do -- are not slowed by the light tiles beside them (measured: -1 %)
+    if (blockIdx.x < 256u) __builtin_amdgcn_s_setprio(3);
+    else if (blockIdx.x < 768u) __builtin_amdgcn_s_setprio(2);
+    else if (blockIdx.x < 1536u) __builtin_amdgcn_s_setprio(1);
     const uint32_t tx = tile % rc.tilesX, ty = tile / rc.tilesX;
     const uint32_t start = tileStart[tile], end = tileEnd[tile];
 #ifdef GS_EXP_BLEND_TIMELINE
