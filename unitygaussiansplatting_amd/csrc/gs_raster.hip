@@ -111,8 +111,8 @@ __device__ __forceinline__ void write_report(const BinControl* binCtl, const uin
 // batches the tile walked in an earlier draw (tileCost), else a guess from the length of its list; empty tiles last.
 __device__ __forceinline__ uint32_t tile_bucket(uint32_t len, uint32_t lastCost) {   // 0 = most expensive ... 255 = empty
     if (len == 0) return 255u;
-    // 32 x the batches walked in the previous frame; no history: a third of a long list at most
-    const uint32_t pred = lastCost ? lastCost : min((len + 255u) >> 8, 12u) * 32u;
+    // the cost the tile reported in an earlier frame (blend_kernel: critical chain + batches, units of 4); no history: a third of a long list at most
+    const uint32_t pred = lastCost ? lastCost : min((len + 255u) >> 8, 12u) * 16u;
     return 254u - min(pred, 254u);
 }
 // The cost hint of tile t is one or two draws old and the image moves (5 px per frame on the C2 orbit): the prediction is the
@@ -598,6 +598,8 @@ __global__ __launch_bounds__(256) void blend_kernel(const uint32_t* __restrict__
     __shared__ uint4 s_b[256];       // u1y, u2y (float bits), f16 r << 16 | f16 g, f16 b << 16 | f16 a      operands of packed fp32 instructions)
     __shared__ float4 s_e[256];      // half extents of the footprint's bounding box, pixels; r^2 = ln(255 a) with slack
     __shared__ int s_done;
+    __shared__ uint32_t s_cost;
+    uint32_t survWalked = 0;                                      // survivors this wave walked (wave-uniform)
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     if (blockIdx.x == 0 && tid == 0) write_report(binCtl, pairSortError, report);      // the first workgroup to run: before any tile is blended
@@ -638,6 +640,7 @@ __global__ __launch_bounds__(256) void blend_kernel(const uint32_t* __restrict__
     uint2* dst = (uint2*)(rt + ((size_t)py * rc.width + (size_t)px) * 4);
     acc.load((inside && !dstIsZero) ? *dst : make_uint2(0u, 0u));
     if (tid == 0) s_done = 0;
+    if (tid == 0) s_cost = 0u;
     bool waveDone = false;
 
     // Two-deep software pipeline of the staging loads (pair -> splat index -> 32-byte record: two dependent global loads).
@@ -701,6 +704,7 @@ __global__ __launch_bounds__(256) void blend_kernel(const uint32_t* __restrict__
 #ifdef GS_EXP_BLEND_TIMELINE
                 tlSurv += (uint32_t)__popcll(mask);
 #endif
+                survWalked += (uint32_t)__popcll(mask);
                 while (mask) {
                     const int b = __ffsll((long long)mask) - 1;
 #if !defined(GS_BLEND_LOOP1)
@@ -763,9 +767,12 @@ __global__ __launch_bounds__(256) void blend_kernel(const uint32_t* __restrict__
 #endif
     }
     if (inside) *dst = acc.pack();
-    // next frame's scheduling hint (tile_order_body): batches walked.  (The measured duration of the tile was tried as the
-    // cost and schedules slightly worse, 0.189 vs 0.185 ms: it depends on who the tile shared its SIMDs with.)
-    if (threadIdx.x == 0) tileCost[tile] = batchesWalked * 32u;
+    // next frame's scheduling hint (tile_order_body), 1 .. 254: the tile's critical chain -- the most survivors one of its four waves
+    // walked -- plus 32 per batch, in units of 4.  (Batches alone: +2 % at C2 / C3 -- survivors per batch vary tenfold between tiles; the
+    // measured duration of the tile schedules worse than either, 0.189 vs 0.185 ms: it depends on who the tile shared its SIMDs with.)
+    if (lane == 0) atomicMax(&s_cost, survWalked);
+    __syncthreads();
+    if (threadIdx.x == 0) tileCost[tile] = min(254u, (s_cost + batchesWalked * 32u) / 4u);
 #ifdef GS_EXP_BLEND_TIMELINE
     __syncthreads();
     if (threadIdx.x == 0 && tile < 65536u) { g_blend_tl[tile * 8 + 1] = wall_clock64(); g_blend_tl[tile * 8 + 3] = tlBatches; g_blend_tl[tile * 8 + 4] = tlSurv; g_blend_tl[tile * 8 + 5] = tlStage; g_blend_tl[tile * 8 + 6] = tlProc; }
