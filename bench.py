@@ -70,8 +70,8 @@ def stage_bytes(n, P, vis, W, H, asset, passes_pair):
                                                                  # the last writes only the order: the sorted keys are materialised on demand)
         # pos/rot/scale/colour/chunk of every splat in, 8-B tile rect + 1 visibility bit out; the SH record is read and the
         # 32-B blend record written only for splats that reach the screen (the 40-B m_GpuView record is materialised on demand)
-        "calc_view": n * (b_asset - sh_item + 8 + 0.125) + vis * (sh_item + 32),
-        "bin": n * (4 + 0.125) + vis * 8 + P * 8,                # order + visibility bit per position, rect per visible splat, (tile, splat) pairs out
+        "calc_view": n * (b_asset - sh_item + 8 + 0.125 + 1.0 / 64) + vis * (sh_item + 32),   # (+ 1 flag byte per wave of 64 splats for the binning)
+        "bin": n * (4 + 1.0 / 64) + vis * 8 + P * 8,             # order + the wave's visibility byte per position, rect per visible splat, (tile, splat) pairs out
         "pair_sort": P * 16 * passes_pair + P * 4,               # Onesweep passes over the pairs + tile-range scan of the keys
         "blend": P * (4 + 32) + W * H * 16,                      # pair index + record per pair, RT read + write
         "resolve": W * H * (8 + 16),                             # RGBA16F in, float RGBA out (the 8-bit sRGB image is written only on request)
