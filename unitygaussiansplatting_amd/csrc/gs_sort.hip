@@ -218,9 +218,6 @@ __device__ unsigned long long g_timeline[16384 * 16];
 #ifndef GS_SORT_XCD_BLOCKS
 #define GS_SORT_XCD_BLOCKS 1
 #endif
-#ifndef GS_SORT_EARLY_VALS
-#define GS_SORT_EARLY_VALS 0
-#endif
 #ifndef GS_SORT_MINWAVES
 #define GS_SORT_MINWAVES 6      // <= 80 VGPRs: three 512-thread workgroups per CU (a handful of loop-invariant values spill to scratch)
 #endif
@@ -310,22 +307,6 @@ __global__ __launch_bounds__(THREADS, GS_SORT_MINWAVES) void onesweep_kernel(con
         if (tid == 0 && part < 16384u) g_timeline[part * 16u + 0] = tl0;
 #endif
         GS_TL(1);                                           // ticket taken, histogram cleared
-#if defined(GS_SORT_PRIO)
-        // experiment: the workgroups of a CU in issue-priority order instead of fair interleaving, so that they leave the ranking one
-        // after the other (and the memory phases of one overlap the ranking of the next) instead of all at the end of the sum
-        {
-#if GS_SORT_PRIO == 1
-            const uint32_t pr = (blockIdx.x / 256u) % 3u;
-#elif GS_SORT_PRIO == 2
-            const uint32_t pr = (part / 256u) % 3u;
-#else
-            const uint32_t pr = (part / 256u) % 2u + 1u;
-#endif
-            if (pr == 0u) __builtin_amdgcn_s_setprio(3);
-            else if (pr == 1u) __builtin_amdgcn_s_setprio(2);
-            else __builtin_amdgcn_s_setprio(0);
-        }
-#endif
 
         const uint32_t partBase = part * (uint32_t)PART;
         const uint32_t valid = min((uint32_t)PART, n - partBase);
@@ -362,22 +343,6 @@ __global__ __launch_bounds__(THREADS, GS_SORT_MINWAVES) void onesweep_kernel(con
             }
         }
 
-#if GS_SORT_EARLY_VALS
-        // experiment: the payload loads right behind the key loads, so that the memory pipes work while the partition ranks
-        // (loads return in order: the ranking only waits for the keys); 16 more registers live through the ranking
-        uint32_t val[KPT];
-        if (full) {
-            const uint32_t* vp = valsIn + waveBase;
-#pragma unroll
-            for (int k = 0; k < KPT; ++k) val[k] = ldg32(vp + k * 64, (uint32_t)lane);
-        } else {
-#pragma unroll
-            for (int k = 0; k < KPT; ++k) {
-                const uint32_t gi = waveBase + (uint32_t)k * 64u + lane;
-                val[k] = (gi < n) ? ldg32(valsIn, gi) : 0u;
-            }
-        }
-#endif
 #ifdef GS_EXP_SORT_TIMELINE
         { uint32_t x = 0;
 #pragma unroll
@@ -458,7 +423,6 @@ __global__ __launch_bounds__(THREADS, GS_SORT_MINWAVES) void onesweep_kernel(con
             s_buf[pos[k]] = key[k];
         }
         // payloads: issued now (the key registers are dead), consumed after the key write-out
-#if !GS_SORT_EARLY_VALS
         uint32_t val[KPT];
         if (full) {
             const uint32_t* vp = valsIn + waveBase;
@@ -471,7 +435,6 @@ __global__ __launch_bounds__(THREADS, GS_SORT_MINWAVES) void onesweep_kernel(con
                 val[k] = (gi < n) ? ldg32(valsIn, gi) : 0u;
             }
         }
-#endif
         GS_TL(4);                                           // keys scattered to LDS, payload loads issued
         // ---- look back over earlier partitions for digit `tid` (keys are parked in LDS by now, so the batch of
         //      status words below replaces the key registers instead of adding to them) ------------------------
