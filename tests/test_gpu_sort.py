@@ -131,3 +131,17 @@ def test_renderer_sort_is_bit_exact_over_frames(gpu_ctx, quality):
     r.ResetOrder()
     assert np.array_equal(r.DownloadOrder(), np.arange(a.splatCount, dtype=np.uint32))
     r.OnDisable()
+
+
+def test_every_sort_test_in_the_other_pass_shape():
+    """The sort picks one of two pass shapes by the expected key count (gs_sort.hip: 16 keys per thread / three workgroups per CU up to
+    24 M keys, 20 keys per thread / two workgroups per CU above).  The order may not depend on it: this file again, in a process that
+    pins shape B for every size (1 key ... 25 M keys, ties, every key width, the renderer's gather pass), and once more with A pinned
+    (sizes above the threshold take B by themselves in the run above)."""
+    import os, subprocess, sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    for shape in ("b", "a"):
+        env = dict(os.environ, GSPLAT_SORT_SHAPE=shape, PYTHONPATH=os.path.dirname(here) + os.pathsep + os.environ.get("PYTHONPATH", ""))
+        r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-x", "-k", "not other_pass_shape"],
+                           env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, f"shape {shape}:\n" + r.stdout[-3000:] + r.stderr[-2000:]

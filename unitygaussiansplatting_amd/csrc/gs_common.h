@@ -239,7 +239,8 @@ int32_t enqueue_histogram(gs_context* ctx, hipStream_t st, const uint32_t* keys,
 // gatherKeys != null (8-bit passes, an even number of them): the first pass reads its keys as gatherKeys[vals[i]].
 int32_t enqueue_sort_passes(gs_context* ctx, hipStream_t stream, SortState& st, SortControl* control, uint32_t* keys, uint32_t* vals,
                             uint32_t nUpper, const uint32_t* nPtr, int passes, uint32_t lastMask = 255u,
-                            gs_renderer* profR = nullptr, int evFirst = -1, int bitsPerPass = 8, const uint32_t* gatherKeys = nullptr, bool skipLastKeys = false);
+                            gs_renderer* profR = nullptr, int evFirst = -1, int bitsPerPass = 8, const uint32_t* gatherKeys = nullptr, bool skipLastKeys = false,
+                            uint32_t expected = 0);   // expected: the key count to tune the pass shape for when nUpper is only a bound (0 = nUpper)
 int32_t enqueue_gather_keys(gs_context* ctx, const uint32_t* keyBySplat, const uint32_t* order, uint32_t* out, uint32_t n);
 constexpr uint32_t kSortMaxCount = 1u << 30;   // 32-bit byte offsets inside the sort kernels
 int32_t enqueue_set_indices(gs_context* ctx, uint32_t* order, uint32_t n);

@@ -1122,7 +1122,11 @@ int32_t bin_and_sort(gs_renderer* r, const gs_frame_params* p, gs_target* rt, co
                        o.costRead, numTiles, schedInBin ? o.tileOrder : (uint32_t*)nullptr);
     GS_TRY(mark_order_use(r));                                  // the next frame's depth sort may overwrite order[] from here on
     prof_record(r, 4);
-    GS_TRY(enqueue_sort_passes(ctx, st, r->pairSort, pairCtl, r->pairKeys, r->pairVals, cap, &binCtl->pairCountClamped, passes, 255u, r, 12, bits));
+    // the host only knows the capacity; the pair count of the last finished frame (pinned report) picks the sort's pass shape
+    const unsigned long long lastPairs = r->hostReport ? *(volatile unsigned long long*)&r->hostReport->pairCount : 0ull;
+    const uint32_t expectPairs = (uint32_t)(lastPairs < (unsigned long long)cap ? lastPairs : (unsigned long long)cap);
+    GS_TRY(enqueue_sort_passes(ctx, st, r->pairSort, pairCtl, r->pairKeys, r->pairVals, cap, &binCtl->pairCountClamped, passes, 255u, r, 12, bits, nullptr, false,
+                               expectPairs ? expectPairs : 1u));
     hipLaunchKernelGGL(tile_ranges_kernel, dim3(max(1u, min(div_up(cap, 2048), (uint32_t)ctx->cuCount * 8u))), dim3(256), 0, st, r->pairKeys,
                        &binCtl->pairCountClamped, o.tileStart, o.tileEnd, numTiles);
     r->lastPairPasses = (uint32_t)passes;

@@ -25,6 +25,7 @@
 // key[order[i]] itself (GATHER instantiation), so CSCalcDistances' random access is a single 4-byte gather hidden
 // inside a pass that is resident anyway, instead of a kernel of its own that waits on a position + ChunkInfo gather.
 #include "gs_common.h"
+#include <cstdlib>
 
 namespace gs {
 
@@ -39,8 +40,14 @@ constexpr int RADIX = 256;
 #endif
 constexpr int THREADS = GS_SORT_THREADS;
 constexpr int WAVES = THREADS / 64;
-constexpr int KPT = GS_SORT_KPT;
-constexpr int PART = THREADS * KPT;
+// Two shapes of a pass, chosen per sort by the expected key count (enqueue_sort_passes):
+//   A  16 keys per thread, 8,192-key partitions, <= 80 VGPRs: three workgroups per CU -- up to 768 partitions (6.3 M keys) in ONE round;
+//   B  20 keys per thread, 10,240-key partitions, <= 128 VGPRs: two workgroups per CU -- longer runs per digit (160-byte stores), a fifth
+//      fewer status words and look-back steps: 8 % faster on 50 M keys, 9 % slower on 6 M (599 partitions on 512 slots = two rounds).
+// All sizing (status words, group words) follows shape A, which has the most partitions.
+constexpr int KPT_A = GS_SORT_KPT, KPT_B = 20;
+constexpr int PART_A = THREADS * KPT_A, PART_B = THREADS * KPT_B;
+constexpr uint32_t kBigSortKeys = 24u << 20;          // expected keys above which shape B is used (four rounds of shape A)
 constexpr uint32_t SPIN_LIMIT = 1u << 24;
 constexpr uint32_t TICKET_CLASSES = 16;        // partition-ticket counters per pass (one 128-B line each)
 #ifndef GS_SORT_GROUP
@@ -50,7 +57,7 @@ constexpr int GROUP = GS_SORT_GROUP;                     // partitions per look-
 
 // per-(partition, digit) status word: {epoch:18 | count:14}; valid for a pass iff its epoch field equals the pass's epoch
 constexpr uint32_t COUNT_BITS = 14, EPOCH_MASK = (1u << 18) - 1u;
-static_assert(PART < (1 << COUNT_BITS), "a partition's digit count must fit the status word");
+static_assert(PART_A < (1 << COUNT_BITS) && PART_B < (1 << COUNT_BITS), "a partition's digit count must fit the status word");
 __device__ __forceinline__ uint32_t pack_status(uint32_t epoch, uint32_t count) { return (epoch << COUNT_BITS) | count; }
 __device__ __forceinline__ uint32_t ld_status(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ unsigned long long ld_word64(const unsigned long long* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -221,12 +228,13 @@ __device__ unsigned long long g_timeline[16384 * 16];
 #ifndef GS_SORT_MINWAVES
 #define GS_SORT_MINWAVES 6      // <= 80 VGPRs: three 512-thread workgroups per CU (a handful of loop-invariant values spill to scratch)
 #endif
-template <int BITS, bool GATHER>
-__global__ __launch_bounds__(THREADS, GS_SORT_MINWAVES) void onesweep_kernel(const uint32_t* __restrict__ keysIn, const uint32_t* __restrict__ valsIn,
+template <int BITS, bool GATHER, int KPT>
+__global__ __launch_bounds__(THREADS, KPT == KPT_A ? GS_SORT_MINWAVES : 4) void onesweep_kernel(const uint32_t* __restrict__ keysIn, const uint32_t* __restrict__ valsIn,
                                                            uint32_t* __restrict__ keysOut, uint32_t* __restrict__ valsOut,
                                                            const uint32_t* __restrict__ hist, uint32_t* status,
                                                            unsigned long long* groupAgg, unsigned long long* groupIncl, uint32_t* ticket, uint32_t* error,
                                                            uint32_t nImm, const uint32_t* nPtr, uint32_t shift, uint32_t epoch, uint32_t digitMask) {
+    constexpr int PART = THREADS * KPT;              // keys per partition
     constexpr int RDX = 1 << BITS;                   // digits of this pass
     constexpr int DW = (RDX + 63) / 64;              // waves that own digits
     __shared__ uint32_t s_hist[WAVES * RDX];         // per-wave digit counts -> wave-exclusive offsets
@@ -246,7 +254,7 @@ __global__ __launch_bounds__(THREADS, GS_SORT_MINWAVES) void onesweep_kernel(con
     // block is no larger than what one XCD runs at once (32 CUs x 3 workgroups), so that every XCD gets the same number of
     // blocks (measured on C2, 749 partitions: blocks of 94 -> 156 us per depth sort, 32 -> 165, 64 (unbalanced) -> 179)
 #ifndef GS_SORT_XCD_MAXBLOCK
-#define GS_SORT_XCD_MAXBLOCK 96
+#define GS_SORT_XCD_MAXBLOCK (KPT == KPT_A ? 96 : 64)
 #endif
     const uint32_t xcdRounds = (numParts + 8u * GS_SORT_XCD_MAXBLOCK - 1u) / (8u * GS_SORT_XCD_MAXBLOCK);
     const uint32_t xcdBlock = max(1u, (numParts + 8u * max(xcdRounds, 1u) - 1u) / (8u * max(xcdRounds, 1u)));
@@ -579,7 +587,7 @@ extern "C" int32_t gs_debug_read_sort_timeline(void* out, size_t bytes) {
 int32_t sort_state_create(gs_context* ctx, SortState& st, uint32_t maxCount) {
     if (maxCount > kSortMaxCount) return fail(GS_ERR_INVALID_ARGUMENT, "sort capacity above 2^30 keys");
     st.maxCount = maxCount;
-    st.maxParts = div_up(maxCount > 0 ? maxCount : 1, PART);
+    st.maxParts = div_up(maxCount > 0 ? maxCount : 1, PART_A);
     GS_HIP(hipMalloc((void**)&st.altKeys, ((size_t)maxCount + 16) * 4));
     GS_HIP(hipMalloc((void**)&st.altVals, ((size_t)maxCount + 16) * 4));
     GS_HIP(hipMalloc((void**)&st.status, (size_t)st.maxParts * RADIX * 4));
@@ -616,7 +624,7 @@ int32_t enqueue_set_indices(gs_context* ctx, uint32_t* order, uint32_t n) {
     return GS_OK;
 }
 
-uint32_t sort_group_words(uint32_t nUpper, int passes) { return (uint32_t)passes * div_up(div_up(max(nUpper, 1u), PART), (uint32_t)GROUP) * RADIX; }
+uint32_t sort_group_words(uint32_t nUpper, int passes) { return (uint32_t)passes * div_up(div_up(max(nUpper, 1u), PART_A), (uint32_t)GROUP) * RADIX; }
 
 int32_t enqueue_sort_keys(gs_context* ctx, hipStream_t stream, const gsm::AssetView& a, const float* m, uint32_t* keyBySplat,
                           SortControl* control, SortControl* nextControl, uint32_t n, SortState& st) {
@@ -645,18 +653,23 @@ int32_t enqueue_histogram(gs_context* ctx, hipStream_t stream, const uint32_t* k
 
 int32_t enqueue_sort_passes(gs_context* ctx, hipStream_t stream, SortState& st, SortControl* control, uint32_t* keys, uint32_t* vals, uint32_t nUpper,
                             const uint32_t* nPtr, int passes, uint32_t lastMask, gs_renderer* profR, int evFirst, int bits, const uint32_t* gatherKeys,
-                            bool skipLastKeys) {
+                            bool skipLastKeys, uint32_t expected) {
     if (passes < 1 || passes > 4) return fail(GS_ERR_INVALID_ARGUMENT, "sort passes");
     if (bits < 6 || bits > 8 || (gatherKeys && bits != 8)) return fail(GS_ERR_INVALID_ARGUMENT, "sort digit width");
     if (nUpper > st.maxCount) return fail(GS_ERR_INVALID_ARGUMENT, "sort count exceeds sorter capacity");
     if (nUpper == 0) return GS_OK;
-    const uint32_t parts = div_up(nUpper, PART);
-    // persistent grid: no more workgroups than are resident at once (3 per CU at <= 80 VGPRs / 43 KB LDS), a multiple of
-    // the ticket classes so that every class is served
-    const uint32_t capacity = max(((uint32_t)ctx->cuCount * 3u / TICKET_CLASSES) * TICKET_CLASSES, TICKET_CLASSES);
+    // shape by the expected key count (the pair sort knows only an upper bound on the host: the caller passes the last frame's count);
+    // the order produced is the same either way.  GSPLAT_SORT_SHAPE=a|b pins it (tests run every size through both).
+    static const int forcedShape = [] { const char* e = getenv("GSPLAT_SORT_SHAPE"); return !e ? 0 : (e[0] == 'a' || e[0] == 'A') ? 1 : (e[0] == 'b' || e[0] == 'B') ? 2 : 0; }();
+    const uint32_t expect = min(expected ? expected : nUpper, nUpper);
+    const bool shapeB = forcedShape ? forcedShape == 2 : expect > kBigSortKeys;
+    const uint32_t parts = div_up(nUpper, shapeB ? (uint32_t)PART_B : (uint32_t)PART_A);
+    // persistent grid: no more workgroups than are resident at once (3 per CU at <= 80 VGPRs / 43 KB LDS, 2 at <= 128 / 52 KB), a
+    // multiple of the ticket classes so that every class is served
+    const uint32_t capacity = max(((uint32_t)ctx->cuCount * (shapeB ? 2u : 3u) / TICKET_CLASSES) * TICKET_CLASSES, TICKET_CLASSES);
     const uint32_t grid = min(div_up(parts, TICKET_CLASSES) * TICKET_CLASSES, capacity);
     uint32_t *ks = keys, *vs = vals, *kd = st.altKeys, *vd = st.altVals;
-    const uint32_t groups = div_up(parts, (uint32_t)GROUP);
+    const uint32_t groups = div_up(div_up(nUpper, (uint32_t)PART_A), (uint32_t)GROUP);       // per-pass stride of the group words: sort_group_words()
     const uint32_t fullMask = (1u << bits) - 1u;
     // st.groupAgg[passes][groups][256] accumulates: it was zeroed by the kernel that produced the keys / their histograms
     if (profR && evFirst >= 0) prof_record(profR, evFirst, stream);
@@ -672,14 +685,16 @@ int32_t enqueue_sort_passes(gs_context* ctx, hipStream_t stream, SortState& st, 
         const uint32_t mask = p == passes - 1 ? (lastMask & fullMask) : fullMask;
         const uint32_t shift = (uint32_t)(bits * p);
         uint32_t* kdst = (skipLastKeys && p == passes - 1) ? (uint32_t*)nullptr : kd;      // the payload (order) is all the caller wants
-#define GS_LAUNCH_ONESWEEP(B, G, KIN) \
-        hipLaunchKernelGGL((onesweep_kernel<B, G>), dim3(grid), dim3(THREADS), 0, stream, KIN, vs, kdst, vd, hist, st.status, agg, st.groupIncl, \
+#define GS_LAUNCH_ONESWEEP_K(B, G, KIN, K) \
+        hipLaunchKernelGGL((onesweep_kernel<B, G, K>), dim3(grid), dim3(THREADS), 0, stream, KIN, vs, kdst, vd, hist, st.status, agg, st.groupIncl, \
                            control->tickets[p], &control->error, nUpper, nPtr, shift, epoch, mask)
+#define GS_LAUNCH_ONESWEEP(B, G, KIN) do { if (shapeB) GS_LAUNCH_ONESWEEP_K(B, G, KIN, KPT_B); else GS_LAUNCH_ONESWEEP_K(B, G, KIN, KPT_A); } while (0)
         if (p == 0 && gatherKeys) GS_LAUNCH_ONESWEEP(8, true, gatherKeys);
         else if (bits == 8) GS_LAUNCH_ONESWEEP(8, false, ks);
         else if (bits == 7) GS_LAUNCH_ONESWEEP(7, false, ks);
         else GS_LAUNCH_ONESWEEP(6, false, ks);
 #undef GS_LAUNCH_ONESWEEP
+#undef GS_LAUNCH_ONESWEEP_K
         uint32_t* t = ks; ks = kd; kd = t;
         t = vs; vs = vd; vd = t;
     }
