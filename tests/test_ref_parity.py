@@ -281,3 +281,28 @@ def test_frame_through_the_reference_shaders_larger_scene():
     got = ref.draw(cam.pixelWidth, cam.pixelHeight, P.near_clip, P.far_clip)[::-1].copy()
     e = rt_diff(got, want).max(axis=-1)
     assert e.max() <= RT_TOL and (e == 0).mean() >= 0.95, (e.max() / RT_TOL, (e == 0).mean())
+
+
+@pytest.mark.parametrize("key", ["C2", "C3", "C2d"])
+def test_bench_scenes_are_pinned_too(key):
+    """The workloads bench.py measures (scenes.CONFIGS: their scale / opacity / position distributions, presets, cameras and target
+    sizes), 60 k splats of each: keys and the whole view record from the fused build of the reference's text are the oracle's bit for bit
+    at the bench's own camera, a quarter turn on and from inside the cloud -- so the parity the bench lines report against the oracle is
+    parity with the reference's arithmetic on that data, not only on tests/common.py's small assets."""
+    from unitygaussiansplatting_amd import creator, scenes
+    cfg = scenes.CONFIGS[key]
+    a = creator.CreateAssetFromSplats(scenes.make_config_splats(cfg, 60_000), cfg.quality, name=key)
+    orc, ref = O.Oracle(a), R.Ref(a, "fused")
+    assert np.array_equal(ref.decode_all().view(np.uint32), orc.decode_all().view(np.uint32)), "LoadSplatData differs"
+    tr = camera.Transform()
+    drawn = 0
+    for az, radius in [(0.0, cfg.eye_radius), (90.25, cfg.eye_radius), (200.0, 0.15 * cfg.eye_radius)]:
+        cam = camera.Camera(position=scenes.orbit_eye(radius, cfg.eye_elev_deg, az), pixelWidth=cfg.width, pixelHeight=cfg.height, fieldOfView=cfg.fov_y)
+        ms = camera.sort_matrix(cam, tr.localToWorldMatrix)
+        orc.reset_order(); ref.set_indices()
+        assert np.array_equal(ref.calc_distances(ms), orc.calc_distances(ms)), "CSCalcDistances keys differ"
+        P = camera.frame_params(cam, tr)
+        vo, vr = orc.calc_view(P), ref.calc_view(P)
+        assert views_equal(vr, vo), "40-byte SplatViewData records differ"
+        drawn += int((vo["pos"][:, 3] > 0).sum())
+    assert drawn > 30_000
