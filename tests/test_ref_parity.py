@@ -306,3 +306,30 @@ def test_bench_scenes_are_pinned_too(key):
         assert views_equal(vr, vo), "40-byte SplatViewData records differ"
         drawn += int((vo["pos"][:, 3] > 0).sum())
     assert drawn > 30_000
+
+
+@pytest.mark.parametrize("key", ["C2", "C2d"])
+def test_bench_scene_frame_through_the_reference_shaders(key):
+    """A frame of a bench scene's sample (40 k splats, the bench camera, a quarter of the target's size) rasterised through the
+    reference's own vert + frag: the oracle's frame within the framebuffer bar.  C2d's splats are large (17 tiles per visible splat at
+    full size): thousands of blends per pixel, the case where a per-blend rounding difference would accumulate."""
+    from unitygaussiansplatting_amd import creator, scenes
+    cfg = scenes.CONFIGS[key]
+    a = creator.CreateAssetFromSplats(scenes.make_config_splats(cfg, 40_000), cfg.quality, name=key)
+    W, H = cfg.width // 4, cfg.height // 4
+    cam = camera.Camera(position=scenes.orbit_eye(cfg.eye_radius, cfg.eye_elev_deg, 0.0), pixelWidth=W, pixelHeight=H, fieldOfView=cfg.fov_y)
+    tr = camera.Transform()
+    orc, ref = O.Oracle(a), R.Ref(a, "fused")
+    ms = camera.sort_matrix(cam, tr.localToWorldMatrix)
+    orc.sort(ms)
+    ref.set_indices()
+    _, ref.order = O.sort_pairs(ref.calc_distances(ms), ref.order)
+    assert np.array_equal(ref.order, orc.order)
+    P = camera.frame_params(cam, tr)
+    orc.calc_view(P)
+    want = orc.draw(P, 0)
+    ref.calc_view(R.flipped(P))
+    got = ref.draw(W, H, P.near_clip, P.far_clip)[::-1].copy()
+    e = rt_diff(got, want).max(axis=-1)
+    assert (want.view(np.uint16)[..., 3] != 0).mean() > 0.2                 # the frame is not empty
+    assert e.max() <= RT_TOL and (e == 0).mean() >= 0.9, (e.max() / RT_TOL, (e == 0).mean())
