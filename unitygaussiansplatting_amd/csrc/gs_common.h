@@ -58,7 +58,7 @@ struct ViewOutputs {
 // first.  It lives in visMask's allocation at an offset that follows from N, so that calc_view_kernel -- whose SGPRs are full of frame
 // constants: one more pointer argument spills a dozen of them to VGPR lanes, +4 % -- needs no argument for it.
 __host__ __device__ inline size_t vis_mask_words(uint32_t n) { return (((size_t)n + 63) / 64 + 7) & ~(size_t)7; }
-__host__ __device__ inline uint8_t* wg_vis_of(unsigned long long* visMask, uint32_t n) { return (uint8_t*)(visMask + vis_mask_words(n)); }
+__host__ __device__ inline uint8_t* wave_flags_of(unsigned long long* visMask, uint32_t n) { return (uint8_t*)(visMask + vis_mask_words(n)); }
 __host__ __device__ inline size_t vis_alloc_bytes(uint32_t n) { return vis_mask_words(n) * 8 + ((size_t)n + 63) / 64 + 64; }
 
 // Onesweep look-back state for one sort (shared by all passes: every pass uses a fresh epoch)
@@ -168,7 +168,7 @@ struct gs_renderer {
     uint32_t* chunkOrder = nullptr;         // identity order of the chunks (DebugChunkBounds draws them in index order)
     float* recW = nullptr;                  // N x 4 B: clip.w of the visible splats, filled by the draw only when the target has a depth attachment
     uint2* rects = nullptr;                 // N x 8 B: x = tx0 | ty0 << 16, y = tiles wide | tiles high << 16 (0 = culled)
-    unsigned long long* visMask = nullptr;  // ceil(N/64) x 8 B: bit s = splat s reaches at least one tile (written by calc_view); + ceil(N/64) B per-wave flags (wg_vis_of)
+    unsigned long long* visMask = nullptr;  // ceil(N/64) x 8 B: bit s = splat s reaches at least one tile (written by calc_view); + ceil(N/64) B per-wave flags (wave_flags_of)
     // edit state read by calc_view (m_GpuEditDeleted / m_GpuEditCutouts, GaussianSplatRenderer.cs:266,269)
     uint32_t* deletedBits = nullptr;        // ceil(N/32) words, or null (_SplatBitsValid = 0)
     uint32_t* cutouts = nullptr;            // GS_MAX_CUTOUTS x 17 dwords

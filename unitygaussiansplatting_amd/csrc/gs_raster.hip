@@ -209,7 +209,7 @@ __device__ unsigned long long g_bin_tl[32768 * 8];
 #define GS_BTL(k) do { } while (0)
 #endif
 template <int PASSES>
-__global__ __launch_bounds__(kBinThreads, GS_BIN_MINWAVES) void bin_emit_kernel(const uint2* __restrict__ rects, const uint8_t* __restrict__ wgVis,
+__global__ __launch_bounds__(kBinThreads, GS_BIN_MINWAVES) void bin_emit_kernel(const uint2* __restrict__ rects, const uint8_t* __restrict__ waveFlags,
                                                                 const uint32_t* __restrict__ order, uint32_t n, uint32_t tilesX,
                                                                 uint32_t* __restrict__ pairKeys, uint32_t* __restrict__ pairVals,
                                                                 uint32_t capacity, BinControl* ctl, unsigned long long* binStatus, unsigned long long* binGroupAgg, unsigned long long* binGroupBase,
@@ -281,7 +281,7 @@ __global__ __launch_bounds__(kBinThreads, GS_BIN_MINWAVES) void bin_emit_kernel(
     // 6.1 M gathers of a per-splat visibility word + 2.3 M rectangles; this kernel is bound by the L2 request rate.
     uint32_t visw[kBinItems];
 #pragma unroll
-    for (int k = 0; k < kBinItems; ++k) visw[k] = (sid[k] != 0xffffffffu) ? (uint32_t)wgVis[sid[k] >> 6] : 0u;
+    for (int k = 0; k < kBinItems; ++k) visw[k] = (sid[k] != 0xffffffffu) ? (uint32_t)waveFlags[sid[k] >> 6] : 0u;
     uint32_t mySum = 0, myVis = 0;
 #pragma unroll
     for (int k = 0; k < kBinItems; ++k) {
@@ -804,7 +804,7 @@ __global__ __launch_bounds__(256) void splat_depth_kernel(gsm::AssetView a, gsm:
 // blend_box evaluates the ray / box test of gs_device_math.h per pixel.
 template <bool CHUNKS>
 __global__ __launch_bounds__(256) void box_setup_kernel(gsm::AssetView a, gsm::FrameConsts P, gsm::RayConsts ray, uint32_t count, gsm::BoxRec* __restrict__ recs,
-                                                        uint2* __restrict__ rects, unsigned long long* __restrict__ visMask, uint8_t* __restrict__ wgVis) {
+                                                        uint2* __restrict__ rects, unsigned long long* __restrict__ visMask, uint8_t* __restrict__ waveFlags) {
     const uint32_t idx = blockIdx.x * 256u + threadIdx.x;
     bool visible = false;
     uint2 rect = make_uint2(0u, 0u);
@@ -851,7 +851,7 @@ __global__ __launch_bounds__(256) void box_setup_kernel(gsm::AssetView a, gsm::F
     }
     const unsigned long long vb = __ballot(visible);
     if ((threadIdx.x & 63u) == 0u && idx < count) visMask[idx >> 6] = vb;
-    if ((threadIdx.x & 63u) == 0u && idx < count) wgVis[idx >> 6] = vb != 0ull ? 1u : 0u;
+    if ((threadIdx.x & 63u) == 0u && idx < count) waveFlags[idx >> 6] = vb != 0ull ? 1u : 0u;
 }
 
 template <int MODE, bool DEPTH>
@@ -1117,7 +1117,7 @@ int32_t bin_and_sort(gs_renderer* r, const gs_frame_params* p, gs_target* rt, co
     const uint32_t binCap = max((uint32_t)ctx->cuCount * (uint32_t)GS_BIN_BLOCKS_PER_CU / kBinTicketClasses * kBinTicketClasses, kBinTicketClasses);
     const uint32_t binGrid = min(div_up(div_up(count, kBinPart), kBinTicketClasses) * kBinTicketClasses, binCap);
     const bool schedInBin = haveCosts && !forceOrderKernel;     // one extra workgroup makes the blend's tile schedule meanwhile
-    hipLaunchKernelGGL(binKernel, dim3(binGrid + (schedInBin ? 1u : 0u)), dim3(kBinThreads), 0, st, r->rects, wg_vis_of(r->visMask, r->n), order, count, rc.tilesX, r->pairKeys,
+    hipLaunchKernelGGL(binKernel, dim3(binGrid + (schedInBin ? 1u : 0u)), dim3(kBinThreads), 0, st, r->rects, wave_flags_of(r->visMask, r->n), order, count, rc.tilesX, r->pairKeys,
                        r->pairVals, cap, binCtl, binStatus, binGroupAgg, binGroupBase, pairCtl->hist, r->pairSort.groupAgg, sort_group_words(cap, passes), (uint32_t*)nextArena, (uint32_t)(r->frameArenaBytes / 4), (uint32_t)bits,
                        o.costRead, numTiles, schedInBin ? o.tileOrder : (uint32_t*)nullptr);
     GS_TRY(mark_order_use(r));                                  // the next frame's depth sort may overwrite order[] from here on
@@ -1192,8 +1192,8 @@ int32_t enqueue_debug_boxes(gs_renderer* r, const gs_frame_params* p, gs_target*
     gsm::RayConsts ray;
     gsm::RayConstsFromFrame(ray, p->matrix_vp, p->proj_m00, p->proj_m11, p->cam_pos_world[0], p->cam_pos_world[1], p->cam_pos_world[2], (float)rt->width, (float)rt->height);
     prof_record(r, 7);
-    if (chunks) hipLaunchKernelGGL(box_setup_kernel<true>, dim3(div_up(count, 256)), dim3(256), 0, st, a, fc, ray, count, r->boxRecs, r->rects, r->visMask, wg_vis_of(r->visMask, r->n));
-    else hipLaunchKernelGGL(box_setup_kernel<false>, dim3(div_up(count, 256)), dim3(256), 0, st, a, fc, ray, count, r->boxRecs, r->rects, r->visMask, wg_vis_of(r->visMask, r->n));
+    if (chunks) hipLaunchKernelGGL(box_setup_kernel<true>, dim3(div_up(count, 256)), dim3(256), 0, st, a, fc, ray, count, r->boxRecs, r->rects, r->visMask, wave_flags_of(r->visMask, r->n));
+    else hipLaunchKernelGGL(box_setup_kernel<false>, dim3(div_up(count, 256)), dim3(256), 0, st, a, fc, ray, count, r->boxRecs, r->rects, r->visMask, wave_flags_of(r->visMask, r->n));
     prof_record(r, 8);
     r->viewValid = false;                                        // rects / visibility bits now describe the boxes: a splat draw needs calc_view again
     DrawSetup ds;

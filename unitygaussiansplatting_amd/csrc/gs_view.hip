@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256) void calc_view_kernel(gsm::AssetView a, gsm::F
             if (outside) {                                                                    // workgroup-uniform
                 if (idx < a.n) rects[idx] = make_uint2(0u, 0u);
                 if ((threadIdx.x & 63u) == 0u && idx < a.n) visMask[idx >> 6] = 0ull;
-                if ((threadIdx.x & 63u) == 0u && idx < a.n) wg_vis_of(visMask, a.n)[idx >> 6] = 0u;
+                if ((threadIdx.x & 63u) == 0u && idx < a.n) wave_flags_of(visMask, a.n)[idx >> 6] = 0u;
                 return;
             }
         }
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(256) void calc_view_kernel(gsm::AssetView a, gsm::F
     if ((threadIdx.x & 63u) == 0u && (idx < a.n)) visMask[idx >> 6] = vb;          // 1 bit per splat
     // 1 byte per wave: what the binning pass tests first (N / 64 bytes, cache resident: a position of the depth order whose 64 index
     // neighbours are all culled costs the binning no further memory request)
-    if ((threadIdx.x & 63u) == 0u && (idx < a.n)) wg_vis_of(visMask, a.n)[idx >> 6] = vb != 0ull ? 1u : 0u;
+    if ((threadIdx.x & 63u) == 0u && (idx < a.n)) wave_flags_of(visMask, a.n)[idx >> 6] = vb != 0ull ? 1u : 0u;
     if (!FULL) return;
 
     // ---- FULL: the 40-byte records, staged through LDS so that the global stores are whole uint4s
