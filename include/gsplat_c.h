@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GS_ABI_VERSION 5
+#define GS_ABI_VERSION 6
 
 typedef enum gs_error {
     GS_OK = 0,
@@ -113,11 +113,12 @@ typedef struct gs_cutout {
 } gs_cutout;
 
 typedef struct gs_frame_stats {
-    uint64_t tile_pairs;        /* P: (16x16 tile, splat) overlaps emitted by the binning kernel this frame */
+    uint64_t tile_pairs;        /* P: (tile, splat) overlaps emitted by the binning kernel this frame, tiles of tile_w x tile_h pixels */
     uint64_t pair_capacity;     /* current capacity of the pair buffers */
     uint32_t visible_splats;    /* splats that survived culling (emitted >= 1 pair) */
     uint32_t tiles_x, tiles_y;
     uint32_t sort_error;        /* != 0 => GS_ERR_SORT_TIMEOUT was raised */
+    uint32_t tile_w, tile_h;    /* the compositor tile of the last draw, pixels (16x16, 32x16 or 32x32: gs_renderer_set_tile_shape) */
 } gs_frame_stats;
 
 /* hipEvent-timed stage durations of the last frame, ms (the four ProfilerMarkers of
@@ -233,6 +234,12 @@ int32_t gs_renderer_set_render_mode(gs_renderer* r, int32_t mode, float point_di
 /* 0 (default): "exact" -- accumulate in fp16 (RTNE after every blend, like the RGBA16F ROP).
  * 1: "fast" -- accumulate in fp32, stop a pixel when 1-A < 1/4096. */
 int32_t gs_renderer_set_blend_mode(gs_renderer* r, int32_t mode);
+/* The compositor's tile, pixels: 16x16, 32x16 or 32x32; 0, 0 (default) = chosen per target size.  The reference has no such
+ * parameter (its rasteriser is fixed-function); here it trades (tile, splat) pairs to list and sort against records each wave
+ * tests per pixel block.  A performance knob only: the frame is bit-identical whatever the shape.  gs_renderer_tile_shape
+ * reports what a draw into a width x height target uses (the override, else the automatic choice, which GSPLAT_TILE=WxH pins). */
+int32_t gs_renderer_set_tile_shape(gs_renderer* r, uint32_t tile_w, uint32_t tile_h);
+int32_t gs_renderer_tile_shape(const gs_renderer* r, uint32_t width, uint32_t height, uint32_t* tile_w, uint32_t* tile_h);
 /* frames = 0: off.  frames > 0: keep a ring of `frames` per-frame hipEvent sets (no host sync while rendering);
  * a frame ends at gs_renderer_draw.  gs_renderer_stage_times averages over the ring and resets it. */
 int32_t gs_renderer_set_profiling(gs_renderer* r, int32_t frames);
@@ -245,7 +252,7 @@ int32_t gs_renderer_download_view(gs_renderer* r, void* out, size_t bytes);     
 /* What the last gs_renderer_calc_view left for the compositor (the per-frame launch, NOT the on-demand full kernel), in
  * splat-index order; any pointer may be NULL:
  *   recs      N x 32 B  {cx, cy, axis1.xy, axis2.xy (float, pixels, y down), f16 r<<16|g, f16 b<<16|a}; only meaningful where visible
- *   rects     N x 2 u32 {tile x0 | y0 << 16, tiles wide | tiles high << 16} of the footprint's inclusive 16x16-tile rectangle; 0,0 = not drawn
+ *   rects     N x 2 u32 {x0 | y0 << 16, (x1 + 1) | (y1 + 1) << 16}: the footprint's inclusive pixel rectangle clamped to the screen; 0,0 = not drawn
  *   vis_mask  ceil(N/64) u64, bit s = splat s reaches at least one tile */
 int32_t gs_renderer_download_raster_records(gs_renderer* r, void* recs, uint32_t* rects, uint64_t* vis_mask);
 int32_t gs_renderer_frame_stats(gs_renderer* r, gs_frame_stats* out);                   /* blocks; reports + clears overflow/timeouts */

@@ -565,9 +565,13 @@ struct Prepared {
     float r, g, b, a;       // colour as the vertex shader unpacks it (f16 -> f32)
     float w;                // view depth of the centre (clip.w): the depth every fragment of the quad is tested with
     int x0, x1, y0, y1;     // pixel rect of the quad's bounding box, clamped to the screen (x0>x1 => nothing)
-    int tx0, tx1, ty0, ty1; // 16x16 tile rect of the *tight* footprint used by the shipped binning kernel
+    int bx0, bx1, by0, by1; // pixel rect of the *tight* footprint used by the shipped binning kernel (bx0 > bx1 => nothing)
+    int tx0, tx1, ty0, ty1; // ... as a rectangle of tiles of the shape set by gso_set_tile_shape (default 16x16)
     bool valid;
 };
+// The compositor tile of the build under test (a performance parameter of the product: 16x16, 32x16 or 32x32 pixels).  Only the
+// (tile, splat) pair COUNT depends on it; frames, records and pixel rectangles do not.
+int g_tile_wl = 4, g_tile_hl = 4;
 
 // ln(x), x positive normal, from fp32 operations only (same bits on any IEEE machine; the binning's footprint must not
 // depend on a libm): mantissa reduced to [0.707, 1.414), atanh series.  |error| < 1e-6.
@@ -624,7 +628,7 @@ inline float fragment_alpha(float power, float a, bool windowed, bool& live) {
 // Shared definition of "is this splat drawn at all, and where": see DESIGN.md "compositor semantics".
 Prepared prepare(const ViewData& v, const gs_frame_params& P) {
     Prepared p; std::memset(&p, 0, sizeof(p));
-    p.x0 = 1; p.x1 = 0; p.tx0 = 1; p.tx1 = 0;
+    p.x0 = 1; p.x1 = 0; p.tx0 = 1; p.tx1 = 0; p.bx0 = 1; p.bx1 = 0;
     const float W = P.screen_w, H = P.screen_h;
     const float w = v.pos[3];
     if (!(w > 0.0f)) return p;                                   // vert: behindCam -> NaN vertex -> primitive discarded
@@ -664,7 +668,8 @@ Prepared prepare(const ViewData& v, const gs_frame_params& P) {
     pix_range(p.cx, fminf(exr, exe) + slack, W, bx0, bx1);
     pix_range(p.cy, fminf(eyr, eye) + slack, H, by0, by1);
     if (bx0 <= bx1 && by0 <= by1) {
-        p.tx0 = bx0 >> 4; p.tx1 = bx1 >> 4; p.ty0 = by0 >> 4; p.ty1 = by1 >> 4;
+        p.bx0 = bx0; p.bx1 = bx1; p.by0 = by0; p.by1 = by1;
+        p.tx0 = bx0 >> g_tile_wl; p.tx1 = bx1 >> g_tile_wl; p.ty0 = by0 >> g_tile_hl; p.ty1 = by1 >> g_tile_hl;
     }
     p.valid = true;
     return p;
@@ -777,6 +782,11 @@ void gso_cov_stages(const gs_asset_desc* d, const gs_frame_params* P, uint32_t i
 }
 void gso_calc_view(const gs_asset_desc* d, const gs_frame_params* P, void* view_out) { gso_calc_view_ex(d, P, nullptr, 0, nullptr, view_out); }
 
+// tile shape (pixels) the pair count of gso_draw* refers to: 16x16 (default), 32x16 or 32x32 -- what gs_frame_stats.tile_w/h reports
+void gso_set_tile_shape(int32_t tile_w, int32_t tile_h) {
+    g_tile_wl = tile_w >= 32 ? 5 : 4; g_tile_hl = tile_h >= 32 ? 5 : 4;
+}
+
 // prepare() of every splat in index order, in the layout of gs_renderer_download_raster_records (include/gsplat_c.h):
 // recs N x 8 u32 (written only for splats that reach a tile), rects N x 2 u32, vis ceil(N/64) u64.
 void gso_raster_records(const void* view_in, uint32_t n, const gs_frame_params* P, uint32_t* recs, uint32_t* rects, uint64_t* vis) {
@@ -792,8 +802,8 @@ void gso_raster_records(const void* view_in, uint32_t n, const gs_frame_params* 
             std::memset(recs + i * 8, 0, 32);
             if (!visible) continue;
             bits |= 1ull << (i & 63);
-            rects[i * 2] = (uint32_t)p.tx0 | ((uint32_t)p.ty0 << 16);
-            rects[i * 2 + 1] = (uint32_t)(p.tx1 - p.tx0 + 1) | ((uint32_t)(p.ty1 - p.ty0 + 1) << 16);
+            rects[i * 2] = (uint32_t)p.bx0 | ((uint32_t)p.by0 << 16);                         // inclusive pixel rectangle, +1 on the far corner
+            rects[i * 2 + 1] = (uint32_t)(p.bx1 + 1) | ((uint32_t)(p.by1 + 1) << 16);
             const float f[6] = { p.cx, p.cy, p.a1x, p.a1y, p.a2x, p.a2y };
             std::memcpy(recs + i * 8, f, 24);
             recs[i * 8 + 6] = view[i].color[0]; recs[i * 8 + 7] = view[i].color[1];
@@ -828,7 +838,7 @@ float gso_fragment_native(const float* q, float a, float* y_out) {
 // splat in order[] (instance order), "Blend OneMinusDstAlpha One" into an RGBA16F target (rt, W*H*4 halfs,
 // row 0 = top).  mode 0: the ROP rounds to fp16 after every blend; mode 1: fp32 accumulation, a pixel stops
 // once 1-A < 1/4096 (the shipped "fast" mode), rounded to fp16 once at the end.
-// tile_pairs_out (optional) = number of (16x16 tile, splat) overlaps of the shipped binning's footprint.
+// tile_pairs_out (optional) = number of (tile, splat) overlaps of the shipped binning's footprint, tiles of gso_set_tile_shape.
 // Parallel over row bands; each band walks all splats in order, so the result is independent of thread count.
 // `win` = {x0, y0, x1, y1} inclusive pixel window (fragments outside are not evaluated; rt is still the full W x H target),
 // so a 50 M-splat / 4K frame can be checked on a crop in seconds.  The pair / visible counts always cover the whole screen.

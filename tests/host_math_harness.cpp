@@ -43,9 +43,11 @@ void hm_prepare_ex(const void* view, uint32_t n, const gs_frame_params* p, int32
     for (uint32_t i = 0; i < n; ++i) {
         gsm::SplatFootprint fp;
         const bool ok = gsm::PrepareSplat(v[i], p->screen_w, p->screen_h, p->near_clip, p->far_clip, fp);
-        out[i * 5 + 0] = fp.tx0; out[i * 5 + 1] = fp.tx1; out[i * 5 + 2] = fp.ty0; out[i * 5 + 3] = fp.ty1; out[i * 5 + 4] = ok;
+        // the header's footprint is a pixel rectangle; reported here as 16x16 tiles (the oracle's default tile shape)
+        const bool any = fp.x0 <= fp.x1;
+        out[i * 5 + 0] = any ? fp.x0 >> 4 : 1; out[i * 5 + 1] = any ? fp.x1 >> 4 : 0; out[i * 5 + 2] = any ? fp.y0 >> 4 : 1; out[i * 5 + 3] = any ? fp.y1 >> 4 : 0; out[i * 5 + 4] = ok;
         cxy[i * 2] = fp.cx; cxy[i * 2 + 1] = fp.cy;
-        if (tiles) tiles[i] = (ok && fp.tx0 <= fp.tx1) ? (uint32_t)((fp.tx1 - fp.tx0 + 1) * (fp.ty1 - fp.ty0 + 1)) : 0u;
+        if (tiles) tiles[i] = (ok && any) ? (uint32_t)(((fp.x1 >> 4) - (fp.x0 >> 4) + 1) * ((fp.y1 >> 4) - (fp.y0 >> 4) + 1)) : 0u;
     }
 }
 // the culling predicate shared by the binning (16x16 tiles, half = 7.5) and the blend kernel (8x8 quadrants, half = 3.5)
@@ -67,7 +69,7 @@ void hm_cull_check(const gs_asset_desc* d, const gs_frame_params* p, uint32_t* o
         gsm::SplatFootprint fp;
         const bool ok = full.front && gsm::PrepareSplat(full.view, c.screenW, c.screenH, c.nearClip, c.farClip, fp);
         out[i * 2] = fast.culled ? 1u : 0u;
-        out[i * 2 + 1] = (ok && fp.tx0 <= fp.tx1) ? (uint32_t)((fp.tx1 - fp.tx0 + 1) * (fp.ty1 - fp.ty0 + 1)) : 0u;
+        out[i * 2 + 1] = (ok && fp.x0 <= fp.x1) ? (uint32_t)(((fp.x1 >> 4) - (fp.x0 >> 4) + 1) * ((fp.y1 >> 4) - (fp.y0 >> 4) + 1)) : 0u;
         if (!fast.culled && fast.front) {       // not culled: the geometry must be the full path's, bit for bit
             if (memcmp(&fast.view, &full.view, sizeof(gsm::ViewData)) != 0) out[i * 2] |= 2u;
         }

@@ -44,6 +44,12 @@ def _p(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
+# The compositor tile the (tile, splat) pair count refers to is a performance parameter of the build under test (16x16, 32x16 or
+# 32x32 pixels; frames do not depend on it).  GPU tests point this hook at the library's choice for a target size
+# (tests/conftest.py: gs_renderer_tile_shape); without a hook the oracle counts 16x16 tiles.
+tile_shape_hook = None
+
+
 class Oracle:
     """Holds an asset description and runs the reference-semantics stages on the CPU."""
 
@@ -55,6 +61,12 @@ class Oracle:
         self.order = np.arange(self.n, dtype=np.uint32)      # CSSetIndices
         self.keys = np.zeros(self.n, np.uint32)
         self.view = np.zeros(self.n, VIEW_DTYPE)
+        self.tile = None                                     # (tile_w, tile_h) for tile_pairs; None = tile_shape_hook or 16x16
+
+    def _set_tile(self, W: int, H: int):
+        t = self.tile or (tile_shape_hook(W, H) if tile_shape_hook else (16, 16))
+        lib().gso_set_tile_shape(C.c_int32(int(t[0])), C.c_int32(int(t[1])))
+        return t
 
     def reset_order(self):
         lib().gso_set_indices(_p(self.order), C.c_uint32(self.n))
@@ -87,6 +99,7 @@ class Oracle:
         vis = C.c_uint32(0)
         win = (C.c_int32 * 4)(*[int(v) for v in window]) if window is not None else None
         sd = np.ascontiguousarray(scene_depth, np.float32) if scene_depth is not None else None
+        self._set_tile(W, H)
         lib().gso_draw_ex(_p(self.view), _p(self.order), C.c_uint32(self.n), C.byref(params), C.c_int32(mode), _p(rt),
                           C.byref(pairs), C.byref(vis), win, _p(sd) if sd is not None else None)
         self.tile_pairs, self.visible = pairs.value, vis.value

@@ -29,7 +29,7 @@ def test_every_declared_symbol_is_exported_and_bound():
 
 def test_version_and_error_strings():
     lib = _lib.lib()
-    assert lib.gs_abi_version() == 5
+    assert lib.gs_abi_version() == 6
     for code in range(0, -9, -1):
         assert lib.gs_error_string(code) not in (None, b"", b"unknown error")
     assert lib.gs_error_string(-99) == b"unknown error"
@@ -38,7 +38,7 @@ def test_version_and_error_strings():
 def test_struct_layouts_match_the_header():
     assert C.sizeof(_abi.gs_asset_desc) == 6 * 4 + 5 * 16
     assert C.sizeof(_abi.gs_frame_params) == (64 + 2 + 2 + 3 + 2 + 2 + 2) * 4
-    assert C.sizeof(_abi.gs_frame_stats) == 32
+    assert C.sizeof(_abi.gs_frame_stats) == 40
     assert C.sizeof(_abi.gs_cutout) == 68            # GaussianCutout.ShaderData: float4x4 + uint
     assert C.sizeof(_abi.gs_stage_times) == 48
     assert _abi.VIEW_DTYPE.itemsize == 40

@@ -55,7 +55,52 @@ def test_framebuffer_parity(gpu_ctx, W, H, mode):
     # resolved float image = lerp(bg, GammaToLinearSpace(C/A), A): the un-premultiply divides the target's tolerance by A,
     # so the bound is the target's 2^-8 over the smallest A that matters (0.5) -- the 8-bit validator metric above is the bar
     assert np.abs(res["o32"] - res["r32"]).max() <= 2.0 ** -7
-    assert res["st"].tiles_x == (W + 15) // 16 and res["st"].tiles_y == (H + 15) // 16
+    tw, th = res["st"].tile_w, res["st"].tile_h
+    assert (tw, th) in ((16, 16), (32, 16), (32, 32)) and res["st"].tiles_x == (W + tw - 1) // tw and res["st"].tiles_y == (H + th - 1) // th
+
+
+@pytest.mark.parametrize("W,H", [(640, 360), (333, 217), (33, 17)])
+@pytest.mark.parametrize("mode", [0, 1])
+def test_tile_shapes_give_the_same_frame(gpu_ctx, W, H, mode):
+    """The compositor tile (16x16, 32x16, 32x32 pixels: gs_renderer_set_tile_shape) is a performance parameter: every pixel blends the
+    same splats in the same order whatever tile it belongs to, so the frames are BIT-identical across shapes (both blend modes: the
+    fast mode's per-pixel early stop does not depend on the tile either); only the (tile, splat) pair count changes, and it equals
+    the oracle's count for that shape."""
+    a = small_asset(60_000, 5, "Medium")
+    cam = default_camera(W=W, H=H, az=40.0)
+    r = GaussianSplatRenderer(gpu_ctx, a)
+    r.OnEnable()
+    r.blendMode = mode
+    rt = RenderTarget(gpu_ctx, W, H)
+    r.SortPoints(cam)
+    r.CalcViewData(cam)                               # once: the per-splat pixel rectangles do not depend on the tile shape
+    orc = O.Oracle(a)
+    orc.sort(camera.sort_matrix(cam, r.transform.localToWorldMatrix))
+    P = r.FrameParams(cam)
+    orc.calc_view(P)
+    frames, pairs = [], []
+    ref = orc.draw(P, mode)
+    for shape in ((16, 16), (32, 16), (32, 32), (0, 0)):
+        r.SetTileShape(*shape)
+        for _ in range(2):                            # the second draw runs with the schedule made from the first one's tile costs
+            rt.Clear()
+            r.Draw(cam, rt)
+            st = r.FrameStats()
+            frames.append(rt.Download())
+            want = shape if shape != (0, 0) else r.TileShape(W, H)
+            assert (st.tile_w, st.tile_h) == want and st.tiles_x == (W + want[0] - 1) // want[0] and st.tiles_y == (H + want[1] - 1) // want[1]
+            orc.tile = want
+            orc.draw(P, mode, window=(0, 0, -1, -1))                 # counts only
+            assert st.tile_pairs == orc.tile_pairs and st.visible_splats == orc.visible
+            pairs.append(int(st.tile_pairs))
+    assert rt_err(frames[0], ref) <= (RT_TOL if mode == 0 else 4e-3)
+    for f in frames[1:]:
+        assert np.array_equal(f, frames[0])
+    assert pairs[0] >= pairs[2] >= pairs[4]           # larger tiles, fewer pairs
+    with pytest.raises(GsError):
+        r.SetTileShape(64, 64)
+    r.OnDisable()
+    rt.Dispose()
 
 
 @pytest.mark.parametrize("quality", ["High", "VeryHigh"])

@@ -57,7 +57,7 @@ class gs_import_formats(C.Structure):
 
 class gs_frame_stats(C.Structure):
     _fields_ = [("tile_pairs", C.c_uint64), ("pair_capacity", C.c_uint64), ("visible_splats", C.c_uint32),
-                ("tiles_x", C.c_uint32), ("tiles_y", C.c_uint32), ("sort_error", C.c_uint32)]
+                ("tiles_x", C.c_uint32), ("tiles_y", C.c_uint32), ("sort_error", C.c_uint32), ("tile_w", C.c_uint32), ("tile_h", C.c_uint32)]
 
 
 class gs_stage_times(C.Structure):

@@ -451,6 +451,23 @@ int32_t gs_renderer_set_blend_mode(gs_renderer* r, int32_t mode) {
     return GS_OK;
 }
 
+int32_t gs_renderer_set_tile_shape(gs_renderer* r, uint32_t tile_w, uint32_t tile_h) {
+    if (!r) return fail(GS_ERR_INVALID_ARGUMENT, "renderer is null");
+    if (tile_w == 0 && tile_h == 0) { r->tileOverrideWL = r->tileOverrideHL = 0; return GS_OK; }
+    if (!((tile_w == 16 && tile_h == 16) || (tile_w == 32 && tile_h == 16) || (tile_w == 32 && tile_h == 32)))
+        return fail(GS_ERR_INVALID_ARGUMENT, "tile shape must be 16x16, 32x16, 32x32 or 0x0 (automatic)");
+    r->tileOverrideWL = tile_w == 16 ? 4u : 5u; r->tileOverrideHL = tile_h == 16 ? 4u : 5u;
+    return GS_OK;
+}
+
+int32_t gs_renderer_tile_shape(const gs_renderer* r, uint32_t width, uint32_t height, uint32_t* tile_w, uint32_t* tile_h) {
+    if (!tile_w || !tile_h) return fail(GS_ERR_INVALID_ARGUMENT, "null argument");
+    uint32_t wl, hl;
+    pick_tile_shape(r, width, height, wl, hl);           // r may be null: the automatic choice
+    *tile_w = 1u << wl; *tile_h = 1u << hl;
+    return GS_OK;
+}
+
 int32_t gs_renderer_set_profiling(gs_renderer* r, int32_t frames) {
     if (!r || frames < 0 || frames > 4096) return fail(GS_ERR_INVALID_ARGUMENT, "frames must be in [0, 4096]");
     GS_TRY(bind_device(r->ctx));
@@ -563,6 +580,7 @@ int32_t gs_renderer_frame_stats(gs_renderer* r, gs_frame_stats* out) {
     memset(out, 0, sizeof(*out));
     out->pair_capacity = r->pairCapacity;
     out->tiles_x = r->lastTilesX; out->tiles_y = r->lastTilesY;
+    out->tile_w = 1u << r->lastTileWL; out->tile_h = 1u << r->lastTileHL;
     if (r->frameInFlight) {
         out->tile_pairs = r->hostReport->pairCount;
         out->visible_splats = r->hostReport->visible;

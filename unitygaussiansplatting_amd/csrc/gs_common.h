@@ -27,7 +27,7 @@ int32_t fail_hip(hipError_t e, const char* what, const char* file, int line);
         if (_r != GS_OK) return _r;     \
     } while (0)
 
-constexpr int kTile = 16;                 // compositor tile edge, pixels
+// (the compositor's tile is 16x16, 32x16 or 32x32 pixels, picked per draw: pick_tile_shape in gs_raster.hip)
 constexpr int kBinThreads = 256;
 #ifndef GS_BIN_ITEMS
 #define GS_BIN_ITEMS 8       // 2048 positions per partition: ~3 rounds of partitions over the persistent grid balance better than 1.5 (measured)
@@ -167,7 +167,7 @@ struct gs_renderer {
     gsm::BoxRec* boxRecs = nullptr;         // N x 64 B, debug box modes only (allocated on first use)
     uint32_t* chunkOrder = nullptr;         // identity order of the chunks (DebugChunkBounds draws them in index order)
     float* recW = nullptr;                  // N x 4 B: clip.w of the visible splats, filled by the draw only when the target has a depth attachment
-    uint2* rects = nullptr;                 // N x 8 B: x = tx0 | ty0 << 16, y = tiles wide | tiles high << 16 (0 = culled)
+    uint2* rects = nullptr;                 // N x 8 B: x = x0 | y0 << 16, y = (x1 + 1) | (y1 + 1) << 16, pixels (0 = culled): gsm::PackPixelRect
     unsigned long long* visMask = nullptr;  // ceil(N/64) x 8 B: bit s = splat s reaches at least one tile (written by calc_view); + ceil(N/64) B per-wave flags (wave_flags_of)
     // edit state read by calc_view (m_GpuEditDeleted / m_GpuEditCutouts, GaussianSplatRenderer.cs:266,269)
     uint32_t* deletedBits = nullptr;        // ceil(N/32) words, or null (_SplatBitsValid = 0)
@@ -195,6 +195,9 @@ struct gs_renderer {
     uint32_t* tileCost = nullptr;           // 2 x arenaTiles x u32: batches each tile walked -- a draw writes copy costIdx and reads (for scheduling) the other
     int costIdx = 0;
     uint32_t costTiles[2] = {0, 0};         // tile count of the draw that wrote each copy (0 = none): a schedule can be made from it for the same count only
+    uint32_t costShape[2] = {0, 0};         // ... and the same tile shape (log2 w | log2 h << 8)
+    uint32_t tileOverrideWL = 0, tileOverrideHL = 0;   // gs_renderer_set_tile_shape: log2 tile width / height, 0 = automatic
+    uint32_t lastTileWL = 4, lastTileHL = 4;           // of the last draw
     uint32_t* tileOrderBuf = nullptr;       // arenaTiles x u32: the blend's tile schedule of the draw in flight
     uint32_t binParts = 0;
     int blendMode = 0;
@@ -252,6 +255,8 @@ void flatten_params(const gs_frame_params* p, gsm::FrameConsts& c);
 int32_t renderer_alloc_raster(gs_renderer* r);
 void renderer_free_raster(gs_renderer* r);
 int32_t enqueue_draw(gs_renderer* r, const gs_frame_params* p, gs_target* rt);
+void auto_tile_shape(uint32_t width, uint32_t height, uint32_t& wl, uint32_t& hl);                       // the automatic tile shape for a target size
+void pick_tile_shape(const gs_renderer* r, uint32_t width, uint32_t height, uint32_t& wl, uint32_t& hl);  // ... or the renderer's override
 int32_t enqueue_debug_points(gs_renderer* r, const gs_frame_params* p, gs_target* rt);   // RenderMode.DebugPoints / DebugPointIndices
 int32_t enqueue_debug_boxes(gs_renderer* r, const gs_frame_params* p, gs_target* rt, bool chunks);   // RenderMode.DebugBoxes / DebugChunkBounds
 int32_t enqueue_resolve(gs_target* t, const float bg[4], bool want8);

@@ -909,7 +909,7 @@ GS_HD ViewData CalcViewData(const AssetView& a, const FrameConsts& P, const Edit
     return CalcViewDataT(a, P, E, idx, src);
 }
 
-// ---- compositor set-up: which splats are drawn, where, and which 16x16 tiles they can touch -----------
+// ---- compositor set-up: which splats are drawn, where, and which pixels (hence tiles) they can touch -----------
 // Restates the vertex stage of RenderGaussianSplats.shader:35-77 plus the fixed-function clipping it relies
 // on (DESIGN.md "compositor semantics"); must stay in step with prepare() in oracle/gs_oracle.cpp.
 GS_HD void PixRange(float c, float e, float size, int& lo, int& hi) {
@@ -984,11 +984,18 @@ GS_HD bool BlockMayTouch(float bcx, float bcy, float half, float cx, float cy, f
 
 struct SplatFootprint {
     float cx, cy;               // centre in pixels, y down
-    int tx0, tx1, ty0, ty1;     // inclusive tile rect (tx0 > tx1: nothing to draw)
+    int x0, x1, y0, y1;         // inclusive PIXEL rect of the tight footprint, clamped to the screen (x0 > x1: nothing to draw); the
+                                // compositor's tile rectangle is this shifted by the tile shape the draw picks (x >> log2 tile width ...)
 };
+// The 8-byte per-splat rectangle calc_view leaves for the binning: x = x0 | y0 << 16, y = (x1 + 1) | (y1 + 1) << 16 (pixels; targets are
+// at most 65535 pixels wide / high); all zero = not drawn.
+GS_HD void PackPixelRect(const SplatFootprint& fp, uint32_t& rx, uint32_t& ry) {
+    rx = (uint32_t)fp.x0 | ((uint32_t)fp.y0 << 16);
+    ry = (uint32_t)(fp.x1 + 1) | ((uint32_t)(fp.y1 + 1) << 16);
+}
 
 GS_HD bool PrepareSplat(const ViewData& v, float W, float H, float nearClip, float farClip, SplatFootprint& fp) {
-    fp.tx0 = 1; fp.tx1 = 0; fp.ty0 = 1; fp.ty1 = 0; fp.cx = 0.0f; fp.cy = 0.0f;
+    fp.x0 = 1; fp.x1 = 0; fp.y0 = 1; fp.y1 = 0; fp.cx = 0.0f; fp.cy = 0.0f;
     const float w = v.pos[3];
     const float a = f16tof32(v.color[1]);
     // the rejections are evaluated as ONE predicate (bitwise &: no short-circuit): a chain of early returns compiles to
@@ -1019,7 +1026,7 @@ GS_HD bool PrepareSplat(const ViewData& v, float W, float H, float nearClip, flo
     PixRange(fp.cx, fminf(exr, exe) + slack, W, x0, x1);
     PixRange(fp.cy, fminf(eyr, eye) + slack, H, y0, y1);
     if (x0 > x1 || y0 > y1) return true;         // drawn by the reference, but every fragment is below 1/255
-    fp.tx0 = x0 >> 4; fp.tx1 = x1 >> 4; fp.ty0 = y0 >> 4; fp.ty1 = y1 >> 4;
+    fp.x0 = x0; fp.x1 = x1; fp.y0 = y0; fp.y1 = y1;
     return true;
 }
 

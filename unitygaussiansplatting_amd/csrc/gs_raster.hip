@@ -4,16 +4,17 @@
 // "Blend OneMinusDstAlpha One" :10-12 into an RGBA16F target, GaussianSplatRenderer.cs:156-166,194-196) and
 // GaussianComposite.shader:25-39.  MI355X has no rasteriser/ROP, so the draw is:
 //   0. (gs_view.hip) calc_view culls each splat like the rasteriser would and writes, in splat order, a 32-byte
-//                  record rec[s] (centre, axes, rgba16f), its inclusive 16x16-tile rectangle rect[s] and 1 visibility bit.
-//   1. bin_emit:   for sorted position i (front to back): visibility bit, then gather rect[order[i]] (8 B) and emit one
+//                  record rec[s] (centre, axes, rgba16f), its inclusive PIXEL rectangle rect[s] and 1 visibility bit.
+//   1. bin_emit:   for sorted position i (front to back): visibility byte, then gather rect[order[i]] (8 B), turn it into a
+//                  rectangle of tiles of the draw's tile shape (16x16, 32x16 or 32x32 pixels: pick_tile_shape) and emit one
 //                  (tile, splat) pair per overlapped tile.  Pair offsets come from a single-pass chained scan (decoupled
 //                  look-back) so pairs are emitted in i order.  Persistent grid, ticketed partitions.
 //   2. pair sort:  STABLE Onesweep sort of the pairs by tile id only (2 passes for <= 65536 tiles): every
 //                  tile's list is then already depth ordered -- no per-tile depth sort.
 //   3. ranges:     tile -> [start, end) in the sorted pair array.
-//   4. blend:      one 256-thread workgroup per tile, one pixel per lane, each wave owns an 8x8 quadrant; tiles are
+//   4. blend:      one workgroup per tile (4, 8 or 16 waves), one pixel per lane, each wave owns an 8x8 quadrant; tiles are
 //                  scheduled by descending cost (the schedule is made by an extra workgroup of bin_emit meanwhile).
-//                  The tile's list is streamed in batches of 256 records staged in LDS (software-pipelined loads); each
+//                  The tile's list is streamed in batches of one record per thread staged in LDS (software-pipelined loads); each
 //                  wave culls the batch against its quadrant (bounding box + separating-axis test) with a ballot and walks
 //                  only the survivors, reading the record with wave-uniform LDS loads, blending front-to-back in registers.
 //                  It also performs a pending gs_target_clear (it writes every pixel of the target).
@@ -210,7 +211,7 @@ __device__ unsigned long long g_bin_tl[32768 * 8];
 #endif
 template <int PASSES>
 __global__ __launch_bounds__(kBinThreads, GS_BIN_MINWAVES) void bin_emit_kernel(const uint2* __restrict__ rects, const uint8_t* __restrict__ waveFlags,
-                                                                const uint32_t* __restrict__ order, uint32_t n, uint32_t tilesX,
+                                                                const uint32_t* __restrict__ order, uint32_t n, uint32_t tilesX, uint32_t tileShift,
                                                                 uint32_t* __restrict__ pairKeys, uint32_t* __restrict__ pairVals,
                                                                 uint32_t capacity, BinControl* ctl, unsigned long long* binStatus, unsigned long long* binGroupAgg, unsigned long long* binGroupBase,
                                                                 uint32_t* pairHist, unsigned long long* __restrict__ groupAgg, uint32_t groupAggWords,
@@ -283,10 +284,17 @@ __global__ __launch_bounds__(kBinThreads, GS_BIN_MINWAVES) void bin_emit_kernel(
 #pragma unroll
     for (int k = 0; k < kBinItems; ++k) visw[k] = (sid[k] != 0xffffffffu) ? (uint32_t)waveFlags[sid[k] >> 6] : 0u;
     uint32_t mySum = 0, myVis = 0;
+    const uint32_t shx = tileShift & 0xffu, shy = tileShift >> 8;       // log2 of the draw's tile width / height (wave-uniform)
 #pragma unroll
     for (int k = 0; k < kBinItems; ++k) {
         rc[k] = make_uint2(0u, 0u);
         if (visw[k]) rc[k] = rects[sid[k]];
+        // pixel rectangle {x0 | y0 << 16, (x1 + 1) | (y1 + 1) << 16} (0 = not drawn) -> tile rectangle {tx0 | ty0 << 16, wide | high << 16}
+        if (rc[k].y != 0u) {
+            const uint32_t tx0 = (rc[k].x & 0xffffu) >> shx, ty0 = (rc[k].x >> 16) >> shy;
+            const uint32_t tx1 = ((rc[k].y & 0xffffu) - 1u) >> shx, ty1 = ((rc[k].y >> 16) - 1u) >> shy;
+            rc[k] = make_uint2(tx0 | (ty0 << 16), (tx1 - tx0 + 1u) | ((ty1 - ty0 + 1u) << 16));
+        }
         const uint32_t c = (rc[k].y & 0xffffu) * (rc[k].y >> 16);
         mySum += c;
         myVis += c ? 1u : 0u;
@@ -533,15 +541,8 @@ template <> struct PixelAcc<0> {
     uint32_t rg, ba;
     __device__ __forceinline__ void load(uint2 d) { rg = d.x; ba = d.y; }
     __device__ __forceinline__ void blend(uint32_t c0, uint32_t c1, float alpha) {
-#ifdef GS_BLEND_PLAIN      // A/B reference: the same arithmetic written in plain C++ (compiler-selected instructions)
-        const float t = 1.0f - half_hi(ba);
-        const uint32_t nr = gsm::f32tof16(fmaf(half_hi(c0) * alpha, t, half_lo(rg))), ng = gsm::f32tof16(fmaf(half_lo(c0) * alpha, t, half_hi(rg)));
-        const uint32_t nb = gsm::f32tof16(fmaf(half_hi(c1) * alpha, t, half_lo(ba))), na = gsm::f32tof16(fmaf(alpha, t, half_hi(ba)));
-        rg = nr | (ng << 16); ba = nb | (na << 16);
-#else
         const float t = mix_one_minus_hi(ba);
         mix_blend4(rg, ba, mix_mul_hi(c0, alpha), mix_mul_lo(c0, alpha), mix_mul_hi(c1, alpha), alpha, t);
-#endif
     }
     // src = (pr, pg, pb, pa) already premultiplied, fp32 (the box fragment shader's output)
     __device__ __forceinline__ void blend_src(float pr, float pg, float pb, float pa) { const float t = mix_one_minus_hi(ba); mix_blend4(rg, ba, pr, pg, pb, pa, t); }
@@ -572,13 +573,18 @@ template <> struct PixelAcc<1> {
 
 typedef uint32_t u4v __attribute__((ext_vector_type(4)));
 
-// One workgroup per 16x16 tile, wave w owns the 8x8 quadrant (w&1, w>>1), one pixel per lane.  The tile's depth-ordered
-// list is streamed 256 pairs at a time: thread t gathers rec[pairVals[bs + t]] and stages, in LDS, everything that does
-// not depend on the pixel (inverse-scaled axes u_k = axis_k/|axis_k|^2, bounding half extents).  Each wave then
+// One workgroup per tile of 2^TWL x 2^THL pixels (16x16, 32x16 or 32x32: 4, 8 or 16 waves), wave w owns the 8x8 quadrant
+// (w % (TW/8), w / (TW/8)), one pixel per lane.  The tile's depth-ordered list is streamed NT = one record per thread at a
+// time: thread t gathers rec[pairVals[bs + t]] and stages, in LDS, everything that does not depend on the pixel
+// (inverse-scaled axes u_k = axis_k/|axis_k|^2, bounding half extents).  Each wave then
 //   (1) tests 64 staged records at once against its quadrant (lane j <-> record j, one ballot), and
 //   (2) walks the survivors in order, reading the record with WAVE-UNIFORM LDS loads (two ds_read_b128 per record:
-//       they issue on the LDS pipe, not the VALU, and the next record is requested before the current one is
-//       evaluated), so the per-(quadrant, splat) VALU cost is the fragment maths alone.
+//       they issue on the LDS pipe, not the VALU), so the per-(quadrant, splat) VALU cost is the fragment maths alone.
+// The tile shape is the draw's (pick_tile_shape): the (tile, splat) pairs -- what bin_emit emits, the pair sort moves and this
+// kernel stages -- shrink with the tile area (a 14-pixel splat touches 3.5 tiles of 16x16 but 2.1 of 32x32) while the per-wave
+// work does not: a wave tests 64 records per ballot (~40 wave instructions) against 22 VALU per survivor, and the survivors
+// of a quadrant are the same whatever tile it belongs to.  Blend order per pixel is unchanged, so the frame is bit-identical
+// across tile shapes (tests/test_gpu_draw.py::test_tile_shapes_give_the_same_frame).
 #ifdef GS_EXP_BLEND_TIMELINE      // experiment build: per-tile start / end (100 MHz wall clock), list length, batches walked
 __device__ unsigned long long g_blend_tl[65536 * 8];
 #endif
@@ -586,17 +592,21 @@ __device__ unsigned long long g_blend_tl[65536 * 8];
 // ZTest LEqual, ZWrite Off against the camera's depth buffer (RenderGaussianSplats.shader:10; the RT is bound with the
 // current depth, GaussianSplatRenderer.cs:195), and all four vertices of a quad carry the centre's depth (:56-60), so a
 // fragment survives iff the splat's view depth clip.w <= the opaque scene's view depth at that pixel.
-template <int MODE, bool DEPTH>
-__global__ __launch_bounds__(256) void blend_kernel(const uint32_t* __restrict__ pairVals, const uint32_t* __restrict__ tileStart,
+template <int MODE, bool DEPTH, int TWL, int THL>
+__global__ __launch_bounds__(64 << (TWL + THL - 6)) void blend_kernel(const uint32_t* __restrict__ pairVals, const uint32_t* __restrict__ tileStart,
                                                     const uint32_t* __restrict__ tileEnd, const uint32_t* __restrict__ tileOrder,
                                                     uint32_t* __restrict__ tileCost, const SplatRec* __restrict__ recs,
                                                     uint16_t* __restrict__ rt, RasterConsts rc, int dstIsZero,
                                                     const float* __restrict__ recW, const float* __restrict__ sceneDepth,
                                                     const BinControl* __restrict__ binCtl, const uint32_t* __restrict__ pairSortError,
                                                     FrameReport* __restrict__ report) {
-    __shared__ float4 s_a[256];      // cx, cy, u1x, u2x      (u_k = axis_k / |axis_k|^2; the x's and the y's of the two axes side by side:
-    __shared__ uint4 s_b[256];       // u1y, u2y (float bits), f16 r << 16 | f16 g, f16 b << 16 | f16 a      operands of packed fp32 instructions)
-    __shared__ float4 s_e[256];      // half extents of the footprint's bounding box, pixels; r^2 = ln(255 a) with slack
+    constexpr int TW = 1 << TWL, TH = 1 << THL;                   // tile, pixels
+    constexpr int NWX = TW / 8, NW = NWX * (TH / 8);              // waves: one per 8x8 quadrant
+    constexpr int NT = 64 * NW;                                   // threads = pixels of the tile = records per batch
+    constexpr uint32_t SLOTS = 2048u * 256u / (uint32_t)NT;       // workgroups resident at once on 256 CUs (8 waves per SIMD)
+    __shared__ float4 s_a[NT];       // cx, cy, u1x, u2x      (u_k = axis_k / |axis_k|^2; the x's and the y's of the two axes side by side:
+    __shared__ uint4 s_b[NT];        // u1y, u2y (float bits), f16 r << 16 | f16 g, f16 b << 16 | f16 a      operands of packed fp32 instructions)
+    __shared__ float4 s_e[NT];       // half extents of the footprint's bounding box, pixels; r^2 = ln(255 a) with slack
     __shared__ int s_done;
     __shared__ uint32_t s_cost;
     uint32_t survWalked = 0;                                      // survivors this wave walked (wave-uniform)
@@ -606,9 +616,9 @@ __global__ __launch_bounds__(256) void blend_kernel(const uint32_t* __restrict__
     const uint32_t tile = tileOrder[blockIdx.x];
     // tiles are dispatched heaviest first (tileOrder); the heaviest also get the higher issue priority on their SIMD, so that the longest
     // survivor chains -- the launch lasts as long as they do -- are not slowed by the light tiles beside them (measured: -1 %)
-    if (blockIdx.x < 256u) __builtin_amdgcn_s_setprio(3);
-    else if (blockIdx.x < 768u) __builtin_amdgcn_s_setprio(2);
-    else if (blockIdx.x < 1536u) __builtin_amdgcn_s_setprio(1);
+    if (blockIdx.x < SLOTS / 8u) __builtin_amdgcn_s_setprio(3);
+    else if (blockIdx.x < 3u * SLOTS / 8u) __builtin_amdgcn_s_setprio(2);
+    else if (blockIdx.x < 6u * SLOTS / 8u) __builtin_amdgcn_s_setprio(1);
     const uint32_t tx = tile % rc.tilesX, ty = tile / rc.tilesX;
     const uint32_t start = tileStart[tile], end = tileEnd[tile];
 #ifdef GS_EXP_BLEND_TIMELINE
@@ -617,19 +627,17 @@ __global__ __launch_bounds__(256) void blend_kernel(const uint32_t* __restrict__
     unsigned long long tlStage = 0, tlProc = 0, tlMark = tl0;
     if (threadIdx.x == 0 && tile < 65536u) { g_blend_tl[tile * 8 + 0] = tl0; g_blend_tl[tile * 8 + 1] = tl0; g_blend_tl[tile * 8 + 2] = end - start; g_blend_tl[tile * 8 + 3] = 0; }
 #endif
+    const int qx0 = (int)tx * TW + (w % NWX) * 8, qy0 = (int)ty * TH + (w / NWX) * 8;
+    const int px = qx0 + (lane & 7), py = qy0 + (lane >> 3);
+    const bool inside = px < (int)rc.width && py < (int)rc.height;
+    uint2* dst = (uint2*)(rt + ((size_t)py * rc.width + (size_t)px) * 4);
     if (start >= end) {                                        // nothing lands on this tile: target unchanged ...
         if (threadIdx.x == 0) tileCost[tile] = 0;
-        if (dstIsZero) {                                       // ... or cleared here, when this draw also performs the pending clear
-            const int px = (int)tx * 16 + (threadIdx.x & 15), py = (int)ty * 16 + (threadIdx.x >> 4);
-            if (px < (int)rc.width && py < (int)rc.height) *(uint2*)(rt + ((size_t)py * rc.width + (size_t)px) * 4) = make_uint2(0u, 0u);
-        }
+        if (dstIsZero && inside) *dst = make_uint2(0u, 0u);    // ... or cleared here, when this draw also performs the pending clear
         return;
     }
     uint32_t batchesWalked = 0;
 
-    const int qx0 = (int)tx * 16 + (w & 1) * 8, qy0 = (int)ty * 16 + (w >> 1) * 8;
-    const int px = qx0 + (lane & 7), py = qy0 + (lane >> 3);
-    const bool inside = px < (int)rc.width && py < (int)rc.height;
     const float fx = (float)px + 0.5f, fy = (float)py + 0.5f;
     const gsm::F2 fxy = { fx, fy };
     const float qminx = (float)qx0 + 0.5f, qmaxx = (float)qx0 + 7.5f, qminy = (float)qy0 + 0.5f, qmaxy = (float)qy0 + 7.5f;
@@ -637,7 +645,6 @@ __global__ __launch_bounds__(256) void blend_kernel(const uint32_t* __restrict__
     PixelAcc<MODE> acc;
     float sceneZ = 0.0f;
     if (DEPTH) sceneZ = inside ? sceneDepth[(size_t)py * rc.width + (size_t)px] : 0.0f;
-    uint2* dst = (uint2*)(rt + ((size_t)py * rc.width + (size_t)px) * 4);
     acc.load((inside && !dstIsZero) ? *dst : make_uint2(0u, 0u));
     if (tid == 0) s_done = 0;
     if (tid == 0) s_cost = 0u;
@@ -656,15 +663,15 @@ __global__ __launch_bounds__(256) void blend_kernel(const uint32_t* __restrict__
         r0 = rp[0]; r1 = rp[1];                                   // cx cy a1x a1y | a2x a2y c0 c1
         if (DEPTH) rw = recW[s0];
     }
-    uint32_t sidxNext = pairVals[min(start + 256u + (uint32_t)tid, lastPair)];
-    for (uint32_t bs = start; bs < end; bs += 256u) {
+    uint32_t sidxNext = pairVals[min(start + (uint32_t)NT + (uint32_t)tid, lastPair)];
+    for (uint32_t bs = start; bs < end; bs += (uint32_t)NT) {
         __syncthreads();
-        if (s_done == 4) break;
+        if (s_done == NW) break;
         ++batchesWalked;
 #ifdef GS_EXP_BLEND_TIMELINE
         ++tlBatches;
 #endif
-        const uint32_t cnt = min(256u, end - bs);
+        const uint32_t cnt = min((uint32_t)NT, end - bs);
         if ((uint32_t)tid < cnt) {
             const float inv1 = 1.0f / gsm::dot2f(r0.z, r0.w, r0.z, r0.w);
             const float inv2 = 1.0f / gsm::dot2f(r1.x, r1.y, r1.x, r1.y);
@@ -682,7 +689,7 @@ __global__ __launch_bounds__(256) void blend_kernel(const uint32_t* __restrict__
             const float4* rp = (const float4*)(recs + sidxNext);
             r0 = rp[0]; r1 = rp[1];
             if (DEPTH) rw = recW[sidxNext];
-            sidxNext = pairVals[min(bs + 512u + (uint32_t)tid, lastPair)];
+            sidxNext = pairVals[min(bs + 2u * (uint32_t)NT + (uint32_t)tid, lastPair)];
         }
         __syncthreads();
 #ifdef GS_EXP_BLEND_TIMELINE
@@ -707,11 +714,7 @@ __global__ __launch_bounds__(256) void blend_kernel(const uint32_t* __restrict__
                 survWalked += (uint32_t)__popcll(mask);
                 while (mask) {
                     const int b = __ffsll((long long)mask) - 1;
-#if !defined(GS_BLEND_LOOP1)
                     mask &= ~(1ull << b);                              // one s_bitset0_b64 instead of a 64-bit subtract + and
-#else
-                    mask &= mask - 1ull;
-#endif
                     const float4 A4 = s_a[c + b];                      // wave-uniform address: LDS broadcast
                     u4v B4 = *(const u4v*)&s_b[c + b];
                     asm volatile("" : "+v"(B4));                       // keep it ONE ds_read_b128 (no piece sunk into the branch)
@@ -722,22 +725,10 @@ __global__ __launch_bounds__(256) void blend_kernel(const uint32_t* __restrict__
                     const float q1 = q.x, q2 = q.y;
                     const float power = -fmaf(q2, q2, q1 * q1);
                     const float y2 = power * 1.44269504088896340736f;                // exp(x) = exp2(x * log2 e), DESIGN.md section 5 #6
-#ifdef GS_BLEND_PLAIN
-                    float alpha = gsm::sat(__builtin_amdgcn_exp2f(y2) * half_lo(B4.w));
-#else
                     float alpha = mix_mul_lo_sat_after_trans(B4.w, __builtin_amdgcn_exp2f(y2));
-#endif
-#if !defined(GS_BLEND_LOOP1)
-                    const int inQuad = (int)(fmaxf(fabsf(q1), fabsf(q2)) <= 2.0f);     // one v_max with |.| modifiers + one compare (NaN q: not inside, as before)
-#else
-                    const int inQuad = (int)(fabsf(q1) <= 2.0f) & (int)(fabsf(q2) <= 2.0f);
-#endif
+                    const int inQuad = (int)(fmaxf(fabsf(q1), fabsf(q2)) <= 2.0f);     // one v_max with |.| modifiers + one compare (NaN q: not inside)
                     bool live;
-#ifdef GS_EXP_NO_ALPHA_WINDOW            // A/B only: the round-2 decision (native alpha against 1/255), to price the window test
-                    if (false) {
-#else
                     if (MODE == 0) {
-#endif
                         // discard decision identical to the oracle's (gsm::DecideAlpha): outside a 16-ulp window around 1/255 the native
                         // alpha decides; inside it -- ~1e-6 of the fragments, a wave-rare branch -- the alpha is recomputed from the
                         // deterministic exp2.  Two float compares (one more than the plain test), the window itself is scalar mask logic.
@@ -767,12 +758,13 @@ __global__ __launch_bounds__(256) void blend_kernel(const uint32_t* __restrict__
 #endif
     }
     if (inside) *dst = acc.pack();
-    // next frame's scheduling hint (tile_order_body), 1 .. 254: the tile's critical chain -- the most survivors one of its four waves
-    // walked -- plus 32 per batch, in units of 4.  (Batches alone: +2 % at C2 / C3 -- survivors per batch vary tenfold between tiles; the
-    // measured duration of the tile schedules worse than either, 0.189 vs 0.185 ms: it depends on who the tile shared its SIMDs with.)
+    // next frame's scheduling hint (tile_order_body), 1 .. 254: the tile's critical chain -- the most survivors one of its waves
+    // walked -- plus NT / 8 per batch (its ballots: 32 for the 256-record batches of a 16x16 tile), in units of 4.  (Batches alone: +2 % at
+    // C2 / C3 -- survivors per batch vary tenfold between tiles; the measured duration of the tile schedules worse than either, 0.189 vs
+    // 0.185 ms: it depends on who the tile shared its SIMDs with.)
     if (lane == 0) atomicMax(&s_cost, survWalked);
     __syncthreads();
-    if (threadIdx.x == 0) tileCost[tile] = min(254u, (s_cost + batchesWalked * 32u) / 4u);
+    if (threadIdx.x == 0) tileCost[tile] = min(254u, (s_cost + batchesWalked * (uint32_t)(NT / 8)) / 4u);
 #ifdef GS_EXP_BLEND_TIMELINE
     __syncthreads();
     if (threadIdx.x == 0 && tile < 65536u) { g_blend_tl[tile * 8 + 1] = wall_clock64(); g_blend_tl[tile * 8 + 3] = tlBatches; g_blend_tl[tile * 8 + 4] = tlSurv; g_blend_tl[tile * 8 + 5] = tlStage; g_blend_tl[tile * 8 + 6] = tlProc; }
@@ -840,8 +832,8 @@ __global__ __launch_bounds__(256) void box_setup_kernel(gsm::AssetView a, gsm::F
         int x0, x1, y0, y1;
         if (gsm::BuildBox(c, B, ray, P.vp, r, g, b, al, rec, x0, x1, y0, y1)) {
             visible = true;
-            rect.x = (uint32_t)(x0 >> 4) | ((uint32_t)(y0 >> 4) << 16);
-            rect.y = (uint32_t)((x1 >> 4) - (x0 >> 4) + 1) | ((uint32_t)((y1 >> 4) - (y0 >> 4) + 1) << 16);
+            rect.x = (uint32_t)x0 | ((uint32_t)y0 << 16);                     // pixel rectangle, as gsm::PackPixelRect
+            rect.y = (uint32_t)(x1 + 1) | ((uint32_t)(y1 + 1) << 16);
             uint4* rp = (uint4*)(recs + idx);
             const uint32_t* w32 = (const uint32_t*)&rec;
 #pragma unroll
@@ -1072,17 +1064,18 @@ struct DrawSetup { RasterConsts rc; uint32_t numTiles; uint32_t *tileStart, *til
 
 // The part of a draw that does not depend on what a "fragment" is: (tile, item) pairs of the visible items in `order`
 // (bin_emit), the stable pair sort by tile, tile ranges, tile schedule + the draw's report.
-int32_t bin_and_sort(gs_renderer* r, const gs_frame_params* p, gs_target* rt, const uint32_t* order, uint32_t count, DrawSetup& o, bool forceOrderKernel) {
+int32_t bin_and_sort(gs_renderer* r, const gs_frame_params* p, gs_target* rt, const uint32_t* order, uint32_t count, DrawSetup& o, bool forceOrderKernel,
+                     uint32_t tileWL, uint32_t tileHL) {
     gs_context* ctx = r->ctx;
     hipStream_t st = ctx->stream;
     RasterConsts& rc = o.rc;
     rc.W = (float)rt->width; rc.H = (float)rt->height; rc.nearClip = p->near_clip; rc.farClip = p->far_clip;
     rc.width = rt->width; rc.height = rt->height;
-    rc.tilesX = div_up(rt->width, kTile); rc.tilesY = div_up(rt->height, kTile);
+    rc.tilesX = div_up(rt->width, 1u << tileWL); rc.tilesY = div_up(rt->height, 1u << tileHL);
     const uint32_t numTiles = o.numTiles = rc.tilesX * rc.tilesY;
     if (numTiles > (1u << 24)) return fail(GS_ERR_INVALID_ARGUMENT, "target too large (more than 2^24 tiles)");
     GS_TRY(ensure_arena(r, numTiles));
-    r->lastTilesX = rc.tilesX; r->lastTilesY = rc.tilesY;
+    r->lastTilesX = rc.tilesX; r->lastTilesY = rc.tilesY; r->lastTileWL = tileWL; r->lastTileHL = tileHL;
 
     r->arenaIdx ^= 1;
     uint8_t* arena = r->frameArena + (size_t)r->arenaIdx * r->frameArenaBytes;          // zeroed by the previous draw's bin_emit (or at allocation)
@@ -1097,8 +1090,9 @@ int32_t bin_and_sort(gs_renderer* r, const gs_frame_params* p, gs_target* rt, co
     o.tileOrder = r->tileOrderBuf;
     o.costWrite = r->tileCost + (size_t)r->costIdx * r->arenaTiles;          // this draw's blend writes it ...
     o.costRead = r->tileCost + (size_t)(r->costIdx ^ 1) * r->arenaTiles;      // ... and is scheduled by what the previous draw wrote
-    const bool haveCosts = r->costTiles[r->costIdx ^ 1] == numTiles;          // (a hint from another tile grid is no hint)
-    r->costTiles[r->costIdx] = numTiles;
+    const uint32_t shapeKey = tileWL | (tileHL << 8);
+    const bool haveCosts = r->costTiles[r->costIdx ^ 1] == numTiles && r->costShape[r->costIdx ^ 1] == shapeKey;   // (a hint from another tile grid is no hint)
+    r->costTiles[r->costIdx] = numTiles; r->costShape[r->costIdx] = shapeKey;
     r->costIdx ^= 1;
     const uint32_t cap = (uint32_t)r->pairCapacity;
 
@@ -1117,7 +1111,7 @@ int32_t bin_and_sort(gs_renderer* r, const gs_frame_params* p, gs_target* rt, co
     const uint32_t binCap = max((uint32_t)ctx->cuCount * (uint32_t)GS_BIN_BLOCKS_PER_CU / kBinTicketClasses * kBinTicketClasses, kBinTicketClasses);
     const uint32_t binGrid = min(div_up(div_up(count, kBinPart), kBinTicketClasses) * kBinTicketClasses, binCap);
     const bool schedInBin = haveCosts && !forceOrderKernel;     // one extra workgroup makes the blend's tile schedule meanwhile
-    hipLaunchKernelGGL(binKernel, dim3(binGrid + (schedInBin ? 1u : 0u)), dim3(kBinThreads), 0, st, r->rects, wave_flags_of(r->visMask, r->n), order, count, rc.tilesX, r->pairKeys,
+    hipLaunchKernelGGL(binKernel, dim3(binGrid + (schedInBin ? 1u : 0u)), dim3(kBinThreads), 0, st, r->rects, wave_flags_of(r->visMask, r->n), order, count, rc.tilesX, shapeKey, r->pairKeys,
                        r->pairVals, cap, binCtl, binStatus, binGroupAgg, binGroupBase, pairCtl->hist, r->pairSort.groupAgg, sort_group_words(cap, passes), (uint32_t*)nextArena, (uint32_t)(r->frameArenaBytes / 4), (uint32_t)bits,
                        o.costRead, numTiles, schedInBin ? o.tileOrder : (uint32_t*)nullptr);
     GS_TRY(mark_order_use(r));                                  // the next frame's depth sort may overwrite order[] from here on
@@ -1143,6 +1137,30 @@ int32_t bin_and_sort(gs_renderer* r, const gs_frame_params* p, gs_target* rt, co
 }
 } // namespace
 
+// The compositor's tile shape for a target: 16x16, 32x16 or 32x32 pixels (log2 width, log2 height).  A performance parameter only
+// -- frames are bit-identical across shapes -- chosen per target size (A/B: profiles/r04_variants.txt),
+// overridden per renderer by gs_renderer_set_tile_shape and process-wide by GSPLAT_TILE=16x16|32x16|32x32.
+void auto_tile_shape(uint32_t width, uint32_t height, uint32_t& wl, uint32_t& hl) {
+    static const int forced = [] {
+        const char* e = getenv("GSPLAT_TILE");
+        if (!e) return 0;
+        if (!strcmp(e, "16x16")) return 1;
+        if (!strcmp(e, "32x16")) return 2;
+        if (!strcmp(e, "32x32")) return 3;
+        return 0;
+    }();
+    int shape = forced;
+    if (!shape) {
+        const unsigned long long px = (unsigned long long)width * height;
+        shape = px >= (1ull << 18) ? 3 : 1;            // small targets (< 512x512) have too few 32x32 tiles to fill 256 CUs
+    }
+    wl = shape == 1 ? 4u : 5u; hl = shape == 3 ? 5u : 4u;
+}
+void pick_tile_shape(const gs_renderer* r, uint32_t width, uint32_t height, uint32_t& wl, uint32_t& hl) {
+    if (r && r->tileOverrideWL) { wl = r->tileOverrideWL; hl = r->tileOverrideHL; return; }
+    auto_tile_shape(width, height, wl, hl);
+}
+
 int32_t enqueue_draw(gs_renderer* r, const gs_frame_params* p, gs_target* rt) {
     hipStream_t st = r->ctx->stream;
     // the per-splat footprints were computed by calc_view: it must have run with the same screen size and clip planes
@@ -1150,7 +1168,9 @@ int32_t enqueue_draw(gs_renderer* r, const gs_frame_params* p, gs_target* rt) {
         return fail(GS_ERR_INVALID_ARGUMENT, "gs_renderer_draw: call gs_renderer_calc_view with the same screen size / clip planes first");
     GS_TRY(join_sort(r));                                       // bin_emit reads order[]
     DrawSetup ds;
-    GS_TRY(bin_and_sort(r, p, rt, r->order, r->n, ds, false));
+    uint32_t twl, thl;
+    pick_tile_shape(r, rt->width, rt->height, twl, thl);
+    GS_TRY(bin_and_sort(r, p, rt, r->order, r->n, ds, false, twl, thl));
     const RasterConsts& rc = ds.rc;
     const uint32_t numTiles = ds.numTiles;
     uint32_t *tileStart = ds.tileStart, *tileEnd = ds.tileEnd, *tileOrder = ds.tileOrder;
@@ -1160,12 +1180,14 @@ int32_t enqueue_draw(gs_renderer* r, const gs_frame_params* p, gs_target* rt) {
         flatten_params(p, fc);
         hipLaunchKernelGGL(splat_depth_kernel, dim3(div_up(r->n, 256)), dim3(256), 0, st, r->asset->view, fc, (const uint32_t*)r->visMask, r->recW);
     }
-#define GS_LAUNCH_BLEND(M, D) hipLaunchKernelGGL((blend_kernel<M, D>), dim3(numTiles), dim3(256), 0, st, r->pairVals, tileStart, tileEnd, tileOrder, \
-                                             ds.costWrite, r->recs, rt->rgba16f, rc, dstIsZero, r->recW, rt->sceneDepth, \
+#define GS_LAUNCH_BLEND_S(M, D, WL, HL) hipLaunchKernelGGL((blend_kernel<M, D, WL, HL>), dim3(numTiles), dim3(64u << (WL + HL - 6)), 0, st, r->pairVals, tileStart, tileEnd, \
+                                             tileOrder, ds.costWrite, r->recs, rt->rgba16f, rc, dstIsZero, r->recW, rt->sceneDepth, \
                                              ds.binCtl, ds.pairSortError, r->hostReportDev)
+#define GS_LAUNCH_BLEND(M, D) do { if (twl == 4u) GS_LAUNCH_BLEND_S(M, D, 4, 4); else if (thl == 4u) GS_LAUNCH_BLEND_S(M, D, 5, 4); else GS_LAUNCH_BLEND_S(M, D, 5, 5); } while (0)
     if (rt->sceneDepth) { if (r->blendMode == 0) GS_LAUNCH_BLEND(0, true); else GS_LAUNCH_BLEND(1, true); }
     else { if (r->blendMode == 0) GS_LAUNCH_BLEND(0, false); else GS_LAUNCH_BLEND(1, false); }
 #undef GS_LAUNCH_BLEND
+#undef GS_LAUNCH_BLEND_S
     prof_record(r, 6);
     GS_HIP(hipGetLastError());
     r->frameInFlight = true;
@@ -1197,7 +1219,7 @@ int32_t enqueue_debug_boxes(gs_renderer* r, const gs_frame_params* p, gs_target*
     prof_record(r, 8);
     r->viewValid = false;                                        // rects / visibility bits now describe the boxes: a splat draw needs calc_view again
     DrawSetup ds;
-    GS_TRY(bin_and_sort(r, p, rt, chunks ? r->chunkOrder : r->order, count, ds, true));   // the box blend writes no report: tile_order_kernel does
+    GS_TRY(bin_and_sort(r, p, rt, chunks ? r->chunkOrder : r->order, count, ds, true, 4u, 4u));   // the box blend writes no report: tile_order_kernel does; 16x16 tiles
 #define GS_LAUNCH_BOX(M, D) hipLaunchKernelGGL((blend_box_kernel<M, D>), dim3(ds.numTiles), dim3(256), 0, st, r->pairVals, ds.tileStart, ds.tileEnd, ds.tileOrder, \
                                            ds.costWrite, r->boxRecs, rt->rgba16f, ds.rc, ray, ds.dstIsZero, rt->sceneDepth)
     if (rt->sceneDepth) { if (r->blendMode == 0) GS_LAUNCH_BOX(0, true); else GS_LAUNCH_BOX(1, true); }

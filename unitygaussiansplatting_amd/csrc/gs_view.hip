@@ -7,7 +7,8 @@
 // global stores are whole, coalesced uint4s:
 //   view[s]  40 B  the reference's SplatViewData (m_GpuView; parity surface)
 //   rec[s]   32 B  centre in pixels + the two axes + rgba16f: what the blend kernel reads per (tile, splat) pair
-//   rect[s]   8 B  inclusive 16x16-tile rectangle of the splat's footprint, or 0 if it is culled
+//   rect[s]   8 B  inclusive pixel rectangle of the splat's footprint (gsm::PackPixelRect), or 0 if it is culled; the draw turns it
+//                  into a tile rectangle of whatever tile shape it composites with
 // Writing rec/rect here (where everything is in registers) means the binning kernel only gathers 8 B per sorted
 // position instead of the 40-B view record, and never writes records itself.
 #include "gs_common.h"
@@ -129,7 +130,7 @@ __global__ __launch_bounds__(256) void calc_view_kernel(gsm::AssetView a, gsm::F
             gsm::CalcViewGeom(a, P, E, idx, vp);
             if (vp.front) shade(vp);
             const bool ok = gsm::PrepareSplat(vp.view, P.screenW, P.screenH, P.nearClip, P.farClip, fp);
-            visible = ok && fp.tx0 <= fp.tx1;
+            visible = ok && fp.x0 <= fp.x1;
         }
     } else {
         // whole-chunk frustum cull: lane c & 7 tests corner c of the chunk's position box against the 6 (pushed-out) planes
@@ -149,7 +150,7 @@ __global__ __launch_bounds__(256) void calc_view_kernel(gsm::AssetView a, gsm::F
         if (idx < a.n) {
             gsm::CalcViewGeom(a, P, E, idx, vp, true, true);       // early out for splats that cannot reach the screen; vp only read if drawn
             const bool ok = vp.front && !vp.culled && gsm::PrepareSplat(vp.view, P.screenW, P.screenH, P.nearClip, P.farClip, fp);
-            visible = ok && fp.tx0 <= fp.tx1;
+            visible = ok && fp.x0 <= fp.x1;
         }
         __syncthreads();
         if (__any(visible) && (threadIdx.x & 63u) == 0u) s_any = 1;          // benign race: every writer stores 1
@@ -162,8 +163,7 @@ __global__ __launch_bounds__(256) void calc_view_kernel(gsm::AssetView a, gsm::F
 
     if (idx < a.n) {
         if (visible) {
-            rect.x = (uint32_t)fp.tx0 | ((uint32_t)fp.ty0 << 16);
-            rect.y = (uint32_t)(fp.tx1 - fp.tx0 + 1) | ((uint32_t)(fp.ty1 - fp.ty0 + 1) << 16);
+            gsm::PackPixelRect(fp, rect.x, rect.y);
             // the blend kernel only ever reads records of splats that reach a tile
             uint4* rp = (uint4*)(recs + idx);
             rp[0] = make_uint4(gsm::f2u(fp.cx), gsm::f2u(fp.cy), gsm::f2u(vp.view.axis1[0]), gsm::f2u(vp.view.axis1[1]));

@@ -44,7 +44,7 @@ namespace GaussianSplatting.Runtime
         }
 
         [StructLayout(LayoutKind.Sequential)]
-        public struct FrameStats { public ulong tilePairs, pairCapacity; public uint visibleSplats, tilesX, tilesY, sortError; }
+        public struct FrameStats { public ulong tilePairs, pairCapacity; public uint visibleSplats, tilesX, tilesY, sortError, tileW, tileH; }
 
         [StructLayout(LayoutKind.Sequential)]
         public struct StageTimes { public float calcDistancesMs, sortMs, calcViewMs, binMs, pairSortMs, blendMs, resolveMs, totalMs; public uint frames; public float onesweepDepthMs, onesweepPairsMs; public uint onesweepPairLaunches; }
@@ -88,6 +88,8 @@ namespace GaussianSplatting.Runtime
         [DllImport(Lib)] public static extern int gs_renderer_set_deleted_bits(IntPtr renderer, uint[] words, UIntPtr wordCount);
         [DllImport(Lib)] public static extern int gs_renderer_set_view_buffer_mode(IntPtr renderer, int everyFrame);
         [DllImport(Lib)] public static extern int gs_renderer_set_blend_mode(IntPtr renderer, int mode);
+        [DllImport(Lib)] public static extern int gs_renderer_set_tile_shape(IntPtr renderer, uint tileW, uint tileH);
+        [DllImport(Lib)] public static extern int gs_renderer_tile_shape(IntPtr renderer, uint width, uint height, out uint tileW, out uint tileH);
         [DllImport(Lib)] public static extern int gs_renderer_set_profiling(IntPtr renderer, int frames);
         [DllImport(Lib)] public static extern int gs_renderer_reserve_pairs(IntPtr renderer, ulong pairCapacity);
         [DllImport(Lib)] public static extern int gs_renderer_download_order(IntPtr renderer, uint[] dst, UIntPtr count);

@@ -361,6 +361,17 @@ class GaussianSplatRenderer:
         """frames = 0 off; > 0: ring of per-frame hipEvent sets, averaged by StageTimes()."""
         check(_lib.lib().gs_renderer_set_profiling(self._r_h, int(frames)), "gs_renderer_set_profiling")
 
+    def SetTileShape(self, tile_w: int = 0, tile_h: int = 0) -> None:
+        """The compositor's tile, pixels: 16x16, 32x16 or 32x32; 0, 0 = automatic (per target size).  A performance knob: the frame
+        is bit-identical whatever the shape."""
+        check(_lib.lib().gs_renderer_set_tile_shape(self._r_h, int(tile_w), int(tile_h)), "gs_renderer_set_tile_shape")
+
+    def TileShape(self, width: int, height: int) -> Tuple[int, int]:
+        """(tile_w, tile_h) a draw into a width x height target composites with."""
+        w, h = C.c_uint32(), C.c_uint32()
+        check(_lib.lib().gs_renderer_tile_shape(self._r_h, int(width), int(height), C.byref(w), C.byref(h)), "gs_renderer_tile_shape")
+        return w.value, h.value
+
     def ReservePairs(self, n: int) -> None:
         check(_lib.lib().gs_renderer_reserve_pairs(self._r_h, n), "gs_renderer_reserve_pairs")
 
