@@ -139,6 +139,10 @@ typedef struct gs_stage_times {
     float onesweep_depth_ms;   /* sum of the 4 depth-sort launches of one frame */
     float onesweep_pairs_ms;   /* sum of the pair-sort launches of one frame */
     uint32_t onesweep_pair_launches;   /* 1..3, by tile count */
+    /* the same launches by their OWN start / stop timestamps (the dispatch's completion signal, as rocprofv3 --kernel-trace reports
+     * them): no event packets and no kernel boundaries inside, so <= the bracketed figures above */
+    float onesweep_depth_kernel_ms;    /* sum over the 4 depth-sort launches */
+    float onesweep_pairs_kernel_ms;    /* sum over the pair-sort launches */
 } gs_stage_times;
 
 int32_t gs_abi_version(void);
@@ -244,9 +248,14 @@ int32_t gs_renderer_tile_shape(const gs_renderer* r, uint32_t width, uint32_t he
  * a frame ends at gs_renderer_draw.  gs_renderer_stage_times averages over the ring and resets it. */
 int32_t gs_renderer_set_profiling(gs_renderer* r, int32_t frames);
 int32_t gs_renderer_reserve_pairs(gs_renderer* r, uint64_t pair_capacity);
+/* Non-blocking: the (tile, splat) pair count reported by the most recent draw whose compositing has STARTED on the GPU (its first
+ * workgroup stores the count into host-visible memory; 0 before any) and the capacity of the pair buffers.  tile_pairs > pair_capacity:
+ * that draw dropped its farthest pairs (the next gs_renderer_draw grows the buffers; gs_renderer_frame_stats reports the frame). */
+int32_t gs_renderer_poll_pairs(gs_renderer* r, uint64_t* tile_pairs, uint64_t* pair_capacity);
 /* blocking readbacks (parity hooks; synchronise the stream) */
 int32_t gs_renderer_download_order(gs_renderer* r, uint32_t* out, size_t count);        /* _OrderBuffer / m_GpuSortKeys */
-int32_t gs_renderer_download_distances(gs_renderer* r, uint32_t* out, size_t count);    /* m_GpuSortDistances (sorted keys after a sort) */
+int32_t gs_renderer_download_distances(gs_renderer* r, uint32_t* out, size_t count);    /* m_GpuSortDistances: the sorted keys of the last gs_renderer_sort
+                                                                                           (also after a later upload_order / reset_order, as in the reference) */
 int32_t gs_renderer_upload_order(gs_renderer* r, const uint32_t* in, size_t count);
 int32_t gs_renderer_download_view(gs_renderer* r, void* out, size_t bytes);             /* N x 40 B SplatViewData */
 /* What the last gs_renderer_calc_view left for the compositor (the per-frame launch, NOT the on-demand full kernel), in

@@ -43,8 +43,8 @@ def views_equal(got: np.ndarray, want: np.ndarray) -> bool:
 
 
 RT_TOL = 2.0 ** -9
-RT_CAP = 2.0 ** -8               # no pixel beyond this, ever
-RT_RARE_PER_PIXEL = 2.0e-6       # pixels that may lie between RT_TOL and RT_CAP: 2 + 2 per megapixel
+RT_CAP = 2.0 ** -8               # with an opt-in outlier allowance (rt_err(..., rare=n)): no pixel beyond this, ever
+RT_RARE_PER_PIXEL = 2.0e-6       # the measured outlier rate behind rare_allowance(): 2 + 2 per megapixel
 
 
 def rt_diff(img: np.ndarray, ref: np.ndarray) -> np.ndarray:
@@ -53,20 +53,35 @@ def rt_diff(img: np.ndarray, ref: np.ndarray) -> np.ndarray:
     return np.abs(a - b) / np.maximum(1.0, np.abs(b))
 
 
-def rt_err(img: np.ndarray, ref: np.ndarray, tol: float = RT_TOL) -> float:
+def rt_abs(img: np.ndarray, ref: np.ndarray) -> float:
+    """Plain max-abs difference of two RGBA16F targets (SURVEY.md section 8c's wording of the bar), reported next to rt_err."""
+    a = np.ascontiguousarray(img, np.uint16).view(np.float16).astype(np.float32)
+    b = np.ascontiguousarray(ref, np.uint16).view(np.float16).astype(np.float32)
+    return float(np.abs(a - b).max()) if a.size else 0.0
+
+
+def rare_allowance(img: np.ndarray) -> int:
+    """The opt-in outlier count for a FULL-SIZE frame: 2 + 2 per megapixel (measured: ONE pixel of the 1920x1080 C3 frame at 1.125 * 2^-9)."""
+    h, w = img.shape[:2]
+    return 2 + int(RT_RARE_PER_PIXEL * h * w)
+
+
+def rt_err(img: np.ndarray, ref: np.ndarray, tol: float = RT_TOL, rare: int = 0) -> float:
     """Parity metric of the RGBA16F target.  Per pixel and channel e = |a - b| / max(1, |b|): the accumulator
     is fp16, a value c in [2^k, 2^(k+1)) has an ulp of 2^(k-10) and premultiplied splat colours are not clamped to 1, so the bound
-    scales with the value (2^-9 = two fp16 ulps of any c in [0.5, 1), at most two of every larger c).
+    scales with the value (2^-9 = two fp16 ulps of any c in [0.5, 1), at most two of every larger c); for |c| <= 1 -- every pixel of
+    the test scenes but a few SH highlights -- it IS the plain max-abs of SURVEY.md section 8c (rt_abs reports that one too).
 
-    The only operation of the frame that is not bit-identical on both sides is exp2 (<= 1 ulp of fp32 in a fragment's alpha; the
-    DISCARD decision is identical since round 3: gs_device_math.h DecideAlpha).  One such ulp moves a blend's fp16 result by one
-    fp16 ulp with probability ~2^-13, the offset then rides along; most pixels never see one (> 99.99 % are bit-equal), some see one
-    or two (<= 2^-9), and about one pixel in a couple of million collects THREE in the same channel (measured: one pixel of the
-    1920x1080 C3 frame at 1.125 * 2^-9).  So: every pixel within RT_CAP = 2^-8, and no more than 2 + 2 per megapixel beyond `tol`.
-    Returns the value to compare with `tol`: the largest e among the pixels within tol if those conditions hold, else the largest e."""
+    Default (rare = 0): the largest e of the frame, no allowance.  The only operation of the frame that is not bit-identical on both
+    sides is exp2 (<= 1 ulp of fp32 in a fragment's alpha; the DISCARD decision is identical: gs_device_math.h DecideAlpha); one such
+    ulp moves a blend's fp16 result by one fp16 ulp with probability ~2^-13 and the offset then rides along: > 99.99 % of the pixels are
+    bit-equal, some carry one or two such ulps (<= 2^-9), and about one pixel in a couple of million collects THREE in one channel.
+    A test of a multi-megapixel frame where that was MEASURED opts in with rare = rare_allowance(img): at most that many pixels may lie
+    in (tol, RT_CAP], none beyond -- then the value returned is the largest e among the pixels within tol."""
     e = rt_diff(img, ref).max(axis=-1).reshape(-1)
+    if e.size == 0:
+        return 0.0
     over = e > tol
-    allowed = 2 + int(RT_RARE_PER_PIXEL * e.size)
-    if tol >= RT_CAP or int(over.sum()) > allowed or float(e.max()) > RT_CAP:
+    if rare <= 0 or tol >= RT_CAP or int(over.sum()) > rare or float(e.max()) > RT_CAP:
         return float(e.max())
     return float(e[~over].max()) if (~over).any() else 0.0

@@ -11,18 +11,6 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
-    if _has_gpu():
-        # the oracle counts (tile, splat) pairs for the tile shape the library composites a target of that size with
-        # (gs_renderer_tile_shape with a null renderer = the automatic choice; tests that override it set Oracle.tile themselves)
-        import ctypes as C
-        import oracle_lib
-        from unitygaussiansplatting_amd import _lib
-
-        def hook(W, H):
-            w, h = C.c_uint32(), C.c_uint32()
-            _lib.check(_lib.lib().gs_renderer_tile_shape(None, int(W), int(H), C.byref(w), C.byref(h)), "gs_renderer_tile_shape")
-            return w.value, h.value
-        oracle_lib.tile_shape_hook = hook
 
 
 def _has_gpu() -> bool:

@@ -45,8 +45,8 @@ def _p(a):
 
 
 # The compositor tile the (tile, splat) pair count refers to is a performance parameter of the build under test (16x16, 32x16 or
-# 32x32 pixels; frames do not depend on it).  GPU tests point this hook at the library's choice for a target size
-# (tests/conftest.py: gs_renderer_tile_shape); without a hook the oracle counts 16x16 tiles.
+# 32x32 pixels; frames do not depend on it): Oracle.tile_pairs counts 16x16 tiles unless Oracle.tile says otherwise; GPU tests compare
+# the library's count with Oracle.pairs(P, frame_stats), the count for the shape the draw reported.
 tile_shape_hook = None
 
 
@@ -104,6 +104,17 @@ class Oracle:
                           C.byref(pairs), C.byref(vis), win, _p(sd) if sd is not None else None)
         self.tile_pairs, self.visible = pairs.value, vis.value
         return rt
+
+    def pairs(self, params: gs_frame_params, tile) -> int:
+        """(tile, splat) pairs of the frame for a given compositor tile: `tile` = (tile_w, tile_h) or a gs_frame_stats (its tile_w / tile_h:
+        the shape the draw under test used -- a performance parameter the library picks per target and scene).  Also sets self.visible."""
+        t = (int(tile.tile_w), int(tile.tile_h)) if hasattr(tile, "tile_w") else (int(tile[0]), int(tile[1]))
+        keep, self.tile = self.tile, t
+        try:
+            self.draw(params, 0, window=(0, 0, -1, -1))          # counts only
+        finally:
+            self.tile = keep
+        return self.tile_pairs
 
     def draw_debug_points(self, params: gs_frame_params, display_index: bool, size: float, rt: np.ndarray | None = None, scene_depth=None):
         W, H = int(params.screen_w), int(params.screen_h)

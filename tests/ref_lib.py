@@ -55,6 +55,62 @@ def _p(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
+# The oracle's canonical arithmetic is BIT-equal to the `fused` build as g++ 11.4 contracts the shader text: a
+# property of one compiler's contraction choices.  oracle/Makefile records the compiler that built oracle/_ref in _ref/COMPILER; with
+# another one the fused build is a different -- equally legitimate -- member of the family, and the tests that assert bit-equality
+# fall back to the bounds of DESIGN.md section 5.1 (what `fused_clang` is held to) instead of failing without a product change.
+PINNED_COMPILER = "g++ (Ubuntu 11.4.0"
+
+
+def fused_compiler() -> str:
+    lib("fused")
+    path = os.path.join(_DIR, "COMPILER")
+    if os.path.exists(path):
+        return open(path).read().strip()
+    try:                                   # an _ref built before the compiler was recorded: it was built in this image
+        return subprocess.run(["g++", "--version"], capture_output=True, text=True).stdout.splitlines()[0].strip()
+    except Exception:
+        return "unknown"
+
+
+def fused_is_pinned() -> bool:
+    return fused_compiler().startswith(PINNED_COMPILER)
+
+
+def assert_axes_close(vr, vo, live):
+    """Axis offsets in pixels.  The 2x2 eigen-decomposition is ill-conditioned for a nearly isotropic screen covariance (the axes of a
+    circle may point anywhere), so an ulp of difference in cov2d can turn the axes of such a splat by a fraction of a degree without
+    changing the ellipse.  Asserted: the ELLIPSE (axis1 axis1^T + axis2 axis2^T, what the fragments see) agrees to rounding noise for
+    every splat, and the axes themselves for all but the ill-conditioned tail (DESIGN.md section 5.1 measured 0.041 px there)."""
+    cat = lambda v: np.concatenate([v["axis1"][live], v["axis2"][live]], axis=1).astype(np.float64)
+    ar, ao = cat(vr), cat(vo)
+    assert np.array_equal(np.isnan(ar), np.isnan(ao))
+    ok = ~np.isnan(ao).any(axis=1)
+    ar, ao = ar[ok], ao[ok]
+    shape = lambda a: np.stack([a[:, 0] ** 2 + a[:, 2] ** 2, a[:, 0] * a[:, 1] + a[:, 2] * a[:, 3], a[:, 1] ** 2 + a[:, 3] ** 2], axis=1)
+    sr, so = shape(ar), shape(ao)
+    rel = np.abs(sr - so).max(axis=1) / np.abs(so).max(axis=1)
+    assert np.quantile(rel, 0.999) <= 2e-5 and rel.max() <= 2e-3, (rel.max(), np.quantile(rel, 0.999))
+    d = np.abs(ar - ao).max(axis=1)
+    assert np.quantile(d, 0.999) <= 1e-3 and np.median(d) <= 1e-5 and d.max() <= 0.5, (d.max(), np.quantile(d, 0.999), np.median(d))
+
+
+
+
+def assert_view_is_the_fused_build(v_fused, v_other):
+    """40-byte SplatViewData records of the `fused` build (v_fused) vs the oracle's / the HIP kernels' (v_other): bit-equal when _ref was
+    built by the pinned compiler; with another compiler (another, equally legitimate, set of contraction choices) the bounds DESIGN.md
+    section 5.1 holds `fused_clang` to: clip position bit-equal, packed colour within half an ulp in < 1e-3 of the records, axes close."""
+    from common import views_equal
+    if fused_is_pinned():
+        assert views_equal(v_fused, v_other), "40-byte SplatViewData records differ from the fused build of the reference text"
+        return
+    print(f"oracle/_ref was built by `{fused_compiler()}` (pinned: {PINNED_COMPILER}...): asserting the section 5.1 bounds instead of bit-equality")
+    assert np.array_equal(v_fused["pos"].view(np.uint32), v_other["pos"].view(np.uint32))
+    assert (v_fused["color"] != v_other["color"]).any(axis=1).mean() <= 1e-3
+    assert_axes_close(v_fused, v_other, v_other["pos"][:, 3] > 0)
+
+
 def flipped(P: gs_frame_params) -> gs_frame_params:
     """The matrices Unity binds when it renders into a texture on D3D / Vulkan / Metal (GL.GetGPUProjectionMatrix(proj, true)):
     projection row 1 negated, so clip.y points down and the D3D viewport stores the picture bottom row first."""

@@ -118,5 +118,5 @@ def test_verylow_asset_renders_like_the_oracle(gpu_ctx):
     assert np.array_equal(r.DownloadOrder(), orc.order)
     assert views_equal(r.DownloadView(), orc.calc_view(P))
     ref = orc.draw(P, 0)
-    assert rt_err(rt.Download(), ref) <= RT_TOL and st.tile_pairs == orc.tile_pairs
+    assert rt_err(rt.Download(), ref) <= RT_TOL and st.tile_pairs == orc.pairs(P, st)
     r.OnDisable()

@@ -76,7 +76,9 @@ def measure(quality: str, n: int, seed: int, extent: float, W: int, H: int):
                 view_colour_max_abs=float(np.abs(col_b - col_f).max()) if col_b.size else 0.0,
                 pairs_delta=int(f["pairs"]) - int(base["pairs"]), visible_delta=int(f["visible"]) - int(base["visible"]),
                 rt_pixels_changed=int((base["rt"] != f["rt"]).any(2).sum()), rt_max_abs=float(d.max()), rt_max_rel=float(rel.max()),
+                rt_pixels_over_2m8=int((rel.max(axis=2) > 2.0 ** -8).sum()),
                 r8_pixels_changed=int((base["r8"] != f["r8"]).any(2).sum()),
+                r8_pixels_over_1=int((np.abs(base["r8"].astype(np.int32) - f["r8"].astype(np.int32)).max(axis=2) > 1).sum()),
                 r8_max_diff=int(np.abs(base["r8"].astype(np.int32) - f["r8"].astype(np.int32)).max()))
     finally:
         O.lib().gso_set_canon(0)
@@ -100,10 +102,11 @@ def test_canonical_arithmetic_choice_stays_inside_the_stated_tolerances(case):
         assert abs(r["pairs_delta"]) <= max(8, n // 5000) and abs(r["visible_delta"]) <= max(4, n // 20000), (label, r)
         # Measured: up to 1.6 * 2^-9 on < 1 % of the pixels -- i.e. the reading of the HLSL moves the framebuffer MORE than the
         # HIP kernels differ from the oracle (<= 2^-9, tests/test_gpu_draw.py); with round 3's canon one pixel of C1 reaches 1.9 * 2^-8
-        # (two depth-neighbours that swap places where they overlap).  The bar for the choice itself is 2^-7 and at
-        # most 2/255 on the resolved 8-bit image (GaussianSplatValidator.cs counts a pixel as different from 3/255).
-        assert r["rt_max_rel"] <= 2.0 ** -7, (label, r)
-        assert r["r8_max_diff"] <= 2, (label, r)                     # the validator counts a pixel from 3/255 (measured: 2 on ONE pixel of C1, else 1)
+        # (two depth-neighbours that swap places where they overlap).  The bar for the choice itself stays 2^-8 per pixel and 1/255 on
+        # the resolved 8-bit image, with an explicit outlier allowance for that measured pixel -- at most 2 pixels above, none beyond
+        # 2^-7 resp. 2/255 (GaussianSplatValidator.cs counts a pixel as different from 3/255) -- rather than a wider bar for every pixel.
+        assert r["rt_pixels_over_2m8"] <= 2 and r["rt_max_rel"] <= 2.0 ** -7, (label, r)
+        assert r["r8_pixels_over_1"] <= 2 and r["r8_max_diff"] <= 2, (label, r)
 
 
 if __name__ == "__main__":

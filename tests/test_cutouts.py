@@ -182,7 +182,8 @@ def test_gpu_view_and_frame_with_cutouts_and_deleted_bits(gpu_ctx, quality):
         ref = orc.draw(P, 0)
         e = rt_err(rt.Download(), ref)
         assert e <= RT_TOL, (name, use_bits, e)
-        assert r.FrameStats().tile_pairs == orc.tile_pairs
+        st = r.FrameStats()
+        assert st.tile_pairs == orc.pairs(P, st)
     r.OnDisable()
 
 

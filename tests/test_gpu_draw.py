@@ -2,14 +2,15 @@
 
 Tolerances: the only non-bit-exact operation is exp2 (v_exp_f32 vs the correctly rounded exp2 of the same
 fp32 argument, <= 1 ulp), which can flip an fp16 rounding of the accumulated colour; the discard decision at alpha = 1/255 is
-identical on both sides.  exact mode: tests/common.py rt_err <= 2^-9 (relative to max(1, |c|); every pixel <= 2^-8, at most
-2 + 2 per megapixel above 2^-9; > 99.99 % of the pixels bit-equal); fast mode: <= 4e-3.  Resolved 8-bit image: PSNR >= 50 dB and no pixel off by >= 3/255 (validator metric,
+identical on both sides.  exact mode: tests/common.py rt_err <= 2^-9 for EVERY pixel (relative to max(1, |c|); the plain max-abs is
+asserted next to it; > 99.99 % of the pixels bit-equal; an outlier allowance exists only as an opt-in, used by the C3 full-size frame
+alone); fast mode: <= 4e-3.  Resolved 8-bit image: PSNR >= 50 dB and no pixel off by >= 3/255 (validator metric,
 GaussianSplatValidator.cs:159-208)."""
 import numpy as np
 import pytest
 
 import oracle_lib as O
-from common import RT_TOL, default_camera, diff_pixels, psnr8, rt_err, small_asset
+from common import RT_TOL, default_camera, diff_pixels, psnr8, rt_abs, rt_err, small_asset
 from unitygaussiansplatting_amd import camera, creator, scenes
 from unitygaussiansplatting_amd._lib import GsError
 from unitygaussiansplatting_amd.renderer import GaussianSplatRenderer, GaussianSplatRenderSystem, RenderTarget
@@ -37,9 +38,10 @@ def render_both(gpu_ctx, a, cam, mode=0, tr=None, **fields):
     orc.calc_view(P)
     ref = orc.draw(P, mode)
     r32, r8 = O.resolve(ref, (0.1, 0.2, 0.3, 1.0))
+    pairs = orc.pairs(P, st)                 # the oracle's (tile, splat) count for the tile shape the draw used
     r.OnDisable()
     rt.Dispose()
-    return dict(img=img, ref=ref, o32=o32, o8=o8, r32=r32, r8=r8, st=st, orc=orc)
+    return dict(img=img, ref=ref, o32=o32, o8=o8, r32=r32, r8=r8, st=st, orc=orc, pairs=pairs)
 
 
 @pytest.mark.parametrize("W,H", [(640, 360), (333, 217), (16, 16), (17, 9), (1920, 1080)])
@@ -49,7 +51,9 @@ def test_framebuffer_parity(gpu_ctx, W, H, mode):
     res = render_both(gpu_ctx, a, default_camera(W=W, H=H, az=40.0), mode)
     e = rt_err(res["img"], res["ref"])
     assert e <= (RT_TOL if mode == 0 else 4e-3), e
-    assert res["st"].tile_pairs == res["orc"].tile_pairs and res["st"].visible_splats == res["orc"].visible
+    if mode == 0:                                   # SURVEY.md section 8c's wording: plain max-abs <= 2^-9 (no value of this scene exceeds 2: same bar)
+        assert rt_abs(res["img"], res["ref"]) <= RT_TOL, rt_abs(res["img"], res["ref"])
+    assert res["st"].tile_pairs == res["pairs"] and res["st"].visible_splats == res["orc"].visible
     assert (res["img"] == res["ref"]).all(axis=2).mean() > 0.995
     assert psnr8(res["o8"], res["r8"]) >= 50.0 and diff_pixels(res["o8"], res["r8"]) == 0
     # resolved float image = lerp(bg, GammaToLinearSpace(C/A), A): the un-premultiply divides the target's tolerance by A,
@@ -89,9 +93,7 @@ def test_tile_shapes_give_the_same_frame(gpu_ctx, W, H, mode):
             frames.append(rt.Download())
             want = shape if shape != (0, 0) else r.TileShape(W, H)
             assert (st.tile_w, st.tile_h) == want and st.tiles_x == (W + want[0] - 1) // want[0] and st.tiles_y == (H + want[1] - 1) // want[1]
-            orc.tile = want
-            orc.draw(P, mode, window=(0, 0, -1, -1))                 # counts only
-            assert st.tile_pairs == orc.tile_pairs and st.visible_splats == orc.visible
+            assert st.tile_pairs == orc.pairs(P, want) and st.visible_splats == orc.visible
             pairs.append(int(st.tile_pairs))
     assert rt_err(frames[0], ref) <= (RT_TOL if mode == 0 else 4e-3)
     for f in frames[1:]:
@@ -108,7 +110,7 @@ def test_framebuffer_parity_other_formats(gpu_ctx, quality):
     a = small_asset(40_000, 8, quality)
     res = render_both(gpu_ctx, a, default_camera(W=500, H=300, az=-30.0), 0, m_SplatScale=1.5, m_OpacityScale=0.7, m_SHOrder=2)
     assert rt_err(res["img"], res["ref"]) <= RT_TOL
-    assert res["st"].tile_pairs == res["orc"].tile_pairs
+    assert res["st"].tile_pairs == res["pairs"]
 
 
 def test_everything_culled_and_single_splat(gpu_ctx):
@@ -116,7 +118,7 @@ def test_everything_culled_and_single_splat(gpu_ctx):
     a = fp32_point_asset([[0.3, 0.1, 0.0]])
     cam = camera.Camera(position=(0, 0, 5), target=(0, 0, 0), pixelWidth=128, pixelHeight=96)
     res = render_both(gpu_ctx, a, cam)
-    assert res["st"].visible_splats == 1 and res["st"].tile_pairs == res["orc"].tile_pairs >= 1
+    assert res["st"].visible_splats == 1 and res["st"].tile_pairs == res["pairs"] >= 1
     assert np.abs(O.f16_to_f32(res["img"]) - O.f16_to_f32(res["ref"])).max() <= 2.0 ** -10
     back = camera.Camera(position=(0, 0, 5), target=(0, 0, 10), pixelWidth=128, pixelHeight=96)      # looking away
     res = render_both(gpu_ctx, a, back)
@@ -134,7 +136,11 @@ def test_pair_buffer_overflow_is_reported_and_recovered(gpu_ctx):
     r = GaussianSplatRenderer(gpu_ctx, a)
     r.OnEnable()
     rt = RenderTarget(gpu_ctx, 1920, 1080)
+    r.SetTileShape(16, 16)                       # the premise (more than the initial 4 M pairs) is a 16x16-tile count
     r.SortPoints(cam); r.CalcViewData(cam); rt.Clear(); r.Draw(cam, rt)
+    gpu_ctx.Synchronize()
+    pairs, cap = r.PollPairs()                   # the non-blocking report: this draw was truncated
+    assert pairs > cap == (1 << 22)
     with pytest.raises(GsError) as e:
         r.FrameStats()
     assert e.value.code == -6
@@ -146,7 +152,7 @@ def test_pair_buffer_overflow_is_reported_and_recovered(gpu_ctx):
     P = r.FrameParams(cam)
     orc.calc_view(P)
     ref = orc.draw(P, 0)
-    assert st.tile_pairs == orc.tile_pairs
+    assert st.tile_pairs == orc.pairs(P, st)
     assert rt_err(rt.Download(), ref) <= RT_TOL
     r.OnDisable()
 

@@ -128,8 +128,17 @@ def test_renderer_sort_is_bit_exact_over_frames(gpu_ctx, quality):
     r.SortPoints(cam)
     orc.sort(camera.sort_matrix(cam, r.transform.localToWorldMatrix))
     assert np.array_equal(r.DownloadOrder(), orc.order)
+    # m_GpuSortDistances stays the SORTED keys of the last sort when the order buffer is overwritten afterwards (the last depth pass
+    # skips the key write and the keys are rebuilt through order[] on demand: they must be rebuilt before order[] changes)
+    sorted_keys = orc.keys.copy()
     r.ResetOrder()
     assert np.array_equal(r.DownloadOrder(), np.arange(a.splatCount, dtype=np.uint32))
+    assert np.array_equal(r.DownloadDistances(), sorted_keys)
+    r.SortPoints(cam)
+    orc.order[:] = np.arange(a.splatCount, dtype=np.uint32)
+    orc.sort(camera.sort_matrix(cam, r.transform.localToWorldMatrix))
+    r.UploadOrder(perm)
+    assert np.array_equal(r.DownloadDistances(), orc.keys) and np.array_equal(r.DownloadOrder(), perm)
     r.OnDisable()
 
 

@@ -114,3 +114,31 @@ def test_view_buffer_every_frame_mode_matches_on_demand(gpu_ctx):
         r.OnDisable(); rt.Dispose()
     assert np.array_equal(res[0][0], res[1][0]) and views_equal(res[0][1], res[1][1]) and res[0][2:] == res[1][2:]
     assert 0 < res[0][3] < a.splatCount
+
+
+@pytest.mark.parametrize("shfmt", ["Norm11", "Float16", "Norm6"])
+def test_chunkless_lossy_sh_asset_on_the_per_frame_path(gpu_ctx, shfmt):
+    """An asset with a lossy SH format but NO chunk blob (gs_asset_create accepts it: _SplatChunkCount = 0, so nothing is chunk-lerped,
+    SplatUtilities.compute / GaussianSplatting.hlsl:521-527): the per-frame calc_view launch (which does not zero-fill its per-splat
+    record) must see shLerp = false like the full kernel and the oracle do -- records, visibility and the frame itself."""
+    from test_gpu_configs import check_raster_records
+    from common import RT_TOL, rt_err
+    from unitygaussiansplatting_amd.renderer import RenderTarget
+    a0 = small_asset(20_000, 9, "VeryHigh", formatSH=getattr(A.SHFormat, shfmt))
+    import copy
+    a = copy.copy(a0)
+    a.chunkData = None
+    cam = default_camera(W=400, H=240, az=70.0)
+    r = GaussianSplatRenderer(gpu_ctx, a)
+    r.OnEnable()
+    rt = RenderTarget(gpu_ctx, cam.pixelWidth, cam.pixelHeight)
+    r.SortPoints(cam); r.CalcViewData(cam); rt.Clear(); r.Draw(cam, rt)
+    st = r.FrameStats()
+    orc = O.Oracle(a)
+    orc.sort(camera.sort_matrix(cam, r.transform.localToWorldMatrix))
+    P = r.FrameParams(cam)
+    orc.calc_view(P)
+    assert check_raster_records(r, orc, P) == st.visible_splats > 1000
+    assert rt_err(rt.Download(), orc.draw(P, 0)) <= RT_TOL and st.tile_pairs == orc.pairs(P, st)
+    assert np.array_equal(r.DownloadView().view(np.uint32), orc.view.view(np.uint32))
+    r.OnDisable(); rt.Dispose()

@@ -90,32 +90,14 @@ def test_canonical_arithmetic_is_the_fused_build_of_the_reference_text(quality, 
         assert np.array_equal(ref.calc_distances(ms), orc.calc_distances(ms)), "CSCalcDistances keys differ"
         P = camera.frame_params(cam, TR, ss, osc, shOrder, shOnly)
         vo, vr = orc.calc_view(P), ref.calc_view(P)
-        assert views_equal(vr, vo), "40-byte SplatViewData records differ"
         live = vo["pos"][:, 3] > 0
         assert live.sum() > 1000
+        R.assert_view_is_the_fused_build(vr, vo)
         if ss == 1.0 and shOrder == 3:                      # another compiler's contraction choices: the same records up to the axes
             vc = R.Ref(a, "fused_clang").calc_view(P)
             assert np.array_equal(vc["pos"].view(np.uint32), vo["pos"].view(np.uint32))
             assert (vc["color"] != vo["color"]).any(axis=1).mean() <= 1e-3
-            assert_axes_close(vc, vo, live)
-
-
-def assert_axes_close(vr, vo, live):
-    """Axis offsets in pixels.  The 2x2 eigen-decomposition is ill-conditioned for a nearly isotropic screen covariance (the axes of a
-    circle may point anywhere), so an ulp of difference in cov2d can turn the axes of such a splat by a fraction of a degree without
-    changing the ellipse.  Asserted: the ELLIPSE (axis1 axis1^T + axis2 axis2^T, what the fragments see) agrees to rounding noise for
-    every splat, and the axes themselves for all but the ill-conditioned tail (DESIGN.md section 5.1 measured 0.041 px there)."""
-    cat = lambda v: np.concatenate([v["axis1"][live], v["axis2"][live]], axis=1).astype(np.float64)
-    ar, ao = cat(vr), cat(vo)
-    assert np.array_equal(np.isnan(ar), np.isnan(ao))
-    ok = ~np.isnan(ao).any(axis=1)
-    ar, ao = ar[ok], ao[ok]
-    shape = lambda a: np.stack([a[:, 0] ** 2 + a[:, 2] ** 2, a[:, 0] * a[:, 1] + a[:, 2] * a[:, 3], a[:, 1] ** 2 + a[:, 3] ** 2], axis=1)
-    sr, so = shape(ar), shape(ao)
-    rel = np.abs(sr - so).max(axis=1) / np.abs(so).max(axis=1)
-    assert np.quantile(rel, 0.999) <= 2e-5 and rel.max() <= 2e-3, (rel.max(), np.quantile(rel, 0.999))
-    d = np.abs(ar - ao).max(axis=1)
-    assert np.quantile(d, 0.999) <= 1e-3 and np.median(d) <= 1e-5 and d.max() <= 0.5, (d.max(), np.quantile(d, 0.999), np.median(d))
+            R.assert_axes_close(vc, vo, live)
 
 
 @pytest.mark.parametrize("quality,fmt", FORMAT_CASES[:4] + FORMAT_CASES[5:])
@@ -150,7 +132,7 @@ def test_every_build_is_inside_the_sensitivity_bounds(which, quality):
     live = (vo["pos"][:, 3] > 0) & (vr["pos"][:, 3] > 0)
     assert (vo["pos"][:, 3] > 0).sum() - live.sum() <= 2
     assert np.abs(vr["pos"][live] - vo["pos"][live]).max() <= 1e-4 * np.abs(vo["pos"][live]).max()
-    assert_axes_close(vr, vo, live)                                                 # section 5.1: 0.041 px for the unfused lerp
+    R.assert_axes_close(vr, vo, live)                                                 # section 5.1: 0.041 px for the unfused lerp
     h = lambda v, sh: O.f16_to_f32(((v >> sh) & 0xffff).astype(np.uint16))
     for word, sh in ((0, 16), (0, 0), (1, 16), (1, 0)):
         co, cr = h(vo["color"][live, word], sh), h(vr["color"][live, word], sh)
@@ -188,7 +170,7 @@ def test_cutouts_and_deleted_bits_through_the_reference_kernel():
     orc, ref = O.Oracle(a), R.Ref(a, "fused")
     vo = orc.calc_view(P, arr, n, deleted).copy()
     vr = ref.calc_view(P, arr, n, deleted)
-    assert views_equal(vr, vo)
+    R.assert_view_is_the_fused_build(vr, vo)
     cut = vo["pos"][:, 3] == 0
     assert 0.2 < cut.mean() < 0.95
     plain = orc.calc_view(P)
@@ -303,7 +285,7 @@ def test_bench_scenes_are_pinned_too(key):
         assert np.array_equal(ref.calc_distances(ms), orc.calc_distances(ms)), "CSCalcDistances keys differ"
         P = camera.frame_params(cam, tr)
         vo, vr = orc.calc_view(P), ref.calc_view(P)
-        assert views_equal(vr, vo), "40-byte SplatViewData records differ"
+        R.assert_view_is_the_fused_build(vr, vo)
         drawn += int((vo["pos"][:, 3] > 0).sum())
     assert drawn > 30_000
 

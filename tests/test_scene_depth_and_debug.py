@@ -66,7 +66,7 @@ def test_gpu_scene_depth_matches_oracle(gpu_ctx, mode):
     ref = orc.draw(P, mode, scene_depth=depth)
     free = orc.draw(P, mode)
     assert rt_err(img, ref) <= (RT_TOL if mode == 0 else 4e-3)
-    assert st.tile_pairs == orc.tile_pairs                                  # binning does not depend on the depth attachment
+    assert st.tile_pairs == orc.pairs(P, st)                                  # binning does not depend on the depth attachment
     assert O.f16_to_f32(img)[:60, :80].max() == 0.0                         # everything is behind the near box
     assert rt_err(img, free) > 0.05                                         # ... and the plane really hides something
     rt.SetSceneDepth(None)                                                  # detached again: the unoccluded frame

@@ -60,6 +60,7 @@ SIGNATURES = {
     "gs_renderer_tile_shape": (C.c_int32, [_P, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "gs_renderer_set_profiling": (C.c_int32, [_P, C.c_int32]),
     "gs_renderer_reserve_pairs": (C.c_int32, [_P, C.c_uint64]),
+    "gs_renderer_poll_pairs": (C.c_int32, [_P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "gs_renderer_download_order": (C.c_int32, [_P, _P, C.c_size_t]),
     "gs_renderer_download_distances": (C.c_int32, [_P, _P, C.c_size_t]),
     "gs_renderer_upload_order": (C.c_int32, [_P, _P, C.c_size_t]),
@@ -99,6 +100,8 @@ def lib():
             raise GsError(-2, "load", f"{LIB_PATH} is missing: build it with `python -m unitygaussiansplatting_amd.build`")
         l = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
+            if os.environ.get("GSPLAT_LIB") and not hasattr(l, name):
+                continue                   # an A/B variant build of an older ABI: the missing entry point fails when it is called
             fn = getattr(l, name)          # AttributeError here = the library does not export a declared symbol
             fn.restype = res
             fn.argtypes = args

@@ -287,10 +287,21 @@ int32_t gs_renderer_destroy(gs_renderer* r) {
     return GS_OK;
 }
 
+// m_GpuSortDistances holds the sorted keys after a sort (GpuSorting.cs:142-198).  The last depth pass skips that write (nothing on the
+// frame's path reads them) and gs_renderer_download_distances rebuilds them as keyBySplat[order[i]] -- which is only right while order[]
+// is the sort's own output: anything that is about to overwrite order[] materialises them first.
+static int32_t materialise_distances(gs_renderer* r) {
+    if (!r->distancesStale) return GS_OK;
+    GS_TRY(enqueue_gather_keys(r->ctx, r->keyBySplat, r->order, r->distances, r->n));
+    r->distancesStale = false;
+    return GS_OK;
+}
+
 int32_t gs_renderer_reset_order(gs_renderer* r) {
     if (!r) return fail(GS_ERR_INVALID_ARGUMENT, "renderer is null");
     GS_TRY(bind_device(r->ctx));
     GS_TRY(join_sort(r));
+    GS_TRY(materialise_distances(r));
     GS_TRY(enqueue_set_indices(r->ctx, r->order, r->n));
     return mark_order_use(r);
 }
@@ -514,6 +525,13 @@ int32_t gs_renderer_reserve_pairs(gs_renderer* r, uint64_t cap) {
     return GS_OK;
 }
 
+int32_t gs_renderer_poll_pairs(gs_renderer* r, uint64_t* tile_pairs, uint64_t* pair_capacity) {
+    if (!r || !tile_pairs || !pair_capacity) return fail(GS_ERR_INVALID_ARGUMENT, "null argument");
+    *tile_pairs = r->hostReport ? (uint64_t)*(volatile unsigned long long*)&r->hostReport->pairCount : 0u;
+    *pair_capacity = r->pairCapacity;
+    return GS_OK;
+}
+
 static int32_t download(gs_context* ctx, void* dst, const void* src, size_t bytes) {
     GS_TRY(bind_device(ctx));
     GS_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
@@ -529,17 +547,15 @@ int32_t gs_renderer_download_order(gs_renderer* r, uint32_t* out, size_t count) 
 int32_t gs_renderer_download_distances(gs_renderer* r, uint32_t* out, size_t count) {
     if (!r || !out || count > r->n) return fail(GS_ERR_INVALID_ARGUMENT, "bad argument");
     GS_TRY(join_sort(r));
-    if (r->distancesStale) {         // m_GpuSortDistances after the sort = the sorted keys (GpuSorting.cs:142-198): materialised on demand
-        GS_TRY(bind_device(r->ctx));
-        GS_TRY(enqueue_gather_keys(r->ctx, r->keyBySplat, r->order, r->distances, r->n));
-        r->distancesStale = false;
-    }
+    GS_TRY(bind_device(r->ctx));
+    GS_TRY(materialise_distances(r));      // the sorted keys, materialised on demand
     return download(r->ctx, out, r->distances, count * 4);
 }
 int32_t gs_renderer_upload_order(gs_renderer* r, const uint32_t* in, size_t count) {
     if (!r || !in || count != r->n) return fail(GS_ERR_INVALID_ARGUMENT, "bad argument");
     GS_TRY(bind_device(r->ctx));
     GS_TRY(join_sort(r));
+    GS_TRY(materialise_distances(r));      // before order[] stops being the sort's output
     GS_HIP(hipMemcpyAsync(r->order, in, count * 4, hipMemcpyHostToDevice, r->ctx->stream));
     GS_HIP(hipStreamSynchronize(r->ctx->stream));
     return GS_OK;
@@ -644,6 +660,8 @@ int32_t gs_renderer_stage_times(gs_renderer* r, gs_stage_times* out) {
     out->onesweep_depth_ms = avg(10, 11);
     out->onesweep_pairs_ms = avg(12, 13);
     out->onesweep_pair_launches = r->lastPairPasses;
+    for (int ps = 0; ps < 4; ++ps) out->onesweep_depth_kernel_ms += avg(14 + 2 * ps, 15 + 2 * ps);
+    for (int ps = 0; ps < (int)r->lastPairPasses && ps < 3; ++ps) out->onesweep_pairs_kernel_ms += avg(22 + 2 * ps, 23 + 2 * ps);
     out->total_ms = out->calc_distances_ms + out->sort_ms + out->calc_view_ms + out->bin_ms + out->pair_sort_ms + out->blend_ms;
     out->frames = (uint32_t)(r->profCompleted < r->profCapacity ? r->profCompleted : r->profCapacity);
     r->profCur = 0; r->profCompleted = 0;

@@ -171,8 +171,10 @@ int32_t gs_comm_info(const gs_comm* c, int32_t* nranks, int32_t* rank) {
 // receives the same handle; on every other rank `asset_on_root` is ignored and *out receives a new asset that owns
 // device copies of the five blobs.  Blocks until the blobs have arrived (a load-time operation).
 // Every rank leaves through the same door: after the header every rank contributes a status word (its argument check on the
-// root, its allocations elsewhere) to one ncclAllReduce(min), so that a rank that cannot take part makes ALL ranks return
-// GS_ERR_COMM together instead of leaving the others parked in a broadcast.
+// root, its allocations elsewhere, any local HIP failure up to that point) to one ncclAllReduce(min), so that a rank that cannot
+// take part makes ALL ranks return GS_ERR_COMM together instead of leaving the others parked in a broadcast.  Errors AFTER the
+// status exchange (a blob broadcast or the final synchronise failing) and errors returned by a collective call itself are fatal
+// for the communicator: destroy it (the other ranks' collectives fail in turn).
 int32_t gs_asset_broadcast(gs_comm* c, gs_asset* asset_on_root, int32_t root, gs_asset** out) {
     if (!c || !out) return fail(GS_ERR_INVALID_ARGUMENT, "null argument");
     *out = nullptr;
@@ -184,29 +186,51 @@ int32_t gs_asset_broadcast(gs_comm* c, gs_asset* asset_on_root, int32_t root, gs
     // a root without a usable asset still enters the collectives (with a header nobody accepts) so that nobody hangs
     const bool rootArgOk = !isRoot || (asset_on_root && asset_on_root->ctx == c->ctx);
 
+    // Local failures on the way to the status exchange are FOLDED into `mine` instead of returning: a rank that left here would
+    // leave the others parked in the next collective.  What cannot be folded is a failure of a collective call itself
+    // (ncclBroadcast / ncclAllReduce returning an error): the communicator is then unusable on this rank -- the caller destroys
+    // it (gs_comm_destroy aborts what is in flight) -- and the other ranks see their own collective fail.
+    int32_t mine = GS_OK;
+    auto note_hip = [&](hipError_t e, const char* what) { if (e != hipSuccess && mine == GS_OK) mine = fail_hip(e, what, __FILE__, __LINE__); };
+
     // ---- header: formats, count, blob sizes
     uint64_t h[kHeaderWords] = {0};
     if (isRoot) {
         if (rootArgOk) pack_header(asset_on_root, h);
-        GS_HIP(hipMemcpyAsync(c->headerDev, h, sizeof(h), hipMemcpyHostToDevice, st));
+        const hipError_t e = hipMemcpyAsync(c->headerDev, h, sizeof(h), hipMemcpyHostToDevice, st);
+        note_hip(e, "asset broadcast: header upload");
+        if (e != hipSuccess) (void)hipMemsetAsync(c->headerDev, 0, sizeof(h), st);      // a header nobody accepts
     }
     GS_NCCL(rccl().Broadcast(c->headerDev, c->headerDev, sizeof(h), ncclUint8, root, c->comm, st));
-    GS_HIP(hipMemcpyAsync(h, c->headerDev, sizeof(h), hipMemcpyDeviceToHost, st));
-    GS_HIP(hipStreamSynchronize(st));
+    {
+        hipError_t e = hipMemcpyAsync(h, c->headerDev, sizeof(h), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        note_hip(e, "asset broadcast: header download");
+        if (e != hipSuccess) memset(h, 0, sizeof(h));
+    }
 
     // ---- this rank's half, then the status exchange
     gs_asset* a = asset_on_root;
-    int32_t mine = GS_OK;
-    if (!header_ok(h)) mine = isRoot ? fail(GS_ERR_INVALID_ARGUMENT, "the root must pass an asset of the comm's context") : fail(GS_ERR_COMM, "asset broadcast: bad header received");
-    else if (!isRoot) mine = receive_alloc(ctx, h, &a);
+    bool allocated = false;
+    if (mine == GS_OK) {
+        if (!header_ok(h)) mine = isRoot ? fail(GS_ERR_INVALID_ARGUMENT, "the root must pass an asset of the comm's context") : fail(GS_ERR_COMM, "asset broadcast: bad header received");
+        else if (!isRoot) { mine = receive_alloc(ctx, h, &a); allocated = mine == GS_OK; }
+    }
     int32_t* statusDev = (int32_t*)(c->headerDev + kHeaderWords - 1);             // last header word: scratch for the status
-    GS_HIP(hipMemcpyAsync(statusDev, &mine, sizeof(int32_t), hipMemcpyHostToDevice, st));
+    {
+        const hipError_t e = hipMemcpyAsync(statusDev, &mine, sizeof(int32_t), hipMemcpyHostToDevice, st);
+        note_hip(e, "asset broadcast: status upload");
+        if (e != hipSuccess) (void)hipMemsetAsync(statusDev, 0xff, sizeof(int32_t), st);   // -1: "this rank failed"
+    }
     GS_NCCL(rccl().AllReduce(statusDev, statusDev, 1, ncclInt32, ncclMin, c->comm, st));
     int32_t all = GS_OK;
-    GS_HIP(hipMemcpyAsync(&all, statusDev, sizeof(int32_t), hipMemcpyDeviceToHost, st));
-    GS_HIP(hipStreamSynchronize(st));
-    if (all != GS_OK) {
-        if (!isRoot && mine == GS_OK) gs_asset_destroy(a);
+    {
+        hipError_t e = hipMemcpyAsync(&all, statusDev, sizeof(int32_t), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) { note_hip(e, "asset broadcast: status download"); all = mine; }   // (this rank cannot learn the verdict: it does not take part in the blobs)
+    }
+    if (all != GS_OK || mine != GS_OK) {
+        if (allocated) gs_asset_destroy(a);
         if (mine != GS_OK) return mine;                                             // the detail of this rank's own failure stands
         gs::set_error_detail("asset broadcast: another rank could not take part (its error %d)", all);
         return GS_ERR_COMM;

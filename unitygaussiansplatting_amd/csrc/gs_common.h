@@ -1,6 +1,7 @@
 // gs_common.h -- host-side object layouts and helpers shared by the .hip translation units.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
@@ -35,7 +36,7 @@ constexpr int kBinThreads = 256;
 constexpr int kBinItems = GS_BIN_ITEMS;   // sorted positions per thread
 constexpr int kBinPart = kBinThreads * kBinItems;
 constexpr uint32_t kBinTicketClasses = 16;
-constexpr int kEvPerFrame = 14;           // hipEvents per profiled frame
+constexpr int kEvPerFrame = 28;           // hipEvents per profiled frame: 0..13 stage brackets; 14..21 / 22..27 start + stop of each depth / pair Onesweep launch
 
 // 32-byte per-splat record consumed by the blend kernel (written by calc_view, splat-index order)
 struct alignas(16) SplatRec {
@@ -85,7 +86,7 @@ struct SortControl {
 // What the host wants to know about a finished draw: stored by the blend's first workgroup (or tile_order_kernel) straight into mapped pinned host memory
 struct FrameReport {
     unsigned long long pairCount;
-    uint32_t binError, pairSortError, visible, pad;
+    uint32_t binError, pairSortError, visible, tileShape;   // tileShape: log2 tile width | log2 tile height << 8 of the draw that reported
 };
 
 // The two words every workgroup hits with an atomic (ticket, visible) sit in their own 128-B lines: same-address
@@ -198,6 +199,7 @@ struct gs_renderer {
     uint32_t costShape[2] = {0, 0};         // ... and the same tile shape (log2 w | log2 h << 8)
     uint32_t tileOverrideWL = 0, tileOverrideHL = 0;   // gs_renderer_set_tile_shape: log2 tile width / height, 0 = automatic
     uint32_t lastTileWL = 4, lastTileHL = 4;           // of the last draw
+    bool adaptTall = false;                            // automatic shape: 32x32 instead of 32x16 (large splats; adapt_tile_shape)
     uint32_t* tileOrderBuf = nullptr;       // arenaTiles x u32: the blend's tile schedule of the draw in flight
     uint32_t binParts = 0;
     int blendMode = 0;

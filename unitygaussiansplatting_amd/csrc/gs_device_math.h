@@ -773,6 +773,10 @@ GS_HD void CalcViewGeom(const AssetView& a, const FrameConsts& P, const EditView
         vp.shMin = { f16tof32(ck.w[13]), f16tof32(ck.w[14]), f16tof32(ck.w[15]) };
         vp.shMax = { f16tof32(ck.w[13] >> 16), f16tof32(ck.w[14] >> 16), f16tof32(ck.w[15] >> 16) };
         vp.shLerp = a.shFmt > 0 && a.shFmt <= 3;
+    } else {
+        // a chunk-less asset (VeryHigh fp32, or a lossy-format asset created without a chunk blob): CalcViewColor reads these
+        // whatever the record's zero-fill above did (outputsOnlyIfDrawn skips it)
+        vp.shLerp = false; vp.shMin = { 0, 0, 0 }; vp.shMax = { 0, 0, 0 };
     }
     vp.col = col;
 

@@ -102,9 +102,10 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
 
 // The draw's report, straight into the host's mapped memory (visible to it once the stream is idle) -- written before the
 // blend's tiles run, so that an overflowing scene is noticed within the pipeline depth.
-__device__ __forceinline__ void write_report(const BinControl* binCtl, const uint32_t* pairSortError, FrameReport* report) {
+__device__ __forceinline__ void write_report(const BinControl* binCtl, const uint32_t* pairSortError, FrameReport* report, uint32_t tileShape) {
     report->pairCount = binCtl->pairCount; report->binError = binCtl->error; report->visible = binCtl->visible;
     report->pairSortError = *pairSortError;
+    report->tileShape = tileShape;                  // log2 tile width | log2 tile height << 8: what pairCount counts
 }
 
 // Scheduling order of the blend's workgroups: tiles by descending expected cost (the hardware hands out workgroups in
@@ -186,9 +187,9 @@ __device__ __forceinline__ void tile_order_body(const uint32_t* __restrict__ til
 __global__ __launch_bounds__(1024) void tile_order_kernel(const uint32_t* __restrict__ tileStart, const uint32_t* __restrict__ tileEnd,
                                                           const uint32_t* __restrict__ tileCost, uint32_t numTiles, uint32_t tilesX, uint32_t* __restrict__ tileOrder,
                                                           const BinControl* __restrict__ binCtl, const uint32_t* __restrict__ pairSortError,
-                                                          FrameReport* __restrict__ report) {
+                                                          FrameReport* __restrict__ report, uint32_t tileShape) {
     __shared__ uint32_t s_cnt[256], s_off[256], s_w[4];
-    if (threadIdx.x == 0) write_report(binCtl, pairSortError, report);
+    if (threadIdx.x == 0) write_report(binCtl, pairSortError, report, tileShape);
     tile_order_body(tileStart, tileEnd, tileCost, numTiles, tilesX, tileOrder, s_cnt, s_off, s_w, 1024u);
 }
 
@@ -612,7 +613,7 @@ __global__ __launch_bounds__(64 << (TWL + THL - 6)) void blend_kernel(const uint
     uint32_t survWalked = 0;                                      // survivors this wave walked (wave-uniform)
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    if (blockIdx.x == 0 && tid == 0) write_report(binCtl, pairSortError, report);      // the first workgroup to run: before any tile is blended
+    if (blockIdx.x == 0 && tid == 0) write_report(binCtl, pairSortError, report, (uint32_t)TWL | ((uint32_t)THL << 8));      // the first workgroup to run: before any tile is blended
     const uint32_t tile = tileOrder[blockIdx.x];
     // tiles are dispatched heaviest first (tileOrder); the heaviest also get the higher issue priority on their SIMD, so that the longest
     // survivor chains -- the launch lasts as long as they do -- are not slowed by the light tiles beside them (measured: -1 %)
@@ -1129,7 +1130,7 @@ int32_t bin_and_sort(gs_renderer* r, const gs_frame_params* p, gs_target* rt, co
     // list lengths) only when there is no cost history for this tile grid (first draw, another target size) or the caller asks
     if (!schedInBin)
         hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, st, o.tileStart, o.tileEnd, o.costRead, numTiles, rc.tilesX, o.tileOrder, binCtl, &pairCtl->error,
-                           r->hostReportDev);
+                           r->hostReportDev, shapeKey);
     prof_record(r, 5);
     o.dstIsZero = rt->clearPending ? 1 : 0;                      // this draw writes every pixel of the target: the clear is folded in
     rt->clearPending = false;
@@ -1138,9 +1139,14 @@ int32_t bin_and_sort(gs_renderer* r, const gs_frame_params* p, gs_target* rt, co
 } // namespace
 
 // The compositor's tile shape for a target: 16x16, 32x16 or 32x32 pixels (log2 width, log2 height).  A performance parameter only
-// -- frames are bit-identical across shapes -- chosen per target size (A/B: profiles/r04_variants.txt),
-// overridden per renderer by gs_renderer_set_tile_shape and process-wide by GSPLAT_TILE=16x16|32x16|32x32.
-void auto_tile_shape(uint32_t width, uint32_t height, uint32_t& wl, uint32_t& hl) {
+// -- frames are bit-identical across shapes (tests/test_gpu_draw.py::test_tile_shapes_give_the_same_frame).  Larger tiles mean fewer
+// (tile, splat) pairs to emit, sort and stage, but every wave of the blend tests the whole tile's list against its 8x8 quadrant, so the
+// blend pays for them (profiles/r04_variants.txt: C2 3.8 tiles of 16x16 per visible splat -> 32x16 wins by 1.4 %, 32x32 loses 0.6 %;
+// C2d 17.5 tiles per splat -> 32x32 wins by 33 %).  So: small targets (< 2^18 pixels: too few large tiles to fill 256 CUs) 16x16;
+// otherwise 32x16, and 32x32 while the scene's splats are large -- judged by the tiles per visible splat of the most recent draw that
+// reported (pinned host memory, no stream query), with hysteresis.  gs_renderer_set_tile_shape overrides per renderer,
+// GSPLAT_TILE=16x16|32x16|32x32 process-wide.
+static int forced_tile_shape() {
     static const int forced = [] {
         const char* e = getenv("GSPLAT_TILE");
         if (!e) return 0;
@@ -1149,16 +1155,28 @@ void auto_tile_shape(uint32_t width, uint32_t height, uint32_t& wl, uint32_t& hl
         if (!strcmp(e, "32x32")) return 3;
         return 0;
     }();
-    int shape = forced;
-    if (!shape) {
-        const unsigned long long px = (unsigned long long)width * height;
-        shape = px >= (1ull << 18) ? 3 : 1;            // small targets (< 512x512) have too few 32x32 tiles to fill 256 CUs
-    }
+    return forced;
+}
+void auto_tile_shape(uint32_t width, uint32_t height, uint32_t& wl, uint32_t& hl) {
+    int shape = forced_tile_shape();
+    if (!shape) shape = (unsigned long long)width * height >= (1ull << 18) ? 2 : 1;
     wl = shape == 1 ? 4u : 5u; hl = shape == 3 ? 5u : 4u;
 }
 void pick_tile_shape(const gs_renderer* r, uint32_t width, uint32_t height, uint32_t& wl, uint32_t& hl) {
     if (r && r->tileOverrideWL) { wl = r->tileOverrideWL; hl = r->tileOverrideHL; return; }
     auto_tile_shape(width, height, wl, hl);
+    if (r && !forced_tile_shape() && wl == 5u && r->adaptTall) hl = 5u;      // large splats: 32x32 (adapt_tile_shape)
+}
+// Called once per splat draw, before the shape is picked: 32x16 <-> 32x32 by the tiles per visible splat the last reporting draw saw.
+static void adapt_tile_shape(gs_renderer* r) {
+    if (!r->hostReport) return;
+    const volatile FrameReport* rep = r->hostReport;                         // (a torn read only mis-steers a hint)
+    const unsigned long long pairs = rep->pairCount;
+    const uint32_t visible = rep->visible, shape = rep->tileShape;
+    if (visible < 1024u) return;
+    const double ratio = (double)pairs / (double)visible;
+    if (shape == (5u | (4u << 8)) && ratio > 6.0) r->adaptTall = true;
+    else if (shape == (5u | (5u << 8)) && ratio < 3.5) r->adaptTall = false;
 }
 
 int32_t enqueue_draw(gs_renderer* r, const gs_frame_params* p, gs_target* rt) {
@@ -1169,6 +1187,7 @@ int32_t enqueue_draw(gs_renderer* r, const gs_frame_params* p, gs_target* rt) {
     GS_TRY(join_sort(r));                                       // bin_emit reads order[]
     DrawSetup ds;
     uint32_t twl, thl;
+    adapt_tile_shape(r);
     pick_tile_shape(r, rt->width, rt->height, twl, thl);
     GS_TRY(bin_and_sort(r, p, rt, r->order, r->n, ds, false, twl, thl));
     const RasterConsts& rc = ds.rc;

@@ -685,9 +685,18 @@ int32_t enqueue_sort_passes(gs_context* ctx, hipStream_t stream, SortState& st, 
         const uint32_t mask = p == passes - 1 ? (lastMask & fullMask) : fullMask;
         const uint32_t shift = (uint32_t)(bits * p);
         uint32_t* kdst = (skipLastKeys && p == passes - 1) ? (uint32_t*)nullptr : kd;      // the payload (order) is all the caller wants
+        // profiling: the launch's OWN start / stop timestamps (hipExtLaunchKernelGGL: taken from the dispatch packet's completion signal, what
+        // rocprofv3 --kernel-trace reports), not a pair of hipEventRecord packets around it -- those add a barrier packet each and
+        // include the kernel boundary (measured: 8-10 % above the kernel's own duration for a 31 us pass)
+        hipEvent_t evStart = nullptr, evStop = nullptr;
+        if (profR && profR->profiling && profR->ev && evFirst >= 0) {
+            const int kb = profR->profCur * kEvPerFrame + (evFirst == 10 ? 14 : 22) + 2 * p;
+            evStart = profR->ev[kb]; evStop = profR->ev[kb + 1];
+            profR->evValid[kb] = profR->evValid[kb + 1] = 1;
+        }
 #define GS_LAUNCH_ONESWEEP_K(B, G, KIN, K) \
-        hipLaunchKernelGGL((onesweep_kernel<B, G, K>), dim3(grid), dim3(THREADS), 0, stream, KIN, vs, kdst, vd, hist, st.status, agg, st.groupIncl, \
-                           control->tickets[p], &control->error, nUpper, nPtr, shift, epoch, mask)
+        hipExtLaunchKernelGGL((onesweep_kernel<B, G, K>), dim3(grid), dim3(THREADS), 0, stream, evStart, evStop, 0, (const uint32_t*)(KIN), (const uint32_t*)vs, kdst, vd, \
+                              (const uint32_t*)hist, st.status, agg, st.groupIncl, (uint32_t*)control->tickets[p], &control->error, nUpper, nPtr, shift, epoch, mask)
 #define GS_LAUNCH_ONESWEEP(B, G, KIN) do { if (shapeB) GS_LAUNCH_ONESWEEP_K(B, G, KIN, KPT_B); else GS_LAUNCH_ONESWEEP_K(B, G, KIN, KPT_A); } while (0)
         if (p == 0 && gatherKeys) GS_LAUNCH_ONESWEEP(8, true, gatherKeys);
         else if (bits == 8) GS_LAUNCH_ONESWEEP(8, false, ks);

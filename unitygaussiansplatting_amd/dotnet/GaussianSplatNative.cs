@@ -47,7 +47,7 @@ namespace GaussianSplatting.Runtime
         public struct FrameStats { public ulong tilePairs, pairCapacity; public uint visibleSplats, tilesX, tilesY, sortError, tileW, tileH; }
 
         [StructLayout(LayoutKind.Sequential)]
-        public struct StageTimes { public float calcDistancesMs, sortMs, calcViewMs, binMs, pairSortMs, blendMs, resolveMs, totalMs; public uint frames; public float onesweepDepthMs, onesweepPairsMs; public uint onesweepPairLaunches; }
+        public struct StageTimes { public float calcDistancesMs, sortMs, calcViewMs, binMs, pairSortMs, blendMs, resolveMs, totalMs; public uint frames; public float onesweepDepthMs, onesweepPairsMs; public uint onesweepPairLaunches; public float onesweepDepthKernelMs, onesweepPairsKernelMs; }
 
         [DllImport(Lib)] public static extern int gs_abi_version();
         [DllImport(Lib)] public static extern IntPtr gs_error_string(int err);
@@ -92,6 +92,7 @@ namespace GaussianSplatting.Runtime
         [DllImport(Lib)] public static extern int gs_renderer_tile_shape(IntPtr renderer, uint width, uint height, out uint tileW, out uint tileH);
         [DllImport(Lib)] public static extern int gs_renderer_set_profiling(IntPtr renderer, int frames);
         [DllImport(Lib)] public static extern int gs_renderer_reserve_pairs(IntPtr renderer, ulong pairCapacity);
+        [DllImport(Lib)] public static extern int gs_renderer_poll_pairs(IntPtr renderer, out ulong tilePairs, out ulong pairCapacity);
         [DllImport(Lib)] public static extern int gs_renderer_download_order(IntPtr renderer, uint[] dst, UIntPtr count);
         [DllImport(Lib)] public static extern int gs_renderer_download_distances(IntPtr renderer, uint[] dst, UIntPtr count);
         [DllImport(Lib)] public static extern int gs_renderer_upload_order(IntPtr renderer, uint[] src, UIntPtr count);

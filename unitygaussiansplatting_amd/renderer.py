@@ -372,6 +372,13 @@ class GaussianSplatRenderer:
         check(_lib.lib().gs_renderer_tile_shape(self._r_h, int(width), int(height), C.byref(w), C.byref(h)), "gs_renderer_tile_shape")
         return w.value, h.value
 
+    def PollPairs(self) -> Tuple[int, int]:
+        """Non-blocking: (pair count of the most recent draw that started compositing, pair capacity); count > capacity = that draw was
+        truncated (its farthest pairs dropped)."""
+        p, c = C.c_uint64(), C.c_uint64()
+        check(_lib.lib().gs_renderer_poll_pairs(self._r_h, C.byref(p), C.byref(c)), "gs_renderer_poll_pairs")
+        return p.value, c.value
+
     def ReservePairs(self, n: int) -> None:
         check(_lib.lib().gs_renderer_reserve_pairs(self._r_h, n), "gs_renderer_reserve_pairs")
 
@@ -441,6 +448,10 @@ class GaussianSplatRenderSystem:
         # statistics (BLOCKING: it serialises host and GPU) and renders the frame again after an overflow, so what it returns is
         # always complete.  Off by default: a render loop keeps the GPU queue full and a scene's first frames grow the buffer.
         self.strictPairs = False
+        # Without strictPairs a truncated frame is still SIGNALLED: after the draws OnPreCullCamera polls (without blocking) what the
+        # most recent draws that reached the GPU reported; True = some renderer's latest report exceeds its pair capacity, i.e. a frame
+        # of the last few was drawn without its farthest pairs (the library grows the buffer at the next draw).
+        self.lastFrameTruncated = False
 
     def RegisterSplat(self, r: GaussianSplatRenderer) -> None:      # :25-36
         if r not in self.m_Splats:
@@ -477,6 +488,11 @@ class GaussianSplatRenderSystem:
             return None
         rt.Clear()
         self.SortAndRenderSplats(cam, rt)
+        self.lastFrameTruncated = False
+        for gs in self.m_ActiveSplats:
+            if gs.m_RenderMode == RenderMode.Splats:
+                pairs, cap = gs.PollPairs()
+                self.lastFrameTruncated |= pairs > cap
         if self.strictPairs:
             overflowed = False
             for gs in self.m_ActiveSplats:
@@ -493,6 +509,7 @@ class GaussianSplatRenderSystem:
                 for gs in self.m_ActiveSplats:
                     gs.CalcViewData(cam)
                     gs.Draw(cam, rt)
+            self.lastFrameTruncated = False                    # what is returned is complete
         if background is not None:
             return rt.Resolve(background)
         return None
