@@ -283,6 +283,15 @@ def main():
     st = r.FrameStats()                   # raises if the last frame overflowed / a sort spin expired
     frame_ms = r.FrameTimes()             # per-frame GPU durations of the instrumented pass (key generation .. blend)
     stage = r.StageTimes()
+    # ---- and a third pass in which every Onesweep launch carries its OWN start / stop timestamps (hipExtLaunchKernelGGL events = the
+    #      dispatch packet's completion signal, what rocprofv3 --kernel-trace reports): the dominant kernel's launch duration without
+    #      kernel boundaries or event packets.  A pass of its own because the timestamped launches perturb the stage brackets.
+    r.SetProfiling(min((args.steps + 1) * len(my_views), 1024))
+    r.SetKernelTiming(True)
+    run_region(fi)
+    r.FrameStats()
+    stage_k = r.StageTimes()
+    r.SetKernelTiming(False)
     r.SetProfiling(0)
 
     ms_per_step = elapsed / args.steps * 1e3
@@ -308,7 +317,7 @@ def main():
         # Onesweep: the launches' OWN start / stop timestamps (gs_stage_times.onesweep_*_kernel_ms: hipExtLaunchKernelGGL events = the dispatch
         # packets' completion signals, what rocprofv3 --kernel-trace reports) -- the hipEventRecord brackets around the launches include
         # the kernel boundaries and two barrier packets and read 8-10 % high.  The other kernels are one launch per stage bracket.
-        sweep_ms = stage.onesweep_depth_kernel_ms + stage.onesweep_pairs_kernel_ms
+        sweep_ms = stage_k.onesweep_depth_kernel_ms + stage_k.onesweep_pairs_kernel_ms
         if not sweep_ms > 0:
             sweep_ms = stage.onesweep_depth_ms + stage.onesweep_pairs_ms
         ktime = {"onesweep_kernel": sweep_ms, "blend_kernel": stage.blend_ms,
@@ -341,7 +350,7 @@ def main():
                     "instrumented_ms_per_step": round(elapsed_instr / args.steps * 1e3, 4),
                     "instrumented_frame_gpu_ms": ({"median": round(float(np.median(frame_ms)), 4), "p95": round(float(np.percentile(frame_ms, 95)), 4),
                                                    "max": round(float(frame_ms.max()), 4), "frames": int(len(frame_ms))} if len(frame_ms) else None),
-                    "timing": "second pass over the same K frames with profiling on: Onesweep launches by their own start/stop timestamps (hipExtLaunchKernelGGL events = rocprofv3's kernel durations), the other stages by hipEventRecord brackets on the launching stream (the events add ~50 us/frame, so ms_per_step is timed without them)",
+                    "timing": "avg_launch_ms of onesweep_kernel: the launches' own start/stop timestamps (hipExtLaunchKernelGGL events = rocprofv3's kernel durations) from a third pass over the same K frames; `stages` and the other kernels: hipEventRecord brackets on the launching stream from a second pass (the events add ~50 us/frame, so ms_per_step is timed without either)",
                     "onesweep_bracketed_ms_per_frame": round(stage.onesweep_depth_ms + stage.onesweep_pairs_ms, 4),
                     "kernel_ms_per_frame": {k: round(v, 4) for k, v in ktime.items()},
                     # (a step renders every view of this rank once: C5 on one GPU = 8 frames per step)

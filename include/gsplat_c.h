@@ -140,7 +140,8 @@ typedef struct gs_stage_times {
     float onesweep_pairs_ms;   /* sum of the pair-sort launches of one frame */
     uint32_t onesweep_pair_launches;   /* 1..3, by tile count */
     /* the same launches by their OWN start / stop timestamps (the dispatch's completion signal, as rocprofv3 --kernel-trace reports
-     * them): no event packets and no kernel boundaries inside, so <= the bracketed figures above */
+     * them): no event packets and no kernel boundaries inside, so <= the bracketed figures above.  0 unless the frames were recorded
+     * with gs_renderer_set_kernel_timing(r, 1). */
     float onesweep_depth_kernel_ms;    /* sum over the 4 depth-sort launches */
     float onesweep_pairs_kernel_ms;    /* sum over the pair-sort launches */
 } gs_stage_times;
@@ -247,6 +248,10 @@ int32_t gs_renderer_tile_shape(const gs_renderer* r, uint32_t width, uint32_t he
 /* frames = 0: off.  frames > 0: keep a ring of `frames` per-frame hipEvent sets (no host sync while rendering);
  * a frame ends at gs_renderer_draw.  gs_renderer_stage_times averages over the ring and resets it. */
 int32_t gs_renderer_set_profiling(gs_renderer* r, int32_t frames);
+/* With profiling on: enabled != 0 makes every Onesweep launch carry its OWN start / stop timestamps (gs_stage_times.onesweep_*_kernel_ms:
+ * the dispatch's completion signal, what rocprofv3 --kernel-trace reports).  Those launches cost a few us each, so the stage brackets of
+ * frames recorded in this mode (sort_ms, pair_sort_ms, total_ms) read high: use it in a pass of its own.  Default off. */
+int32_t gs_renderer_set_kernel_timing(gs_renderer* r, int32_t enabled);
 int32_t gs_renderer_reserve_pairs(gs_renderer* r, uint64_t pair_capacity);
 /* Non-blocking: the (tile, splat) pair count reported by the most recent draw whose compositing has STARTED on the GPU (its first
  * workgroup stores the count into host-visible memory; 0 before any) and the capacity of the pair buffers.  tile_pairs > pair_capacity:

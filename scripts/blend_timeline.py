@@ -15,11 +15,21 @@ else:
     asset = creator.CreateAssetFromSplats(scenes.make_config_splats(cfg), cfg.quality, name=key); asset.Save("/tmp/gsplat_cache")
 ctx = GpuContext(0); r = GaussianSplatRenderer(ctx, asset); r.OnEnable()
 rt = RenderTarget(ctx, cfg.width, cfg.height)
+shape = os.environ.get("TILE")
+if shape:
+    r.SetTileShape(*[int(v) for v in shape.split("x")])
 for f in range(6):
+    if f == 5:
+        _z = np.zeros(8, np.uint64); C.CDLL(_lib.LIB_PATH).gs_debug_read_blend_stats(_z.ctypes.data_as(C.c_void_p), C.c_int32(1))     # count the last frame only
     cam = camera.Camera(position=scenes.orbit_eye(cfg.eye_radius, cfg.eye_elev_deg, 0.25 * f), pixelWidth=cfg.width, pixelHeight=cfg.height, fieldOfView=cfg.fov_y)
     r.SortPoints(cam); r.CalcViewData(cam); rt.Clear(); r.Draw(cam, rt); r.FrameStats()
 lib = C.CDLL(_lib.LIB_PATH)
-tiles = ((cfg.width + 15) // 16) * ((cfg.height + 15) // 16)
+stw = r.FrameStats()
+tiles = stw.tiles_x * stw.tiles_y
+nw = (stw.tile_w // 8) * (stw.tile_h // 8)
+print(f"tile {stw.tile_w}x{stw.tile_h}: {tiles} tiles of {nw} waves")
+stats = np.zeros(8, np.uint64)
+lib.gs_debug_read_blend_stats(stats.ctypes.data_as(C.c_void_p), C.c_int32(1))
 buf = np.zeros((65536, 8), np.uint64)
 assert lib.gs_debug_read_blend_timeline(buf.ctypes.data_as(C.c_void_p), C.c_size_t(buf.nbytes)) == 0
 t = buf[:tiles].astype(np.int64)
@@ -32,7 +42,7 @@ print(f"per walked batch: staging {tstage.sum() / max(1, bat.sum()):.2f} us, pro
 print(f"tiles {tiles}: kernel span {en.max():.1f} us; tile duration median {np.median(dur):.1f} p90 {np.percentile(dur,90):.1f} p99 {np.percentile(dur,99):.1f} max {dur.max():.1f} us")
 print(f"start times: median {np.median(st):.1f} p90 {np.percentile(st,90):.1f} max {st.max():.1f}")
 print(f"list length: median {np.median(cnt):.0f} max {cnt.max()};  batches walked / batches in list: {bat.sum()} / {((cnt + 255) // 256).sum()}  ({100.0 * bat.sum() / max(1, ((cnt + 255) // 256).sum()):.1f} %)")
-print(f"sum of tile durations {dur.sum():.0f} us over {256 * 8} slots = {dur.sum() / 2048:.1f} us")
+print(f"sum of tile durations {dur.sum():.0f} us over {2048 * 4 // nw} slots = {dur.sum() / (2048 * 4 // nw):.1f} us")
 idx = np.argsort(-en)[:12]
 print("last tiles to finish: (tile, start, end, list, batches)")
 for i in idx: print(f"  {i:5d} {st[i]:7.1f} {en[i]:7.1f} {cnt[i]:6d} {bat[i]:4d}")
@@ -41,3 +51,4 @@ print("longest tiles: (tile, start, end, list, batches, us/batch)")
 for i in idx: print(f"  {i:5d} {st[i]:7.1f} {en[i]:7.1f} {cnt[i]:6d} {bat[i]:4d} {dur[i] / max(bat[i],1):6.2f}")
 span = en.max()
 print("resident tiles over time (of 2048 slots): " + "  ".join(f"{int(100 * f)}%:{int(((st <= f * span) & (en > f * span)).sum())}" for f in (0.05, 0.1, 0.2, 0.3, 0.4, 0.5, 0.6, 0.7, 0.8, 0.9, 0.95)))
+print(f"wave activity (last frame): sum of batches walked by each wave {int(stats[0])} / sum over tiles of waves x batches {int(stats[1])} = {float(stats[0]) / max(1.0, float(stats[1])):.3f};  waves by own/tile batches in fifths: {[int(v) for v in stats[2:7]]}")

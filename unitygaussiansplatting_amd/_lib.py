@@ -59,6 +59,7 @@ SIGNATURES = {
     "gs_renderer_set_tile_shape": (C.c_int32, [_P, C.c_uint32, C.c_uint32]),
     "gs_renderer_tile_shape": (C.c_int32, [_P, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "gs_renderer_set_profiling": (C.c_int32, [_P, C.c_int32]),
+    "gs_renderer_set_kernel_timing": (C.c_int32, [_P, C.c_int32]),
     "gs_renderer_reserve_pairs": (C.c_int32, [_P, C.c_uint64]),
     "gs_renderer_poll_pairs": (C.c_int32, [_P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "gs_renderer_download_order": (C.c_int32, [_P, _P, C.c_size_t]),

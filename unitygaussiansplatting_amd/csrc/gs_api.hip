@@ -504,6 +504,12 @@ int32_t gs_renderer_set_profiling(gs_renderer* r, int32_t frames) {
     return GS_OK;
 }
 
+int32_t gs_renderer_set_kernel_timing(gs_renderer* r, int32_t enabled) {
+    if (!r) return fail(GS_ERR_INVALID_ARGUMENT, "renderer is null");
+    r->kernelTiming = enabled != 0;
+    return GS_OK;
+}
+
 int32_t gs_renderer_reserve_pairs(gs_renderer* r, uint64_t cap) {
     if (!r) return fail(GS_ERR_INVALID_ARGUMENT, "renderer is null");
     if (cap <= r->pairCapacity) return GS_OK;

@@ -148,6 +148,7 @@ struct gs_target {
     static constexpr int kResolveRing = 64;
     hipEvent_t* rev = nullptr;              // 2 x kResolveRing events, or null (profiling off)
     bool profiling = false;
+    bool kernelTiming = false;              // gs_renderer_set_kernel_timing: Onesweep launches carry their own start / stop events
     int revCount = 0;                       // resolves recorded since the last read (may exceed the ring: the oldest are overwritten)
 };
 
@@ -207,6 +208,7 @@ struct gs_renderer {
     float pointDisplaySize = 3.0f;          // m_PointDisplaySize
     // profiling: a ring of per-frame hipEvent sets (slot advances at the end of gs_renderer_draw)
     bool profiling = false;
+    bool kernelTiming = false;              // gs_renderer_set_kernel_timing: Onesweep launches carry their own start / stop events
     hipEvent_t* ev = nullptr;               // profCapacity x kEvPerFrame
     uint8_t* evValid = nullptr;
     int profCapacity = 0, profCur = 0, profCompleted = 0;

@@ -210,7 +210,12 @@ __device__ unsigned long long g_bin_tl[32768 * 8];
 #else
 #define GS_BTL(k) do { } while (0)
 #endif
-template <int PASSES>
+// TILECNT (targets of <= kBinTileCounters tiles): the pair sort's digit histograms are not accumulated per emitted pair (one LDS atomic for
+// the low digit + a ballot-aggregated add per higher digit: ~35 of the emission's ~140 wave instructions per 64 pairs) but as ONE LDS
+// atomic per pair into a per-TILE counter -- neighbouring output slots are neighbouring tiles: distinct addresses -- folded into the
+// digit histograms once, when the persistent workgroup is done.
+constexpr uint32_t kBinTileCounters = 2048;
+template <int PASSES, bool TILECNT>
 __global__ __launch_bounds__(kBinThreads, GS_BIN_MINWAVES) void bin_emit_kernel(const uint2* __restrict__ rects, const uint8_t* __restrict__ waveFlags,
                                                                 const uint32_t* __restrict__ order, uint32_t n, uint32_t tilesX, uint32_t tileShift,
                                                                 uint32_t* __restrict__ pairKeys, uint32_t* __restrict__ pairVals,
@@ -220,6 +225,7 @@ __global__ __launch_bounds__(kBinThreads, GS_BIN_MINWAVES) void bin_emit_kernel(
                                                                 const uint32_t* __restrict__ schedCost, uint32_t schedTiles, uint32_t* __restrict__ schedOut) {
     constexpr int SUB = 4;                                   // k's per emission batch: 256 positions per wave
     __shared__ uint32_t s_hist[3 * 256];
+    __shared__ uint32_t s_tile[TILECNT ? kBinTileCounters : 1];
     __shared__ uint32_t s_wtot[4], s_wvis[4];
     __shared__ uint32_t s_part;
     __shared__ unsigned long long s_base;
@@ -240,6 +246,7 @@ __global__ __launch_bounds__(kBinThreads, GS_BIN_MINWAVES) void bin_emit_kernel(
     }
     const uint32_t bid = blockIdx.x - (schedOut ? 1u : 0u);      // index among the binning workgroups
     for (int j = tid; j < 3 * 256; j += kBinThreads) s_hist[j] = 0;
+    if (TILECNT) for (uint32_t j = tid; j < kBinTileCounters; j += kBinThreads) s_tile[j] = 0;
     for (uint32_t j = bid * (uint32_t)kBinThreads + (uint32_t)tid; j < groupAggWords; j += binBlocks * (uint32_t)kBinThreads) groupAgg[j] = 0ull;   // for the pair sort's look-back
     // the zero-initialised per-draw arena of the NEXT draw (the two copies alternate: no memset launch per draw)
     for (uint32_t j = bid * (uint32_t)kBinThreads + (uint32_t)tid; j < nextArenaWords; j += binBlocks * (uint32_t)kBinThreads) nextArena[j] = 0u;
@@ -442,10 +449,11 @@ __global__ __launch_bounds__(kBinThreads, GS_BIN_MINWAVES) void bin_emit_kernel(
                 const uint32_t boff = j << 2;                    // j < capacity <= 2^30: scalar base + 32-bit byte offset
                 *(uint32_t*)((uint8_t*)pk + boff) = tile;
                 *(uint32_t*)((uint8_t*)pv + boff) = s;           // payload = splat index: the blend kernel reads rec[splat]
-                atomicAdd(&s_hist[tile & digitMask], 1u);        // neighbouring slots are neighbouring tiles: distinct bins
+                if (TILECNT) atomicAdd(&s_tile[tile], 1u);       // neighbouring slots are neighbouring tiles: distinct counters
+                else atomicAdd(&s_hist[tile & digitMask], 1u);   // ... distinct bins
             }
-            if (PASSES >= 2) hist_add_aggregated(s_hist + 256, (tile >> digitBits) & digitMask, wr);
-            if (PASSES >= 3) hist_add_aggregated(s_hist + 512, (tile >> (2u * digitBits)) & digitMask, wr);
+            if (!TILECNT && PASSES >= 2) hist_add_aggregated(s_hist + 256, (tile >> digitBits) & digitMask, wr);
+            if (!TILECNT && PASSES >= 3) hist_add_aggregated(s_hist + 512, (tile >> (2u * digitBits)) & digitMask, wr);
         }
         __builtin_amdgcn_wave_barrier();
     }
@@ -454,6 +462,17 @@ __global__ __launch_bounds__(kBinThreads, GS_BIN_MINWAVES) void bin_emit_kernel(
     }   // next partition
 
     // ---- flush the pair-sort digit histograms and the visible count ---------------------------------------------
+    if (TILECNT) {                                               // per-tile counts -> digit histograms (the tile grid has <= kBinTileCounters tiles)
+        __syncthreads();
+        for (uint32_t t = tid; t < kBinTileCounters; t += kBinThreads) {
+            const uint32_t c = s_tile[t];
+            if (c) {
+                atomicAdd(&s_hist[t & digitMask], c);
+                if (PASSES >= 2) atomicAdd(&s_hist[256 + ((t >> digitBits) & digitMask)], c);
+            }
+        }
+        __syncthreads();
+    }
     if (tid == 0 && visAcc) atomicAdd(&ctl->visible, visAcc);
     for (int j = tid; j < PASSES * 256; j += kBinThreads) {
         const uint32_t c = s_hist[j];
@@ -582,12 +601,16 @@ typedef uint32_t u4v __attribute__((ext_vector_type(4)));
 //   (2) walks the survivors in order, reading the record with WAVE-UNIFORM LDS loads (two ds_read_b128 per record:
 //       they issue on the LDS pipe, not the VALU), so the per-(quadrant, splat) VALU cost is the fragment maths alone.
 // The tile shape is the draw's (pick_tile_shape): the (tile, splat) pairs -- what bin_emit emits, the pair sort moves and this
-// kernel stages -- shrink with the tile area (a 14-pixel splat touches 3.5 tiles of 16x16 but 2.1 of 32x32) while the per-wave
-// work does not: a wave tests 64 records per ballot (~40 wave instructions) against 22 VALU per survivor, and the survivors
-// of a quadrant are the same whatever tile it belongs to.  Blend order per pixel is unchanged, so the frame is bit-identical
-// across tile shapes (tests/test_gpu_draw.py::test_tile_shapes_give_the_same_frame).
+// kernel stages -- shrink with the tile area (a 14-pixel splat touches 3.5 tiles of 16x16 but 2.1 of 32x32).  The survivors of a
+// quadrant are the same whatever tile it belongs to, but every wave tests the whole tile's list against its quadrant (64 records per
+// ballot, ~40 wave instructions): 0.57 x the pairs at 4 x the waves per record is 2.3 x the tests, +18 % blend time at C2 for 32x32
+// (+7 % for 32x16) -- which is why the shape is picked per scene (pick_tile_shape).  Compacting every batch into per-16x16-sub-block
+// index lists first (so that a wave tests only its sub-block's records) was built and measured: the extra barrier and the index
+// indirection in the survivor walk cost more than the tests saved (+9 % blend, profiles/r04_variants.txt call 3).  Blend order per
+// pixel is unchanged, so the frame is bit-identical across tile shapes (tests/test_gpu_draw.py::test_tile_shapes_give_the_same_frame).
 #ifdef GS_EXP_BLEND_TIMELINE      // experiment build: per-tile start / end (100 MHz wall clock), list length, batches walked
 __device__ unsigned long long g_blend_tl[65536 * 8];
+__device__ unsigned long long g_blend_stats[8];      // [0] sum over waves of the batches the wave walked, [1] sum over tiles of waves x batches, [2..6] waves by (own / tile) batches
 #endif
 // DEPTH: the target has a depth attachment (gs_target_set_scene_depth): the reference draws the splats with the default
 // ZTest LEqual, ZWrite Off against the camera's depth buffer (RenderGaussianSplats.shader:10; the RT is bound with the
@@ -624,7 +647,7 @@ __global__ __launch_bounds__(64 << (TWL + THL - 6)) void blend_kernel(const uint
     const uint32_t start = tileStart[tile], end = tileEnd[tile];
 #ifdef GS_EXP_BLEND_TIMELINE
     const unsigned long long tl0 = wall_clock64();
-    uint32_t tlBatches = 0, tlSurv = 0;
+    uint32_t tlBatches = 0, tlSurv = 0, tlMine = 0;
     unsigned long long tlStage = 0, tlProc = 0, tlMark = tl0;
     if (threadIdx.x == 0 && tile < 65536u) { g_blend_tl[tile * 8 + 0] = tl0; g_blend_tl[tile * 8 + 1] = tl0; g_blend_tl[tile * 8 + 2] = end - start; g_blend_tl[tile * 8 + 3] = 0; }
 #endif
@@ -696,6 +719,9 @@ __global__ __launch_bounds__(64 << (TWL + THL - 6)) void blend_kernel(const uint
 #ifdef GS_EXP_BLEND_TIMELINE
         { const unsigned long long now = wall_clock64(); tlStage += now - tlMark; tlMark = now; }
 #endif
+#ifdef GS_EXP_BLEND_TIMELINE
+        if (!waveDone) ++tlMine;
+#endif
         if (!waveDone) {
             for (uint32_t c = 0; c < cnt; c += 64u) {
                 const uint32_t j = c + lane;
@@ -743,7 +769,7 @@ __global__ __launch_bounds__(64 << (TWL + THL - 6)) void blend_kernel(const uint
                     } else {
                         live = (inQuad & (int)(alpha >= 1.0f / 255.0f)) != 0;
                     }
-                    if (DEPTH) live = live && (s_e[c + b].w <= sceneZ);                // ZTest LEqual on the quad's (single) depth
+                    if (DEPTH) live = live && (s_e[c + b].w <= sceneZ);                  // ZTest LEqual on the quad's (single) depth
                     if (MODE == 1) live = live && !acc.saturated();
                     if (live) acc.blend(B4.z, B4.w, alpha);
                 }
@@ -767,6 +793,8 @@ __global__ __launch_bounds__(64 << (TWL + THL - 6)) void blend_kernel(const uint
     __syncthreads();
     if (threadIdx.x == 0) tileCost[tile] = min(254u, (s_cost + batchesWalked * (uint32_t)(NT / 8)) / 4u);
 #ifdef GS_EXP_BLEND_TIMELINE
+    if (lane == 0) { atomicAdd(&g_blend_stats[0], (unsigned long long)tlMine); atomicAdd(&g_blend_stats[2 + min(4u, tlMine * 5u / max(batchesWalked, 1u))], 1ull); }
+    if (threadIdx.x == 0) atomicAdd(&g_blend_stats[1], (unsigned long long)batchesWalked * NW);
     __syncthreads();
     if (threadIdx.x == 0 && tile < 65536u) { g_blend_tl[tile * 8 + 1] = wall_clock64(); g_blend_tl[tile * 8 + 3] = tlBatches; g_blend_tl[tile * 8 + 4] = tlSurv; g_blend_tl[tile * 8 + 5] = tlStage; g_blend_tl[tile * 8 + 6] = tlProc; }
 #endif
@@ -775,6 +803,12 @@ __global__ __launch_bounds__(64 << (TWL + THL - 6)) void blend_kernel(const uint
 extern "C" int32_t gs_debug_read_blend_timeline(void* out, size_t bytes) {
     (void)hipDeviceSynchronize();
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_blend_tl), bytes) == hipSuccess ? 0 : -2;
+}
+extern "C" int32_t gs_debug_read_blend_stats(unsigned long long* out8, int32_t reset) {
+    (void)hipDeviceSynchronize();
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_blend_stats), 64) != hipSuccess) return -2;
+    if (reset) { unsigned long long z[8] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_blend_stats), z, 64); }
+    return 0;
 }
 #endif
 
@@ -1104,7 +1138,12 @@ int32_t bin_and_sort(gs_renderer* r, const gs_frame_params* p, gs_target* rt, co
     if (numTiles <= 256) { passes = 1; bits = numTiles <= 64 ? 6 : (numTiles <= 128 ? 7 : 8); }
     else if (numTiles <= 65536) { passes = 2; bits = numTiles <= 4096 ? 6 : (numTiles <= 16384 ? 7 : 8); }
     else { passes = 3; bits = 8; }
-    auto binKernel = passes == 1 ? bin_emit_kernel<1> : (passes == 2 ? bin_emit_kernel<2> : bin_emit_kernel<3>);
+#ifndef GS_BIN_TILE_COUNTERS
+#define GS_BIN_TILE_COUNTERS 1
+#endif
+    const bool tileCnt = GS_BIN_TILE_COUNTERS && numTiles <= kBinTileCounters;       // (<= 2048 tiles means <= 2 passes)
+    auto binKernel = passes == 1 ? (tileCnt ? bin_emit_kernel<1, true> : bin_emit_kernel<1, false>)
+                   : (passes == 2 ? (tileCnt ? bin_emit_kernel<2, true> : bin_emit_kernel<2, false>) : bin_emit_kernel<3, false>);
     // persistent: as many workgroups as are resident at once, a multiple of the ticket classes
 #ifndef GS_BIN_BLOCKS_PER_CU
 #define GS_BIN_BLOCKS_PER_CU 5      // 90 VGPRs at 8 positions per thread: five 256-thread workgroups per CU

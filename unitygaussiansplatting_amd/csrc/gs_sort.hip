@@ -277,7 +277,12 @@ __global__ __launch_bounds__(THREADS, KPT == KPT_A ? GS_SORT_MINWAVES : 4) void 
     if (tid < RDX)
         for (int k = 0; k < w; ++k) histExcl += s_htot[k];
 
-    for (;;) {
+#ifndef GS_SORT_STATIC_ONE_ROUND
+#define GS_SORT_STATIC_ONE_ROUND 1
+#endif
+    const bool oneRound = GS_SORT_STATIC_ONE_ROUND && gridDim.x >= numParts;    // (uniform)
+    for (uint32_t round = 0;; ++round) {
+        if (oneRound && round) break;
         __syncthreads();                                    // previous partition's LDS reads are finished
 #ifdef GS_EXP_SORT_TIMELINE
         const unsigned long long tl0 = wall_clock64();
@@ -290,10 +295,19 @@ __global__ __launch_bounds__(THREADS, KPT == KPT_A ? GS_SORT_MINWAVES : 4) void 
         // a workgroup still only waits on partitions that are running or will run without needing a new slot.
         if (tid == 0) {
             const uint32_t cls = blockIdx.x % TICKET_CLASSES;
+            // One round (the grid covers every partition, all of them resident at once -- a 6 M-key pass): the ticket a workgroup
+            // would draw is known, blockIdx / classes, so the atomic's round trip (~1.2 us at the head of a ~31 us pass) is skipped.
+#if GS_SORT_STATIC_ONE_ROUND
+            const uint32_t t = oneRound ? blockIdx.x / TICKET_CLASSES : __hip_atomic_fetch_add(ticket + cls * 32u, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
             const uint32_t t = __hip_atomic_fetch_add(ticket + cls * 32u, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
             uint32_t p = t * TICKET_CLASSES + cls;
+#ifndef GS_SORT_XCD_ALL
+#define GS_SORT_XCD_ALL 0       // 1: XCD blocks in every pass, not only the gather pass (A/B: do neighbouring partitions' runs merge in a shared L2?)
+#endif
 #if GS_SORT_XCD_BLOCKS
-            if (GATHER) {
+            if (GATHER || GS_SORT_XCD_ALL) {
                 // The gathered key array does not fit one XCD's L2, but the 16 keys of a 64-byte sector belong to spatial
                 // neighbours (the asset is in Morton order), which are close in the previous depth order too: they are asked for
                 // within a few partitions of each other.  Workgroup b runs on XCD b % 8 (MI355X_MICROARCH.md) = cls % 8, so
@@ -685,11 +699,13 @@ int32_t enqueue_sort_passes(gs_context* ctx, hipStream_t stream, SortState& st, 
         const uint32_t mask = p == passes - 1 ? (lastMask & fullMask) : fullMask;
         const uint32_t shift = (uint32_t)(bits * p);
         uint32_t* kdst = (skipLastKeys && p == passes - 1) ? (uint32_t*)nullptr : kd;      // the payload (order) is all the caller wants
-        // profiling: the launch's OWN start / stop timestamps (hipExtLaunchKernelGGL: taken from the dispatch packet's completion signal, what
-        // rocprofv3 --kernel-trace reports), not a pair of hipEventRecord packets around it -- those add a barrier packet each and
-        // include the kernel boundary (measured: 8-10 % above the kernel's own duration for a 31 us pass)
+        // kernel timing (gs_renderer_set_kernel_timing): the launch's OWN start / stop timestamps (hipExtLaunchKernelGGL: taken from the
+        // dispatch packet's completion signal, what rocprofv3 --kernel-trace reports), not a pair of hipEventRecord packets around the
+        // launches -- those include the kernel boundaries and a barrier packet each (8-10 % above the kernel's own duration for a 31 us
+        // pass).  The timestamped launches cost ~6 us each themselves, which is why this is a mode of its own and not part of the
+        // stage brackets (with it on, sort_ms / pair_sort_ms read ~25 us high).
         hipEvent_t evStart = nullptr, evStop = nullptr;
-        if (profR && profR->profiling && profR->ev && evFirst >= 0) {
+        if (profR && profR->profiling && profR->kernelTiming && profR->ev && evFirst >= 0) {
             const int kb = profR->profCur * kEvPerFrame + (evFirst == 10 ? 14 : 22) + 2 * p;
             evStart = profR->ev[kb]; evStop = profR->ev[kb + 1];
             profR->evValid[kb] = profR->evValid[kb + 1] = 1;

@@ -91,6 +91,7 @@ namespace GaussianSplatting.Runtime
         [DllImport(Lib)] public static extern int gs_renderer_set_tile_shape(IntPtr renderer, uint tileW, uint tileH);
         [DllImport(Lib)] public static extern int gs_renderer_tile_shape(IntPtr renderer, uint width, uint height, out uint tileW, out uint tileH);
         [DllImport(Lib)] public static extern int gs_renderer_set_profiling(IntPtr renderer, int frames);
+        [DllImport(Lib)] public static extern int gs_renderer_set_kernel_timing(IntPtr renderer, int enabled);
         [DllImport(Lib)] public static extern int gs_renderer_reserve_pairs(IntPtr renderer, ulong pairCapacity);
         [DllImport(Lib)] public static extern int gs_renderer_poll_pairs(IntPtr renderer, out ulong tilePairs, out ulong pairCapacity);
         [DllImport(Lib)] public static extern int gs_renderer_download_order(IntPtr renderer, uint[] dst, UIntPtr count);

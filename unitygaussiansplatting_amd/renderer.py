@@ -372,6 +372,10 @@ class GaussianSplatRenderer:
         check(_lib.lib().gs_renderer_tile_shape(self._r_h, int(width), int(height), C.byref(w), C.byref(h)), "gs_renderer_tile_shape")
         return w.value, h.value
 
+    def SetKernelTiming(self, enabled: bool) -> None:
+        """With profiling on: Onesweep launches carry their own start/stop timestamps (StageTimes().onesweep_*_kernel_ms); perturbs the stage brackets."""
+        check(_lib.lib().gs_renderer_set_kernel_timing(self._r_h, int(bool(enabled))), "gs_renderer_set_kernel_timing")
+
     def PollPairs(self) -> Tuple[int, int]:
         """Non-blocking: (pair count of the most recent draw that started compositing, pair capacity); count > capacity = that draw was
         truncated (its farthest pairs dropped)."""
