@@ -1,6 +1,6 @@
 """Tile-shape A/B on a GPU box, one process per configuration (the asset is built once):
 
-    python scripts/ab_tiles.py C2 [frames] [shape ...]      # shapes like 16x16 32x16 32x32 (default: all three + auto)
+    python scripts/ab_tiles.py C2 [frames] [shape ...]      # shapes like 16x16 32x16 32x32 auto (default: the three fixed ones)
 For every shape: hipEvent stage means over `frames` profiled frames, then the un-instrumented wall time per frame, one JSON line each.
 GSPLAT_LIB selects a variant build (a build without gs_renderer_set_tile_shape is measured once, as it is)."""
 import json, os, sys, time
@@ -34,13 +34,13 @@ def frame(f):
     r.SortPointsPrepared(m16); r.CalcViewDataPrepared(p); rt.Clear(); r.DrawPrepared(p, rt); rt.ResolveAsync((0, 0, 0, 1))
 has_shapes = hasattr(r, "SetTileShape")
 for sh in shapes:
-    w, h = (int(v) for v in sh.split("x"))
+    w, h = (0, 0) if sh == "auto" else tuple(int(v) for v in sh.split("x"))      # auto: the library's own choice (adapts over the warm-up frames)
     if has_shapes:
         try:
             r.SetTileShape(w, h)
         except Exception as e:                                       # an older variant build
             has_shapes = False
-    for f in range(6):                                               # warm-up: grows the pair buffers, makes the schedule's cost history
+    for f in range(8):                                               # warm-up: grows the pair buffers, makes the schedule's cost history, lets the automatic shape settle
         frame(f)
         try:
             st = r.FrameStats()
