@@ -8,7 +8,12 @@ from unitygaussiansplatting_amd import _lib, camera, creator, scenes
 from unitygaussiansplatting_amd.renderer import GaussianSplatRenderer, GpuContext, RenderTarget
 key = sys.argv[1] if len(sys.argv) > 1 else "C2"
 cfg = scenes.CONFIGS[key]
-asset = creator.CreateAssetFromSplatsNative(scenes.make_config_splats(cfg), cfg.quality, name=key)
+from unitygaussiansplatting_amd.asset import GaussianSplatAsset
+cache = f"/tmp/gsplat_cache/{key}.json"
+if os.path.exists(cache):
+    asset = GaussianSplatAsset.Load(cache)
+else:
+    asset = creator.CreateAssetFromSplatsNative(scenes.make_config_splats(cfg), cfg.quality, name=key); asset.Save("/tmp/gsplat_cache")
 ctx = GpuContext(0)
 r = GaussianSplatRenderer(ctx, asset); r.OnEnable()
 rt = RenderTarget(ctx, cfg.width, cfg.height)

@@ -204,6 +204,9 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(const uint32_t* __rest
 #ifndef GS_BIN_MINWAVES
 #define GS_BIN_MINWAVES 1
 #endif
+#ifndef GS_BIN_QUIET_WAIT
+#define GS_BIN_QUIET_WAIT 1
+#endif
 #ifdef GS_EXP_BIN_TIMELINE        // experiment build: per-partition phase timestamps (100 MHz wall clock) of the LAST launch
 __device__ unsigned long long g_bin_tl[32768 * 8];
 #define GS_BTL(k) do { if (threadIdx.x == 0 && part < 32768u) g_bin_tl[part * 8u + (k)] = wall_clock64(); } while (0)
@@ -356,7 +359,22 @@ __global__ __launch_bounds__(kBinThreads, GS_BIN_MINWAVES) void bin_emit_kernel(
             }
             if (lane == 0) __hip_atomic_store(binGroupBase + grp, BFLAG_INCL | excl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else {                                                         // ---- the earlier partitions of the own group + the group's base
+#if GS_BIN_QUIET_WAIT
+            // First wait for the group's base with ONE request per poll.  A 64-lane poll of the status words is 64 agent-scope (L1-bypassing)
+            // L2 requests, and in the steady state ~40 % of the resident workgroups are waiting here at any time: their polling alone
+            // loads the L2 request path that the other workgroups' rectangle gathers and pair stores need (per-partition timeline:
+            // emission 4-7 us in the first round, when nobody polls, 15-21 us later).  The base is the last thing to arrive -- it needs
+            // every earlier group complete -- so once it is there the status words of the own group almost always are, too.
+            while (!failed) {
+                unsigned long long b0 = 0ull;
+                if (lane == 0) b0 = __hip_atomic_load(binGroupBase + grp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (__builtin_amdgcn_readfirstlane((uint32_t)(b0 >> 32)) & (uint32_t)(BFLAG_INCL >> 32)) break;
+                if (++spins > BIN_SPIN_LIMIT) { if (lane == 0) atomicOr(&ctl->error, 2u); failed = true; }
+                __builtin_amdgcn_s_sleep(4);
+            }
+#endif
             for (;;) {
+                if (failed) break;
                 const int idx = (int)part - 1 - lane;
                 const bool mine = idx >= (int)grpStart;
                 unsigned long long s = 0ull;
@@ -479,6 +497,7 @@ __global__ __launch_bounds__(kBinThreads, GS_BIN_MINWAVES) void bin_emit_kernel(
         if (c) atomicAdd(&pairHist[j], c);
     }
 }
+
 
 #ifdef GS_EXP_BIN_TIMELINE
 extern "C" int32_t gs_debug_read_bin_timeline(void* out, size_t bytes) {
@@ -606,7 +625,10 @@ typedef uint32_t u4v __attribute__((ext_vector_type(4)));
 // ballot, ~40 wave instructions): 0.57 x the pairs at 4 x the waves per record is 2.3 x the tests, +18 % blend time at C2 for 32x32
 // (+7 % for 32x16) -- which is why the shape is picked per scene (pick_tile_shape).  Compacting every batch into per-16x16-sub-block
 // index lists first (so that a wave tests only its sub-block's records) was built and measured: the extra barrier and the index
-// indirection in the survivor walk cost more than the tests saved (+9 % blend, profiles/r04_variants.txt call 3).  Blend order per
+// indirection in the survivor walk cost more than the tests saved (+9 % blend, profiles/r04_variants.txt call 3).  So was letting a
+// wave LEAVE as soon as its quadrant is finished (s_barrier only counts the waves alive; the others re-deal the list): 22 % of a tile's
+// wave x batch slots belong to finished waves, but freeing them changes nothing (+-1 %, call 6) -- the launch is not short of wave slots,
+// its SIMDs are VALU-busy 126 of 187 us on average and unevenly loaded.  Blend order per
 // pixel is unchanged, so the frame is bit-identical across tile shapes (tests/test_gpu_draw.py::test_tile_shapes_give_the_same_frame).
 #ifdef GS_EXP_BLEND_TIMELINE      // experiment build: per-tile start / end (100 MHz wall clock), list length, batches walked
 __device__ unsigned long long g_blend_tl[65536 * 8];
@@ -1144,6 +1166,7 @@ int32_t bin_and_sort(gs_renderer* r, const gs_frame_params* p, gs_target* rt, co
     const bool tileCnt = GS_BIN_TILE_COUNTERS && numTiles <= kBinTileCounters;       // (<= 2048 tiles means <= 2 passes)
     auto binKernel = passes == 1 ? (tileCnt ? bin_emit_kernel<1, true> : bin_emit_kernel<1, false>)
                    : (passes == 2 ? (tileCnt ? bin_emit_kernel<2, true> : bin_emit_kernel<2, false>) : bin_emit_kernel<3, false>);
+    const uint32_t binThreads = kBinThreads;
     // persistent: as many workgroups as are resident at once, a multiple of the ticket classes
 #ifndef GS_BIN_BLOCKS_PER_CU
 #define GS_BIN_BLOCKS_PER_CU 5      // 90 VGPRs at 8 positions per thread: five 256-thread workgroups per CU
@@ -1151,7 +1174,7 @@ int32_t bin_and_sort(gs_renderer* r, const gs_frame_params* p, gs_target* rt, co
     const uint32_t binCap = max((uint32_t)ctx->cuCount * (uint32_t)GS_BIN_BLOCKS_PER_CU / kBinTicketClasses * kBinTicketClasses, kBinTicketClasses);
     const uint32_t binGrid = min(div_up(div_up(count, kBinPart), kBinTicketClasses) * kBinTicketClasses, binCap);
     const bool schedInBin = haveCosts && !forceOrderKernel;     // one extra workgroup makes the blend's tile schedule meanwhile
-    hipLaunchKernelGGL(binKernel, dim3(binGrid + (schedInBin ? 1u : 0u)), dim3(kBinThreads), 0, st, r->rects, wave_flags_of(r->visMask, r->n), order, count, rc.tilesX, shapeKey, r->pairKeys,
+    hipLaunchKernelGGL(binKernel, dim3(binGrid + (schedInBin ? 1u : 0u)), dim3(binThreads), 0, st, r->rects, wave_flags_of(r->visMask, r->n), order, count, rc.tilesX, shapeKey, r->pairKeys,
                        r->pairVals, cap, binCtl, binStatus, binGroupAgg, binGroupBase, pairCtl->hist, r->pairSort.groupAgg, sort_group_words(cap, passes), (uint32_t*)nextArena, (uint32_t)(r->frameArenaBytes / 4), (uint32_t)bits,
                        o.costRead, numTiles, schedInBin ? o.tileOrder : (uint32_t*)nullptr);
     GS_TRY(mark_order_use(r));                                  // the next frame's depth sort may overwrite order[] from here on
