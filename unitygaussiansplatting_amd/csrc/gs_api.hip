@@ -330,11 +330,9 @@ int32_t gs_renderer_sort(gs_renderer* r, const float m[16]) {
     // (_SplatSortKeys, SplatUtilities.compute:76) is the first Onesweep pass's key load
     GS_TRY(enqueue_sort_keys(ctx, st, r->asset->view, m, r->keyBySplat, control, r->depthControl + (r->depthControlIdx ^ 1), r->n, r->depthSort));
     gs::prof_record(r, 1, st);
-    #ifndef GS_SORT_SKIP_LAST_KEYS
-#define GS_SORT_SKIP_LAST_KEYS 1     // the last depth pass writes only the order: nothing on the frame's path reads the sorted keys
-#endif
-    GS_TRY(enqueue_sort_passes(ctx, st, r->depthSort, control, r->distances, r->order, r->n, nullptr, 4, 255u, r, 10, 8, r->keyBySplat, GS_SORT_SKIP_LAST_KEYS != 0));
-    r->distancesStale = GS_SORT_SKIP_LAST_KEYS != 0;
+    // (skipLastKeys: the last depth pass writes only the order -- nothing on the frame's path reads the sorted keys; materialise_distances)
+    GS_TRY(enqueue_sort_passes(ctx, st, r->depthSort, control, r->distances, r->order, r->n, nullptr, 4, 255u, r, 10, 8, r->keyBySplat, true));
+    r->distancesStale = true;
     gs::prof_record(r, 2, st);
     if (ctx->overlap) {
         GS_HIP(hipEventRecord(r->evSortDone, st));

@@ -30,10 +30,8 @@ int32_t fail_hip(hipError_t e, const char* what, const char* file, int line);
 
 // (the compositor's tile is 16x16, 32x16 or 32x32 pixels, picked per draw: pick_tile_shape in gs_raster.hip)
 constexpr int kBinThreads = 256;
-#ifndef GS_BIN_ITEMS
-#define GS_BIN_ITEMS 8       // 2048 positions per partition: ~3 rounds of partitions over the persistent grid balance better than 1.5 (measured)
-#endif
-constexpr int kBinItems = GS_BIN_ITEMS;   // sorted positions per thread
+constexpr int kBinItems = 8;              // sorted positions per thread: 2048 per partition (~3 rounds of partitions over the persistent grid balance better
+                                          // than 1.5; 12 / 16 per thread: -5 % at C2 / C4, +6 % at C3 -- r04 calls 7, 8)
 constexpr int kBinPart = kBinThreads * kBinItems;
 constexpr uint32_t kBinTicketClasses = 16;
 constexpr int kEvPerFrame = 28;           // hipEvents per profiled frame: 0..13 stage brackets; 14..21 / 22..27 start + stop of each depth / pair Onesweep launch

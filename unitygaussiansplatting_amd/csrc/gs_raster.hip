@@ -201,25 +201,13 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(const uint32_t* __rest
 // are produced 64 consecutive output slots at a time, each lane finding its source position from marks dropped at the
 // first slot of every position and a DPP max-scan -- global stores of pairs are therefore fully coalesced whatever the
 // footprints are (a splat covering the whole screen is just a long run), and no lane idles behind a neighbour's big splat.
-#ifndef GS_BIN_MINWAVES
-#define GS_BIN_MINWAVES 1
-#endif
-#ifndef GS_BIN_QUIET_WAIT
-#define GS_BIN_QUIET_WAIT 1
-#endif
-#ifdef GS_EXP_BIN_TIMELINE        // experiment build: per-partition phase timestamps (100 MHz wall clock) of the LAST launch
-__device__ unsigned long long g_bin_tl[32768 * 8];
-#define GS_BTL(k) do { if (threadIdx.x == 0 && part < 32768u) g_bin_tl[part * 8u + (k)] = wall_clock64(); } while (0)
-#else
-#define GS_BTL(k) do { } while (0)
-#endif
 // TILECNT (targets of <= kBinTileCounters tiles): the pair sort's digit histograms are not accumulated per emitted pair (one LDS atomic for
 // the low digit + a ballot-aggregated add per higher digit: ~35 of the emission's ~140 wave instructions per 64 pairs) but as ONE LDS
 // atomic per pair into a per-TILE counter -- neighbouring output slots are neighbouring tiles: distinct addresses -- folded into the
 // digit histograms once, when the persistent workgroup is done.
 constexpr uint32_t kBinTileCounters = 2048;
 template <int PASSES, bool TILECNT>
-__global__ __launch_bounds__(kBinThreads, GS_BIN_MINWAVES) void bin_emit_kernel(const uint2* __restrict__ rects, const uint8_t* __restrict__ waveFlags,
+__global__ __launch_bounds__(kBinThreads) void bin_emit_kernel(const uint2* __restrict__ rects, const uint8_t* __restrict__ waveFlags,
                                                                 const uint32_t* __restrict__ order, uint32_t n, uint32_t tilesX, uint32_t tileShift,
                                                                 uint32_t* __restrict__ pairKeys, uint32_t* __restrict__ pairVals,
                                                                 uint32_t capacity, BinControl* ctl, unsigned long long* binStatus, unsigned long long* binGroupAgg, unsigned long long* binGroupBase,
@@ -261,9 +249,6 @@ __global__ __launch_bounds__(kBinThreads, GS_BIN_MINWAVES) void bin_emit_kernel(
     // t * classes + c; see the same scheme in gs_sort.hip for why a workgroup still only waits on running partitions.
     for (;;) {
     __syncthreads();                                             // s_part / s_wtot / s_base of the previous partition are no longer read
-#ifdef GS_EXP_BIN_TIMELINE
-    const unsigned long long btl0 = wall_clock64();
-#endif
     if (tid == 0) {
         const uint32_t cls = bid % kBinTicketClasses;
         const uint32_t t = __hip_atomic_fetch_add(&ctl->tickets[cls * 32u], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -272,10 +257,6 @@ __global__ __launch_bounds__(kBinThreads, GS_BIN_MINWAVES) void bin_emit_kernel(
     __syncthreads();
     const uint32_t part = s_part;
     if (part >= numParts) break;
-#ifdef GS_EXP_BIN_TIMELINE
-    if (tid == 0 && part < 32768u) g_bin_tl[part * 8u + 0] = btl0;
-#endif
-    GS_BTL(1);                                                   // ticket known
     const uint32_t waveBase = part * (uint32_t)kBinPart + (uint32_t)w * (64u * kBinItems);
 
     // ---- per sorted position: gather the splat's tile rectangle (8 B, written by calc_view) ----------------------
@@ -310,7 +291,6 @@ __global__ __launch_bounds__(kBinThreads, GS_BIN_MINWAVES) void bin_emit_kernel(
         mySum += c;
         myVis += c ? 1u : 0u;
     }
-    GS_BTL(2);                                                   // order, visibility bits and rectangles arrived (mySum depends on them)
     const uint32_t waveTotal = wave_sum_u32(mySum);
     const uint32_t waveVis = wave_sum_u32(myVis);
     if (lane == 0) { s_wtot[w] = waveTotal; s_wvis[w] = waveVis; }
@@ -359,7 +339,6 @@ __global__ __launch_bounds__(kBinThreads, GS_BIN_MINWAVES) void bin_emit_kernel(
             }
             if (lane == 0) __hip_atomic_store(binGroupBase + grp, BFLAG_INCL | excl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else {                                                         // ---- the earlier partitions of the own group + the group's base
-#if GS_BIN_QUIET_WAIT
             // First wait for the group's base with ONE request per poll.  A 64-lane poll of the status words is 64 agent-scope (L1-bypassing)
             // L2 requests, and in the steady state ~40 % of the resident workgroups are waiting here at any time: their polling alone
             // loads the L2 request path that the other workgroups' rectangle gathers and pair stores need (per-partition timeline:
@@ -372,7 +351,6 @@ __global__ __launch_bounds__(kBinThreads, GS_BIN_MINWAVES) void bin_emit_kernel(
                 if (++spins > BIN_SPIN_LIMIT) { if (lane == 0) atomicOr(&ctl->error, 2u); failed = true; }
                 __builtin_amdgcn_s_sleep(4);
             }
-#endif
             for (;;) {
                 if (failed) break;
                 const int idx = (int)part - 1 - lane;
@@ -403,9 +381,7 @@ __global__ __launch_bounds__(kBinThreads, GS_BIN_MINWAVES) void bin_emit_kernel(
             }
         }
     }
-    GS_BTL(3);                                                   // wave 0: scan done
     __syncthreads();
-    GS_BTL(4);
     // global offset of this wave's first pair: wave-uniform, so the pair arrays are addressed as scalar base + 32-bit slot
     // and the capacity test is a 32-bit compare against the number of this wave's slots that fit
     const unsigned long long gbaseV = s_base + wbase;
@@ -476,7 +452,6 @@ __global__ __launch_bounds__(kBinThreads, GS_BIN_MINWAVES) void bin_emit_kernel(
         __builtin_amdgcn_wave_barrier();
     }
 
-    GS_BTL(5);                                                   // wave 0's emission done
     }   // next partition
 
     // ---- flush the pair-sort digit histograms and the visible count ---------------------------------------------
@@ -499,12 +474,6 @@ __global__ __launch_bounds__(kBinThreads, GS_BIN_MINWAVES) void bin_emit_kernel(
 }
 
 
-#ifdef GS_EXP_BIN_TIMELINE
-extern "C" int32_t gs_debug_read_bin_timeline(void* out, size_t bytes) {
-    (void)hipDeviceSynchronize();
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bin_tl), bytes) == hipSuccess ? 0 : -2;
-}
-#endif
 
 // tile -> [start, end) in the tile-sorted pair array (both zero in the fresh arena: a tile nothing lands on stays empty).
 // Eight keys per thread from two 16-byte loads (the key buffers are 16-byte aligned and padded by 16 entries), plus the one
@@ -630,10 +599,6 @@ typedef uint32_t u4v __attribute__((ext_vector_type(4)));
 // wave x batch slots belong to finished waves, but freeing them changes nothing (+-1 %, call 6) -- the launch is not short of wave slots,
 // its SIMDs are VALU-busy 126 of 187 us on average and unevenly loaded.  Blend order per
 // pixel is unchanged, so the frame is bit-identical across tile shapes (tests/test_gpu_draw.py::test_tile_shapes_give_the_same_frame).
-#ifdef GS_EXP_BLEND_TIMELINE      // experiment build: per-tile start / end (100 MHz wall clock), list length, batches walked
-__device__ unsigned long long g_blend_tl[65536 * 8];
-__device__ unsigned long long g_blend_stats[8];      // [0] sum over waves of the batches the wave walked, [1] sum over tiles of waves x batches, [2..6] waves by (own / tile) batches
-#endif
 // DEPTH: the target has a depth attachment (gs_target_set_scene_depth): the reference draws the splats with the default
 // ZTest LEqual, ZWrite Off against the camera's depth buffer (RenderGaussianSplats.shader:10; the RT is bound with the
 // current depth, GaussianSplatRenderer.cs:195), and all four vertices of a quad carry the centre's depth (:56-60), so a
@@ -667,12 +632,6 @@ __global__ __launch_bounds__(64 << (TWL + THL - 6)) void blend_kernel(const uint
     else if (blockIdx.x < 6u * SLOTS / 8u) __builtin_amdgcn_s_setprio(1);
     const uint32_t tx = tile % rc.tilesX, ty = tile / rc.tilesX;
     const uint32_t start = tileStart[tile], end = tileEnd[tile];
-#ifdef GS_EXP_BLEND_TIMELINE
-    const unsigned long long tl0 = wall_clock64();
-    uint32_t tlBatches = 0, tlSurv = 0, tlMine = 0;
-    unsigned long long tlStage = 0, tlProc = 0, tlMark = tl0;
-    if (threadIdx.x == 0 && tile < 65536u) { g_blend_tl[tile * 8 + 0] = tl0; g_blend_tl[tile * 8 + 1] = tl0; g_blend_tl[tile * 8 + 2] = end - start; g_blend_tl[tile * 8 + 3] = 0; }
-#endif
     const int qx0 = (int)tx * TW + (w % NWX) * 8, qy0 = (int)ty * TH + (w / NWX) * 8;
     const int px = qx0 + (lane & 7), py = qy0 + (lane >> 3);
     const bool inside = px < (int)rc.width && py < (int)rc.height;
@@ -714,9 +673,6 @@ __global__ __launch_bounds__(64 << (TWL + THL - 6)) void blend_kernel(const uint
         __syncthreads();
         if (s_done == NW) break;
         ++batchesWalked;
-#ifdef GS_EXP_BLEND_TIMELINE
-        ++tlBatches;
-#endif
         const uint32_t cnt = min((uint32_t)NT, end - bs);
         if ((uint32_t)tid < cnt) {
             const float inv1 = 1.0f / gsm::dot2f(r0.z, r0.w, r0.z, r0.w);
@@ -738,12 +694,6 @@ __global__ __launch_bounds__(64 << (TWL + THL - 6)) void blend_kernel(const uint
             sidxNext = pairVals[min(bs + 2u * (uint32_t)NT + (uint32_t)tid, lastPair)];
         }
         __syncthreads();
-#ifdef GS_EXP_BLEND_TIMELINE
-        { const unsigned long long now = wall_clock64(); tlStage += now - tlMark; tlMark = now; }
-#endif
-#ifdef GS_EXP_BLEND_TIMELINE
-        if (!waveDone) ++tlMine;
-#endif
         if (!waveDone) {
             for (uint32_t c = 0; c < cnt; c += 64u) {
                 const uint32_t j = c + lane;
@@ -757,9 +707,6 @@ __global__ __launch_bounds__(64 << (TWL + THL - 6)) void blend_kernel(const uint
                     hit = hit && gsm::BlockMayTouch((float)qx0 + 4.0f, (float)qy0 + 4.0f, 3.5f, ra.x, ra.y, ra.z, gsm::u2f(rb.x), ra.w, gsm::u2f(rb.y), re.z);
                 }
                 unsigned long long mask = __ballot(hit);
-#ifdef GS_EXP_BLEND_TIMELINE
-                tlSurv += (uint32_t)__popcll(mask);
-#endif
                 survWalked += (uint32_t)__popcll(mask);
                 while (mask) {
                     const int b = __ffsll((long long)mask) - 1;
@@ -802,9 +749,6 @@ __global__ __launch_bounds__(64 << (TWL + THL - 6)) void blend_kernel(const uint
                 }
             }
         }
-#ifdef GS_EXP_BLEND_TIMELINE
-        { const unsigned long long now = wall_clock64(); tlProc += now - tlMark; tlMark = now; }
-#endif
     }
     if (inside) *dst = acc.pack();
     // next frame's scheduling hint (tile_order_body), 1 .. 254: the tile's critical chain -- the most survivors one of its waves
@@ -814,25 +758,7 @@ __global__ __launch_bounds__(64 << (TWL + THL - 6)) void blend_kernel(const uint
     if (lane == 0) atomicMax(&s_cost, survWalked);
     __syncthreads();
     if (threadIdx.x == 0) tileCost[tile] = min(254u, (s_cost + batchesWalked * (uint32_t)(NT / 8)) / 4u);
-#ifdef GS_EXP_BLEND_TIMELINE
-    if (lane == 0) { atomicAdd(&g_blend_stats[0], (unsigned long long)tlMine); atomicAdd(&g_blend_stats[2 + min(4u, tlMine * 5u / max(batchesWalked, 1u))], 1ull); }
-    if (threadIdx.x == 0) atomicAdd(&g_blend_stats[1], (unsigned long long)batchesWalked * NW);
-    __syncthreads();
-    if (threadIdx.x == 0 && tile < 65536u) { g_blend_tl[tile * 8 + 1] = wall_clock64(); g_blend_tl[tile * 8 + 3] = tlBatches; g_blend_tl[tile * 8 + 4] = tlSurv; g_blend_tl[tile * 8 + 5] = tlStage; g_blend_tl[tile * 8 + 6] = tlProc; }
-#endif
 }
-#ifdef GS_EXP_BLEND_TIMELINE
-extern "C" int32_t gs_debug_read_blend_timeline(void* out, size_t bytes) {
-    (void)hipDeviceSynchronize();
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_blend_tl), bytes) == hipSuccess ? 0 : -2;
-}
-extern "C" int32_t gs_debug_read_blend_stats(unsigned long long* out8, int32_t reset) {
-    (void)hipDeviceSynchronize();
-    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_blend_stats), 64) != hipSuccess) return -2;
-    if (reset) { unsigned long long z[8] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_blend_stats), z, 64); }
-    return 0;
-}
-#endif
 
 // View depth (centerClipPos.w, SplatUtilities.compute:199-200) of every visible splat, for the scene-depth test of the blend:
 // only launched by a draw whose target has a depth attachment, so the default path neither computes nor stores it.  Same
@@ -1160,18 +1086,13 @@ int32_t bin_and_sort(gs_renderer* r, const gs_frame_params* p, gs_target* rt, co
     if (numTiles <= 256) { passes = 1; bits = numTiles <= 64 ? 6 : (numTiles <= 128 ? 7 : 8); }
     else if (numTiles <= 65536) { passes = 2; bits = numTiles <= 4096 ? 6 : (numTiles <= 16384 ? 7 : 8); }
     else { passes = 3; bits = 8; }
-#ifndef GS_BIN_TILE_COUNTERS
-#define GS_BIN_TILE_COUNTERS 1
-#endif
-    const bool tileCnt = GS_BIN_TILE_COUNTERS && numTiles <= kBinTileCounters;       // (<= 2048 tiles means <= 2 passes)
+    const bool tileCnt = numTiles <= kBinTileCounters;       // (<= 2048 tiles means <= 2 passes)
     auto binKernel = passes == 1 ? (tileCnt ? bin_emit_kernel<1, true> : bin_emit_kernel<1, false>)
                    : (passes == 2 ? (tileCnt ? bin_emit_kernel<2, true> : bin_emit_kernel<2, false>) : bin_emit_kernel<3, false>);
     const uint32_t binThreads = kBinThreads;
     // persistent: as many workgroups as are resident at once, a multiple of the ticket classes
-#ifndef GS_BIN_BLOCKS_PER_CU
-#define GS_BIN_BLOCKS_PER_CU 5      // 90 VGPRs at 8 positions per thread: five 256-thread workgroups per CU
-#endif
-    const uint32_t binCap = max((uint32_t)ctx->cuCount * (uint32_t)GS_BIN_BLOCKS_PER_CU / kBinTicketClasses * kBinTicketClasses, kBinTicketClasses);
+    constexpr uint32_t kBinBlocksPerCu = 5;      // 90 VGPRs at 8 positions per thread: five 256-thread workgroups per CU
+    const uint32_t binCap = max((uint32_t)ctx->cuCount * kBinBlocksPerCu / kBinTicketClasses * kBinTicketClasses, kBinTicketClasses);
     const uint32_t binGrid = min(div_up(div_up(count, kBinPart), kBinTicketClasses) * kBinTicketClasses, binCap);
     const bool schedInBin = haveCosts && !forceOrderKernel;     // one extra workgroup makes the blend's tile schedule meanwhile
     hipLaunchKernelGGL(binKernel, dim3(binGrid + (schedInBin ? 1u : 0u)), dim3(binThreads), 0, st, r->rects, wave_flags_of(r->visMask, r->n), order, count, rc.tilesX, shapeKey, r->pairKeys,

@@ -32,28 +32,19 @@ namespace gs {
 namespace {
 
 constexpr int RADIX = 256;
-#ifndef GS_SORT_THREADS
-#define GS_SORT_THREADS 512
-#endif
-#ifndef GS_SORT_KPT
-#define GS_SORT_KPT 16
-#endif
-constexpr int THREADS = GS_SORT_THREADS;
+constexpr int THREADS = 512;
 constexpr int WAVES = THREADS / 64;
 // Two shapes of a pass, chosen per sort by the expected key count (enqueue_sort_passes):
 //   A  16 keys per thread, 8,192-key partitions, <= 80 VGPRs: three workgroups per CU -- up to 768 partitions (6.3 M keys) in ONE round;
 //   B  20 keys per thread, 10,240-key partitions, <= 128 VGPRs: two workgroups per CU -- longer runs per digit (160-byte stores), a fifth
 //      fewer status words and look-back steps: 8 % faster on 50 M keys, 9 % slower on 6 M (599 partitions on 512 slots = two rounds).
 // All sizing (status words, group words) follows shape A, which has the most partitions.
-constexpr int KPT_A = GS_SORT_KPT, KPT_B = 20;
+constexpr int KPT_A = 16, KPT_B = 20;
 constexpr int PART_A = THREADS * KPT_A, PART_B = THREADS * KPT_B;
 constexpr uint32_t kBigSortKeys = 24u << 20;          // expected keys above which shape B is used (four rounds of shape A)
 constexpr uint32_t SPIN_LIMIT = 1u << 24;
 constexpr uint32_t TICKET_CLASSES = 16;        // partition-ticket counters per pass (one 128-B line each)
-#ifndef GS_SORT_GROUP
-#define GS_SORT_GROUP 32
-#endif
-constexpr int GROUP = GS_SORT_GROUP;                     // partitions per look-back group (~sqrt of the partition count of a 6 M key sort)
+constexpr int GROUP = 32;                     // partitions per look-back group (~sqrt of the partition count of a 6 M key sort)
 
 // per-(partition, digit) status word: {epoch:18 | count:14}; valid for a pass iff its epoch field equals the pass's epoch
 constexpr uint32_t COUNT_BITS = 14, EPOCH_MASK = (1u << 18) - 1u;
@@ -129,9 +120,7 @@ __global__ __launch_bounds__(256) void histogram_kernel(const uint32_t* __restri
 // 1024-thread workgroup per CU (few workgroups = few flushes of the LDS histograms into the 1024 global bins, whose
 // same-address atomics serialise), each thread keeps ILP chunks in flight; a quarter of a workgroup = one 256-splat chunk,
 // so ChunkInfo is wave-uniform.
-#ifndef GS_KEYS_ILP
-#define GS_KEYS_ILP 4
-#endif
+constexpr uint32_t kKeysIlp = 4;             // 256-splat chunks in flight per quarter workgroup of sort_keys_kernel
 template <int POSFMT>
 __global__ __launch_bounds__(1024) void sort_keys_kernel(gsm::AssetView a, float m20, float m21, float m22, float m23,
                                                          uint32_t* __restrict__ keyBySplat, uint32_t* __restrict__ hist, uint32_t n,
@@ -143,7 +132,7 @@ __global__ __launch_bounds__(1024) void sort_keys_kernel(gsm::AssetView a, float
     // the control block (histograms, tickets, error) of the NEXT sort: the two blocks alternate, so no memset launch per sort
     for (uint32_t j = blockIdx.x * 1024u + threadIdx.x; j < (uint32_t)(sizeof(SortControl) / 4); j += gridDim.x * 1024u) nextControl[j] = 0u;
     __syncthreads();
-    constexpr uint32_t ILP = GS_KEYS_ILP;
+    constexpr uint32_t ILP = kKeysIlp;
     const uint32_t chunks = (n + 255u) >> 8;
     const uint32_t sub = threadIdx.x >> 8, t = threadIdx.x & 255u;
     const uint32_t step = gridDim.x * (4u * ILP);
@@ -213,23 +202,10 @@ __global__ __launch_bounds__(1024) void sort_keys_kernel(gsm::AssetView a, float
 // Register diet (the kernel is latency-bound, so resident waves matter): payloads are loaded only after the keys
 // have left the registers for LDS, local positions overwrite the ranks, and the digit of each output slot is kept
 // packed 4 per register instead of a 32-bit global index per slot.
-#ifdef GS_EXP_SORT_TIMELINE       // experiment build: per-partition phase timestamps (100 MHz wall clock) of the LAST launch
-__device__ unsigned long long g_timeline[16384 * 16];
-#define GS_TL(k) do { if (threadIdx.x == 0 && part < 16384u) g_timeline[part * 16u + (k)] = wall_clock64(); } while (0)
-#else
-#define GS_TL(k) do { } while (0)
-#endif
-#ifndef GS_SORT_LOOKBACK_BATCH
-#define GS_SORT_LOOKBACK_BATCH 16
-#endif
-#ifndef GS_SORT_XCD_BLOCKS
-#define GS_SORT_XCD_BLOCKS 1
-#endif
-#ifndef GS_SORT_MINWAVES
-#define GS_SORT_MINWAVES 6      // <= 80 VGPRs: three 512-thread workgroups per CU (a handful of loop-invariant values spill to scratch)
-#endif
+constexpr int kLookbackBatch = 16;           // status words requested per look-back round
+constexpr int kMinWavesA = 6;                // shape A: <= 80 VGPRs = three 512-thread workgroups per CU (a handful of loop-invariant values spill to scratch)
 template <int BITS, bool GATHER, int KPT>
-__global__ __launch_bounds__(THREADS, KPT == KPT_A ? GS_SORT_MINWAVES : 4) void onesweep_kernel(const uint32_t* __restrict__ keysIn, const uint32_t* __restrict__ valsIn,
+__global__ __launch_bounds__(THREADS, KPT == KPT_A ? kMinWavesA : 4) void onesweep_kernel(const uint32_t* __restrict__ keysIn, const uint32_t* __restrict__ valsIn,
                                                            uint32_t* __restrict__ keysOut, uint32_t* __restrict__ valsOut,
                                                            const uint32_t* __restrict__ hist, uint32_t* status,
                                                            unsigned long long* groupAgg, unsigned long long* groupIncl, uint32_t* ticket, uint32_t* error,
@@ -253,10 +229,8 @@ __global__ __launch_bounds__(THREADS, KPT == KPT_A ? GS_SORT_MINWAVES : 4) void 
     // partitions per XCD block of the GATHER pass: the input is cut into 8 r equal blocks, r = the fewest rounds for which a
     // block is no larger than what one XCD runs at once (32 CUs x 3 workgroups), so that every XCD gets the same number of
     // blocks (measured on C2, 749 partitions: blocks of 94 -> 156 us per depth sort, 32 -> 165, 64 (unbalanced) -> 179)
-#ifndef GS_SORT_XCD_MAXBLOCK
-#define GS_SORT_XCD_MAXBLOCK (KPT == KPT_A ? 96 : 64)
-#endif
-    const uint32_t xcdRounds = (numParts + 8u * GS_SORT_XCD_MAXBLOCK - 1u) / (8u * GS_SORT_XCD_MAXBLOCK);
+    constexpr uint32_t kXcdMaxBlock = KPT == KPT_A ? 96 : 64;
+    const uint32_t xcdRounds = (numParts + 8u * kXcdMaxBlock - 1u) / (8u * kXcdMaxBlock);
     const uint32_t xcdBlock = max(1u, (numParts + 8u * max(xcdRounds, 1u) - 1u) / (8u * max(xcdRounds, 1u)));
     (void)xcdBlock;
 
@@ -277,16 +251,10 @@ __global__ __launch_bounds__(THREADS, KPT == KPT_A ? GS_SORT_MINWAVES : 4) void 
     if (tid < RDX)
         for (int k = 0; k < w; ++k) histExcl += s_htot[k];
 
-#ifndef GS_SORT_STATIC_ONE_ROUND
-#define GS_SORT_STATIC_ONE_ROUND 1
-#endif
-    const bool oneRound = GS_SORT_STATIC_ONE_ROUND && gridDim.x >= numParts;    // (uniform)
+    const bool oneRound = gridDim.x >= numParts;          // (uniform) every partition has a resident workgroup
     for (uint32_t round = 0;; ++round) {
         if (oneRound && round) break;
         __syncthreads();                                    // previous partition's LDS reads are finished
-#ifdef GS_EXP_SORT_TIMELINE
-        const unsigned long long tl0 = wall_clock64();
-#endif
         // Partition tickets.  One counter would serialise every workgroup of the grid on a single L2 channel (~12 ns per
         // same-address atomic: the 768th workgroup starts 9 us late in a 35 us pass), so there are TICKET_CLASSES counters
         // in separate 128-B lines; workgroup b draws from counter b % TICKET_CLASSES and ticket t of class c is partition
@@ -297,17 +265,9 @@ __global__ __launch_bounds__(THREADS, KPT == KPT_A ? GS_SORT_MINWAVES : 4) void 
             const uint32_t cls = blockIdx.x % TICKET_CLASSES;
             // One round (the grid covers every partition, all of them resident at once -- a 6 M-key pass): the ticket a workgroup
             // would draw is known, blockIdx / classes, so the atomic's round trip (~1.2 us at the head of a ~31 us pass) is skipped.
-#if GS_SORT_STATIC_ONE_ROUND
             const uint32_t t = oneRound ? blockIdx.x / TICKET_CLASSES : __hip_atomic_fetch_add(ticket + cls * 32u, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#else
-            const uint32_t t = __hip_atomic_fetch_add(ticket + cls * 32u, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#endif
             uint32_t p = t * TICKET_CLASSES + cls;
-#ifndef GS_SORT_XCD_ALL
-#define GS_SORT_XCD_ALL 0       // 1: XCD blocks in every pass, not only the gather pass (A/B: do neighbouring partitions' runs merge in a shared L2?)
-#endif
-#if GS_SORT_XCD_BLOCKS
-            if (GATHER || GS_SORT_XCD_ALL) {
+            if (GATHER) {                  // (XCD blocks in the plain passes too -- do neighbouring partitions' runs merge in a shared L2? -- measured: no change, r04 call 4)
                 // The gathered key array does not fit one XCD's L2, but the 16 keys of a 64-byte sector belong to spatial
                 // neighbours (the asset is in Morton order), which are close in the previous depth order too: they are asked for
                 // within a few partitions of each other.  Workgroup b runs on XCD b % 8 (MI355X_MICROARCH.md) = cls % 8, so
@@ -318,17 +278,12 @@ __global__ __launch_bounds__(THREADS, KPT == KPT_A ? GS_SORT_MINWAVES : 4) void 
                 const uint32_t x = cls & 7u, u = t * 2u + (cls >> 3);       // u-th partition of XCD x
                 p = ((u / xb) * 8u + x) * xb + (u % xb);
             }
-#endif
             s_part = p;
         }
         for (int k = tid; k < WAVES * RDX; k += THREADS) s_hist[k] = 0;
         __syncthreads();
         const uint32_t part = s_part;
         if (part >= numParts) break;
-#ifdef GS_EXP_SORT_TIMELINE
-        if (tid == 0 && part < 16384u) g_timeline[part * 16u + 0] = tl0;
-#endif
-        GS_TL(1);                                           // ticket taken, histogram cleared
 
         const uint32_t partBase = part * (uint32_t)PART;
         const uint32_t valid = min((uint32_t)PART, n - partBase);
@@ -365,13 +320,6 @@ __global__ __launch_bounds__(THREADS, KPT == KPT_A ? GS_SORT_MINWAVES : 4) void 
             }
         }
 
-#ifdef GS_EXP_SORT_TIMELINE
-        { uint32_t x = 0;
-#pragma unroll
-          for (int k = 0; k < KPT; ++k) x |= key[k];
-          asm volatile("" :: "v"(x)); }                     // wait for the key loads before the timestamp
-#endif
-        GS_TL(2);                                           // keys arrived
         // ---- rank inside the wave: multi-split by one ballot per digit bit, running per-wave LDS histogram ------------
         uint32_t pos[KPT];                                   // rank now, local position later
         uint32_t* wh = s_hist + w * RDX;
@@ -401,7 +349,6 @@ __global__ __launch_bounds__(THREADS, KPT == KPT_A ? GS_SORT_MINWAVES : 4) void 
             asm volatile("" : "+v"(key[k]));
         }
         __syncthreads();
-        GS_TL(3);                                           // ranked
 
         // ---- partition digit counts, wave-exclusive offsets, local exclusive scan over digits --------
         // (threads >= RDX only help with loads/stores; digit `tid` is owned by thread tid < RDX)
@@ -457,7 +404,6 @@ __global__ __launch_bounds__(THREADS, KPT == KPT_A ? GS_SORT_MINWAVES : 4) void 
                 val[k] = (gi < n) ? ldg32(valsIn, gi) : 0u;
             }
         }
-        GS_TL(4);                                           // keys scattered to LDS, payload loads issued
         // ---- look back over earlier partitions for digit `tid` (keys are parked in LDS by now, so the batch of
         //      status words below replaces the key registers instead of adding to them) ------------------------
         if (tid < RDX) {
@@ -475,18 +421,12 @@ __global__ __launch_bounds__(THREADS, KPT == KPT_A ? GS_SORT_MINWAVES : 4) void 
                 //      else the group aggregate once all GROUP members have added to it -- which depends on ranking only,
                 //      not on anyone's look-back.
                 // LB words are requested per round and consumed in order.
-                constexpr int LB = GS_SORT_LOOKBACK_BATCH;
+                constexpr int LB = kLookbackBatch;
                 const int grp = (int)(part / GROUP), grpStart = grp * GROUP;
                 int q = (int)part - 1;
                 uint32_t spins = 0;
                 bool done = false;
-#ifdef GS_EXP_SORT_TIMELINE
-                uint32_t tlRounds = 0;
-#endif
                 while (!done && q >= grpStart) {                                   // ---- level 1: own group
-#ifdef GS_EXP_SORT_TIMELINE
-                    ++tlRounds;
-#endif
                     uint32_t sv[LB];
 #pragma unroll
                     for (int b = 0; b < LB; ++b) {
@@ -510,9 +450,6 @@ __global__ __launch_bounds__(THREADS, KPT == KPT_A ? GS_SORT_MINWAVES : 4) void 
                 }
                 int j = grp - 1;
                 while (!done && j >= 0) {                                          // ---- level 2: whole groups (all of them full)
-#ifdef GS_EXP_SORT_TIMELINE
-                    ++tlRounds;
-#endif
                     constexpr int GB = 4;
                     unsigned long long incl[GB], agg[GB];
 #pragma unroll
@@ -540,9 +477,6 @@ __global__ __launch_bounds__(THREADS, KPT == KPT_A ? GS_SORT_MINWAVES : 4) void 
                         __builtin_amdgcn_s_sleep(1);
                     }
                 }
-#ifdef GS_EXP_SORT_TIMELINE
-                if (tid == 0 && part < 16384u) { g_timeline[part * 16u + 10] = tlRounds; g_timeline[part * 16u + 11] = (unsigned long long)((int)part - 1 - q) + (unsigned long long)(grp - 1 - j) * 1000ull; g_timeline[part * 16u + 12] = spins; }
-#endif
             }
             // the last partition of a group that knows its prefix publishes the group's inclusive prefix: a shortcut for
             // every later group's level 2 (those that find it stop there; those that do not use the aggregates)
@@ -550,9 +484,7 @@ __global__ __launch_bounds__(THREADS, KPT == KPT_A ? GS_SORT_MINWAVES : 4) void 
                 st_word64(groupIncl + (size_t)(part / GROUP) * RADIX + tid, ((unsigned long long)epoch << 32) | (unsigned long long)(exclPrefix + total));
             s_gbase[tid] = histExcl + exclPrefix - lbase;
         }
-        GS_TL(5);                                           // look-back done (thread 0 = digit 0)
         __syncthreads();
-        GS_TL(6);                                           // everyone's look-back done
         uint32_t dpack[(KPT + 3) / 4];
 #pragma unroll
         for (int k = 0; k < (KPT + 3) / 4; ++k) dpack[k] = 0;
@@ -567,17 +499,14 @@ __global__ __launch_bounds__(THREADS, KPT == KPT_A ? GS_SORT_MINWAVES : 4) void 
             }
         }
         __syncthreads();
-        GS_TL(7);                                           // keys written out
 #pragma unroll
         for (int k = 0; k < KPT; ++k) s_buf[pos[k]] = val[k];
         __syncthreads();
-        GS_TL(8);                                           // payloads in LDS
 #pragma unroll
         for (int k = 0; k < KPT; ++k) {
             const uint32_t j = (uint32_t)tid + (uint32_t)k * THREADS;
             if (j < valid) stg32(valsOut, s_gbase[(dpack[k >> 2] >> (8 * (k & 3))) & 255u] + j, s_buf[j]);
         }
-        GS_TL(9);                                           // payload stores issued
     }
 }
 
@@ -591,12 +520,6 @@ inline uint32_t div_up(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
 
 } // namespace
 
-#ifdef GS_EXP_SORT_TIMELINE
-extern "C" int32_t gs_debug_read_sort_timeline(void* out, size_t bytes) {
-    (void)hipDeviceSynchronize();
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_timeline), bytes) == hipSuccess ? 0 : -2;
-}
-#endif
 
 int32_t sort_state_create(gs_context* ctx, SortState& st, uint32_t maxCount) {
     if (maxCount > kSortMaxCount) return fail(GS_ERR_INVALID_ARGUMENT, "sort capacity above 2^30 keys");
@@ -644,10 +567,7 @@ int32_t enqueue_sort_keys(gs_context* ctx, hipStream_t stream, const gsm::AssetV
                           SortControl* control, SortControl* nextControl, uint32_t n, SortState& st) {
     // `control` was zeroed by the previous sort's launch of this kernel (or at creation); this launch zeroes `nextControl`
     const uint32_t chunks = div_up(n, 256u);
-#ifndef GS_KEYS_WGS_PER_CU
-#define GS_KEYS_WGS_PER_CU 1
-#endif
-    const uint32_t grid = max(1u, min(div_up(chunks, 4u * GS_KEYS_ILP), (uint32_t)ctx->cuCount * GS_KEYS_WGS_PER_CU));
+    const uint32_t grid = max(1u, min(div_up(chunks, 4u * kKeysIlp), (uint32_t)ctx->cuCount));      // one 1024-thread workgroup per CU
 #define GS_LAUNCH_KEYS(F) hipLaunchKernelGGL(sort_keys_kernel<F>, dim3(grid), dim3(1024), 0, stream, a, m[8], m[9], m[10], m[11], keyBySplat, \
                                              control->hist, n, st.groupAgg, sort_group_words(n, 4), (uint32_t*)nextControl)
     switch (a.posFmt) { case 0: GS_LAUNCH_KEYS(0); break; case 1: GS_LAUNCH_KEYS(1); break; case 2: GS_LAUNCH_KEYS(2); break; default: GS_LAUNCH_KEYS(3); break; }
