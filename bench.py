@@ -352,14 +352,14 @@ def main():
                     "alg_bytes_per_launch": int(k_bytes), "avg_launch_ms": round(k_ms, 4)}
 
         # dominant kernel = largest total time per frame.  Since round 4 that is a near tie between the six Onesweep launches and the ONE
-        # blend launch (the larger tiles shrink the pair sort).  The blend is VALU-bound (SQ counters: its SIMDs issue VALU 67 % of the launch,
+        # blend launch (the larger tiles shrink the pair sort).  The blend is VALU-bound (SQ counters: its SIMDs issue VALU ~65 % of the launch,
         # 4.8 cycles per instruction; exp + the per-blend fp16 rounding) -- an HBM fraction says nothing about it -- so when it is the
         # dominant one, `roofline` reports it as the contract asks AND `roofline_streaming` carries the dominant bandwidth-bound kernel.
         dom = max(ktime, key=lambda k: ktime[k])
         roofline = roof(dom)
         roofline_streaming = None
         if dom == "blend_kernel":
-            roofline["note_bound"] = ("blend_kernel is VALU-bound, not HBM-bound (profiles/r03_sq_counters_c2.txt: VALU issue 67 % of the launch; 22 VALU per (8x8 quadrant, "
+            roofline["note_bound"] = ("blend_kernel is VALU-bound, not HBM-bound (profiles/r04_sq_counters_c2.txt: VALU issue ~65 % of the launch; 22 VALU per (8x8 quadrant, "
                                       "survivor)); its HBM fraction is reported because the contract asks for the dominant kernel's, it is not a quality measure -- see roofline_streaming")
             stream_dom = max((k for k in ktime if k != "blend_kernel"), key=lambda k: ktime[k])
             roofline_streaming = roof(stream_dom)
