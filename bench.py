@@ -27,6 +27,7 @@ from __future__ import annotations
 
 import argparse
 import ctypes as C
+import gc
 import json
 import os
 import sys
@@ -270,6 +271,11 @@ def main():
     # The un-instrumented region -- exactly K frames between barrier + synchronize -- is run `repeats` times back to back over the same
     # frames; ms_per_step and value are the MEDIAN region's (min / max / every region reported next to them): one 14 ms region alone is a
     # coin-flip inside +-4 % on these boxes.
+    # Python's cyclic collector is off while frames are timed (as timeit does): with torch imported a full collection walks a few hundred
+    # thousand objects -- tens of milliseconds -- and when it strikes at the head of a region, while the queue is still empty, the GPU waits
+    # for the host (measured: the fifth 50-frame region of C2 / C3 took 10-40 ms longer in five of six runs; profiles/r04_bench_regions_c2.json).
+    gc.collect()
+    gc.disable()
     regions = [run_region(fi) for _ in range(max(args.repeats, 1))]
     elapsed = float(np.median(regions))
     # ---- the same K frames again with the per-stage hipEvents recorded (14 per frame, on the stream each kernel is
@@ -292,6 +298,7 @@ def main():
     r.FrameStats()
     stage_k = r.StageTimes()
     r.SetKernelTiming(False)
+    gc.enable()
     r.SetProfiling(0)
 
     ms_per_step = elapsed / args.steps * 1e3
