@@ -3,8 +3,11 @@ no compute calls)."""
 import ctypes as C
 import os
 import re
+import subprocess
+import sys
 
 import numpy as np
+import pytest
 
 from unitygaussiansplatting_amd import _abi, _lib
 
@@ -58,6 +61,27 @@ def test_argument_validation_without_a_device():
         h = C.c_void_p()
         assert lib.gs_context_create(0, None, C.byref(h)) == _abi.GS_ERR_NO_DEVICE      # fails loudly, no CPU fallback
         assert not h
+
+
+def test_automatic_tile_shape_is_host_logic():
+    """gs_renderer_tile_shape(NULL, w, h) = the compositor tile a fresh renderer would pick for a w x h target (host code, no device):
+    16x16 below 2^18 pixels, 32x16 from there on (32x32 only after a draw reported > 6 tiles per visible splat: tests/test_gpu_draw.py);
+    GSPLAT_TILE pins it for the whole process, which is why the pinned cases run in a child process."""
+    lib = _lib.lib()
+    if os.environ.get("GSPLAT_TILE"):
+        pytest.skip("GSPLAT_TILE pins the shape")
+    tw, th = C.c_uint32(0), C.c_uint32(0)
+    for (w, h), want in {(320, 200): (16, 16), (511, 512): (16, 16), (512, 512): (32, 16), (1200, 797): (32, 16), (1920, 1080): (32, 16),
+                         (3840, 2160): (32, 16), (65535, 65535): (32, 16), (1, 1): (16, 16)}.items():
+        assert lib.gs_renderer_tile_shape(None, w, h, C.byref(tw), C.byref(th)) == 0
+        assert (tw.value, th.value) == want, (w, h, tw.value, th.value)
+    assert lib.gs_renderer_tile_shape(None, 64, 64, None, C.byref(th)) == _abi.GS_ERR_INVALID_ARGUMENT
+    assert lib.gs_renderer_set_tile_shape(None, 16, 16) == _abi.GS_ERR_INVALID_ARGUMENT
+    code = ("import ctypes as C; from unitygaussiansplatting_amd import _lib; l = _lib.lib(); a, b = C.c_uint32(), C.c_uint32();"
+            "assert l.gs_renderer_tile_shape(None, 320, 200, C.byref(a), C.byref(b)) == 0; print(a.value, b.value)")
+    for pin, want in (("32x32", "32 32"), ("16x16", "16 16"), ("nonsense", "16 16")):
+        out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, GSPLAT_TILE=pin, PYTHONPATH=ROOT), capture_output=True, text=True, timeout=120)
+        assert out.returncode == 0 and out.stdout.split("\n")[0].strip() == want, (pin, out.stdout, out.stderr[-500:])
 
 
 def test_product_code_never_references_the_oracle():
