@@ -118,7 +118,7 @@ typedef struct gs_frame_stats {
     uint32_t visible_splats;    /* splats that survived culling (emitted >= 1 pair) */
     uint32_t tiles_x, tiles_y;
     uint32_t sort_error;        /* != 0 => GS_ERR_SORT_TIMEOUT was raised */
-    uint32_t tile_w, tile_h;    /* the compositor tile of the last draw, pixels (16x16, 32x16 or 32x32: gs_renderer_set_tile_shape) */
+    uint32_t tile_w, tile_h;    /* the compositor tile of the last draw, pixels (16x16, 32x16 or 32x32: gs_renderer_set_tile_shape); 0 x 0 before the first draw */
 } gs_frame_stats;
 
 /* hipEvent-timed stage durations of the last frame, ms (the four ProfilerMarkers of

@@ -600,7 +600,7 @@ int32_t gs_renderer_frame_stats(gs_renderer* r, gs_frame_stats* out) {
     memset(out, 0, sizeof(*out));
     out->pair_capacity = r->pairCapacity;
     out->tiles_x = r->lastTilesX; out->tiles_y = r->lastTilesY;
-    out->tile_w = 1u << r->lastTileWL; out->tile_h = 1u << r->lastTileHL;
+    out->tile_w = r->lastTileWL ? 1u << r->lastTileWL : 0u; out->tile_h = r->lastTileHL ? 1u << r->lastTileHL : 0u;      // 0 x 0: nothing drawn yet
     if (r->frameInFlight) {
         out->tile_pairs = r->hostReport->pairCount;
         out->visible_splats = r->hostReport->visible;
