@@ -30,6 +30,23 @@ __global__ void calib_scatter_runs32(uint32_t* out, size_t n) {
         out[dst] = (uint32_t)i;
     }
 }
+// bin_emit's rectangle gather (and, with 4-byte words, the Onesweep gather pass): `m` random 8-byte gathers over an array of `n` uint2
+// (6.13 M x 8 B = 49 MB like C2's rects[]; 2.2 M gathers like its visible splats).  What does FETCH_SIZE tally for a LONE request?
+// requested bytes = 8 m; sectors touched <= m (64 B each).  index = a multiplicative hash: no two neighbouring lanes share a sector.
+__global__ void calib_gather_b64(const uint2* __restrict__ in, uint32_t* out, uint32_t n, uint32_t m) {
+    uint32_t acc = 0;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x) {
+        const uint32_t j = (uint32_t)(((unsigned long long)i * 2654435761ull + 12345ull) % n);
+        const uint2 v = in[j];
+        acc += v.x ^ v.y;
+    }
+    if (acc == 0x12345678u) out[0] = acc;
+}
+__global__ void calib_gather_b32(const uint32_t* __restrict__ in, uint32_t* out, uint32_t n, uint32_t m) {
+    uint32_t acc = 0;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x) acc += in[(uint32_t)(((unsigned long long)i * 2654435761ull + 12345ull) % n)];
+    if (acc == 0x12345678u) out[0] = acc;
+}
 int main() {
     const size_t bytes = 1ull << 30;    // 1 GiB: four times the 256 MiB Infinity Cache
     void *a, *b;
@@ -42,8 +59,12 @@ int main() {
         calib_write_b32<<<4096, 256>>>((uint32_t*)b, bytes / 4);
         calib_write_b128<<<4096, 256>>>((uint4*)b, bytes / 16);
         calib_scatter_runs32<<<4096, 256>>>((uint32_t*)b, bytes / 4);
+        // flush the caches between the gather probes with a 1-GiB read (the array would otherwise sit in L2 / Infinity Cache from the last rep)
+        calib_gather_b64<<<2048, 256>>>((const uint2*)a, (uint32_t*)b, 6131954u, 2200000u);
+        calib_read_b128<<<4096, 256>>>((const uint4*)a, (uint32_t*)b, bytes / 16);
+        calib_gather_b32<<<2048, 256>>>((const uint32_t*)a, (uint32_t*)b, 6131954u, 6131954u);
     }
     CK(hipDeviceSynchronize());
-    printf("calib done: every kernel moves %zu bytes\n", bytes);
+    printf("calib done: every streaming kernel moves %zu bytes; calib_gather_b64 = 2,200,000 gathers of 8 B over 49 MB, calib_gather_b32 = 6,131,954 gathers of 4 B over 24.5 MB\n", bytes);
     return 0;
 }
