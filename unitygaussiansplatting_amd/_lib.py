@@ -65,6 +65,9 @@ SIGNATURES = {
     "gs_renderer_download_order": (C.c_int32, [_P, _P, C.c_size_t]),
     "gs_renderer_download_distances": (C.c_int32, [_P, _P, C.c_size_t]),
     "gs_renderer_upload_order": (C.c_int32, [_P, _P, C.c_size_t]),
+    "gs_renderer_set_sort_mode": (C.c_int32, [_P, C.c_int32]),
+    "gs_renderer_sort_mode": (C.c_int32, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "gs_renderer_download_visible_order": (C.c_int32, [_P, _P, C.c_size_t, C.POINTER(C.c_uint32)]),
     "gs_renderer_download_view": (C.c_int32, [_P, _P, C.c_size_t]),
     "gs_renderer_download_raster_records": (C.c_int32, [_P, _P, _P, _P]),
     "gs_renderer_frame_stats": (C.c_int32, [_P, C.POINTER(gs_frame_stats)]),

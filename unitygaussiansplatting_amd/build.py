@@ -8,7 +8,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libgsplat_hip.so")
-SOURCES = ["gs_api.hip", "gs_sort.hip", "gs_view.hip", "gs_raster.hip", "gs_comm.hip", "gs_import.cpp"]
+SOURCES = ["gs_api.hip", "gs_sort.hip", "gs_vissort.hip", "gs_view.hip", "gs_raster.hip", "gs_comm.hip", "gs_import.cpp"]
 HEADERS = ["gs_common.h", "gs_device_math.h", os.path.join("..", "..", "include", "gsplat_c.h")]
 # -ffp-contract=off: the kernels' arithmetic is written with explicit fmaf(); nothing else may fuse, so that
 # results match the oracle's canonical arithmetic bit for bit.

@@ -74,6 +74,7 @@ const char* gs_error_string(int32_t err) {
         case GS_ERR_SORT_TIMEOUT: return "sort look-back timed out";
         case GS_ERR_NO_DEVICE: return "no HIP device";
         case GS_ERR_COMM: return "RCCL communication error";
+        case GS_ERR_TIE_OVERFLOW: return "visible-only sort: a run of more than 64 equal keys needed the sort history (the renderer switched to full sorts; render the frame again)";
         default: return "unknown error";
     }
 }
@@ -254,7 +255,7 @@ int32_t gs_renderer_create(gs_context* ctx, gs_asset* asset, gs_renderer** out) 
     if (rc == GS_OK) chk(hipMemsetAsync(r->depthControl, 0, 2 * sizeof(SortControl), ctx->stream), "clear sort control");
     chk(hipEventCreateWithFlags(&r->evOrderFree, hipEventDisableTiming), "create event");
     chk(hipEventCreateWithFlags(&r->evSortDone, hipEventDisableTiming), "create event");
-    if (rc == GS_OK) rc = sort_state_create(ctx, r->depthSort, r->n);
+    if (rc == GS_OK) rc = sort_state_create(ctx, r->depthSort, r->n, true);        // (small partitions: the visible-only sort)
     if (rc == GS_OK) rc = renderer_alloc_raster(r);
     if (rc == GS_OK) rc = enqueue_set_indices(ctx, r->order, r->n);
     if (rc == GS_OK) chk(hipMemsetAsync(r->view, 0, (size_t)r->n * sizeof(gsm::ViewData), ctx->stream), "clear view");
@@ -282,6 +283,7 @@ int32_t gs_renderer_destroy(gs_renderer* r) {
     if (r->cutoutsCopied) (void)hipEventDestroy(r->cutoutsCopied);
     sort_state_destroy(r->depthSort);
     renderer_free_raster(r);
+    vis_free(r);
     if (r->ev) { for (int k = 0; k < r->profCapacity * kEvPerFrame; ++k) (void)hipEventDestroy(r->ev[k]); delete[] r->ev; delete[] r->evValid; }
     delete r;
     return GS_OK;
@@ -303,15 +305,60 @@ int32_t gs_renderer_reset_order(gs_renderer* r) {
     GS_TRY(join_sort(r));
     GS_TRY(materialise_distances(r));
     GS_TRY(enqueue_set_indices(r->ctx, r->order, r->n));
+    // CSSetIndices: the order buffer is the identity again and the stable-sort history starts over -- which is also what lets
+    // GS_SORT_VISIBLE (re)start (gs_renderer_set_sort_mode)
+    r->visBaseIdentity = true; r->visFallback = false; r->visHistDepth = 0; r->visHistDropped = 0; r->visOrderValid = false;
     return mark_order_use(r);
 }
 
 static void rec_ev(gs_renderer* r, int k) { gs::prof_record(r, k); }
 
+static int32_t enqueue_full_sort(gs_renderer* r, const float m[16]);
+
+// The order buffer the reference would hold after the sorts recorded in visHist: CSSetIndices' identity stably sorted by every kept
+// matrix, oldest first (one full sort each).  Exact unless rows have fallen off the history (visHistDropped).
+static int32_t materialise_full_order(gs_renderer* r) {
+    GS_TRY(join_sort(r));
+    GS_TRY(enqueue_set_indices(r->ctx, r->order, r->n));
+    GS_TRY(mark_order_use(r));
+    r->distancesStale = false;
+    for (int j = r->visHistDepth - 1; j >= 0; --j) {
+        float m[16] = { 0.f };
+        memcpy(m + 8, r->visHist[j], 16);
+        GS_TRY(enqueue_full_sort(r, m));
+    }
+    return join_sort(r);                                         // (overlap: the sorts ran on the second queue)
+}
+
+// The visible sort's fix-up met a run of equal keys it cannot order (VIS_TIE_OVERFLOW in the report of a draw binned from visIdx): from
+// here on the renderer sorts all N like the reference -- starting from the order buffer the reference would hold now.
+static int32_t vis_fall_back(gs_renderer* r) {
+    if (!vis_active(r)) return GS_OK;
+    GS_TRY(materialise_full_order(r));
+    r->visFallback = true;
+    r->visBaseIdentity = r->visHistDepth == 0;
+    r->visOrderValid = false;
+    return GS_OK;
+}
+static bool vis_overflow_reported(const gs_renderer* r) {
+    return r->visDrawn && r->frameInFlight && r->hostReport && (*(volatile uint32_t*)&r->hostReport->tieFlags & VIS_TIE_OVERFLOW) != 0u;
+}
+
 int32_t gs_renderer_sort(gs_renderer* r, const float m[16]) {
     if (!r || !m) return fail(GS_ERR_INVALID_ARGUMENT, "null argument");
+    GS_TRY(bind_device(r->ctx));
+    if (vis_active(r)) {
+        // GS_SORT_VISIBLE: SortPoints only says which matrix the order is sorted by from now on; the sort itself runs in gs_renderer_draw,
+        // over the splats that are drawn (gs_vissort.hip)
+        vis_push_matrix(r, m);
+        return GS_OK;
+    }
+    r->visBaseIdentity = false;                                  // the order buffer now holds a sort made outside the visible-only mode
+    return enqueue_full_sort(r, m);
+}
+
+static int32_t enqueue_full_sort(gs_renderer* r, const float m[16]) {
     gs_context* ctx = r->ctx;
-    GS_TRY(bind_device(ctx));
     // SortPoints depends on nothing else the frame computes (the C# merely records it before CalcViewData, :120-126), and
     // nothing but the draw's bin_emit reads its result.  With overlap on, the whole sort (keys + the four Onesweep passes)
     // runs on the context's second queue: it starts as soon as the main queue is done with order[] (evOrderFree: the
@@ -349,6 +396,7 @@ int32_t gs_renderer_calc_view(gs_renderer* r, const gs_frame_params* p) {
     e.deletedBits = r->deletedBits; e.cutouts = r->cutouts; e.cutoutCount = r->cutoutCount;
     GS_TRY(enqueue_calc_view(r->ctx, r->asset->view, p, e, view_outputs(r), r->alwaysWriteView));
     r->viewMaterialised = r->alwaysWriteView;
+    r->visOrderValid = false;                                    // the visible set may have changed
     r->lastParams = *p;
     r->viewW = p->screen_w; r->viewH = p->screen_h; r->viewNear = p->near_clip; r->viewFar = p->far_clip; r->viewValid = true;
     rec_ev(r, 8);
@@ -364,7 +412,12 @@ static int32_t maybe_grow_pairs(gs_renderer* r) {
     const unsigned long long seen = *(volatile unsigned long long*)&r->hostReport->pairCount;
     // at the 2^30 ceiling there is nothing to grow: the draw goes ahead truncated (gs_renderer_frame_stats reports the frame), so
     // that a later frame that fits renders normally and rewrites the report
-    if (seen > r->pairCapacity && r->pairCapacity < kSortMaxCount) return gs_renderer_reserve_pairs(r, seen + seen / 4);
+    if (seen > r->pairCapacity) {
+        // latch the truncated draw for gs_renderer_poll_pairs: by the time a pipelined host polls, the capacity has grown (below) and the
+        // report belongs to a later draw
+        if (seen > r->truncPairs) { r->truncPairs = seen; r->truncCapacity = r->pairCapacity; }
+        if (r->pairCapacity < kSortMaxCount) return gs_renderer_reserve_pairs(r, seen + seen / 4);
+    }
     return GS_OK;
 }
 
@@ -375,6 +428,7 @@ int32_t gs_renderer_draw(gs_renderer* r, const gs_frame_params* p, gs_target* rt
     GS_TRY(bind_device(r->ctx));
     if (r->renderMode == GS_RENDER_DEBUG_POINTS || r->renderMode == GS_RENDER_DEBUG_POINT_INDICES) return enqueue_debug_points(r, p, rt);
     GS_TRY(maybe_grow_pairs(r));
+    if (vis_overflow_reported(r)) GS_TRY(vis_fall_back(r));      // noticed within the pipeline depth, like a pair overflow
     if (r->renderMode == GS_RENDER_DEBUG_BOXES) return enqueue_debug_boxes(r, p, rt, false);
     if (r->renderMode == GS_RENDER_DEBUG_CHUNK_BOUNDS) return enqueue_debug_boxes(r, p, rt, true);
     return enqueue_draw(r, p, rt);
@@ -531,6 +585,11 @@ int32_t gs_renderer_reserve_pairs(gs_renderer* r, uint64_t cap) {
 
 int32_t gs_renderer_poll_pairs(gs_renderer* r, uint64_t* tile_pairs, uint64_t* pair_capacity) {
     if (!r || !tile_pairs || !pair_capacity) return fail(GS_ERR_INVALID_ARGUMENT, "null argument");
+    if (r->truncPairs) {                                         // a truncated draw the library has already reacted to: handed out once
+        *tile_pairs = r->truncPairs; *pair_capacity = r->truncCapacity;
+        r->truncPairs = r->truncCapacity = 0;
+        return GS_OK;
+    }
     *tile_pairs = r->hostReport ? (uint64_t)*(volatile unsigned long long*)&r->hostReport->pairCount : 0u;
     *pair_capacity = r->pairCapacity;
     return GS_OK;
@@ -546,7 +605,43 @@ static int32_t download(gs_context* ctx, void* dst, const void* src, size_t byte
 int32_t gs_renderer_download_order(gs_renderer* r, uint32_t* out, size_t count) {
     if (!r || !out || count > r->n) return fail(GS_ERR_INVALID_ARGUMENT, "bad argument");
     GS_TRY(join_sort(r));
+    if (vis_active(r)) { GS_TRY(bind_device(r->ctx)); GS_TRY(materialise_full_order(r)); }      // the reference's whole buffer, rebuilt from the kept matrices
     return download(r->ctx, out, r->order, count * 4);
+}
+int32_t gs_renderer_download_visible_order(gs_renderer* r, uint32_t* out, size_t capacity, uint32_t* count) {
+    if (!r || !count || (capacity && !out)) return fail(GS_ERR_INVALID_ARGUMENT, "bad argument");
+    *count = 0;
+    if (!vis_active(r)) return fail(GS_ERR_INVALID_ARGUMENT, "the visible-only sort mode is not active (gs_renderer_set_sort_mode / gs_renderer_reset_order)");
+    if (!r->viewValid) return fail(GS_ERR_INVALID_ARGUMENT, "gs_renderer_calc_view has not run");
+    GS_TRY(bind_device(r->ctx));
+    if (!r->visOrderValid) GS_TRY(enqueue_visible_sort(r));
+    uint32_t v = 0;
+    GS_TRY(download(r->ctx, &v, &vis_control(r)->count, 4));
+    *count = v;
+    const size_t take = v < capacity ? v : capacity;
+    if (take) GS_TRY(download(r->ctx, out, r->visIdx, take * 4));
+    return GS_OK;
+}
+int32_t gs_renderer_set_sort_mode(gs_renderer* r, int32_t mode) {
+    if (!r || (mode != GS_SORT_FULL && mode != GS_SORT_VISIBLE)) return fail(GS_ERR_INVALID_ARGUMENT, "sort mode must be GS_SORT_FULL or GS_SORT_VISIBLE");
+    if (mode == r->sortMode) return GS_OK;
+    GS_TRY(bind_device(r->ctx));
+    if (mode == GS_SORT_VISIBLE) {
+        GS_TRY(vis_alloc(r));
+        r->sortMode = mode;                                      // active while the order buffer is CSSetIndices' identity (+ sorts made in this mode)
+        r->visOrderValid = false;
+        return GS_OK;
+    }
+    // back to the reference's SortPoints: it continues from the order buffer the reference would hold now
+    if (vis_active(r) && r->visHistDepth > 0) { GS_TRY(materialise_full_order(r)); r->visBaseIdentity = false; }
+    r->sortMode = mode;
+    return GS_OK;
+}
+int32_t gs_renderer_sort_mode(const gs_renderer* r, int32_t* mode, int32_t* active) {
+    if (!r) return fail(GS_ERR_INVALID_ARGUMENT, "renderer is null");
+    if (mode) *mode = r->sortMode;
+    if (active) *active = vis_active(r) ? 1 : 0;
+    return GS_OK;
 }
 int32_t gs_renderer_download_distances(gs_renderer* r, uint32_t* out, size_t count) {
     if (!r || !out || count > r->n) return fail(GS_ERR_INVALID_ARGUMENT, "bad argument");
@@ -562,6 +657,7 @@ int32_t gs_renderer_upload_order(gs_renderer* r, const uint32_t* in, size_t coun
     GS_TRY(materialise_distances(r));      // before order[] stops being the sort's output
     GS_HIP(hipMemcpyAsync(r->order, in, count * 4, hipMemcpyHostToDevice, r->ctx->stream));
     GS_HIP(hipStreamSynchronize(r->ctx->stream));
+    r->visBaseIdentity = false; r->visOrderValid = false;        // a custom order: GS_SORT_VISIBLE waits for the next gs_renderer_reset_order
     return GS_OK;
 }
 int32_t gs_renderer_download_view(gs_renderer* r, void* out, size_t bytes) {
@@ -605,8 +701,22 @@ int32_t gs_renderer_frame_stats(gs_renderer* r, gs_frame_stats* out) {
         out->tile_pairs = r->hostReport->pairCount;
         out->visible_splats = r->hostReport->visible;
         out->sort_error = depthErr | r->hostReport->pairSortError | (r->hostReport->binError & 2u);
+        if (r->visDrawn) {
+            uint32_t visErr = 0;
+            GS_HIP(hipMemcpy(&visErr, &vis_control(r)->error, 4, hipMemcpyDeviceToHost));
+            out->sort_error |= visErr;
+            out->sort_mode = GS_SORT_VISIBLE;
+            // pairs no kept matrix separates are in index order -- which IS the reference's order while the history is complete; only once
+            // rows have been dropped can an older matrix have ordered them differently
+            out->tie_exhausted = r->visHistDropped ? r->hostReport->tieExhausted : 0u;
+        }
     } else out->sort_error = depthErr;
     if (out->sort_error) return fail(GS_ERR_SORT_TIMEOUT, "a bounded look-back spin expired");
+    if (vis_overflow_reported(r)) {
+        r->visDrawn = false;                                     // reported once
+        GS_TRY(vis_fall_back(r));
+        return fail(GS_ERR_TIE_OVERFLOW, "a run of more than 64 equal sort keys needed the sort history; the renderer now sorts all splats -- render the frame again");
+    }
     if (r->frameInFlight && out->tile_pairs > r->pairCapacity) {
         const unsigned long long want = out->tile_pairs + out->tile_pairs / 4;
         r->frameInFlight = false;                                    // reported once, whatever the growth below does
@@ -628,7 +738,7 @@ int32_t gs_renderer_frame_times(gs_renderer* r, float* out_ms, int32_t capacity,
     for (int sidx = 0; sidx < slots && *count < capacity; ++sidx) {
         const int base = sidx * kEvPerFrame;
         // first event of the frame: key generation if the frame sorted, else calc_view; last: after the blend
-        const int first = r->evValid[base + 0] ? 0 : 7;
+        const int first = (r->evValid[base + 0] && !r->visDrawn) ? 0 : 7;      // (a visible-sort frame starts with calc_view: its sort runs inside the draw)
         float ms = 0.f;
         if (r->evValid[base + first] && r->evValid[base + 6] && hipEventElapsedTime(&ms, r->ev[base + first], r->ev[base + 6]) == hipSuccess)
             out_ms[(*count)++] = ms;
@@ -675,7 +785,8 @@ int32_t gs_renderer_stage_times(gs_renderer* r, gs_stage_times* out) {
 
 // ---- target ----------------------------------------------------------------------------------------------
 int32_t gs_target_create(gs_context* ctx, uint32_t w, uint32_t h, gs_target** out) {
-    if (!ctx || !out || w == 0 || h == 0 || w > 65536 || h > 65536) return fail(GS_ERR_INVALID_ARGUMENT, "bad argument");
+    // (<= 65535: the per-splat pixel rectangle stores x1 + 1 and y1 + 1 in 16-bit fields, gsm::PackPixelRect)
+    if (!ctx || !out || w == 0 || h == 0 || w > 65535 || h > 65535) return fail(GS_ERR_INVALID_ARGUMENT, "bad argument");
     *out = nullptr;
     GS_TRY(bind_device(ctx));
     gs_target* t = new (std::nothrow) gs_target();
@@ -790,7 +901,7 @@ int32_t gs_sorter_create(gs_context* ctx, uint32_t max_count, gs_sorter** out) {
     gs_sorter* s = new (std::nothrow) gs_sorter();
     if (!s) return fail(GS_ERR_OUT_OF_MEMORY, "host allocation");
     s->ctx = ctx;
-    int32_t rc = sort_state_create(ctx, s->st, max_count);
+    int32_t rc = sort_state_create(ctx, s->st, max_count, true);     // (every pass shape available: small counts sort in 4,096-key partitions)
     if (rc == GS_OK && hipMalloc((void**)&s->control, sizeof(SortControl)) != hipSuccess) rc = fail(GS_ERR_OUT_OF_MEMORY, "alloc sort control");
     if (rc != GS_OK) { gs_sorter_destroy(s); return rc; }
     *out = s;

@@ -70,6 +70,7 @@ struct SortState {
     uint32_t maxGroups = 0;
     uint32_t maxCount = 0;
     uint32_t maxParts = 0;
+    uint32_t partMin = 8192;                // keys in the smallest partition a pass may use (gs_sort.hip: shape A, or shape C for a depth sort)
     uint32_t epoch = 0;                     // last epoch used on `status` / `groupIncl` (18 bits, never 0)
 };
 
@@ -85,7 +86,24 @@ struct SortControl {
 struct FrameReport {
     unsigned long long pairCount;
     uint32_t binError, pairSortError, visible, tileShape;   // tileShape: log2 tile width | log2 tile height << 8 of the draw that reported
+    uint32_t tieFlags, tieExhausted;                        // GS_SORT_VISIBLE draws: VisControl::tieFlags / tieExhausted of the draw's visible sort (else 0)
 };
+
+// ---- GS_SORT_VISIBLE (gs_vissort.hip): the depth sort of the VISIBLE splats only --------------------------------------------------
+constexpr int kVisHistory = 32;            // distinct sort matrices (row 2) kept, most recent first: the tie-break chain of the stable sort history
+constexpr uint32_t kVisMaxBlocks = 1024;   // workgroups of visible_keys_kernel (one status word each)
+constexpr uint32_t kVisTieWaveMax = 64;    // longest run of equal keys the in-kernel fix-up orders (one wave); longer: VIS_TIE_OVERFLOW -> full path
+constexpr uint32_t VIS_TIE_OVERFLOW = 1u;  // VisControl::tieFlags bit
+// small per-sort control block, two copies used alternately: each visible_keys launch zeroes the other one for the next sort
+struct VisControl {
+    uint32_t count;                // V: visible splats compacted this frame (the depth sort's device-side key count)
+    uint32_t tieFlags;             // VIS_TIE_OVERFLOW: a run of equal keys longer than kVisTieWaveMax was left in index order
+    uint32_t tieExhausted;         // pairs of tied splats with different positions that no kept matrix separates (ordered by index)
+    uint32_t error;                // bounded spin expired
+    uint32_t pad[28];
+    uint32_t status[kVisMaxBlocks];// visible count of block b, + 1 (0 = not published yet)
+};
+struct TieHistory { float row[kVisHistory][4]; uint32_t depth; };   // row[0] = the matrix the keys were made with; depth >= 1
 
 // The two words every workgroup hits with an atomic (ticket, visible) sit in their own 128-B lines: same-address
 // atomics serialise in one L2 channel (~11 ns each), so they must not also queue behind each other.
@@ -93,7 +111,8 @@ struct BinControl {
     unsigned long long pairCount; // P: total pairs this frame (may exceed capacity => overflow)
     uint32_t pairCountClamped;    // min(P, capacity), what the pair sort / ranges / blend see
     uint32_t error;
-    uint32_t pad0[28];
+    uint32_t tieFlags, tieExhausted;   // copied from the visible sort's VisControl by bin_emit (GS_SORT_VISIBLE draws), for the report
+    uint32_t pad0[26];
     uint32_t visible;
     uint32_t pad1[31];
     uint32_t tickets[16 * 32];    // kBinTicketClasses partition-ticket counters, one per 128-B line
@@ -146,7 +165,6 @@ struct gs_target {
     static constexpr int kResolveRing = 64;
     hipEvent_t* rev = nullptr;              // 2 x kResolveRing events, or null (profiling off)
     bool profiling = false;
-    bool kernelTiming = false;              // gs_renderer_set_kernel_timing: Onesweep launches carry their own start / stop events
     int revCount = 0;                       // resolves recorded since the last read (may exceed the ring: the oldest are overwritten)
 };
 
@@ -197,7 +215,7 @@ struct gs_renderer {
     uint32_t costTiles[2] = {0, 0};         // tile count of the draw that wrote each copy (0 = none): a schedule can be made from it for the same count only
     uint32_t costShape[2] = {0, 0};         // ... and the same tile shape (log2 w | log2 h << 8)
     uint32_t tileOverrideWL = 0, tileOverrideHL = 0;   // gs_renderer_set_tile_shape: log2 tile width / height, 0 = automatic
-    uint32_t lastTileWL = 4, lastTileHL = 4;           // of the last draw
+    uint32_t lastTileWL = 0, lastTileHL = 0;           // of the last draw (0 x 0: nothing drawn yet)
     bool adaptTall = false;                            // automatic shape: 32x32 instead of 32x16 (large splats; adapt_tile_shape)
     uint32_t* tileOrderBuf = nullptr;       // arenaTiles x u32: the blend's tile schedule of the draw in flight
     uint32_t binParts = 0;
@@ -220,6 +238,27 @@ struct gs_renderer {
     uint32_t lastTilesX = 0, lastTilesY = 0, lastPairPasses = 0;
     bool frameInFlight = false;
     float resolveMs = 0.f;
+    // a truncated draw, latched when the next draw notices it (maybe_grow_pairs) and handed out once by gs_renderer_poll_pairs: the
+    // report itself is overwritten and the capacity grown before a pipelined host gets to poll
+    unsigned long long truncPairs = 0, truncCapacity = 0;
+    // ---- GS_SORT_VISIBLE (gs_renderer_set_sort_mode; gs_vissort.hip) ----
+    int sortMode = 0;                       // gs_sort_mode
+    bool visBaseIdentity = true;            // order[] is (logically) CSSetIndices' identity: the reference's order = identity stably sorted by visHist, oldest first
+    bool visFallback = false;               // a tie run the fix-up cannot order was seen: full sorts until gs_renderer_reset_order
+    bool visOrderValid = false;             // visIdx holds the sorted visible order of the last calc_view under visHist[0]
+    bool visDrawn = false;                  // the draw in flight was binned from visIdx (its report carries tie flags)
+    float visHist[gs::kVisHistory][4];      // distinct sort-matrix rows (m[8..11]), most recent first
+    int visHistDepth = 0;
+    uint32_t visHistDropped = 0;            // rows that fell off the end of visHist since the last reset (the chain is then truncated)
+    uint32_t* visKeys = nullptr;            // N x u32 each, allocated on first use: compacted (key, splat index) of the visible splats, sorted in place
+    uint32_t* visIdx = nullptr;
+    uint32_t* visRectX = nullptr;           // N x u32 each: the pixel rectangle (rects[visIdx[i]].x / .y) by SORTED position (vis_offsets_kernel's gather)
+    uint32_t* visRectY = nullptr;
+    uint32_t* visPairOffset = nullptr;      // N x u32: first (tile, splat) pair slot of every sorted position (vis_offsets_kernel)
+    uint32_t* visChunkStart = nullptr;      // per chunk of 1024 pair slots: the sorted position its first slot belongs to; sized by the pair capacity
+    uint32_t visChunkCap = 0;
+    gs::VisControl* visControl = nullptr;   // two blocks, used alternately
+    int visControlIdx = 0;
 };
 
 namespace gs {
@@ -228,13 +267,13 @@ int32_t join_sort(gs_renderer* r);          // make ctx->stream wait for a sort 
 int32_t mark_order_use(gs_renderer* r);     // the main queue has just been given work that reads / writes order[]: the next sort waits for it
 void prof_end_frame(gs_renderer* r);
 // sort entry points (gs_sort.hip)
-int32_t sort_state_create(gs_context* ctx, SortState& st, uint32_t maxCount);
+int32_t sort_state_create(gs_context* ctx, SortState& st, uint32_t maxCount, bool smallPartitions = false);
 void sort_state_destroy(SortState& st);
 // keys of all splats in index order (CSCalcDistances' arithmetic) + the four digit histograms; the gather through the
 // previous order is done by the first sort pass (enqueue_sort_passes with gatherKeys)
 int32_t enqueue_sort_keys(gs_context* ctx, hipStream_t st, const gsm::AssetView& a, const float* matSort, uint32_t* keyBySplat,
                           SortControl* control, SortControl* nextControl, uint32_t n, SortState& sort);
-uint32_t sort_group_words(uint32_t nUpper, int passes);   // 8-byte words of SortState::groupAgg a sort of nUpper keys uses (to be zeroed before the passes)
+uint32_t sort_group_words(const SortState& st, uint32_t nUpper, int passes);   // 8-byte words of SortState::groupAgg a sort of nUpper keys uses (to be zeroed before the passes)
 int32_t enqueue_histogram(gs_context* ctx, hipStream_t st, const uint32_t* keys, uint32_t n, const uint32_t* nPtr, int passes, uint32_t lastMask,
                           SortControl* control, SortState& sort);
 // `passes` Onesweep passes.  The raw digit histograms must already be in control->hist and sort.groupAgg zeroed.  Result ends in (keys, vals) when
@@ -249,6 +288,14 @@ int32_t enqueue_sort_passes(gs_context* ctx, hipStream_t stream, SortState& st, 
 int32_t enqueue_gather_keys(gs_context* ctx, const uint32_t* keyBySplat, const uint32_t* order, uint32_t* out, uint32_t n);
 constexpr uint32_t kSortMaxCount = 1u << 30;   // 32-bit byte offsets inside the sort kernels
 int32_t enqueue_set_indices(gs_context* ctx, uint32_t* order, uint32_t n);
+// visible-only depth sort (gs_vissort.hip)
+inline bool vis_active(const gs_renderer* r) { return r->sortMode == GS_SORT_VISIBLE && r->visBaseIdentity && !r->visFallback; }
+int32_t vis_alloc(gs_renderer* r);                                   // visKeys / visIdx / visControl, on first use
+void vis_free(gs_renderer* r);
+void vis_push_matrix(gs_renderer* r, const float* matrixSort);       // gs_renderer_sort in visible mode: history bookkeeping only
+// visMask (calc_view's or box_setup's visibility bits) -> r->visIdx = the visible items in the reference's depth order, count in visControl
+int32_t enqueue_visible_sort(gs_renderer* r);
+inline const VisControl* vis_control(const gs_renderer* r) { return r->visControl + r->visControlIdx; }
 // view (gs_view.hip)
 int32_t enqueue_calc_view(gs_context* ctx, const gsm::AssetView& a, const gs_frame_params* p, const gsm::EditView& e, const ViewOutputs& out, bool full);
 ViewOutputs view_outputs(gs_renderer* r);

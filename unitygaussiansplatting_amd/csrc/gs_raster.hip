@@ -21,6 +21,7 @@
 // Semantics (DESIGN.md "compositor semantics") are those of the reference rasteriser: oriented quad |q|<=2,
 // alpha = saturate(exp(-|q|^2) * a), discard < 1/255, dst = src*(1-dst.a) + dst, fp16 rounding per blend.
 #include "gs_common.h"
+#include <cstdlib>
 
 namespace gs {
 
@@ -106,6 +107,7 @@ __device__ __forceinline__ void write_report(const BinControl* binCtl, const uin
     report->pairCount = binCtl->pairCount; report->binError = binCtl->error; report->visible = binCtl->visible;
     report->pairSortError = *pairSortError;
     report->tileShape = tileShape;                  // log2 tile width | log2 tile height << 8: what pairCount counts
+    report->tieFlags = binCtl->tieFlags; report->tieExhausted = binCtl->tieExhausted;      // (GS_SORT_VISIBLE draws; else 0)
 }
 
 // Scheduling order of the blend's workgroups: tiles by descending expected cost (the hardware hands out workgroups in
@@ -474,6 +476,289 @@ __global__ __launch_bounds__(kBinThreads) void bin_emit_kernel(const uint2* __re
 }
 
 
+// ---- GS_SORT_VISIBLE draws: the binning of V depth-sorted, all-visible positions as two streaming kernels -----------------------------
+// bin_emit (above) gives every wave its own 256 positions and lets it emit their pairs alone.  Over the FULL order that balances itself:
+// near the camera, where the splats are large on screen, most splats are culled, so a partition holds few of them.  The visible order has no
+// such dilution -- its first partitions are 1024 of the largest splats each, emitted by four waves while a thousand workgroups wait (measured,
+// C3: 308 us against 106 us for the full order; C2d 260 against 99).  Here the pair array itself is what is partitioned:
+//   vis_offsets_kernel   the rectangle gather, then the first output slot of every position (exclusive scan of the tile counts, one fat workgroup
+//                        per CU over a contiguous range of positions: count, publish, sum the <= 255 totals before, add) and, for every chunk of
+//                        kEmitChunk output slots, the position its first slot belongs to (the position that straddles the boundary writes it: no
+//                        search anywhere);
+//   vis_emit_kernel      one chunk of kEmitChunk output slots per workgroup and step, whatever the footprints are: load the positions that
+//                        own them (coalesced: offset, index, rectangle by sorted position -- vis_offsets_kernel made the gather and left the
+//                        rectangles there), find every slot's owner with marks + a max-scan, write four consecutive pairs per thread.
+// No chunk waits for another one.  Side duties of bin_emit (pair-sort histograms, zeroing the next draw's arena and the pair sort's
+// aggregates, visible count, the draw's pair count, the tile schedule) are split between the two.
+constexpr int kVoThreads = 1024;
+constexpr uint32_t kEmitChunk = 1024;
+constexpr int kEmitThreads = 256;
+constexpr int kEmitBatches = 5;                                  // x 256 positions >= kEmitChunk + 1 owners of one chunk
+
+__device__ __forceinline__ uint32_t rect_tiles(uint32_t rx, uint32_t ry, uint32_t shx, uint32_t shy, uint32_t& tx, uint32_t& twh) {
+    // pixel rectangle {x0 | y0 << 16, (x1 + 1) | (y1 + 1) << 16} (0 = not drawn) -> tile rectangle {tx0 | ty0 << 16, wide | high << 16}; returns wide * high
+    if (ry == 0u) { tx = 0u; twh = 0u; return 0u; }
+    const uint32_t tx0 = (rx & 0xffffu) >> shx, ty0 = (rx >> 16) >> shy;
+    const uint32_t tx1 = ((ry & 0xffffu) - 1u) >> shx, ty1 = ((ry >> 16) - 1u) >> shy;
+    tx = tx0 | (ty0 << 16); twh = (tx1 - tx0 + 1u) | ((ty1 - ty0 + 1u) << 16);
+    return (tx1 - tx0 + 1u) * (ty1 - ty0 + 1u);
+}
+
+__device__ __forceinline__ unsigned long long wave_incl_scan_u64(unsigned long long v, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const unsigned long long u = __shfl_up(v, o, 64); if (lane >= o) v += u; }
+    return v;
+}
+__device__ __forceinline__ uint32_t sat32(unsigned long long v) { return v < 0xffffffffull ? (uint32_t)v : 0xffffffffu; }
+
+// One fat workgroup per CU over a contiguous range of sorted positions, four CONSECUTIVE positions per thread and step (16-byte loads and
+// stores).  Pass 1: the rectangle gather -- rects[order[i]], the one random access of the binning: 2.2 M sectors at C2, four in flight per
+// thread -- left by sorted position (rectX / rectY) for the emission, tile counts, block-local exclusive offsets.  Then the block's total is
+// published and the totals of the blocks before it summed (block b only waits on blocks the dispatcher started before it).  Pass 2 adds the
+// base and lets every position that straddles a multiple of kEmitChunk claim that chunk.
+__global__ __launch_bounds__(kVoThreads) void vis_offsets_kernel(const uint2* __restrict__ rects, const uint32_t* __restrict__ order, const VisControl* __restrict__ vis,
+                                                                 uint32_t nImm, uint32_t tileShift, uint32_t capacity, BinControl* ctl, unsigned long long* status,
+                                                                 uint32_t* pairOffset, uint32_t* __restrict__ chunkStart, uint32_t capChunks,
+                                                                 uint32_t* __restrict__ rectX, uint32_t* __restrict__ rectY,
+                                                                 unsigned long long* __restrict__ groupAgg, uint32_t groupAggWords, uint32_t* __restrict__ nextArena, uint32_t nextArenaWords) {
+    constexpr int NW = kVoThreads / 64;
+    constexpr uint32_t STEP = kVoThreads * 4u;
+    __shared__ unsigned long long s_w64[NW];
+    __shared__ uint32_t s_w32[NW];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    for (uint32_t j = blockIdx.x * (uint32_t)kVoThreads + tid; j < groupAggWords; j += gridDim.x * (uint32_t)kVoThreads) groupAgg[j] = 0ull;      // for the pair sort's look-back
+    for (uint32_t j = blockIdx.x * (uint32_t)kVoThreads + tid; j < nextArenaWords; j += gridDim.x * (uint32_t)kVoThreads) nextArena[j] = 0u;       // the NEXT draw's zeroed arena
+    const uint32_t V = min(vis->count, nImm);
+    const uint32_t shx = tileShift & 0xffu, shy = tileShift >> 8;
+    const uint32_t R = ((V + gridDim.x - 1u) / gridDim.x + 3u) & ~3u;      // positions per block, a multiple of 4 (V <= 2^30)
+    const uint32_t b0 = min(blockIdx.x * R, V), b1 = min(b0 + R, V);
+    if (blockIdx.x == 0u && tid == 0) { ctl->tieFlags = vis->tieFlags; ctl->tieExhausted = vis->tieExhausted; }      // what the visible sort's fix-up reported, for the draw's report
+    // ---- pass 1
+    unsigned long long running = 0ull;                           // block-local first slot of the next step (uniform)
+    uint32_t drawn = 0u;
+    for (uint32_t t0 = b0; t0 < b1; t0 += STEP) {
+        const uint32_t i0 = t0 + (uint32_t)tid * 4u;
+        const bool all4 = i0 + 3u < b1;
+        uint32_t o[4];
+        if (all4) { const uint4 ov = *(const uint4*)(order + i0); o[0] = ov.x; o[1] = ov.y; o[2] = ov.z; o[3] = ov.w; }
+        else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] = order[min(i0 + (uint32_t)k, V - 1u)];              // (V >= 1: the loop runs)
+        }
+        uint2 rc[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) rc[k] = rects[o[k]];
+        uint32_t c[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { uint32_t a, b; c[k] = (i0 + (uint32_t)k < b1) ? rect_tiles(rc[k].x, rc[k].y, shx, shy, a, b) : 0u; drawn += c[k] ? 1u : 0u; }
+        const unsigned long long mine = (unsigned long long)c[0] + c[1] + c[2] + c[3];
+        const unsigned long long incl = wave_incl_scan_u64(mine, lane);
+        __syncthreads();                                         // the previous step's s_w64 is no longer read
+        if (lane == 63) s_w64[w] = incl;
+        __syncthreads();
+        unsigned long long wbase = 0ull, stepTotal = 0ull;
+#pragma unroll
+        for (int k = 0; k < NW; ++k) { const unsigned long long t = s_w64[k]; wbase += (k < w) ? t : 0ull; stepTotal += t; }
+        unsigned long long l = running + wbase + incl - mine;
+        uint32_t lo[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { lo[k] = sat32(l); l += c[k]; }
+        if (all4) {
+            *(uint4*)(rectX + i0) = make_uint4(rc[0].x, rc[1].x, rc[2].x, rc[3].x);
+            *(uint4*)(rectY + i0) = make_uint4(rc[0].y, rc[1].y, rc[2].y, rc[3].y);
+            *(uint4*)(pairOffset + i0) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) if (i0 + (uint32_t)k < b1) { rectX[i0 + k] = rc[k].x; rectY[i0 + k] = rc[k].y; pairOffset[i0 + k] = lo[k]; }
+        }
+        running += stepTotal;
+    }
+    const unsigned long long total = running;
+#pragma unroll
+    for (int o2 = 32; o2 > 0; o2 >>= 1) drawn += __shfl_xor(drawn, o2, 64);
+    __syncthreads();
+    if (lane == 0) s_w32[w] = drawn;
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t d = 0u;
+        for (int k = 0; k < NW; ++k) d += s_w32[k];
+        __hip_atomic_store(status + blockIdx.x, total + 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (d) atomicAdd(&ctl->visible, d);
+    }
+    // ---- the totals of the blocks before this one
+    unsigned long long before = 0ull;
+    for (uint32_t j = (uint32_t)tid; j < blockIdx.x; j += kVoThreads) {
+        unsigned long long v = 0ull; uint32_t spins = 0;
+        for (;;) {
+            v = __hip_atomic_load(status + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (v) break;
+            if (++spins > BIN_SPIN_LIMIT) { atomicOr(&ctl->error, 2u); v = 1ull; break; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        before += v - 1ull;
+    }
+#pragma unroll
+    for (int o2 = 32; o2 > 0; o2 >>= 1) before += __shfl_xor(before, o2, 64);
+    __syncthreads();
+    if (lane == 0) s_w64[w] = before;
+    __syncthreads();                                             // (also: pass 1's pairOffset stores are visible to the whole block)
+    unsigned long long base = 0ull;
+    for (int k = 0; k < NW; ++k) base += s_w64[k];
+    if (blockIdx.x == gridDim.x - 1u && tid == 0) {
+        const unsigned long long P = base + total;
+        ctl->pairCount = P;
+        ctl->pairCountClamped = (uint32_t)(P < (unsigned long long)capacity ? P : (unsigned long long)capacity);
+        if (P > (unsigned long long)capacity) atomicOr(&ctl->error, 1u);
+    }
+    // ---- pass 2: global offsets; the position whose slots straddle a multiple of kEmitChunk is that chunk's first owner
+    for (uint32_t t0 = b0; t0 < b1; t0 += STEP) {
+        const uint32_t i0 = t0 + (uint32_t)tid * 4u;
+        uint32_t l[5];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) l[k] = (i0 + (uint32_t)k < b1) ? pairOffset[i0 + k] : sat32(total);      // (l[4]: the next thread's first: read before anyone writes)
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (i0 + (uint32_t)k >= b1) continue;
+            const unsigned long long off = l[k] == 0xffffffffu ? 0xffffffffull : base + l[k];
+            pairOffset[i0 + k] = sat32(off);                     // (slots beyond the capacity, <= 2^30, are never emitted)
+            const uint32_t c = l[k + 1] - l[k];
+            if (c && off < 0xffffffffull) {
+                const unsigned long long c0 = (off + kEmitChunk - 1ull) / kEmitChunk, c1 = (off + c - 1ull) / kEmitChunk;
+                for (unsigned long long cc = c0; cc <= c1 && cc < (unsigned long long)capChunks; ++cc) chunkStart[cc] = i0 + (uint32_t)k;
+            }
+        }
+    }
+}
+
+template <int PASSES, bool TILECNT>
+__global__ __launch_bounds__(kEmitThreads) void vis_emit_kernel(const uint32_t* __restrict__ order, const uint32_t* __restrict__ rectX, const uint32_t* __restrict__ rectY,
+                                                                const uint32_t* __restrict__ pairOffset, const uint32_t* __restrict__ chunkStart,
+                                                                const VisControl* __restrict__ vis, uint32_t nImm, const BinControl* __restrict__ ctl,
+                                                                uint32_t tilesX, uint32_t tileShift, uint32_t* __restrict__ pairKeys, uint32_t* __restrict__ pairVals,
+                                                                uint32_t* pairHist, uint32_t digitBits,
+                                                                const uint32_t* __restrict__ schedCost, uint32_t schedTiles, uint32_t* __restrict__ schedOut) {
+    constexpr int NPOS = kEmitBatches * kEmitThreads;
+    __shared__ uint32_t s_hist[3 * 256];
+    __shared__ uint32_t s_tile[TILECNT ? kBinTileCounters : 1];
+    __shared__ uint32_t s_off[NPOS], s_sid[NPOS], s_tx[NPOS], s_twh[NPOS];
+    __shared__ uint32_t s_mark[kEmitChunk];
+    __shared__ uint32_t s_wmax[kEmitThreads / 64];
+    __shared__ uint32_t s_npos;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const uint32_t binBlocks = gridDim.x - (schedOut ? 1u : 0u);
+    if (schedOut && blockIdx.x == 0u) {       // the blend's tile schedule of THIS draw, from the costs the previous draw left (as in bin_emit)
+        tile_order_body(nullptr, nullptr, schedCost, schedTiles, tilesX, schedOut, s_hist, s_hist + 256, s_hist + 512, (uint32_t)kEmitThreads);
+        return;
+    }
+    const uint32_t bid = blockIdx.x - (schedOut ? 1u : 0u);
+    for (int j = tid; j < 3 * 256; j += kEmitThreads) s_hist[j] = 0;
+    if (TILECNT) for (uint32_t j = tid; j < kBinTileCounters; j += kEmitThreads) s_tile[j] = 0;
+    const uint32_t V = min(vis->count, nImm);
+    const uint32_t Pc = ctl->pairCountClamped;
+    const uint32_t shx = tileShift & 0xffu, shy = tileShift >> 8;
+    const uint32_t digitMask = (1u << digitBits) - 1u;
+    uint32_t p0 = bid * kEmitChunk < Pc ? chunkStart[bid] : 0u;
+    for (uint32_t s0 = bid * kEmitChunk; s0 < Pc; s0 += binBlocks * kEmitChunk) {
+        const uint32_t s1 = min(s0 + kEmitChunk, Pc);
+        const uint32_t sNext = s0 + binBlocks * kEmitChunk;
+        const uint32_t p0Next = sNext < Pc ? chunkStart[sNext / kEmitChunk] : 0u;      // (in flight while this chunk is emitted)
+        __syncthreads();                                         // the previous chunk's LDS is no longer read
+        if (tid == 0) s_npos = 0;
+#pragma unroll
+        for (int k = 0; k < (int)(kEmitChunk / kEmitThreads); ++k) s_mark[k * kEmitThreads + tid] = 0u;
+        __syncthreads();
+        // ---- the positions that own slots of [s0, s1): p0, p0 + 1, ... while their first slot is below s1 (offsets ascend).  Two batches of
+        //      256 positions are requested at once (a chunk of 1024 slots rarely has more owners); the others only if those were all taken.
+        auto place = [&](int k, uint32_t off, uint32_t sid, uint32_t rx, uint32_t ry) {
+            const uint32_t j = (uint32_t)k * kEmitThreads + (uint32_t)tid;
+            const bool take = p0 + j < V && off < s1;
+            if (take) {
+                uint32_t tx, twh;
+                const uint32_t c = rect_tiles(rx, ry, shx, shy, tx, twh);
+                s_off[j] = off; s_sid[j] = sid; s_tx[j] = tx; s_twh[j] = twh;
+                // the position's first slot inside the chunk gets its index (+1); one that began in an earlier chunk owns slot 0 onwards
+                if (c) s_mark[off > s0 ? off - s0 : 0u] = j + 1u;
+            }
+            const unsigned long long tk = __ballot(take);
+            if (lane == 0 && tk) atomicAdd(&s_npos, (uint32_t)__popcll(tk));
+        };
+        {
+            const uint32_t qa = min(p0 + (uint32_t)tid, V - 1u), qb = min(p0 + kEmitThreads + (uint32_t)tid, V - 1u);      // (V >= 1 here: there are pairs)
+            const uint32_t offA = pairOffset[qa], sidA = order[qa], rxA = rectX[qa], ryA = rectY[qa];                           // unconditional loads
+            const uint32_t offB = pairOffset[qb], sidB = order[qb], rxB = rectX[qb], ryB = rectY[qb];
+            place(0, offA, sidA, rxA, ryA);
+            place(1, offB, sidB, rxB, ryB);
+        }
+        __syncthreads();
+        for (int k = 2; k < kEmitBatches && s_npos >= (uint32_t)k * kEmitThreads; ++k) {      // (uniform)
+            const uint32_t q = min(p0 + (uint32_t)k * kEmitThreads + (uint32_t)tid, V - 1u);
+            place(k, pairOffset[q], order[q], rectX[q], rectY[q]);
+            __syncthreads();
+        }
+        p0 = p0Next;
+        // ---- owner of every slot: inclusive max-scan of the marks (positions ascend with the slots); four consecutive slots per thread
+        constexpr int SPT = kEmitChunk / kEmitThreads;
+        uint32_t m[SPT];
+#pragma unroll
+        for (int k = 0; k < SPT; ++k) m[k] = s_mark[tid * SPT + k];
+#pragma unroll
+        for (int k = 1; k < SPT; ++k) m[k] = max(m[k], m[k - 1]);
+        const uint32_t wincl = wave_incl_max_scan_dpp(m[SPT - 1]);
+        if (lane == 63) s_wmax[w] = wincl;
+        uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)wincl, 0x138, 0xf, 0xf, false);      // wave_shr:1: the lanes below (lane 0 gets 0)
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < kEmitThreads / 64; ++k) prev = max(prev, (k < w) ? s_wmax[k] : 0u);
+        uint32_t tiles[SPT], sids[SPT];
+        bool live[SPT];
+#pragma unroll
+        for (int k = 0; k < SPT; ++k) {
+            const uint32_t slot = s0 + (uint32_t)(tid * SPT + k);
+            const uint32_t e = max(max(m[k], prev), 1u) - 1u;
+            const uint32_t o = slot - s_off[e];
+            const uint32_t twh = s_twh[e], tx0 = s_tx[e];
+            uint32_t ty, tx;
+            slot_to_xy(o, max(twh & 0xffffu, 1u), ty, tx);
+            tiles[k] = __umul24((tx0 >> 16) + ty, tilesX) + (tx0 & 0xffffu) + tx;
+            sids[k] = s_sid[e];
+            live[k] = slot < s1;
+        }
+        if (live[SPT - 1]) {                                     // all four: one 16-byte store per array
+            static_assert(SPT == 4, "four slots per thread");
+            *(uint4*)(pairKeys + s0 + tid * SPT) = make_uint4(tiles[0], tiles[1], tiles[2], tiles[3]);
+            *(uint4*)(pairVals + s0 + tid * SPT) = make_uint4(sids[0], sids[1], sids[2], sids[3]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < SPT; ++k) if (live[k]) { pairKeys[s0 + tid * SPT + k] = tiles[k]; pairVals[s0 + tid * SPT + k] = sids[k]; }
+        }
+#pragma unroll
+        for (int k = 0; k < SPT; ++k) {
+            if (live[k]) {
+                if (TILECNT) atomicAdd(&s_tile[tiles[k]], 1u);
+                else atomicAdd(&s_hist[tiles[k] & digitMask], 1u);
+            }
+            if (!TILECNT && PASSES >= 2) hist_add_aggregated(s_hist + 256, (tiles[k] >> digitBits) & digitMask, live[k]);
+            if (!TILECNT && PASSES >= 3) hist_add_aggregated(s_hist + 512, (tiles[k] >> (2u * digitBits)) & digitMask, live[k]);
+        }
+    }
+    // ---- flush the pair-sort digit histograms
+    __syncthreads();
+    if (TILECNT) {
+        for (uint32_t t = tid; t < kBinTileCounters; t += kEmitThreads) {
+            const uint32_t c = s_tile[t];
+            if (c) {
+                atomicAdd(&s_hist[t & digitMask], c);
+                if (PASSES >= 2) atomicAdd(&s_hist[256 + ((t >> digitBits) & digitMask)], c);
+            }
+        }
+        __syncthreads();
+    }
+    for (int j = tid; j < PASSES * 256; j += kEmitThreads) {
+        const uint32_t c = s_hist[j];
+        if (c) atomicAdd(&pairHist[j], c);
+    }
+}
 
 // tile -> [start, end) in the tile-sorted pair array (both zero in the fresh arena: a tile nothing lands on stays empty).
 // Eight keys per thread from two 16-byte loads (the key buffers are 16-byte aligned and padded by 16 entries), plus the one
@@ -972,7 +1257,7 @@ int32_t ensure_arena(gs_renderer* r, uint32_t numTiles) {
     size_t off = 0;
     off = align_up(sizeof(BinControl), 256);
     r->offPairControl = off; off += align_up(sizeof(SortControl), 256);
-    r->offBinStatus = off;   off += align_up((size_t)r->binParts * 8, 256);
+    r->offBinStatus = off;   off += align_up((size_t)max(r->binParts, 256u) * 8, 256);      // (>= one word per workgroup of vis_offsets_kernel: one per CU)
     r->offBinGroupAgg = off; off += align_up((size_t)((r->binParts + 63) / 64) * 8, 256);
     r->offBinGroupBase = off; off += align_up((size_t)((r->binParts + 63) / 64) * 8, 256);
     r->offTileStart = off;   off += align_up((size_t)numTiles * 4, 256);
@@ -1048,7 +1333,7 @@ struct DrawSetup { RasterConsts rc; uint32_t numTiles; uint32_t *tileStart, *til
 // The part of a draw that does not depend on what a "fragment" is: (tile, item) pairs of the visible items in `order`
 // (bin_emit), the stable pair sort by tile, tile ranges, tile schedule + the draw's report.
 int32_t bin_and_sort(gs_renderer* r, const gs_frame_params* p, gs_target* rt, const uint32_t* order, uint32_t count, DrawSetup& o, bool forceOrderKernel,
-                     uint32_t tileWL, uint32_t tileHL) {
+                     uint32_t tileWL, uint32_t tileHL, const VisControl* vis = nullptr) {
     gs_context* ctx = r->ctx;
     hipStream_t st = ctx->stream;
     RasterConsts& rc = o.rc;
@@ -1095,8 +1380,27 @@ int32_t bin_and_sort(gs_renderer* r, const gs_frame_params* p, gs_target* rt, co
     const uint32_t binCap = max((uint32_t)ctx->cuCount * kBinBlocksPerCu / kBinTicketClasses * kBinTicketClasses, kBinTicketClasses);
     const uint32_t binGrid = min(div_up(div_up(count, kBinPart), kBinTicketClasses) * kBinTicketClasses, binCap);
     const bool schedInBin = haveCosts && !forceOrderKernel;     // one extra workgroup makes the blend's tile schedule meanwhile
+    if (vis) {
+        // GS_SORT_VISIBLE: offsets + output-partitioned emission (see vis_offsets_kernel)
+        const uint32_t capChunks = div_up(cap, kEmitChunk) + 1u;
+        if (r->visChunkCap < capChunks) {
+            if (r->visChunkStart) { GS_HIP(hipStreamSynchronize(st)); (void)hipFree(r->visChunkStart); r->visChunkStart = nullptr; r->visChunkCap = 0; }
+            GS_HIP(hipMalloc((void**)&r->visChunkStart, (size_t)capChunks * 4));
+            r->visChunkCap = capChunks;
+        }
+        const uint32_t voGrid = max(1u, min(min((uint32_t)ctx->cuCount, 256u), div_up(count, (uint32_t)kVoThreads)));
+        hipLaunchKernelGGL(vis_offsets_kernel, dim3(voGrid), dim3(kVoThreads), 0, st, (const uint2*)r->rects, order, vis, count, shapeKey, cap, binCtl, binStatus,
+                           r->visPairOffset, r->visChunkStart, capChunks, r->visRectX, r->visRectY,
+                           r->pairSort.groupAgg, sort_group_words(r->pairSort, cap, passes), (uint32_t*)nextArena, (uint32_t)(r->frameArenaBytes / 4));
+        const uint32_t emitGrid = (uint32_t)ctx->cuCount * (tileCnt ? 4u : 5u);      // resident at once (36 / 28 KB of LDS)
+        auto emitKernel = passes == 1 ? (tileCnt ? vis_emit_kernel<1, true> : vis_emit_kernel<1, false>)
+                        : (passes == 2 ? (tileCnt ? vis_emit_kernel<2, true> : vis_emit_kernel<2, false>) : vis_emit_kernel<3, false>);
+        hipLaunchKernelGGL(emitKernel, dim3(emitGrid + (schedInBin ? 1u : 0u)), dim3(kEmitThreads), 0, st, order, (const uint32_t*)r->visRectX, (const uint32_t*)r->visRectY,
+                           (const uint32_t*)r->visPairOffset, (const uint32_t*)r->visChunkStart, vis, count, (const BinControl*)binCtl, rc.tilesX, shapeKey, r->pairKeys, r->pairVals,
+                           pairCtl->hist, (uint32_t)bits, o.costRead, numTiles, schedInBin ? o.tileOrder : (uint32_t*)nullptr);
+    } else
     hipLaunchKernelGGL(binKernel, dim3(binGrid + (schedInBin ? 1u : 0u)), dim3(binThreads), 0, st, r->rects, wave_flags_of(r->visMask, r->n), order, count, rc.tilesX, shapeKey, r->pairKeys,
-                       r->pairVals, cap, binCtl, binStatus, binGroupAgg, binGroupBase, pairCtl->hist, r->pairSort.groupAgg, sort_group_words(cap, passes), (uint32_t*)nextArena, (uint32_t)(r->frameArenaBytes / 4), (uint32_t)bits,
+                       r->pairVals, cap, binCtl, binStatus, binGroupAgg, binGroupBase, pairCtl->hist, r->pairSort.groupAgg, sort_group_words(r->pairSort, cap, passes), (uint32_t*)nextArena, (uint32_t)(r->frameArenaBytes / 4), (uint32_t)bits,
                        o.costRead, numTiles, schedInBin ? o.tileOrder : (uint32_t*)nullptr);
     GS_TRY(mark_order_use(r));                                  // the next frame's depth sort may overwrite order[] from here on
     prof_record(r, 4);
@@ -1162,6 +1466,21 @@ static void adapt_tile_shape(gs_renderer* r) {
     else if (shape == (5u | (5u << 8)) && ratio < 3.5) r->adaptTall = false;
 }
 
+// A draw with a SMALLER tile than the last one (the adaptive 32x32 -> 32x16 flip, or gs_renderer_set_tile_shape) lists the same splats
+// on up to area-ratio times as many tiles, while the pair buffers are only kept at 1.25 x what the last draw needed: grow them first, so
+// that the knob stays what the header says it is -- performance only, the frame bit-identical -- instead of truncating the first frame.
+static int32_t reserve_for_smaller_tile(gs_renderer* r, uint32_t twl, uint32_t thl) {
+    if (!r->frameInFlight || !r->hostReport || !r->lastTileWL) return GS_OK;
+    const uint32_t lastArea = r->lastTileWL + r->lastTileHL, area = twl + thl;      // log2 areas
+    if (area >= lastArea) return GS_OK;
+    const unsigned long long seen = *(volatile unsigned long long*)&r->hostReport->pairCount;
+    unsigned long long want = (seen << (lastArea - area));
+    want += want / 4u;
+    if (want > kSortMaxCount) want = kSortMaxCount;
+    if (want > r->pairCapacity) return gs_renderer_reserve_pairs(r, want);
+    return GS_OK;
+}
+
 int32_t enqueue_draw(gs_renderer* r, const gs_frame_params* p, gs_target* rt) {
     hipStream_t st = r->ctx->stream;
     // the per-splat footprints were computed by calc_view: it must have run with the same screen size and clip planes
@@ -1172,7 +1491,18 @@ int32_t enqueue_draw(gs_renderer* r, const gs_frame_params* p, gs_target* rt) {
     uint32_t twl, thl;
     adapt_tile_shape(r);
     pick_tile_shape(r, rt->width, rt->height, twl, thl);
-    GS_TRY(bin_and_sort(r, p, rt, r->order, r->n, ds, false, twl, thl));
+    GS_TRY(reserve_for_smaller_tile(r, twl, thl));
+    if (vis_active(r)) {
+        // GS_SORT_VISIBLE: the depth sort runs HERE, over the splats calc_view found visible (gs_vissort.hip), with the matrix of the last
+        // gs_renderer_sort -- also on a frame that did not call it (m_SortNthFrame > 1: the reference's stale order, restricted to this
+        // frame's visible set, is this frame's visible set sorted by the stale matrix)
+        if (!r->visOrderValid) GS_TRY(enqueue_visible_sort(r));
+        GS_TRY(bin_and_sort(r, p, rt, r->visIdx, r->n, ds, false, twl, thl, vis_control(r)));
+        r->visDrawn = true;
+    } else {
+        GS_TRY(bin_and_sort(r, p, rt, r->order, r->n, ds, false, twl, thl));
+        r->visDrawn = false;
+    }
     const RasterConsts& rc = ds.rc;
     const uint32_t numTiles = ds.numTiles;
     uint32_t *tileStart = ds.tileStart, *tileEnd = ds.tileEnd, *tileOrder = ds.tileOrder;
@@ -1221,7 +1551,16 @@ int32_t enqueue_debug_boxes(gs_renderer* r, const gs_frame_params* p, gs_target*
     prof_record(r, 8);
     r->viewValid = false;                                        // rects / visibility bits now describe the boxes: a splat draw needs calc_view again
     DrawSetup ds;
-    GS_TRY(bin_and_sort(r, p, rt, chunks ? r->chunkOrder : r->order, count, ds, true, 4u, 4u));   // the box blend writes no report: tile_order_kernel does; 16x16 tiles
+    if (!chunks && vis_active(r)) {
+        // GS_SORT_VISIBLE: the boxes are drawn through the order buffer too -- the same visible-only sort, over the boxes' visibility bits
+        GS_TRY(enqueue_visible_sort(r));
+        r->visOrderValid = false;                                // (of the boxes, not of a calc_view)
+        GS_TRY(bin_and_sort(r, p, rt, r->visIdx, count, ds, true, 4u, 4u, vis_control(r)));
+        r->visDrawn = true;
+    } else {
+        GS_TRY(bin_and_sort(r, p, rt, chunks ? r->chunkOrder : r->order, count, ds, true, 4u, 4u));   // the box blend writes no report: tile_order_kernel does; 16x16 tiles
+        r->visDrawn = false;
+    }
 #define GS_LAUNCH_BOX(M, D) hipLaunchKernelGGL((blend_box_kernel<M, D>), dim3(ds.numTiles), dim3(256), 0, st, r->pairVals, ds.tileStart, ds.tileEnd, ds.tileOrder, \
                                            ds.costWrite, r->boxRecs, rt->rgba16f, ds.rc, ray, ds.dstIsZero, rt->sceneDepth)
     if (rt->sceneDepth) { if (r->blendMode == 0) GS_LAUNCH_BOX(0, true); else GS_LAUNCH_BOX(1, true); }

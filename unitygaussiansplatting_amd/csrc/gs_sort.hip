@@ -38,10 +38,15 @@ constexpr int WAVES = THREADS / 64;
 //   A  16 keys per thread, 8,192-key partitions, <= 80 VGPRs: three workgroups per CU -- up to 768 partitions (6.3 M keys) in ONE round;
 //   B  20 keys per thread, 10,240-key partitions, <= 128 VGPRs: two workgroups per CU -- longer runs per digit (160-byte stores), a fifth
 //      fewer status words and look-back steps: 8 % faster on 50 M keys, 9 % slower on 6 M (599 partitions on 512 slots = two rounds).
-// All sizing (status words, group words) follows shape A, which has the most partitions.
-constexpr int KPT_A = 16, KPT_B = 20;
-constexpr int PART_A = THREADS * KPT_A, PART_B = THREADS * KPT_B;
+//   C   8 keys per thread, 4,096-key partitions (round 5): for SMALL sorts -- the depth sort of the visible splats only (2.2 M keys at C2 =
+//      267 partitions of shape A on 768 slots: a third of the chip busy, the pass as long as one partition's chain).  Half the keys per
+//      partition halve that chain's load / rank / scatter phases and put two partitions on every CU.  Plain 8-bit passes only.
+// Sizing (status words, group words) follows the smallest partition a sort may use (SortState::partMin: shape C for the depth sort, A otherwise).
+constexpr int KPT_A = 16, KPT_B = 20, KPT_C = 8;
+constexpr int PART_A = THREADS * KPT_A, PART_B = THREADS * KPT_B, PART_C = THREADS * KPT_C;
+constexpr int PART_MIN = PART_C;
 constexpr uint32_t kBigSortKeys = 24u << 20;          // expected keys above which shape B is used (four rounds of shape A)
+constexpr uint32_t kSmallSortKeys = 7u << 19;         // expected keys (3.67 M) up to which shape C is used: its partitions then fit one round of the grid
 constexpr uint32_t SPIN_LIMIT = 1u << 24;
 constexpr uint32_t TICKET_CLASSES = 16;        // partition-ticket counters per pass (one 128-B line each)
 constexpr int GROUP = 32;                     // partitions per look-back group (~sqrt of the partition count of a 6 M key sort)
@@ -205,7 +210,7 @@ __global__ __launch_bounds__(1024) void sort_keys_kernel(gsm::AssetView a, float
 constexpr int kLookbackBatch = 16;           // status words requested per look-back round
 constexpr int kMinWavesA = 6;                // shape A: <= 80 VGPRs = three 512-thread workgroups per CU (a handful of loop-invariant values spill to scratch)
 template <int BITS, bool GATHER, int KPT>
-__global__ __launch_bounds__(THREADS, KPT == KPT_A ? kMinWavesA : 4) void onesweep_kernel(const uint32_t* __restrict__ keysIn, const uint32_t* __restrict__ valsIn,
+__global__ __launch_bounds__(THREADS, KPT == KPT_B ? 4 : kMinWavesA) void onesweep_kernel(const uint32_t* __restrict__ keysIn, const uint32_t* __restrict__ valsIn,
                                                            uint32_t* __restrict__ keysOut, uint32_t* __restrict__ valsOut,
                                                            const uint32_t* __restrict__ hist, uint32_t* status,
                                                            unsigned long long* groupAgg, unsigned long long* groupIncl, uint32_t* ticket, uint32_t* error,
@@ -251,7 +256,12 @@ __global__ __launch_bounds__(THREADS, KPT == KPT_A ? kMinWavesA : 4) void oneswe
     if (tid < RDX)
         for (int k = 0; k < w; ++k) histExcl += s_htot[k];
 
-    const bool oneRound = gridDim.x >= numParts;          // (uniform) every partition has a resident workgroup
+    // (uniform) the grid covers every partition: workgroup b takes partition b without an atomic.  Only in the plain passes, where the
+    // static mapping is the identity -- a partition then only ever waits on partitions of workgroups with a SMALLER blockIdx, which the
+    // dispatcher started before it, so forward progress does not depend on how many workgroups are resident (another process on the GPU,
+    // a part with less LDS).  The gather pass permutes partitions over XCDs (workgroup 1 would wait on workgroups 8, 16, ...): it keeps
+    // the atomic tickets, which hand partitions out in dependency order to whoever is running.
+    const bool oneRound = !GATHER && gridDim.x >= numParts;
     for (uint32_t round = 0;; ++round) {
         if (oneRound && round) break;
         __syncthreads();                                    // previous partition's LDS reads are finished
@@ -263,8 +273,8 @@ __global__ __launch_bounds__(THREADS, KPT == KPT_A ? kMinWavesA : 4) void oneswe
         // a workgroup still only waits on partitions that are running or will run without needing a new slot.
         if (tid == 0) {
             const uint32_t cls = blockIdx.x % TICKET_CLASSES;
-            // One round (the grid covers every partition, all of them resident at once -- a 6 M-key pass): the ticket a workgroup
-            // would draw is known, blockIdx / classes, so the atomic's round trip (~1.2 us at the head of a ~31 us pass) is skipped.
+            // One round (the grid covers every partition -- a 6 M-key pass): the ticket a workgroup would draw is known, blockIdx / classes
+            // (partition = blockIdx), so the atomic's round trip (~1.2 us at the head of a ~31 us pass) is skipped.
             const uint32_t t = oneRound ? blockIdx.x / TICKET_CLASSES : __hip_atomic_fetch_add(ticket + cls * 32u, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             uint32_t p = t * TICKET_CLASSES + cls;
             if (GATHER) {                  // (XCD blocks in the plain passes too -- do neighbouring partitions' runs merge in a shared L2? -- measured: no change, r04 call 4)
@@ -521,10 +531,11 @@ inline uint32_t div_up(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
 } // namespace
 
 
-int32_t sort_state_create(gs_context* ctx, SortState& st, uint32_t maxCount) {
+int32_t sort_state_create(gs_context* ctx, SortState& st, uint32_t maxCount, bool smallPartitions) {
     if (maxCount > kSortMaxCount) return fail(GS_ERR_INVALID_ARGUMENT, "sort capacity above 2^30 keys");
     st.maxCount = maxCount;
-    st.maxParts = div_up(maxCount > 0 ? maxCount : 1, PART_A);
+    st.partMin = smallPartitions ? (uint32_t)PART_MIN : (uint32_t)PART_A;       // the smallest partition a pass of this sort may use: sizes the status / group words
+    st.maxParts = div_up(maxCount > 0 ? maxCount : 1, st.partMin);
     GS_HIP(hipMalloc((void**)&st.altKeys, ((size_t)maxCount + 16) * 4));
     GS_HIP(hipMalloc((void**)&st.altVals, ((size_t)maxCount + 16) * 4));
     GS_HIP(hipMalloc((void**)&st.status, (size_t)st.maxParts * RADIX * 4));
@@ -561,7 +572,7 @@ int32_t enqueue_set_indices(gs_context* ctx, uint32_t* order, uint32_t n) {
     return GS_OK;
 }
 
-uint32_t sort_group_words(uint32_t nUpper, int passes) { return (uint32_t)passes * div_up(div_up(max(nUpper, 1u), PART_A), (uint32_t)GROUP) * RADIX; }
+uint32_t sort_group_words(const SortState& st, uint32_t nUpper, int passes) { return (uint32_t)passes * div_up(div_up(max(nUpper, 1u), st.partMin), (uint32_t)GROUP) * RADIX; }
 
 int32_t enqueue_sort_keys(gs_context* ctx, hipStream_t stream, const gsm::AssetView& a, const float* m, uint32_t* keyBySplat,
                           SortControl* control, SortControl* nextControl, uint32_t n, SortState& st) {
@@ -569,7 +580,7 @@ int32_t enqueue_sort_keys(gs_context* ctx, hipStream_t stream, const gsm::AssetV
     const uint32_t chunks = div_up(n, 256u);
     const uint32_t grid = max(1u, min(div_up(chunks, 4u * kKeysIlp), (uint32_t)ctx->cuCount));      // one 1024-thread workgroup per CU
 #define GS_LAUNCH_KEYS(F) hipLaunchKernelGGL(sort_keys_kernel<F>, dim3(grid), dim3(1024), 0, stream, a, m[8], m[9], m[10], m[11], keyBySplat, \
-                                             control->hist, n, st.groupAgg, sort_group_words(n, 4), (uint32_t*)nextControl)
+                                             control->hist, n, st.groupAgg, sort_group_words(st, n, 4), (uint32_t*)nextControl)
     switch (a.posFmt) { case 0: GS_LAUNCH_KEYS(0); break; case 1: GS_LAUNCH_KEYS(1); break; case 2: GS_LAUNCH_KEYS(2); break; default: GS_LAUNCH_KEYS(3); break; }
 #undef GS_LAUNCH_KEYS
     GS_HIP(hipGetLastError());
@@ -580,7 +591,7 @@ int32_t enqueue_histogram(gs_context* ctx, hipStream_t stream, const uint32_t* k
                           SortState& st) {
     GS_HIP(hipMemsetAsync(control, 0, sizeof(SortControl), stream));
     const uint32_t grid = max(1u, min(div_up(n, 256), (uint32_t)ctx->cuCount * 4u));
-    hipLaunchKernelGGL(histogram_kernel, dim3(grid), dim3(256), 0, stream, keys, n, nPtr, passes, lastMask, control->hist, st.groupAgg, sort_group_words(n, passes));
+    hipLaunchKernelGGL(histogram_kernel, dim3(grid), dim3(256), 0, stream, keys, n, nPtr, passes, lastMask, control->hist, st.groupAgg, sort_group_words(st, n, passes));
     GS_HIP(hipGetLastError());
     return GS_OK;
 }
@@ -594,16 +605,19 @@ int32_t enqueue_sort_passes(gs_context* ctx, hipStream_t stream, SortState& st, 
     if (nUpper == 0) return GS_OK;
     // shape by the expected key count (the pair sort knows only an upper bound on the host: the caller passes the last frame's count);
     // the order produced is the same either way.  GSPLAT_SORT_SHAPE=a|b pins it (tests run every size through both).
-    static const int forcedShape = [] { const char* e = getenv("GSPLAT_SORT_SHAPE"); return !e ? 0 : (e[0] == 'a' || e[0] == 'A') ? 1 : (e[0] == 'b' || e[0] == 'B') ? 2 : 0; }();
+    static const int forcedShape = [] { const char* e = getenv("GSPLAT_SORT_SHAPE");
+                                        return !e ? 0 : (e[0] == 'a' || e[0] == 'A') ? 1 : (e[0] == 'b' || e[0] == 'B') ? 2 : (e[0] == 'c' || e[0] == 'C') ? 3 : 0; }();
     const uint32_t expect = min(expected ? expected : nUpper, nUpper);
-    const bool shapeB = forcedShape ? forcedShape == 2 : expect > kBigSortKeys;
-    const uint32_t parts = div_up(nUpper, shapeB ? (uint32_t)PART_B : (uint32_t)PART_A);
+    const bool canC = bits == 8 && !gatherKeys && st.partMin <= (uint32_t)PART_C;      // shape C exists for the plain 8-bit passes of a sort sized for it
+    const bool shapeC = canC && (forcedShape ? forcedShape == 3 : expect <= kSmallSortKeys);
+    const bool shapeB = !shapeC && (forcedShape ? forcedShape == 2 : expect > kBigSortKeys);
+    const uint32_t parts = div_up(nUpper, shapeC ? (uint32_t)PART_C : shapeB ? (uint32_t)PART_B : (uint32_t)PART_A);
     // persistent grid: no more workgroups than are resident at once (3 per CU at <= 80 VGPRs / 43 KB LDS, 2 at <= 128 / 52 KB), a
     // multiple of the ticket classes so that every class is served
     const uint32_t capacity = max(((uint32_t)ctx->cuCount * (shapeB ? 2u : 3u) / TICKET_CLASSES) * TICKET_CLASSES, TICKET_CLASSES);
     const uint32_t grid = min(div_up(parts, TICKET_CLASSES) * TICKET_CLASSES, capacity);
     uint32_t *ks = keys, *vs = vals, *kd = st.altKeys, *vd = st.altVals;
-    const uint32_t groups = div_up(div_up(nUpper, (uint32_t)PART_A), (uint32_t)GROUP);       // per-pass stride of the group words: sort_group_words()
+    const uint32_t groups = div_up(div_up(nUpper, st.partMin), (uint32_t)GROUP);             // per-pass stride of the group words: sort_group_words()
     const uint32_t fullMask = (1u << bits) - 1u;
     // st.groupAgg[passes][groups][256] accumulates: it was zeroed by the kernel that produced the keys / their histograms
     if (profR && evFirst >= 0) prof_record(profR, evFirst, stream);
@@ -635,6 +649,7 @@ int32_t enqueue_sort_passes(gs_context* ctx, hipStream_t stream, SortState& st, 
                               (const uint32_t*)hist, st.status, agg, st.groupIncl, (uint32_t*)control->tickets[p], &control->error, nUpper, nPtr, shift, epoch, mask)
 #define GS_LAUNCH_ONESWEEP(B, G, KIN) do { if (shapeB) GS_LAUNCH_ONESWEEP_K(B, G, KIN, KPT_B); else GS_LAUNCH_ONESWEEP_K(B, G, KIN, KPT_A); } while (0)
         if (p == 0 && gatherKeys) GS_LAUNCH_ONESWEEP(8, true, gatherKeys);
+        else if (shapeC) GS_LAUNCH_ONESWEEP_K(8, false, ks, KPT_C);
         else if (bits == 8) GS_LAUNCH_ONESWEEP(8, false, ks);
         else if (bits == 7) GS_LAUNCH_ONESWEEP(7, false, ks);
         else GS_LAUNCH_ONESWEEP(6, false, ks);

@@ -1,0 +1,423 @@
+// gs_vissort.hip -- GS_SORT_VISIBLE: the depth sort of the splats that are DRAWN, instead of all N.
+//
+// The reference sorts every splat every frame because its sort precedes its cull (SortPoints, GaussianSplatRenderer.cs:612-639, is
+// recorded before CalcViewData, :579-610, and CSCalcDistances -- SplatUtilities.compute:69-82 -- keys all of _SplatCount).  Only the
+// order among the splats that reach the screen is observable, and calc_view (gs_view.hip) needs nothing from the sort.  So in this
+// mode the frame runs calc_view first and then, over its visibility bits:
+//   1. visible_keys_kernel   keys of the V visible splats (CSCalcDistances' arithmetic, the matrix of the last gs_renderer_sort) compacted
+//                            in SPLAT-INDEX order into (visKeys, visIdx), the four digit histograms of those keys, V itself;
+//   2. four plain Onesweep passes (gs_sort.hip) over V pairs -- no gather pass, no keys of culled splats;
+//   3. tie_fix_kernel        the reference's order among EQUAL keys.  Its sort is stable and its input is the previous frame's order,
+//                            so the order buffer is sorted lexicographically by (key under M_k, key under M_k-1, ..., key under M_1,
+//                            index): tied splats keep what the earlier sort matrices gave them.  A stable sort of an index-ordered
+//                            compaction leaves ties in index order; the fix-up re-orders every run of equal keys by that chain,
+//                            re-evaluating the tied splats' keys under the kept matrices (gs_renderer::visHist, most recent first;
+//                            a matrix that occurs twice only counts where it occurs first, so a static camera keeps ONE).  Runs of
+//                            2..4 are ordered by the thread that finds them, 5..64 by a wave; a longer run that the history would have to
+//                            order is reported (VIS_TIE_OVERFLOW) and the renderer falls back to full sorts (gs_api.hip).
+// The draw (gs_raster.hip: vis_offsets_kernel + vis_emit_kernel) then bins the V sorted entries instead of walking N positions of the full order.
+// Host-side bookkeeping (the matrix history) lives at the end of this file; the API around it in gs_api.hip.
+#include "gs_common.h"
+#include <cstdlib>
+
+namespace gs {
+
+namespace {
+
+constexpr int VTHREADS = 512;                 // <= 80 VGPRs: three blocks = 24 waves per CU (the kernel is a chain of dependent round trips; waves hide them)
+constexpr int VWAVES = VTHREADS / 64;
+constexpr uint32_t VIS_SPIN_LIMIT = 1u << 24;
+
+inline uint32_t div_up(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
+
+__device__ __forceinline__ uint32_t wave_incl_scan32(uint32_t v, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = __shfl_up(v, o, 64);
+        if (lane >= o) v += t;
+    }
+    return v;
+}
+
+// add 1 to an LDS histogram bin, wave-aggregated when every active lane hits the same bin (the high digits of depth keys)
+__device__ __forceinline__ void lds_hist_add(uint32_t* h, uint32_t d) {
+    const uint32_t first = __builtin_amdgcn_readfirstlane(d);
+    const unsigned long long act = __ballot(1);
+    if (__all(d == first)) {
+        if ((int)(threadIdx.x & 63) == __ffsll((long long)act) - 1) atomicAdd(&h[first], (uint32_t)__popcll(act));
+    } else {
+        atomicAdd(&h[d], 1u);
+    }
+}
+
+// Block b owns the visibility words [b * blockWords, (b + 1) * blockWords) -- 64 splats per word, blockWords a multiple of 4 so that a
+// word never straddles a 256-splat chunk.  Its first output slot is the number of visible splats before it: every block publishes its
+// own count as soon as it has summed its words (status[b] = count + 1) and sums the counts of the blocks before it -- at most
+// kVisMaxBlocks words, one or two per thread.  Block b only waits on blocks with a SMALLER index, which the dispatcher has started before it,
+// so the wait does not depend on how many workgroups are resident.  HIST = false: no sort follows (nothing was ever sorted: the order
+// is the index order), only the compaction.
+template <int POSFMT, bool HIST>
+__global__ __launch_bounds__(VTHREADS, 6) void visible_keys_kernel(gsm::AssetView a, float m20, float m21, float m22, float m23,
+                                                                const unsigned long long* __restrict__ visMask, uint32_t words, uint32_t blockWords,
+                                                                uint32_t* __restrict__ outKeys, uint32_t* __restrict__ outIdx, uint32_t* __restrict__ hist,
+                                                                VisControl* vc, uint32_t* __restrict__ nextVc,
+                                                                unsigned long long* __restrict__ groupAgg, uint32_t groupAggWords, uint32_t* __restrict__ nextControl) {
+    __shared__ uint32_t s_h[4 * 256];
+    __shared__ unsigned long long s_m[VTHREADS];
+    __shared__ uint32_t s_off[VTHREADS];
+    __shared__ uint32_t s_live[VTHREADS];
+    __shared__ uint32_t s_w[VWAVES];
+    __shared__ uint32_t s_bcast[2];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    // housekeeping for the sort passes that follow and for the NEXT sort (the control blocks alternate: no memset launch per frame)
+    if (HIST) {
+        for (int j = tid; j < 4 * 256; j += VTHREADS) s_h[j] = 0;
+        for (uint32_t j = blockIdx.x * (uint32_t)VTHREADS + tid; j < groupAggWords; j += gridDim.x * (uint32_t)VTHREADS) groupAgg[j] = 0ull;
+    }
+    for (uint32_t j = blockIdx.x * (uint32_t)VTHREADS + tid; j < (uint32_t)(sizeof(SortControl) / 4); j += gridDim.x * (uint32_t)VTHREADS) nextControl[j] = 0u;
+    for (uint32_t j = blockIdx.x * (uint32_t)VTHREADS + tid; j < (uint32_t)(sizeof(VisControl) / 4); j += gridDim.x * (uint32_t)VTHREADS) nextVc[j] = 0u;
+
+    const uint32_t w0 = blockIdx.x * blockWords, w1 = min(w0 + blockWords, words);
+    // ---- this block's visible count
+    uint32_t cnt = 0;
+    for (uint32_t wi = w0 + tid; wi < w1; wi += VTHREADS) cnt += (uint32_t)__popcll(visMask[wi]);      // (bits of splats >= n are never set)
+    {
+        const uint32_t incl = wave_incl_scan32(cnt, lane);
+        if (lane == 63) s_w[w] = incl;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t t = 0;
+#pragma unroll
+        for (int k = 0; k < VWAVES; ++k) t += s_w[k];
+        s_bcast[0] = t;
+        __hip_atomic_store(&vc->status[blockIdx.x], t + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    const uint32_t total = s_bcast[0];
+    // ---- the counts of the blocks before this one
+    uint32_t before = 0;
+    for (uint32_t j = (uint32_t)tid; j < blockIdx.x; j += VTHREADS) {
+        uint32_t v = 0, spins = 0;
+        for (;;) {
+            v = __hip_atomic_load(&vc->status[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (v) break;
+            if (++spins > VIS_SPIN_LIMIT) { atomicOr(&vc->error, 1u); v = 1u; break; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        before += v - 1u;
+    }
+    {
+        const uint32_t incl = wave_incl_scan32(before, lane);
+        __syncthreads();                                          // s_w is free again
+        if (lane == 63) s_w[w] = incl;
+    }
+    __syncthreads();
+    uint32_t running = 0;                                         // first output slot of the next sub-tile (uniform)
+#pragma unroll
+    for (int k = 0; k < VWAVES; ++k) running += s_w[k];
+    if (blockIdx.x == gridDim.x - 1u && tid == 0) vc->count = running + total;
+    if (total == 0u) return;                                      // (uniform; nothing in s_h)
+
+    const bool chunked = a.chunkCount != 0u;
+    const uint8_t* cbase = chunked ? a.chunk : (const uint8_t*)visMask;      // (no chunks: any readable 64 bytes, never used)
+    const uint32_t lastChunk = chunked ? a.chunkCount - 1u : 0u;
+    typedef gsm::RawVec<POSFMT> Raw;
+    constexpr uint32_t ILP = 4;                                   // live words in flight per wave
+
+    // ---- sub-tiles of 1024 words (one per thread): offsets by a block scan, the words that hold a visible splat compacted into a list
+    //      so that the waves share them evenly, four words in flight per wave
+    for (uint32_t s0 = w0; s0 < w1; s0 += VTHREADS) {
+        __syncthreads();                                          // the previous sub-tile's s_m / s_off / s_live / s_w are no longer read
+        const uint32_t wi = s0 + tid;
+        const unsigned long long m = wi < w1 ? visMask[wi] : 0ull;
+        const uint32_t c = (uint32_t)__popcll(m);
+        const uint32_t packed = c | ((m != 0ull ? 1u : 0u) << 20);           // visible splats (< 2^17 per sub-tile) and live words in one scan
+        const uint32_t incl = wave_incl_scan32(packed, lane);
+        if (lane == 63) s_w[w] = incl;
+        __syncthreads();
+        uint32_t wbase = 0, subTotal = 0;
+#pragma unroll
+        for (int k = 0; k < VWAVES; ++k) { const uint32_t t = s_w[k]; wbase += (k < w) ? t : 0u; subTotal += t; }
+        const uint32_t excl = wbase + incl - packed;
+        s_m[tid] = m;
+        s_off[tid] = running + (excl & 0xfffffu);
+        if (m != 0ull) s_live[excl >> 20] = (uint32_t)tid;
+        __syncthreads();
+        const uint32_t nLive = subTotal >> 20;
+        running += subTotal & 0xfffffu;
+
+        for (uint32_t k0 = (uint32_t)w * ILP; k0 < nLive; k0 += VWAVES * ILP) {          // wave-uniform
+            Raw raw[ILP]; uint4 bx[ILP]; uint2 bz[ILP]; uint32_t sidx[ILP], off[ILP]; unsigned long long mm[ILP];
+#pragma unroll
+            for (uint32_t k = 0; k < ILP; ++k) {
+                const uint32_t t = s_live[min(k0 + k, nLive - 1u)];           // (a clamped duplicate is masked out below)
+                mm[k] = (k0 + k < nLive) ? s_m[t] : 0ull;
+                off[k] = s_off[t];
+                const uint32_t word = s0 + t;
+                sidx[k] = word * 64u + (uint32_t)lane;
+                // unconditional loads (index clamped): a load inside a divergent branch is waited for at the end of the branch
+                const uint32_t li = min(sidx[k], a.n - 1u);
+                raw[k] = gsm::LoadRawT<POSFMT>(a.pos, (uint64_t)li * gsm::vecStrideT<POSFMT>());
+                const uint8_t* cp = cbase + (size_t)min(word >> 2, lastChunk) * 64u;           // ChunkInfo.posX/Y/Z bounds: wave-uniform address
+                bx[k] = *(const uint4*)(cp + 16);
+                bz[k] = *(const uint2*)(cp + 32);
+            }
+#pragma unroll
+            for (uint32_t k = 0; k < ILP; ++k) {
+                if (!((mm[k] >> lane) & 1ull)) continue;
+                gsm::V3 pos = gsm::DecodeRawT<POSFMT>(raw[k], (uint64_t)sidx[k] * gsm::vecStrideT<POSFMT>());
+                if (chunked && (sidx[k] >> 8) <= lastChunk) {              // LoadSplatPos' chunk de-normalisation (ChunkLerpPos), same expressions
+                    pos.x = gsm::lerpf(gsm::u2f(bx[k].x), gsm::u2f(bx[k].y), pos.x);
+                    pos.y = gsm::lerpf(gsm::u2f(bx[k].z), gsm::u2f(bx[k].w), pos.y);
+                    pos.z = gsm::lerpf(gsm::u2f(bz[k].x), gsm::u2f(bz[k].y), pos.z);
+                }
+                const uint32_t key = gsm::SortKeyOf(pos, m20, m21, m22, m23);
+                const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(mm[k] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm[k], 0u));
+                const uint32_t p = off[k] + below;
+                outKeys[p] = key;
+                outIdx[p] = sidx[k];
+                if (HIST) {
+                    lds_hist_add(s_h, key & 255u);
+                    lds_hist_add(s_h + 256, (key >> 8) & 255u);
+                    lds_hist_add(s_h + 512, (key >> 16) & 255u);
+                    lds_hist_add(s_h + 768, key >> 24);
+                }
+            }
+        }
+    }
+    if (HIST) {
+        // two neighbouring bins per 64-bit atomic (a bin never reaches 2^32: no carry into its neighbour): every block holds every value
+        // of the low digits, so the ~700 blocks queue on each bin's address (~12 ns per same-address atomic)
+        __syncthreads();
+        for (int j = tid; j < 2 * 256; j += VTHREADS) {
+            const unsigned long long c = (unsigned long long)s_h[2 * j] | ((unsigned long long)s_h[2 * j + 1] << 32);
+            if (c) atomicAdd((unsigned long long*)hist + j, c);
+        }
+    }
+}
+
+// ---- the reference's order among equal keys ---------------------------------------------------------------------------------------
+struct TiePos { float x, y, z; };
+// does splat A (index ea, position pa) precede splat B in the reference's order buffer, given that their keys under row 0 are equal?
+// rows: the kept sort matrices in LDS (row h = 4 floats), most recent first; the chain ends in the splat index (CSSetIndices).
+__device__ __forceinline__ bool tie_precedes(const float* rows, uint32_t depth, const TiePos& pa, uint32_t ea, const TiePos& pb, uint32_t eb, uint32_t* exhausted) {
+    if (gsm::f2u(pa.x) == gsm::f2u(pb.x) && gsm::f2u(pa.y) == gsm::f2u(pb.y) && gsm::f2u(pa.z) == gsm::f2u(pb.z)) return ea < eb;     // equal under every matrix
+    for (uint32_t h = 1; h < depth; ++h) {
+        const float* r = rows + 4 * h;
+        const uint32_t ka = gsm::SortKeyOf(gsm::V3{ pa.x, pa.y, pa.z }, r[0], r[1], r[2], r[3]);
+        const uint32_t kb = gsm::SortKeyOf(gsm::V3{ pb.x, pb.y, pb.z }, r[0], r[1], r[2], r[3]);
+        if (ka != kb) return ka < kb;
+    }
+    if (ea < eb) atomicAdd(exhausted, 1u);                        // (each unordered pair once) different positions, no kept matrix separates them
+    return ea < eb;
+}
+
+constexpr int TIE_THREADS = 256, TIE_ITEMS = 8, TIE_SEG = TIE_THREADS * TIE_ITEMS;
+// One workgroup per segment of TIE_SEG sorted positions: every thread looks at TIE_ITEMS of them for the START of a run of equal keys
+// (about one position in twenty at C2: 2.2 M keys on the ~2^25 floats of the depth range), the starts are compacted into LDS and dealt
+// to the threads, so that the re-ordering -- two or three dependent random gathers (index -> position, ChunkInfo) and a few dozen VALU
+// instructions per run -- runs on full waves.  A run belongs to the segment its first position lies in, whatever it extends into.
+__global__ __launch_bounds__(TIE_THREADS) void tie_fix_kernel(gsm::AssetView a, TieHistory H, const uint32_t* __restrict__ keys, uint32_t* idx,
+                                                              const uint32_t* __restrict__ nPtr, uint32_t nImm, VisControl* vc) {
+    __shared__ float s_rows[kVisHistory * 4];
+    __shared__ uint32_t s_start[TIE_SEG / 2];                     // a run has >= 2 positions
+    __shared__ uint32_t s_long[TIE_SEG / 5 + 8];
+    __shared__ uint32_t s_nStart, s_nLong;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const uint32_t n = min(*nPtr, nImm);
+    const uint32_t depth = H.depth;
+    for (uint32_t j = tid; j < depth * 4u; j += TIE_THREADS) s_rows[j] = H.row[j >> 2][j & 3u];
+    for (uint32_t seg = blockIdx.x; (unsigned long long)seg * TIE_SEG < n; seg += gridDim.x) {
+        __syncthreads();
+        if (tid == 0) { s_nStart = 0; s_nLong = 0; }
+        __syncthreads();
+        const uint32_t base = seg * (uint32_t)TIE_SEG;
+#pragma unroll
+        for (int k = 0; k < TIE_ITEMS; ++k) {
+            const uint32_t i = base + (uint32_t)k * TIE_THREADS + (uint32_t)tid;
+            // (three loads per position, two of them cache hits; indices clamped so that the loads are unconditional)
+            const uint32_t kc = keys[min(i, n - 1u)], kp = keys[min(i, n - 1u) - (i > 0u && i < n ? 1u : 0u)], kn = keys[min(i + 1u, n - 1u)];
+            const bool start = i + 1u < n && kn == kc && (i == 0u || kp != kc);
+            if (start) s_start[atomicAdd(&s_nStart, 1u)] = i;
+        }
+        __syncthreads();
+        const uint32_t nStart = s_nStart;
+        for (uint32_t s = tid; s < nStart; s += TIE_THREADS) {
+            const uint32_t i = s_start[s];
+            // (every load below is independent of the others: the keys behind the start and the run's first four indices in one round trip)
+            const uint32_t kc = keys[i], k2 = keys[min(i + 2u, n - 1u)], k3 = keys[min(i + 3u, n - 1u)], k4 = keys[min(i + 4u, n - 1u)];
+            uint32_t e[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) e[j] = idx[min(i + (uint32_t)j, n - 1u)];
+            const bool m2 = i + 2u < n && k2 == kc, m3 = m2 && i + 3u < n && k3 == kc, m4 = m3 && i + 4u < n && k4 == kc;
+            const uint32_t L = m4 ? 5u : (m3 ? 4u : (m2 ? 3u : 2u));
+            if (L > 4u) { s_long[atomicAdd(&s_nLong, 1u)] = i; continue; }
+            // ---- runs of 2..4: rank by counting with the chain comparison, in registers
+            TiePos p[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const gsm::V3 q = gsm::LoadSplatPos(a, e[j]);
+                p[j] = TiePos{ q.x, q.y, q.z };
+            }
+            uint32_t rank[4] = { 0u, 0u, 0u, 0u };
+#pragma unroll
+            for (int x = 0; x < 4; ++x)
+#pragma unroll
+                for (int y = x + 1; y < 4; ++y)
+                    if ((uint32_t)y < L) {
+                        const bool xy = tie_precedes(s_rows, depth, p[x], e[x], p[y], e[y], &vc->tieExhausted);
+                        rank[xy ? y : x] += 1u;
+                    }
+            // (the compaction was in index order and the sort is stable: the run arrives sorted by index, so most runs -- whose previous
+            // keys ascend with the index as often as not -- are already in place)
+            bool moved = false;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) moved = moved || ((uint32_t)j < L && rank[j] != (uint32_t)j);
+            if (moved) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if ((uint32_t)j < L) idx[i + rank[j]] = e[j];
+            }
+        }
+        __syncthreads();
+        // ---- runs of 5..64: one wave each, a lane per member, rank by counting against every other member (v_readlane broadcasts)
+        const uint32_t nLong = s_nLong;
+        for (uint32_t q = (uint32_t)w; q < nLong; q += TIE_THREADS / 64) {
+            const uint32_t i = s_long[q];
+            const uint32_t kc = keys[i];
+            const bool same = i + (uint32_t)lane < n && keys[min(i + (uint32_t)lane, n - 1u)] == kc;
+            const unsigned long long bal = __ballot(same);
+            const uint32_t L = bal == ~0ull ? 64u : (uint32_t)__ffsll((long long)~bal) - 1u;
+            if (L == 64u && i + 64u < n && keys[i + 64u] == kc) {       // longer than a wave: left in index order, reported
+                if (lane == 0) atomicOr(&vc->tieFlags, VIS_TIE_OVERFLOW);
+                continue;
+            }
+            const bool mine = (uint32_t)lane < L;
+            const uint32_t e = idx[min(i + (uint32_t)lane, n - 1u)];
+            const gsm::V3 pq = gsm::LoadSplatPos(a, mine ? e : idx[i]);
+            const TiePos p = { pq.x, pq.y, pq.z };
+            uint32_t rank = 0;
+            for (uint32_t j = 0; j < L; ++j) {
+                const uint32_t ej = (uint32_t)__builtin_amdgcn_readlane((int)e, (int)j);
+                const TiePos pj = { __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p.x), (int)j)), __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p.y), (int)j)),
+                                    __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p.z), (int)j)) };
+                if (mine && j != (uint32_t)lane) {
+                    // (the pair is counted as exhausted by the lane with the larger index only: tie_precedes counts when its first splat is the smaller)
+                    const bool jFirst = tie_precedes(s_rows, depth, pj, ej, p, e, &vc->tieExhausted);
+                    rank += jFirst ? 1u : 0u;
+                }
+            }
+            if (mine) idx[i + rank] = e;
+        }
+    }
+}
+
+} // namespace
+
+int32_t vis_alloc(gs_renderer* r) {
+    if (r->visKeys) return GS_OK;
+    uint32_t *k = nullptr, *v = nullptr, *x = nullptr, *y = nullptr, *po = nullptr; VisControl* c = nullptr;
+    hipError_t e = hipMalloc((void**)&k, ((size_t)r->n + 16) * 4);
+    if (e == hipSuccess) e = hipMalloc((void**)&v, ((size_t)r->n + 16) * 4);
+    if (e == hipSuccess) e = hipMalloc((void**)&x, ((size_t)r->n + 16) * 4);
+    if (e == hipSuccess) e = hipMalloc((void**)&y, ((size_t)r->n + 16) * 4);
+    if (e == hipSuccess) e = hipMalloc((void**)&po, ((size_t)r->n + 16) * 4);
+    if (e == hipSuccess) e = hipMalloc((void**)&c, 2 * sizeof(VisControl));
+    if (e == hipSuccess) e = hipMemsetAsync(c, 0, 2 * sizeof(VisControl), r->ctx->stream);
+    if (e != hipSuccess) {
+        if (k) (void)hipFree(k);
+        if (v) (void)hipFree(v);
+        if (x) (void)hipFree(x);
+        if (y) (void)hipFree(y);
+        if (po) (void)hipFree(po);
+        if (c) (void)hipFree(c);
+        return fail_hip(e, "allocate the visible-sort buffers", __FILE__, __LINE__);
+    }
+    r->visKeys = k; r->visIdx = v; r->visRectX = x; r->visRectY = y; r->visPairOffset = po; r->visControl = c; r->visControlIdx = 0;
+    return GS_OK;
+}
+
+void vis_free(gs_renderer* r) {
+    if (r->visKeys) (void)hipFree(r->visKeys);
+    if (r->visIdx) (void)hipFree(r->visIdx);
+    if (r->visRectX) (void)hipFree(r->visRectX);
+    if (r->visRectY) (void)hipFree(r->visRectY);
+    if (r->visPairOffset) (void)hipFree(r->visPairOffset);
+    if (r->visChunkStart) (void)hipFree(r->visChunkStart);
+    if (r->visControl) (void)hipFree(r->visControl);
+    r->visKeys = r->visIdx = r->visRectX = r->visRectY = r->visPairOffset = r->visChunkStart = nullptr; r->visControl = nullptr; r->visChunkCap = 0;
+}
+
+// The stable sort history as a list of DISTINCT rows, most recent first.  Sorting by a matrix that is already the head changes
+// nothing (a stable sort of a sorted sequence); one that occurs deeper moves to the front (where it occurs again further down the
+// lexicographic chain it can no longer decide anything: everything still tied there is tied under it).
+void vis_push_matrix(gs_renderer* r, const float* m) {
+    const float* row = m + 8;
+    int found = -1;
+    for (int j = 0; j < r->visHistDepth && found < 0; ++j)
+        if (memcmp(r->visHist[j], row, 16) == 0) found = j;
+    if (found == 0) return;
+    int last;
+    if (found > 0) last = found;                                  // rows 0 .. found-1 move down one, over the duplicate
+    else if (r->visHistDepth < kVisHistory) last = r->visHistDepth++;
+    else { last = kVisHistory - 1; r->visHistDropped++; }       // the oldest row falls off: the chain is truncated from here on
+    for (int j = last; j > 0; --j) memcpy(r->visHist[j], r->visHist[j - 1], 16);
+    memcpy(r->visHist[0], row, 16);
+    r->visOrderValid = false;
+}
+
+int32_t enqueue_visible_sort(gs_renderer* r) {
+    gs_context* ctx = r->ctx;
+    hipStream_t st = ctx->stream;
+    GS_TRY(vis_alloc(r));
+    const gsm::AssetView& a = r->asset->view;
+    const uint32_t n = r->n;
+    const uint32_t words = div_up(n, 64u);
+    // blocks of >= 128 visibility words (8,192 splats: 16 words per wave), at most ~1000 of them (C2: 749 on the 768 slots of 256 CUs)
+    static const uint32_t minWords = [] { const char* e = getenv("GSPLAT_VIS_BLOCKWORDS"); const int v = e ? atoi(e) : 0; return v >= 16 ? (uint32_t)v : 128u; }();
+    uint32_t blockWords = max(minWords, div_up(words, 1000u));
+    blockWords = (blockWords + 3u) & ~3u;
+    const uint32_t grid = div_up(words, blockWords);
+    if (grid > kVisMaxBlocks) return fail(GS_ERR_INVALID_ARGUMENT, "visible sort: too many blocks");
+    r->visControlIdx ^= 1;
+    VisControl* vc = r->visControl + r->visControlIdx;             // zeroed by the previous visible sort (or at allocation)
+    VisControl* nextVc = r->visControl + (r->visControlIdx ^ 1);
+    r->depthControlIdx ^= 1;
+    SortControl* control = r->depthControl + r->depthControlIdx;
+    SortControl* nextControl = r->depthControl + (r->depthControlIdx ^ 1);
+    const bool sorted = r->visHistDepth > 0;                       // nothing was ever sorted: CSSetIndices' order = the index order of the compaction
+    static const float zeroRow[4] = { 0.f, 0.f, 0.f, 0.f };
+    const float* row = sorted ? r->visHist[0] : zeroRow;
+    prof_record(r, 0, st);
+#define GS_LAUNCH_VK(F, HI) hipLaunchKernelGGL((visible_keys_kernel<F, HI>), dim3(grid), dim3(VTHREADS), 0, st, a, row[0], row[1], row[2], row[3], \
+                                               (const unsigned long long*)r->visMask, words, blockWords, r->visKeys, r->visIdx, control->hist, vc, (uint32_t*)nextVc, \
+                                               r->depthSort.groupAgg, sort_group_words(r->depthSort, n, 4), (uint32_t*)nextControl)
+#define GS_LAUNCH_VKF(F) do { if (sorted) GS_LAUNCH_VK(F, true); else GS_LAUNCH_VK(F, false); } while (0)
+    switch (a.posFmt) { case 0: GS_LAUNCH_VKF(0); break; case 1: GS_LAUNCH_VKF(1); break; case 2: GS_LAUNCH_VKF(2); break; default: GS_LAUNCH_VKF(3); break; }
+#undef GS_LAUNCH_VKF
+#undef GS_LAUNCH_VK
+    GS_HIP(hipGetLastError());
+    prof_record(r, 1, st);
+    if (sorted) {
+        // the pass shape follows the visible count of the last draw that reported (the host only knows the bound N)
+        const uint32_t lastVisible = (r->hostReport && r->frameInFlight) ? *(volatile uint32_t*)&r->hostReport->visible : 0u;
+        const bool needKeys = r->visHistDepth > 1;                 // the fix-up reads the sorted keys; with one matrix a tie is already in index order
+        GS_TRY(enqueue_sort_passes(ctx, st, r->depthSort, control, r->visKeys, r->visIdx, n, &vc->count, 4, 255u, r, 10, 8, nullptr, !needKeys,
+                                   lastVisible ? lastVisible : max(n / 3u, 1u)));
+        if (needKeys) {
+            TieHistory H;
+            memcpy(H.row, r->visHist, sizeof(H.row));
+            H.depth = (uint32_t)r->visHistDepth;
+            const uint32_t tgrid = max(1u, min(div_up(n, (uint32_t)TIE_SEG), (uint32_t)ctx->cuCount * 8u));
+            hipLaunchKernelGGL(tie_fix_kernel, dim3(tgrid), dim3(TIE_THREADS), 0, st, a, H, (const uint32_t*)r->visKeys, r->visIdx,
+                               (const uint32_t*)&vc->count, n, vc);
+            GS_HIP(hipGetLastError());
+        }
+    }
+    prof_record(r, 2, st);
+    r->visOrderValid = true;
+    return GS_OK;
+}
+
+} // namespace gs

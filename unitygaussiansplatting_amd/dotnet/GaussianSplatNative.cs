@@ -44,7 +44,7 @@ namespace GaussianSplatting.Runtime
         }
 
         [StructLayout(LayoutKind.Sequential)]
-        public struct FrameStats { public ulong tilePairs, pairCapacity; public uint visibleSplats, tilesX, tilesY, sortError, tileW, tileH; }
+        public struct FrameStats { public ulong tilePairs, pairCapacity; public uint visibleSplats, tilesX, tilesY, sortError, tileW, tileH, sortMode, tieExhausted; }
 
         [StructLayout(LayoutKind.Sequential)]
         public struct StageTimes { public float calcDistancesMs, sortMs, calcViewMs, binMs, pairSortMs, blendMs, resolveMs, totalMs; public uint frames; public float onesweepDepthMs, onesweepPairsMs; public uint onesweepPairLaunches; public float onesweepDepthKernelMs, onesweepPairsKernelMs; }
@@ -97,6 +97,10 @@ namespace GaussianSplatting.Runtime
         [DllImport(Lib)] public static extern int gs_renderer_download_order(IntPtr renderer, uint[] dst, UIntPtr count);
         [DllImport(Lib)] public static extern int gs_renderer_download_distances(IntPtr renderer, uint[] dst, UIntPtr count);
         [DllImport(Lib)] public static extern int gs_renderer_upload_order(IntPtr renderer, uint[] src, UIntPtr count);
+        // gs_sort_mode: 0 = GS_SORT_FULL (SortPoints as the reference runs it), 1 = GS_SORT_VISIBLE (cull first, sort what is drawn)
+        [DllImport(Lib)] public static extern int gs_renderer_set_sort_mode(IntPtr renderer, int mode);
+        [DllImport(Lib)] public static extern int gs_renderer_sort_mode(IntPtr renderer, out int mode, out int active);
+        [DllImport(Lib)] public static extern int gs_renderer_download_visible_order(IntPtr renderer, uint[] dst, UIntPtr capacity, out uint count);
         [DllImport(Lib)] public static extern int gs_renderer_set_render_mode(IntPtr renderer, int mode, float pointDisplaySize);
         [DllImport(Lib)] public static extern int gs_renderer_download_view(IntPtr renderer, IntPtr dst, UIntPtr bytes);
         [DllImport(Lib)] public static extern int gs_renderer_download_raster_records(IntPtr renderer, IntPtr recs, IntPtr rects, IntPtr visMask);

@@ -17,7 +17,8 @@ from typing import List, Optional, Tuple
 import numpy as np
 
 from . import _lib
-from ._abi import (GS_ERR_PAIR_OVERFLOW, VIEW_DTYPE, gs_frame_params, gs_frame_stats, gs_stage_times, make_asset_desc)
+from ._abi import (GS_ERR_PAIR_OVERFLOW, GS_ERR_TIE_OVERFLOW, GS_SORT_FULL, GS_SORT_VISIBLE, VIEW_DTYPE, gs_frame_params, gs_frame_stats, gs_stage_times,
+                   make_asset_desc)
 from ._lib import GsError, check
 from .asset import GaussianSplatAsset, kCurrentVersion
 from .camera import Camera, Transform, frame_params, sort_matrix
@@ -48,6 +49,11 @@ class RenderMode(enum.IntEnum):          # GaussianSplatRenderer.RenderMode (:21
     DebugPointIndices = 2
     DebugBoxes = 3
     DebugChunkBounds = 4
+
+
+class SortMode(enum.IntEnum):            # gs_sort_mode: what SortPoints sorts (no counterpart in the reference, whose sort precedes its cull)
+    Full = GS_SORT_FULL                  # all N splats, every SortPoints, like GaussianSplatRenderer.SortPoints (:612-639)
+    Visible = GS_SORT_VISIBLE            # cull first: only the splats CalcViewData found visible, inside Draw
 
 
 class GpuContext:
@@ -204,6 +210,7 @@ class GaussianSplatRenderer:
         self.m_Cutouts: Optional[List[Optional[GaussianCutout]]] = None      # :244
         self.m_FrameCounter = 0
         self.blendMode = 0            # 0 exact (fp16 ROP rounding), 1 fast (fp32 accumulate)
+        self.sortMode = SortMode.Full # applied to the native renderer when its resources are created (SetSortMode changes it later)
         self._asset_h = C.c_void_p()
         self._r_h = C.c_void_p()
         self._keep: list = []
@@ -246,6 +253,8 @@ class GaussianSplatRenderer:
         self._keep = []                              # data was copied to the GPU
         check(_lib.lib().gs_renderer_create(self.ctx._h, self._asset_h, C.byref(self._r_h)), "gs_renderer_create")
         self.m_SplatCount = a.splatCount
+        if self.sortMode != SortMode.Full:
+            check(_lib.lib().gs_renderer_set_sort_mode(self._r_h, int(self.sortMode)), "gs_renderer_set_sort_mode")
 
     def DisposeResourcesForAsset(self) -> None:     # :527-565
         l = _lib.lib()
@@ -356,6 +365,27 @@ class GaussianSplatRenderer:
         """True: run the reference's full CSCalcViewData every frame (m_GpuView written); False (default): colours only for
         splats that reach the screen, m_GpuView materialised by DownloadView on demand."""
         check(_lib.lib().gs_renderer_set_view_buffer_mode(self._r_h, int(bool(every_frame))), "gs_renderer_set_view_buffer_mode")
+
+    def SetSortMode(self, mode: SortMode) -> None:
+        """SortMode.Visible: cull before sorting -- SortPoints only records its matrix and Draw sorts the splats CalcViewData found visible
+        (same frame, same order among the drawn splats; include/gsplat_c.h gs_renderer_set_sort_mode for the conditions)."""
+        self.sortMode = SortMode(mode)
+        if self._r_h:
+            check(_lib.lib().gs_renderer_set_sort_mode(self._r_h, int(self.sortMode)), "gs_renderer_set_sort_mode")
+
+    def SortModeActive(self) -> bool:
+        """True while the visible-only path is what the next Draw uses (the mode is set, the order buffer is CSSetIndices' identity plus sorts
+        made in this mode, and no tie overflow has sent the renderer back to full sorts)."""
+        m, a = C.c_int32(), C.c_int32()
+        check(_lib.lib().gs_renderer_sort_mode(self._r_h, C.byref(m), C.byref(a)), "gs_renderer_sort_mode")
+        return bool(a.value)
+
+    def DownloadVisibleOrder(self) -> np.ndarray:
+        """SortMode.Visible: the depth-ordered indices of the visible splats (the visible subsequence of the reference's _OrderBuffer)."""
+        out = np.empty(self.m_SplatCount, np.uint32)
+        cnt = C.c_uint32()
+        check(_lib.lib().gs_renderer_download_visible_order(self._r_h, out.ctypes.data, len(out), C.byref(cnt)), "gs_renderer_download_visible_order")
+        return out[:cnt.value].copy()
 
     def SetProfiling(self, frames: int) -> None:
         """frames = 0 off; > 0: ring of per-frame hipEvent sets, averaged by StageTimes()."""
@@ -505,9 +535,9 @@ class GaussianSplatRenderSystem:
                 try:
                     gs.FrameStats()
                 except GsError as e:
-                    if e.code != GS_ERR_PAIR_OVERFLOW:
+                    if e.code not in (GS_ERR_PAIR_OVERFLOW, GS_ERR_TIE_OVERFLOW):
                         raise
-                    overflowed = True                         # the buffer has been grown by the call
+                    overflowed = True                         # the buffer has been grown / the renderer has fallen back to full sorts by the call
             if overflowed:                                     # same frame again: the order is already sorted, only the draws repeat
                 rt.Clear()
                 for gs in self.m_ActiveSplats:
