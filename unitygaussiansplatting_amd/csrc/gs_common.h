@@ -74,9 +74,15 @@ struct SortState {
     uint32_t epoch = 0;                     // last epoch used on `status` / `groupIncl` (18 bits, never 0)
 };
 
+// The digit histograms of a sort are accumulated by hundreds of workgroups flushing their LDS counts with global atomics; atomics on
+// the same 128-byte line queue behind each other at the memory side, and 1024 bins are only 32 lines (visible_keys_kernel: 749 workgroups x
+// 512 atomics = 12,000 per line, most of its 26 us).  So there are kHistReplicas copies, 4 KB apart; workgroup b adds to copy b % kHistReplicas
+// and the one reader (every Onesweep workgroup, once per pass) sums the copies.
+constexpr int kHistReplicas = 8;
+constexpr int kHistStride = 4 * 256;      // words between two copies
 // small per-sort control block (zeroed by one memset before each sort)
 struct SortControl {
-    uint32_t hist[4 * 256];       // digit histograms, then exclusive offsets
+    uint32_t hist[kHistReplicas * kHistStride];   // digit histograms [copy][pass][digit]: raw counts
     uint32_t tickets[4][16 * 32]; // partition tickets: per pass, 16 counters (ticket classes) in separate 128-B lines
     uint32_t error;               // != 0: bounded spin expired
     uint32_t pad[3];
@@ -101,8 +107,12 @@ struct VisControl {
     uint32_t tieExhausted;         // pairs of tied splats with different positions that no kept matrix separates (ordered by index)
     uint32_t error;                // bounded spin expired
     uint32_t pad[28];
-    uint32_t status[kVisMaxBlocks];// visible count of block b, + 1 (0 = not published yet)
+    // visible count of block b, + 1 (0 = not published yet), one word per 64 bytes: block b polls the words of ALL blocks before it with
+    // agent-scope loads, and loads of one 128-byte line queue behind each other at the memory side (749 blocks: 280,000 loads on 24 lines
+    // when the words were packed)
+    uint32_t status[kVisMaxBlocks * 16];
 };
+constexpr uint32_t kVisStatusStride = 16;
 struct TieHistory { float row[kVisHistory][4]; uint32_t depth; };   // row[0] = the matrix the keys were made with; depth >= 1
 
 // The two words every workgroup hits with an atomic (ticket, visible) sit in their own 128-B lines: same-address

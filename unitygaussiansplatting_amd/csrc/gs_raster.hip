@@ -469,9 +469,10 @@ __global__ __launch_bounds__(kBinThreads) void bin_emit_kernel(const uint2* __re
         __syncthreads();
     }
     if (tid == 0 && visAcc) atomicAdd(&ctl->visible, visAcc);
+    uint32_t* myHist = pairHist + (bid % (uint32_t)kHistReplicas) * (uint32_t)kHistStride;      // SortControl::hist: one of the copies
     for (int j = tid; j < PASSES * 256; j += kBinThreads) {
         const uint32_t c = s_hist[j];
-        if (c) atomicAdd(&pairHist[j], c);
+        if (c) atomicAdd(&myHist[j], c);
     }
 }
 
@@ -481,16 +482,16 @@ __global__ __launch_bounds__(kBinThreads) void bin_emit_kernel(const uint2* __re
 // near the camera, where the splats are large on screen, most splats are culled, so a partition holds few of them.  The visible order has no
 // such dilution -- its first partitions are 1024 of the largest splats each, emitted by four waves while a thousand workgroups wait (measured,
 // C3: 308 us against 106 us for the full order; C2d 260 against 99).  Here the pair array itself is what is partitioned:
-//   vis_offsets_kernel   the rectangle gather, then the first output slot of every position (exclusive scan of the tile counts, one fat workgroup
-//                        per CU over a contiguous range of positions: count, publish, sum the <= 255 totals before, add) and, for every chunk of
-//                        kEmitChunk output slots, the position its first slot belongs to (the position that straddles the boundary writes it: no
-//                        search anywhere);
+//   vis_count_kernel     the rectangle gather rects[order[i]] (left by sorted position for the emission), tile counts, block-local offsets,
+//                        block and group totals -- thin workgroups, nobody waits;
+//   vis_offsets_kernel   global offsets (groups before + earlier blocks of the own group: one load per thread) and, for every chunk of kEmitChunk
+//                        output slots, the position its first slot belongs to (the position that straddles the boundary writes it: no search
+//                        anywhere); the draw's totals;
 //   vis_emit_kernel      one chunk of kEmitChunk output slots per workgroup and step, whatever the footprints are: load the positions that
 //                        own them (coalesced: offset, index, rectangle by sorted position -- vis_offsets_kernel made the gather and left the
 //                        rectangles there), find every slot's owner with marks + a max-scan, write four consecutive pairs per thread.
 // No chunk waits for another one.  Side duties of bin_emit (pair-sort histograms, zeroing the next draw's arena and the pair sort's
 // aggregates, visible count, the draw's pair count, the tile schedule) are split between the two.
-constexpr int kVoThreads = 1024;
 constexpr uint32_t kEmitChunk = 1024;
 constexpr int kEmitThreads = 256;
 constexpr int kEmitBatches = 5;                                  // x 256 positions >= kEmitChunk + 1 owners of one chunk
@@ -504,62 +505,51 @@ __device__ __forceinline__ uint32_t rect_tiles(uint32_t rx, uint32_t ry, uint32_
     return (tx1 - tx0 + 1u) * (ty1 - ty0 + 1u);
 }
 
-__device__ __forceinline__ unsigned long long wave_incl_scan_u64(unsigned long long v, int lane) {
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const unsigned long long u = __shfl_up(v, o, 64); if (lane >= o) v += u; }
-    return v;
-}
 __device__ __forceinline__ uint32_t sat32(unsigned long long v) { return v < 0xffffffffull ? (uint32_t)v : 0xffffffffu; }
 
-// One fat workgroup per CU over a contiguous range of sorted positions, four CONSECUTIVE positions per thread and step (16-byte loads and
-// stores).  Pass 1: the rectangle gather -- rects[order[i]], the one random access of the binning: 2.2 M sectors at C2, four in flight per
-// thread -- left by sorted position (rectX / rectY) for the emission, tile counts, block-local exclusive offsets.  Then the block's total is
-// published and the totals of the blocks before it summed (block b only waits on blocks the dispatcher started before it).  Pass 2 adds the
-// base and lets every position that straddles a multiple of kEmitChunk claim that chunk.
-__global__ __launch_bounds__(kVoThreads) void vis_offsets_kernel(const uint2* __restrict__ rects, const uint32_t* __restrict__ order, const VisControl* __restrict__ vis,
-                                                                 uint32_t nImm, uint32_t tileShift, uint32_t capacity, BinControl* ctl, unsigned long long* status,
-                                                                 uint32_t* pairOffset, uint32_t* __restrict__ chunkStart, uint32_t capChunks,
-                                                                 uint32_t* __restrict__ rectX, uint32_t* __restrict__ rectY,
-                                                                 unsigned long long* __restrict__ groupAgg, uint32_t groupAggWords, uint32_t* __restrict__ nextArena, uint32_t nextArenaWords) {
-    constexpr int NW = kVoThreads / 64;
-    constexpr uint32_t STEP = kVoThreads * 4u;
-    __shared__ unsigned long long s_w64[NW];
-    __shared__ uint32_t s_w32[NW];
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    for (uint32_t j = blockIdx.x * (uint32_t)kVoThreads + tid; j < groupAggWords; j += gridDim.x * (uint32_t)kVoThreads) groupAgg[j] = 0ull;      // for the pair sort's look-back
-    for (uint32_t j = blockIdx.x * (uint32_t)kVoThreads + tid; j < nextArenaWords; j += gridDim.x * (uint32_t)kVoThreads) nextArena[j] = 0u;       // the NEXT draw's zeroed arena
+// vis_count_kernel: 256 sorted positions per WAVE, four CONSECUTIVE positions per lane (16-byte loads and stores), no barrier anywhere, as many
+// waves resident as fit -- the rectangle gather rects[order[i]] is the one random access of the binning (2.2 M sectors at C2) and its rate
+// is the misses the CUs keep in flight, i.e. resident waves x independent gathers per lane.  Leaves, by sorted position, the rectangle
+// (rectX / rectY) and the wave-LOCAL first pair slot; per wave block its pair total (+ drawn positions), added to the word of its group of 64
+// wave blocks.  Nobody waits for anybody.  The grid follows the visible count the last draw reported; it strides, so any count is covered.
+constexpr int kVcThreads = 256;
+constexpr uint32_t kVcBlock = 256u;                              // positions per wave block
+constexpr uint32_t kVcGroup = 64;                                // wave blocks per group word
+__global__ __launch_bounds__(kVcThreads) void vis_count_kernel(const uint2* __restrict__ rects, const uint32_t* __restrict__ order, const VisControl* __restrict__ vis,
+                                                               uint32_t nImm, uint32_t tileShift, BinControl* ctl, unsigned long long* __restrict__ blockSum,
+                                                               unsigned long long* groupSum, uint32_t* __restrict__ pairOffset,
+                                                               uint32_t* __restrict__ rectX, uint32_t* __restrict__ rectY,
+                                                               unsigned long long* __restrict__ groupAgg, uint32_t groupAggWords, uint32_t* __restrict__ nextArena, uint32_t nextArenaWords) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    for (uint32_t j = blockIdx.x * (uint32_t)kVcThreads + tid; j < groupAggWords; j += gridDim.x * (uint32_t)kVcThreads) groupAgg[j] = 0ull;      // for the pair sort's look-back
+    for (uint32_t j = blockIdx.x * (uint32_t)kVcThreads + tid; j < nextArenaWords; j += gridDim.x * (uint32_t)kVcThreads) nextArena[j] = 0u;       // the NEXT draw's zeroed arena
     const uint32_t V = min(vis->count, nImm);
-    const uint32_t shx = tileShift & 0xffu, shy = tileShift >> 8;
-    const uint32_t R = ((V + gridDim.x - 1u) / gridDim.x + 3u) & ~3u;      // positions per block, a multiple of 4 (V <= 2^30)
-    const uint32_t b0 = min(blockIdx.x * R, V), b1 = min(b0 + R, V);
     if (blockIdx.x == 0u && tid == 0) { ctl->tieFlags = vis->tieFlags; ctl->tieExhausted = vis->tieExhausted; }      // what the visible sort's fix-up reported, for the draw's report
-    // ---- pass 1
-    unsigned long long running = 0ull;                           // block-local first slot of the next step (uniform)
-    uint32_t drawn = 0u;
-    for (uint32_t t0 = b0; t0 < b1; t0 += STEP) {
-        const uint32_t i0 = t0 + (uint32_t)tid * 4u;
+    const uint32_t shx = tileShift & 0xffu, shy = tileShift >> 8;
+    const uint32_t waves = gridDim.x * (uint32_t)(kVcThreads / 64);
+    for (uint32_t wb = blockIdx.x * (uint32_t)(kVcThreads / 64) + (uint32_t)(tid >> 6); (unsigned long long)wb * kVcBlock < V; wb += waves) {      // (wave-uniform)
+        const uint32_t b0 = wb * kVcBlock, b1 = min(b0 + kVcBlock, V);
+        const uint32_t i0 = b0 + (uint32_t)lane * 4u;
         const bool all4 = i0 + 3u < b1;
         uint32_t o[4];
         if (all4) { const uint4 ov = *(const uint4*)(order + i0); o[0] = ov.x; o[1] = ov.y; o[2] = ov.z; o[3] = ov.w; }
         else {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) o[k] = order[min(i0 + (uint32_t)k, V - 1u)];              // (V >= 1: the loop runs)
+            for (int k = 0; k < 4; ++k) o[k] = order[min(i0 + (uint32_t)k, V - 1u)];
         }
         uint2 rc[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) rc[k] = rects[o[k]];
-        uint32_t c[4];
+        uint32_t c[4], drawn = 0u;
 #pragma unroll
         for (int k = 0; k < 4; ++k) { uint32_t a, b; c[k] = (i0 + (uint32_t)k < b1) ? rect_tiles(rc[k].x, rc[k].y, shx, shy, a, b) : 0u; drawn += c[k] ? 1u : 0u; }
         const unsigned long long mine = (unsigned long long)c[0] + c[1] + c[2] + c[3];
-        const unsigned long long incl = wave_incl_scan_u64(mine, lane);
-        __syncthreads();                                         // the previous step's s_w64 is no longer read
-        if (lane == 63) s_w64[w] = incl;
-        __syncthreads();
-        unsigned long long wbase = 0ull, stepTotal = 0ull;
+        unsigned long long incl = mine;
 #pragma unroll
-        for (int k = 0; k < NW; ++k) { const unsigned long long t = s_w64[k]; wbase += (k < w) ? t : 0ull; stepTotal += t; }
-        unsigned long long l = running + wbase + incl - mine;
+        for (int d = 1; d < 64; d <<= 1) { const unsigned long long u = __shfl_up(incl, d, 64); if (lane >= d) incl += u; }
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) drawn += __shfl_xor(drawn, d, 64);
+        unsigned long long l = incl - mine;
         uint32_t lo[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) { lo[k] = sat32(l); l += c[k]; }
@@ -571,57 +561,74 @@ __global__ __launch_bounds__(kVoThreads) void vis_offsets_kernel(const uint2* __
 #pragma unroll
             for (int k = 0; k < 4; ++k) if (i0 + (uint32_t)k < b1) { rectX[i0 + k] = rc[k].x; rectY[i0 + k] = rc[k].y; pairOffset[i0 + k] = lo[k]; }
         }
-        running += stepTotal;
-    }
-    const unsigned long long total = running;
-#pragma unroll
-    for (int o2 = 32; o2 > 0; o2 >>= 1) drawn += __shfl_xor(drawn, o2, 64);
-    __syncthreads();
-    if (lane == 0) s_w32[w] = drawn;
-    __syncthreads();
-    if (tid == 0) {
-        uint32_t d = 0u;
-        for (int k = 0; k < NW; ++k) d += s_w32[k];
-        __hip_atomic_store(status + blockIdx.x, total + 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (d) atomicAdd(&ctl->visible, d);
-    }
-    // ---- the totals of the blocks before this one
-    unsigned long long before = 0ull;
-    for (uint32_t j = (uint32_t)tid; j < blockIdx.x; j += kVoThreads) {
-        unsigned long long v = 0ull; uint32_t spins = 0;
-        for (;;) {
-            v = __hip_atomic_load(status + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (v) break;
-            if (++spins > BIN_SPIN_LIMIT) { atomicOr(&ctl->error, 2u); v = 1ull; break; }
-            __builtin_amdgcn_s_sleep(1);
+        if (lane == 63) {
+            // {drawn positions:20 | pairs:44}: a wave block holds 256 positions of <= 2^24 tiles each, a group 64 of them: neither field overflows
+            const unsigned long long word = ((unsigned long long)drawn << 44) | incl;
+            blockSum[wb] = word;
+            __hip_atomic_fetch_add(groupSum + wb / kVcGroup, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        before += v - 1ull;
     }
+}
+
+// vis_offsets_kernel: the same wave blocks again (a launch boundary = every total is there).  A wave block's first slot = the words of the
+// groups before its own + the words of the earlier blocks of its group (a few loads per lane, no waiting); the wave-local offsets become global
+// ones and every position whose slots straddle a multiple of kEmitChunk claims that chunk for the emission.  Workgroup 0 also leaves the draw's
+// totals.
+__global__ __launch_bounds__(kVcThreads) void vis_offsets_kernel(const VisControl* __restrict__ vis, uint32_t nImm, uint32_t capacity, BinControl* ctl,
+                                                                 const unsigned long long* __restrict__ blockSum, const unsigned long long* __restrict__ groupSum,
+                                                                 uint32_t* pairOffset, uint32_t* __restrict__ chunkStart, uint32_t capChunks) {
+    constexpr int NW = kVcThreads / 64;
+    constexpr unsigned long long PAIRS = (1ull << 44) - 1ull;
+    __shared__ unsigned long long s_w64[2 * NW];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const uint32_t V = min(vis->count, nImm);
+    const uint32_t numBlocks = (V + kVcBlock - 1u) / kVcBlock, numGroups = (numBlocks + kVcGroup - 1u) / kVcGroup;
+    if (blockIdx.x == 0u) {                                      // the draw's totals (also when nothing is visible)
+        unsigned long long pairs = 0ull, drawn = 0ull;          // (the two fields separately: over many groups either would carry)
+        for (uint32_t j = (uint32_t)tid; j < numGroups; j += kVcThreads) { const unsigned long long g = groupSum[j]; pairs += g & PAIRS; drawn += g >> 44; }
 #pragma unroll
-    for (int o2 = 32; o2 > 0; o2 >>= 1) before += __shfl_xor(before, o2, 64);
-    __syncthreads();
-    if (lane == 0) s_w64[w] = before;
-    __syncthreads();                                             // (also: pass 1's pairOffset stores are visible to the whole block)
-    unsigned long long base = 0ull;
-    for (int k = 0; k < NW; ++k) base += s_w64[k];
-    if (blockIdx.x == gridDim.x - 1u && tid == 0) {
-        const unsigned long long P = base + total;
-        ctl->pairCount = P;
-        ctl->pairCountClamped = (uint32_t)(P < (unsigned long long)capacity ? P : (unsigned long long)capacity);
-        if (P > (unsigned long long)capacity) atomicOr(&ctl->error, 1u);
-    }
-    // ---- pass 2: global offsets; the position whose slots straddle a multiple of kEmitChunk is that chunk's first owner
-    for (uint32_t t0 = b0; t0 < b1; t0 += STEP) {
-        const uint32_t i0 = t0 + (uint32_t)tid * 4u;
-        uint32_t l[5];
-#pragma unroll
-        for (int k = 0; k < 5; ++k) l[k] = (i0 + (uint32_t)k < b1) ? pairOffset[i0 + k] : sat32(total);      // (l[4]: the next thread's first: read before anyone writes)
+        for (int d = 32; d > 0; d >>= 1) { pairs += __shfl_xor(pairs, d, 64); drawn += __shfl_xor(drawn, d, 64); }
+        if (lane == 0) { s_w64[w] = pairs; s_w64[NW + w] = drawn; }
         __syncthreads();
+        if (tid == 0) {
+            unsigned long long P = 0ull, D = 0ull;
+            for (int k = 0; k < NW; ++k) { P += s_w64[k]; D += s_w64[NW + k]; }
+            ctl->pairCount = P;
+            ctl->pairCountClamped = (uint32_t)(P < (unsigned long long)capacity ? P : (unsigned long long)capacity);
+            if (P > (unsigned long long)capacity) atomicOr(&ctl->error, 1u);
+            ctl->visible = (uint32_t)D;
+        }
+    }
+    const uint32_t waves = gridDim.x * (uint32_t)NW;
+    for (uint32_t wb = blockIdx.x * (uint32_t)NW + (uint32_t)w; (unsigned long long)wb * kVcBlock < V; wb += waves) {      // (wave-uniform)
+        const uint32_t b0 = wb * kVcBlock, b1 = min(b0 + kVcBlock, V);
+        const uint32_t grp = wb / kVcGroup, grpStart = grp * kVcGroup;
+        unsigned long long acc = 0ull;
+        for (uint32_t j = (uint32_t)lane; j < grp; j += 64u) acc += groupSum[j] & PAIRS;             // (2^14 positions x 2^24 tiles per group fit the field)
+        if (grpStart + (uint32_t)lane < wb) acc += blockSum[grpStart + lane] & PAIRS;                // < 64 earlier wave blocks of the own group
+        const unsigned long long total = blockSum[wb] & PAIRS;
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) acc += __shfl_xor(acc, d, 64);
+        const unsigned long long base = acc;
+        const uint32_t i0 = b0 + (uint32_t)lane * 4u;
+        uint32_t l[5];
+        const bool all4 = i0 + 3u < b1;
+        if (all4) { const uint4 lv = *(const uint4*)(pairOffset + i0); l[0] = lv.x; l[1] = lv.y; l[2] = lv.z; l[3] = lv.w; }
+        else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) l[k] = (i0 + (uint32_t)k < b1) ? pairOffset[i0 + k] : sat32(total);
+        }
+        l[4] = (uint32_t)__shfl_down((int)l[0], 1, 64);          // the next lane's first (wave-local offsets: read before anyone writes)
+        if (lane == 63 || i0 + 4u >= b1) l[4] = sat32(total);
+        uint32_t g[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) g[k] = sat32(l[k] == 0xffffffffu ? 0xffffffffull : base + l[k]);      // (slots beyond the capacity, <= 2^30, are never emitted)
+        if (all4) *(uint4*)(pairOffset + i0) = make_uint4(g[0], g[1], g[2], g[3]);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             if (i0 + (uint32_t)k >= b1) continue;
             const unsigned long long off = l[k] == 0xffffffffu ? 0xffffffffull : base + l[k];
-            pairOffset[i0 + k] = sat32(off);                     // (slots beyond the capacity, <= 2^30, are never emitted)
+            if (!all4) pairOffset[i0 + k] = g[k];
             const uint32_t c = l[k + 1] - l[k];
             if (c && off < 0xffffffffull) {
                 const unsigned long long c0 = (off + kEmitChunk - 1ull) / kEmitChunk, c1 = (off + c - 1ull) / kEmitChunk;
@@ -754,9 +761,10 @@ __global__ __launch_bounds__(kEmitThreads) void vis_emit_kernel(const uint32_t* 
         }
         __syncthreads();
     }
+    uint32_t* myHist = pairHist + (bid % (uint32_t)kHistReplicas) * (uint32_t)kHistStride;      // SortControl::hist: one of the copies
     for (int j = tid; j < PASSES * 256; j += kEmitThreads) {
         const uint32_t c = s_hist[j];
-        if (c) atomicAdd(&pairHist[j], c);
+        if (c) atomicAdd(&myHist[j], c);
     }
 }
 
@@ -1257,8 +1265,9 @@ int32_t ensure_arena(gs_renderer* r, uint32_t numTiles) {
     size_t off = 0;
     off = align_up(sizeof(BinControl), 256);
     r->offPairControl = off; off += align_up(sizeof(SortControl), 256);
-    r->offBinStatus = off;   off += align_up((size_t)max(r->binParts, 256u) * 8, 256);      // (>= one word per workgroup of vis_offsets_kernel: one per CU)
-    r->offBinGroupAgg = off; off += align_up((size_t)((r->binParts + 63) / 64) * 8, 256);
+    // (GS_SORT_VISIBLE draws reuse the two arrays: one word per 256 positions = 8 binParts, one per 64 of those)
+    r->offBinStatus = off;   off += align_up((size_t)(8u * r->binParts + 1u) * 8, 256);
+    r->offBinGroupAgg = off; off += align_up((size_t)((8u * r->binParts + 64u) / 64u + 1u) * 8, 256);
     r->offBinGroupBase = off; off += align_up((size_t)((r->binParts + 63) / 64) * 8, 256);
     r->offTileStart = off;   off += align_up((size_t)numTiles * 4, 256);
     r->offTileEnd = off;     off += align_up((size_t)numTiles * 4, 256);
@@ -1388,10 +1397,18 @@ int32_t bin_and_sort(gs_renderer* r, const gs_frame_params* p, gs_target* rt, co
             GS_HIP(hipMalloc((void**)&r->visChunkStart, (size_t)capChunks * 4));
             r->visChunkCap = capChunks;
         }
-        const uint32_t voGrid = max(1u, min(min((uint32_t)ctx->cuCount, 256u), div_up(count, (uint32_t)kVoThreads)));
-        hipLaunchKernelGGL(vis_offsets_kernel, dim3(voGrid), dim3(kVoThreads), 0, st, (const uint2*)r->rects, order, vis, count, shapeKey, cap, binCtl, binStatus,
-                           r->visPairOffset, r->visChunkStart, capChunks, r->visRectX, r->visRectY,
+        // (blockSum lives in the arena's bin-status words, groupSum -- zeroed, accumulated with atomics -- in its bin-group words: ensure_arena sizes both)
+        // (the host only knows the bound N: the grids follow the visible count of the last draw that reported, + 1/8, and stride)
+        const uint32_t lastVis = (r->hostReport && r->frameInFlight) ? *(volatile uint32_t*)&r->hostReport->visible : 0u;
+        const uint32_t gridFor = lastVis ? min(count, lastVis + lastVis / 8u + 4096u) : count;
+        // (8 workgroups per CU = every wave slot; 2 .. 64 per CU measured within 1 us of each other at C2, r05 call 11: the gather is at the
+        // memory system's random-sector rate whatever is in flight)
+        const uint32_t vcGrid = max(1u, min(div_up(gridFor, kVcBlock * (uint32_t)(kVcThreads / 64)), (uint32_t)ctx->cuCount * 8u));
+        hipLaunchKernelGGL(vis_count_kernel, dim3(vcGrid), dim3(kVcThreads), 0, st, (const uint2*)r->rects, order, vis, count, shapeKey, binCtl, binStatus, binGroupAgg,
+                           r->visPairOffset, r->visRectX, r->visRectY,
                            r->pairSort.groupAgg, sort_group_words(r->pairSort, cap, passes), (uint32_t*)nextArena, (uint32_t)(r->frameArenaBytes / 4));
+        hipLaunchKernelGGL(vis_offsets_kernel, dim3(vcGrid), dim3(kVcThreads), 0, st, vis, count, cap, binCtl, (const unsigned long long*)binStatus, (const unsigned long long*)binGroupAgg,
+                           r->visPairOffset, r->visChunkStart, capChunks);
         const uint32_t emitGrid = (uint32_t)ctx->cuCount * (tileCnt ? 4u : 5u);      // resident at once (36 / 28 KB of LDS)
         auto emitKernel = passes == 1 ? (tileCnt ? vis_emit_kernel<1, true> : vis_emit_kernel<1, false>)
                         : (passes == 2 ? (tileCnt ? vis_emit_kernel<2, true> : vis_emit_kernel<2, false>) : vis_emit_kernel<3, false>);

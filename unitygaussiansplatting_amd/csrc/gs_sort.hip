@@ -113,9 +113,10 @@ __global__ __launch_bounds__(256) void histogram_kernel(const uint32_t* __restri
         for (int p = 0; p < passes; ++p) lds_hist_add(s_h + p * RADIX, (key >> (8 * p)) & (p == passes - 1 ? lastMask : 255u));
     }
     __syncthreads();
+    uint32_t* myHist = hist + (blockIdx.x % (uint32_t)kHistReplicas) * (uint32_t)kHistStride;      // SortControl::hist: one of the copies
     for (int j = threadIdx.x; j < passes * RADIX; j += 256) {
         const uint32_t c = s_h[j];
-        if (c) atomicAdd(&hist[j], c);
+        if (c) atomicAdd(&myHist[j], c);
     }
 }
 
@@ -194,9 +195,10 @@ __global__ __launch_bounds__(1024) void sort_keys_kernel(gsm::AssetView a, float
         }
     }
     __syncthreads();
+    uint32_t* myHist = hist + (blockIdx.x % (uint32_t)kHistReplicas) * (uint32_t)kHistStride;      // SortControl::hist: one of the copies
     for (int j = threadIdx.x; j < 4 * RADIX; j += 1024) {
         const uint32_t c = s_h[j];
-        if (c) atomicAdd(&hist[j], c);
+        if (c) atomicAdd(&myHist[j], c);
     }
 }
 
@@ -244,14 +246,21 @@ __global__ __launch_bounds__(THREADS, KPT == KPT_B ? 4 : kMinWavesA) void oneswe
     uint32_t histExcl = 0;
     bool digitLive = false;                            // some key of the whole input holds this digit
     if (tid < RDX) {
-        const uint32_t c = hist[tid];
+        uint32_t c = 0;
+#pragma unroll
+        for (int rp = 0; rp < kHistReplicas; ++rp) c += hist[rp * kHistStride + tid];      // the copies of SortControl::hist (independent loads)
         digitLive = c != 0u;
         const uint32_t incl = wave_incl_scan(c, lane);
         if (lane == 63) s_htot[w] = incl;
         histExcl = incl - c;
     }
     bool quadLive = false;                             // threads < RDX/4 publish four digits' status words at a time
-    if (tid < RDX / 4) { const uint4 h4 = ((const uint4*)hist)[tid]; quadLive = (h4.x | h4.y | h4.z | h4.w) != 0u; }
+    if (tid < RDX / 4) {
+        uint32_t any = 0;
+#pragma unroll
+        for (int rp = 0; rp < kHistReplicas; ++rp) { const uint4 h4 = ((const uint4*)(hist + rp * kHistStride))[tid]; any |= h4.x | h4.y | h4.z | h4.w; }
+        quadLive = any != 0u;
+    }
     __syncthreads();
     if (tid < RDX)
         for (int k = 0; k < w; ++k) histExcl += s_htot[k];

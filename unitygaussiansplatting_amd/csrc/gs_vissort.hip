@@ -91,7 +91,7 @@ __global__ __launch_bounds__(VTHREADS, 6) void visible_keys_kernel(gsm::AssetVie
 #pragma unroll
         for (int k = 0; k < VWAVES; ++k) t += s_w[k];
         s_bcast[0] = t;
-        __hip_atomic_store(&vc->status[blockIdx.x], t + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&vc->status[blockIdx.x * kVisStatusStride], t + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
     const uint32_t total = s_bcast[0];
@@ -100,7 +100,7 @@ __global__ __launch_bounds__(VTHREADS, 6) void visible_keys_kernel(gsm::AssetVie
     for (uint32_t j = (uint32_t)tid; j < blockIdx.x; j += VTHREADS) {
         uint32_t v = 0, spins = 0;
         for (;;) {
-            v = __hip_atomic_load(&vc->status[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            v = __hip_atomic_load(&vc->status[j * kVisStatusStride], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (v) break;
             if (++spins > VIS_SPIN_LIMIT) { atomicOr(&vc->error, 1u); v = 1u; break; }
             __builtin_amdgcn_s_sleep(1);
@@ -190,9 +190,10 @@ __global__ __launch_bounds__(VTHREADS, 6) void visible_keys_kernel(gsm::AssetVie
         // two neighbouring bins per 64-bit atomic (a bin never reaches 2^32: no carry into its neighbour): every block holds every value
         // of the low digits, so the ~700 blocks queue on each bin's address (~12 ns per same-address atomic)
         __syncthreads();
+        unsigned long long* myHist = (unsigned long long*)(hist + (blockIdx.x % (uint32_t)kHistReplicas) * (uint32_t)kHistStride);      // SortControl::hist: one of the copies
         for (int j = tid; j < 2 * 256; j += VTHREADS) {
             const unsigned long long c = (unsigned long long)s_h[2 * j] | ((unsigned long long)s_h[2 * j + 1] << 32);
-            if (c) atomicAdd((unsigned long long*)hist + j, c);
+            if (c) atomicAdd(myHist + j, c);
         }
     }
 }
@@ -374,9 +375,9 @@ int32_t enqueue_visible_sort(gs_renderer* r) {
     const gsm::AssetView& a = r->asset->view;
     const uint32_t n = r->n;
     const uint32_t words = div_up(n, 64u);
-    // blocks of >= 128 visibility words (8,192 splats: 16 words per wave), at most ~1000 of them (C2: 749 on the 768 slots of 256 CUs)
-    static const uint32_t minWords = [] { const char* e = getenv("GSPLAT_VIS_BLOCKWORDS"); const int v = e ? atoi(e) : 0; return v >= 16 ? (uint32_t)v : 128u; }();
-    uint32_t blockWords = max(minWords, div_up(words, 1000u));
+    // blocks of >= 64 visibility words (4,096 splats), at most ~1000 of them (C2: 998 blocks of 96 words; measured on MI355X, r05 call 11: 22.7 us
+    // against 25.0 with 128-word and 30.0 with 256-word blocks -- the kernel is a chain of dependent round trips, more blocks in flight hide them)
+    uint32_t blockWords = max(64u, div_up(words, 1000u));
     blockWords = (blockWords + 3u) & ~3u;
     const uint32_t grid = div_up(words, blockWords);
     if (grid > kVisMaxBlocks) return fail(GS_ERR_INVALID_ARGUMENT, "visible sort: too many blocks");
