@@ -9,7 +9,7 @@ import numpy as np
 from unitygaussiansplatting_amd import camera, creator, scenes
 from unitygaussiansplatting_amd.asset import GaussianSplatAsset
 from unitygaussiansplatting_amd._lib import GsError
-from unitygaussiansplatting_amd.renderer import GaussianSplatRenderer, GpuContext, RenderTarget
+from unitygaussiansplatting_amd.renderer import GaussianSplatRenderer, GpuContext, RenderTarget, SortMode
 
 key = sys.argv[1] if len(sys.argv) > 1 else "C2"
 frames = int(sys.argv[2]) if len(sys.argv) > 2 else 30
@@ -23,6 +23,7 @@ else:
     asset.Save("/tmp/gsplat_cache")
 ctx = GpuContext(0)
 r = GaussianSplatRenderer(ctx, asset)
+r.sortMode = SortMode.Visible if os.environ.get("GS_SORT_MODE", "visible") == "visible" else SortMode.Full      # GS_SORT_MODE=full: the reference-shaped sort
 r.OnEnable()
 r.blendMode = mode
 r.m_SHOrder = int(os.environ.get("GS_SH_ORDER", "3"))
@@ -64,5 +65,5 @@ if noprof:
     sys.exit(0)
 t = r.StageTimes()
 out = {k: round(getattr(t, k), 4) for k, _ in t._fields_ if k.endswith("_ms") and k != "resolve_ms"}
-out.update(wall_ms=round(wall, 4), P=int(st.tile_pairs), lib=os.path.basename(os.environ.get("GSPLAT_LIB", "default")), mode=mode, cfg=key, sh=r.m_SHOrder)
+out.update(wall_ms=round(wall, 4), P=int(st.tile_pairs), V=int(st.visible_splats), sort=("visible" if r.SortModeActive() else "full"), lib=os.path.basename(os.environ.get("GSPLAT_LIB", "default")), mode=mode, cfg=key, sh=r.m_SHOrder)
 print(json.dumps(out), flush=True)

@@ -18,3 +18,28 @@ for k, cs in sorted(acc.items()):
         if c in m:
             extra = f"  ({100 * m[c] / wc:5.1f} % of wave cycles)" if wc and c in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS", "SQ_ACTIVE_INST_VMEM", "SQ_WAIT_INST_LDS") else ""
             print(f"   {c:24s} {m[c]:16.0f}{extra}")
+
+# ---- profiles/valu_insts.json: SQ_INSTS_VALU per launch of the VALU-bound kernels, for bench.py's VALU roofline (python scripts/pmc_sq_summary.py C2 r05)
+if len(sys.argv) > 1:
+    import json
+    cfg = sys.argv[1]; tag = sys.argv[2] if len(sys.argv) > 2 else ""
+    P_ = V_ = None
+    try:
+        jl = [l for l in open(os.path.join(P, "p1.log")) if l.startswith("{")]
+        jj = json.loads(jl[-1]); P_ = jj.get("P"); V_ = jj.get("V")
+    except Exception:
+        pass
+    ks = {}
+    for k, cs in acc.items():
+        base = re.sub(r"<.*", "", k)
+        if base in ("blend_kernel", "calc_view_kernel") and "SQ_INSTS_VALU" in cs:
+            v = cs["SQ_INSTS_VALU"]
+            ks[base] = {"valu_wave_insts": int(sum(v) / len(v)), "launches_sampled": len(v)}
+    path = os.path.join(ROOT, "profiles", "valu_insts.json")
+    allc = {}
+    if os.path.exists(path):
+        try: allc = json.load(open(path)).get("configs", {})
+        except Exception: allc = {}
+    allc[cfg] = {"config": cfg, "tile_pairs_P": P_, "visible_splats": V_, "kernels": ks,
+                 "source": f"rocprofv3 --pmc SQ_INSTS_VALU ... on `scripts/bench_stages.py {cfg}` (scripts/pmc_sq.sh), {tag}: mean wave-level VALU instructions per launch"}
+    json.dump({"configs": allc}, open(path, "w"), indent=1)

@@ -2,14 +2,23 @@
   profiles/<tag>_rocprof_kernel_stats_<cfg>.txt   per-kernel time summary (--kernel-trace --stats)
   profiles/hbm_traffic.json                       HBM bytes per launch per kernel from the FETCH_SIZE / WRITE_SIZE PMC passes,
                                                   corrected with factors calibrated on known-byte-count kernels in the same session
-Usage: python scripts/pmc_traffic.py <tag> [config]"""
+Usage: python scripts/pmc_traffic.py <tag> [config] [visible|full]     (the sort mode the bench ran in; stored under "<config>_visible" / "<config>")"""
 import csv, glob, json, os, re, sys
 from collections import defaultdict
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 config = sys.argv[2] if len(sys.argv) > 2 else "C2"
-P = os.path.join(ROOT, "gpurun_out", "prof_" + config)
+mode = sys.argv[3] if len(sys.argv) > 3 else "visible"
+key = config + ("_visible" if mode == "visible" else "")
+P = os.path.join(ROOT, "gpurun_out", "prof_" + key)
 if not os.path.isdir(P): P = os.path.join(ROOT, "gpurun_out", "prof")
+# the frame the counters were collected on (bench.py refuses to pair a stored traffic with a frame whose pair count differs by > 2 %)
+bench_P = bench_V = None
+try:
+    bl = [l for l in open(os.path.join(P, "bench_FETCH_SIZE.json")) if l.startswith("{")]
+    bj = json.loads(bl[-1]); bench_P = bj["config"]["tile_pairs_P"]; bench_V = bj["config"]["visible_splats"]
+except Exception:
+    pass
 
 def short(name):
     name = name.replace("(anonymous namespace)::", "").replace("void ", "")
@@ -28,14 +37,24 @@ cf, cw = counters("calib_FETCH_SIZE"), counters("calib_WRITE_SIZE")
 cal = {}
 for k in ("calib_read_b32", "calib_read_b128"):
     if k in cf: cal[k] = {"FETCH_SIZE_KiB": sum(cf[k]) / len(cf[k]), "true_over_counter": GIB_KIB / (sum(cf[k]) / len(cf[k]))}
+# random gathers (round 5): what FETCH_SIZE tallies per LONE request -- 2,200,000 8-byte / 6,131,954 4-byte gathers (scripts/probes/pmc_calib.hip)
+for k, cnt in (("calib_gather_b64", 2200000), ("calib_gather_b32", 6131954)):
+    if k in cf: cal[k] = {"FETCH_SIZE_KiB": sum(cf[k]) / len(cf[k]), "bytes_tallied_per_gather": sum(cf[k]) / len(cf[k]) * 1024 / cnt,
+                          "note": "a coalesced stream is tallied at half its bytes (x2.0); a lone gather at ~42 B, i.e. at face value (factor 1.0 .. 64/42 = 1.53 if every request moved a whole 64-byte sector)"}
 for k in ("calib_write_b32", "calib_write_b128", "calib_scatter_runs32"):
     if k in cw: cal[k] = {"WRITE_SIZE_KiB": sum(cw[k]) / len(cw[k]), "true_over_counter": GIB_KIB / (sum(cw[k]) / len(cw[k]))}
     if k in cf: cal[k]["FETCH_SIZE_KiB_of_a_pure_write"] = sum(cf[k]) / len(cf[k])
 # which calibration applies to which kernel's dominant access width
 READ_CAL = {"onesweep_kernel": "calib_read_b32", "sort_keys_kernel": "calib_read_b32", "splat_depth_kernel": "calib_read_b32", "bin_emit_kernel": "calib_read_b32",
-            "tile_ranges_kernel": "calib_read_b32", "calc_view_kernel": "calib_read_b128", "blend_kernel": "calib_read_b128", "resolve_kernel": "calib_read_b128"}
+            "tile_ranges_kernel": "calib_read_b32", "calc_view_kernel": "calib_read_b128", "blend_kernel": "calib_read_b128", "resolve_kernel": "calib_read_b128",
+            "visible_keys_kernel": "calib_read_b32", "tie_fix_kernel": "calib_read_b32", "vis_count_kernel": "calib_read_b128", "vis_offsets_kernel": "calib_read_b128",
+            "vis_emit_kernel": "calib_read_b32"}
 WRITE_CAL = {"onesweep_kernel": "calib_scatter_runs32", "sort_keys_kernel": "calib_write_b32", "bin_emit_kernel": "calib_write_b32",
-             "calc_view_kernel": "calib_write_b128", "blend_kernel": "calib_write_b128", "resolve_kernel": "calib_write_b128"}
+             "calc_view_kernel": "calib_write_b128", "blend_kernel": "calib_write_b128", "resolve_kernel": "calib_write_b128",
+             "visible_keys_kernel": "calib_write_b32", "vis_count_kernel": "calib_write_b128", "vis_offsets_kernel": "calib_write_b128", "vis_emit_kernel": "calib_write_b128"}
+# kernels whose reads are dominated by LONE random gathers: the streaming factor (x2.0) over-counts them (profiles/r05_calib_gather.txt); their
+# traffic is reported as a range -- fetch counter at face value (x1.0) .. at the streaming factor (x2.0) -- and `hbm_bytes_per_launch` is the LOWER end
+GATHER_KERNELS = {"bin_emit_kernel", "vis_count_kernel"}
 def by_base(c):
     out = defaultdict(list)
     for k, v in c.items():
@@ -53,9 +72,13 @@ for k in sorted(set(bf) | set(bw)):
     kernels[base] = {"launches_sampled": len(bf.get(k, [])), "FETCH_SIZE_KiB_per_launch": round(f_kib, 1), "WRITE_SIZE_KiB_per_launch": round(w_kib, 1),
                      "read_factor": round(rf, 3), "write_factor": round(wf, 3),
                      "hbm_bytes_per_launch": int((f_kib * rf + w_kib * wf) * 1024)}
+    if base in GATHER_KERNELS:
+        kernels[base].update({"read_factor": 1.0, "hbm_bytes_per_launch": int((f_kib * 1.0 + w_kib * wf) * 1024), "hbm_bytes_per_launch_upper": int((f_kib * rf + w_kib * wf) * 1024),
+                              "note": "gather-dominated reads: FETCH_SIZE at face value (lower bound) .. at the streaming factor (upper bound); profiles/r05_calib_gather.txt"})
 os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
 tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-entry = {"config": config, "source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on `bench.py --config {config} --warmup 5`, {tag}",
+entry = {"config": config, "sort_mode": mode, "tile_pairs_P": bench_P, "visible_splats": bench_V,
+         "source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on `bench.py --config {config} --sort-mode {mode} --warmup 5`, {tag}",
          "units": "counters are KiB; true bytes = counter * factor * 1024, factors calibrated on 1-GiB kernels of the same access width in the same session",
          "calibration": cal, "kernels": kernels}
 allcfg = {}
@@ -65,7 +88,7 @@ if os.path.exists(tpath):
         allcfg = old.get("configs", {}) if "configs" in old else ({old["config"]: old} if "config" in old else {})
     except Exception:
         allcfg = {}
-allcfg[config] = entry
+allcfg[key] = entry
 json.dump({"configs": allcfg}, open(tpath, "w"), indent=1)
 
 # ---- kernel time summary
@@ -78,9 +101,9 @@ for f in glob.glob(os.path.join(P, "stats", "*", "*_kernel_trace.csv")):
         t = trace[short(r["Kernel_Name"])]
         t[0] = max(t[0], int(r.get("VGPR_Count", 0) or 0)); t[1] = max(t[1], int(r.get("SGPR_Count", 0) or 0)); t[2] = max(t[2], int(r.get("LDS_Block_Size", 0) or 0))
         t[3] = max(t[3], int(r.get("Grid_Size", 0) or r.get("Grid_Size_X", 0) or 0))
-outp = os.path.join(ROOT, "profiles", f"{tag}_rocprof_kernel_stats_{config.lower()}.txt")
+outp = os.path.join(ROOT, "profiles", f"{tag}_rocprof_kernel_stats_{key.lower()}.txt")
 with open(outp, "w") as o:
-    o.write(f"# rocprofv3 --kernel-trace --stats -- python bench.py --steps 20 --warmup 5 --cpu-baseline off   ({config}, {tag})\n")
+    o.write(f"# rocprofv3 --kernel-trace --stats -- python bench.py --config {config} --sort-mode {mode} --steps 20 --warmup 5 --cpu-baseline off --repeats 1   ({tag}; P = {bench_P}, visible = {bench_V})\n")
     o.write(f"{'kernel':34s} {'calls':>6s} {'total_us':>11s} {'avg_us':>9s} {'min_us':>9s} {'max_us':>9s} {'pct':>6s} {'vgpr':>5s} {'sgpr':>5s} {'lds':>6s} {'grid':>9s}\n")
     for r in sorted(rows, key=lambda r: -float(r["TotalDurationNs"])):
         n = short(r["Name"]); t = trace.get(n, [0, 0, 0, 0])

@@ -99,6 +99,30 @@ def test_bench_gpus_2_without_gpus_fails_loudly():
     assert "GPU" in (p.stderr + p.stdout)
 
 
+@pytest.mark.parametrize("config,want_views", [("C5", [[0, 2, 4, 6], [1, 3, 5, 7]]), ("C2", [[0], [1]])])
+def test_bench_two_ranks_dry_run_under_gloo(config, want_views):
+    """bench.py's N > 1 control flow without GPUs (`--dry-run`: no device work): the self-spawn under torch.distributed.run on 127.0.0.1,
+    the gloo host group, the per-rank view assignment, the max-over-ranks reduction and the schema of the N > 1 JSON line."""
+    import json
+    import subprocess
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--config", config, "--steps", "4", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout                                  # rank 0 alone prints
+    out = json.loads(lines[0])
+    assert out["dry_run"] is True and out["n_gpus"] == 2 and out["steps"] == 4
+    assert out["views_per_rank"] == want_views
+    assert out["ms_per_step_per_rank"] == [1.0, 2.0] and out["ms_per_step"] == 2.0      # the pretend regions: rank k takes (1 + k) ms per step; MAX over ranks
+    assert out["scaling"] == ("strong" if config == "C5" else "weak")
+    assert out["config"]["host_group"] == "gloo" and "rccl_ranks" in out["config"]
+    for k in ("metric", "value", "unit", "higher_is_better", "vs_baseline", "dtype", "data", "roofline", "roofline_blend", "roofline_streaming", "cpu_baseline"):
+        assert k in out
+
+
 @pytest.mark.gpu
 def test_rccl_asset_broadcast_single_rank(gpu_ctx):
     """gs_comm_create / gs_asset_broadcast with nranks = 1 (librccl called directly from the library): the asset that comes

@@ -176,22 +176,22 @@ int32_t gs_comm_info(const gs_comm* c, int32_t* nranks, int32_t* rank) {
 // status exchange (a blob broadcast or the final synchronise failing) and errors returned by a collective call itself are fatal
 // for the communicator: destroy it (the other ranks' collectives fail in turn).
 int32_t gs_asset_broadcast(gs_comm* c, gs_asset* asset_on_root, int32_t root, gs_asset** out) {
-    if (!c || !out) return fail(GS_ERR_INVALID_ARGUMENT, "null argument");
+    if (!c || !out) return fail(GS_ERR_INVALID_ARGUMENT, "null argument");      // (no communicator: there is no collective to leave others parked in)
     *out = nullptr;
-    if (root < 0 || root >= c->nranks) return fail(GS_ERR_INVALID_ARGUMENT, "root out of range");
-    const bool isRoot = c->rank == root;
-    gs_context* ctx = c->ctx;
-    GS_HIP(hipSetDevice(ctx->device));
-    hipStream_t st = ctx->stream;
-    // a root without a usable asset still enters the collectives (with a header nobody accepts) so that nobody hangs
-    const bool rootArgOk = !isRoot || (asset_on_root && asset_on_root->ctx == c->ctx);
-
     // Local failures on the way to the status exchange are FOLDED into `mine` instead of returning: a rank that left here would
-    // leave the others parked in the next collective.  What cannot be folded is a failure of a collective call itself
-    // (ncclBroadcast / ncclAllReduce returning an error): the communicator is then unusable on this rank -- the caller destroys
-    // it (gs_comm_destroy aborts what is in flight) -- and the other ranks see their own collective fail.
+    // leave the others parked in the next collective -- that includes a bad `root` (the rank still takes part, as a receiver of root 0's
+    // header, and reports its own error after the exchange) and a hipSetDevice that fails.  What cannot be folded is a failure of a
+    // collective call itself (ncclBroadcast / ncclAllReduce returning an error): the communicator is then unusable on this rank -- the
+    // caller destroys it (gs_comm_destroy aborts what is in flight) -- and the other ranks see their own collective fail.
     int32_t mine = GS_OK;
     auto note_hip = [&](hipError_t e, const char* what) { if (e != hipSuccess && mine == GS_OK) mine = fail_hip(e, what, __FILE__, __LINE__); };
+    if (root < 0 || root >= c->nranks) { mine = fail(GS_ERR_INVALID_ARGUMENT, "root out of range"); root = 0; }
+    const bool isRoot = c->rank == root;
+    gs_context* ctx = c->ctx;
+    note_hip(hipSetDevice(ctx->device), "asset broadcast: hipSetDevice");
+    hipStream_t st = ctx->stream;
+    // a root without a usable asset (or with an error of its own so far) still enters the collectives, with a header nobody accepts, so that nobody hangs
+    const bool rootArgOk = !isRoot || (mine == GS_OK && asset_on_root && asset_on_root->ctx == c->ctx);
 
     // ---- header: formats, count, blob sizes
     uint64_t h[kHeaderWords] = {0};
