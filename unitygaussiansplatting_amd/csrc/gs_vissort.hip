@@ -66,9 +66,10 @@ __global__ __launch_bounds__(VTHREADS, 6) void visible_keys_kernel(gsm::AssetVie
     __shared__ unsigned long long s_m[VTHREADS];
     __shared__ uint32_t s_off[VTHREADS];
     __shared__ uint32_t s_live[VTHREADS];
-    __shared__ uint32_t s_w[VWAVES];
+    __shared__ uint32_t s_w[VWAVES], s_w2[VWAVES];
     __shared__ uint32_t s_bcast[2];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    if (tid == 0) s_bcast[1] = 0;                                 // (read after the barriers of the first scan)
     // housekeeping for the sort passes that follow and for the NEXT sort (the control blocks alternate: no memset launch per frame)
     if (HIST) {
         for (int j = tid; j < 4 * 256; j += VTHREADS) s_h[j] = 0;
@@ -78,23 +79,91 @@ __global__ __launch_bounds__(VTHREADS, 6) void visible_keys_kernel(gsm::AssetVie
     for (uint32_t j = blockIdx.x * (uint32_t)VTHREADS + tid; j < (uint32_t)(sizeof(VisControl) / 4); j += gridDim.x * (uint32_t)VTHREADS) nextVc[j] = 0u;
 
     const uint32_t w0 = blockIdx.x * blockWords, w1 = min(w0 + blockWords, words);
-    // ---- this block's visible count
-    uint32_t cnt = 0;
-    for (uint32_t wi = w0 + tid; wi < w1; wi += VTHREADS) cnt += (uint32_t)__popcll(visMask[wi]);      // (bits of splats >= n are never set)
-    {
-        const uint32_t incl = wave_incl_scan32(cnt, lane);
-        if (lane == 63) s_w[w] = incl;
-    }
-    __syncthreads();
-    if (tid == 0) {
-        uint32_t t = 0;
+    const bool chunked = a.chunkCount != 0u;
+    const uint8_t* cbase = chunked ? a.chunk : (const uint8_t*)visMask;      // (no chunks: any readable 64 bytes, never used)
+    const uint32_t lastChunk = chunked ? a.chunkCount - 1u : 0u;
+    typedef gsm::RawVec<POSFMT> Raw;
+    constexpr uint32_t ILP = 4;                                   // live words in flight per wave
+    struct Batch { Raw raw[ILP]; uint4 bx[ILP]; uint2 bz[ILP]; uint32_t sidx[ILP], off[ILP]; unsigned long long mm[ILP]; };
+    // the words of a sub-tile that hold a visible splat are compacted into s_live, so that the waves share them evenly: entry k0 .. k0 + ILP - 1
+    auto load_batch = [&](Batch& B, uint32_t s0, uint32_t k0, uint32_t nLive) {
 #pragma unroll
-        for (int k = 0; k < VWAVES; ++k) t += s_w[k];
-        s_bcast[0] = t;
-        __hip_atomic_store(&vc->status[blockIdx.x * kVisStatusStride], t + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    __syncthreads();
-    const uint32_t total = s_bcast[0];
+        for (uint32_t k = 0; k < ILP; ++k) {
+            const uint32_t t = s_live[min(k0 + k, nLive - 1u)];               // (a clamped duplicate is masked out below)
+            B.mm[k] = (k0 + k < nLive) ? s_m[t] : 0ull;
+            B.off[k] = s_off[t];
+            const uint32_t word = s0 + t;
+            B.sidx[k] = word * 64u + (uint32_t)lane;
+            // unconditional loads (index clamped): a load inside a divergent branch is waited for at the end of the branch
+            const uint32_t li = min(B.sidx[k], a.n - 1u);
+            B.raw[k] = gsm::LoadRawT<POSFMT>(a.pos, (uint64_t)li * gsm::vecStrideT<POSFMT>());
+            const uint8_t* cp = cbase + (size_t)min(word >> 2, lastChunk) * 64u;               // ChunkInfo.posX/Y/Z bounds: wave-uniform address
+            B.bx[k] = *(const uint4*)(cp + 16);
+            B.bz[k] = *(const uint2*)(cp + 32);
+        }
+    };
+    auto process_batch = [&](const Batch& B, uint32_t firstSlot) {
+#pragma unroll
+        for (uint32_t k = 0; k < ILP; ++k) {
+            if (!((B.mm[k] >> lane) & 1ull)) continue;
+            gsm::V3 pos = gsm::DecodeRawT<POSFMT>(B.raw[k], (uint64_t)B.sidx[k] * gsm::vecStrideT<POSFMT>());
+            if (chunked && (B.sidx[k] >> 8) <= lastChunk) {              // LoadSplatPos' chunk de-normalisation (ChunkLerpPos), same expressions
+                pos.x = gsm::lerpf(gsm::u2f(B.bx[k].x), gsm::u2f(B.bx[k].y), pos.x);
+                pos.y = gsm::lerpf(gsm::u2f(B.bx[k].z), gsm::u2f(B.bx[k].w), pos.y);
+                pos.z = gsm::lerpf(gsm::u2f(B.bz[k].x), gsm::u2f(B.bz[k].y), pos.z);
+            }
+            const uint32_t key = gsm::SortKeyOf(pos, m20, m21, m22, m23);
+            const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(B.mm[k] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)B.mm[k], 0u));
+            const uint32_t p = firstSlot + B.off[k] + below;
+            outKeys[p] = key;
+            outIdx[p] = B.sidx[k];
+            if (HIST) {
+                lds_hist_add(s_h, key & 255u);
+                lds_hist_add(s_h + 256, (key >> 8) & 255u);
+                lds_hist_add(s_h + 512, (key >> 16) & 255u);
+                lds_hist_add(s_h + 768, key >> 24);
+            }
+        }
+    };
+    // one sub-tile of VTHREADS words (one per thread): the words into s_m, their sub-tile-local first slots into s_off (block scan), the live ones
+    // into s_live; returns {visible splats : 20 | live words << 20} of the sub-tile
+    auto scan_subtile = [&](unsigned long long m) -> uint32_t {
+        const uint32_t c = (uint32_t)__popcll(m);
+        const uint32_t packed = c | ((m != 0ull ? 1u : 0u) << 20);           // visible splats (< 2^17 per sub-tile) and live words in one scan
+        const uint32_t incl = wave_incl_scan32(packed, lane);
+        if (lane == 63) s_w[w] = incl;
+        __syncthreads();
+        uint32_t wbase = 0, subTotal = 0;
+#pragma unroll
+        for (int k = 0; k < VWAVES; ++k) { const uint32_t t = s_w[k]; wbase += (k < w) ? t : 0u; subTotal += t; }
+        const uint32_t excl = wbase + incl - packed;
+        s_m[tid] = m;
+        s_off[tid] = excl & 0xfffffu;
+        if (m != 0ull) s_live[excl >> 20] = (uint32_t)tid;
+        __syncthreads();
+        return subTotal;
+    };
+
+    // ---- the first sub-tile (the whole block unless the asset is huge): its words are read ONCE, its scan gives the block's count, and the
+    //      positions of every wave's first batch are requested BEFORE the block waits for the counts of the blocks before it
+    const unsigned long long m0 = w0 + (uint32_t)tid < w1 ? visMask[w0 + tid] : 0ull;          // (bits of splats >= n are never set)
+    uint32_t extra = 0;
+    for (uint32_t wi = w0 + VTHREADS + tid; wi < w1; wi += VTHREADS) extra += (uint32_t)__popcll(visMask[wi]);       // (further sub-tiles: count only, for now)
+    const uint32_t sub0 = scan_subtile(m0);
+    const uint32_t nLive0 = sub0 >> 20;
+    if (w1 - w0 > (uint32_t)VTHREADS) {                           // (uniform) block total = first sub-tile + the rest
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) extra += __shfl_xor(extra, o, 64);
+        if (lane == 0) atomicAdd(&s_bcast[1], extra);            // (s_bcast[1] zeroed below, before the barrier inside scan_subtile ... see init)
+        __syncthreads();
+        extra = s_bcast[1];
+    } else extra = 0;
+    const uint32_t total = (sub0 & 0xfffffu) + extra;
+    if (tid == 0) __hip_atomic_store(&vc->status[blockIdx.x * kVisStatusStride], total + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    Batch first;
+    const uint32_t kFirst = (uint32_t)w * ILP;
+    const bool haveFirst = kFirst < nLive0;                       // (wave-uniform)
+    if (haveFirst) load_batch(first, w0, kFirst, nLive0);
     // ---- the counts of the blocks before this one
     uint32_t before = 0;
     for (uint32_t j = (uint32_t)tid; j < blockIdx.x; j += VTHREADS) {
@@ -107,88 +176,38 @@ __global__ __launch_bounds__(VTHREADS, 6) void visible_keys_kernel(gsm::AssetVie
         }
         before += v - 1u;
     }
-    {
-        const uint32_t incl = wave_incl_scan32(before, lane);
-        __syncthreads();                                          // s_w is free again
-        if (lane == 63) s_w[w] = incl;
-    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) before += __shfl_xor(before, o, 64);
+    if (lane == 0) s_w2[w] = before;
     __syncthreads();
-    uint32_t running = 0;                                         // first output slot of the next sub-tile (uniform)
+    uint32_t running = 0;                                         // first output slot of the block / of the next sub-tile (uniform)
 #pragma unroll
-    for (int k = 0; k < VWAVES; ++k) running += s_w[k];
+    for (int k = 0; k < VWAVES; ++k) running += s_w2[k];
     if (blockIdx.x == gridDim.x - 1u && tid == 0) vc->count = running + total;
-    if (total == 0u) return;                                      // (uniform; nothing in s_h)
-
-    const bool chunked = a.chunkCount != 0u;
-    const uint8_t* cbase = chunked ? a.chunk : (const uint8_t*)visMask;      // (no chunks: any readable 64 bytes, never used)
-    const uint32_t lastChunk = chunked ? a.chunkCount - 1u : 0u;
-    typedef gsm::RawVec<POSFMT> Raw;
-    constexpr uint32_t ILP = 4;                                   // live words in flight per wave
-
-    // ---- sub-tiles of 1024 words (one per thread): offsets by a block scan, the words that hold a visible splat compacted into a list
-    //      so that the waves share them evenly, four words in flight per wave
-    for (uint32_t s0 = w0; s0 < w1; s0 += VTHREADS) {
-        __syncthreads();                                          // the previous sub-tile's s_m / s_off / s_live / s_w are no longer read
-        const uint32_t wi = s0 + tid;
-        const unsigned long long m = wi < w1 ? visMask[wi] : 0ull;
-        const uint32_t c = (uint32_t)__popcll(m);
-        const uint32_t packed = c | ((m != 0ull ? 1u : 0u) << 20);           // visible splats (< 2^17 per sub-tile) and live words in one scan
-        const uint32_t incl = wave_incl_scan32(packed, lane);
-        if (lane == 63) s_w[w] = incl;
-        __syncthreads();
-        uint32_t wbase = 0, subTotal = 0;
-#pragma unroll
-        for (int k = 0; k < VWAVES; ++k) { const uint32_t t = s_w[k]; wbase += (k < w) ? t : 0u; subTotal += t; }
-        const uint32_t excl = wbase + incl - packed;
-        s_m[tid] = m;
-        s_off[tid] = running + (excl & 0xfffffu);
-        if (m != 0ull) s_live[excl >> 20] = (uint32_t)tid;
-        __syncthreads();
-        const uint32_t nLive = subTotal >> 20;
-        running += subTotal & 0xfffffu;
-
-        for (uint32_t k0 = (uint32_t)w * ILP; k0 < nLive; k0 += VWAVES * ILP) {          // wave-uniform
-            Raw raw[ILP]; uint4 bx[ILP]; uint2 bz[ILP]; uint32_t sidx[ILP], off[ILP]; unsigned long long mm[ILP];
-#pragma unroll
-            for (uint32_t k = 0; k < ILP; ++k) {
-                const uint32_t t = s_live[min(k0 + k, nLive - 1u)];           // (a clamped duplicate is masked out below)
-                mm[k] = (k0 + k < nLive) ? s_m[t] : 0ull;
-                off[k] = s_off[t];
-                const uint32_t word = s0 + t;
-                sidx[k] = word * 64u + (uint32_t)lane;
-                // unconditional loads (index clamped): a load inside a divergent branch is waited for at the end of the branch
-                const uint32_t li = min(sidx[k], a.n - 1u);
-                raw[k] = gsm::LoadRawT<POSFMT>(a.pos, (uint64_t)li * gsm::vecStrideT<POSFMT>());
-                const uint8_t* cp = cbase + (size_t)min(word >> 2, lastChunk) * 64u;           // ChunkInfo.posX/Y/Z bounds: wave-uniform address
-                bx[k] = *(const uint4*)(cp + 16);
-                bz[k] = *(const uint2*)(cp + 32);
+    if (total != 0u) {                                            // (uniform)
+        if (haveFirst) process_batch(first, running);
+        for (uint32_t k0 = kFirst + VWAVES * ILP; k0 < nLive0; k0 += VWAVES * ILP) {        // wave-uniform
+            Batch B;
+            load_batch(B, w0, k0, nLive0);
+            process_batch(B, running);
+        }
+        running += sub0 & 0xfffffu;
+        // ---- further sub-tiles (assets beyond ~32 M splats)
+        for (uint32_t s0 = w0 + VTHREADS; s0 < w1; s0 += VTHREADS) {
+            __syncthreads();                                      // the previous sub-tile's s_m / s_off / s_live / s_w are no longer read
+            const uint32_t wi = s0 + tid;
+            const uint32_t sub = scan_subtile(wi < w1 ? visMask[wi] : 0ull);
+            const uint32_t nLive = sub >> 20;
+            for (uint32_t k0 = (uint32_t)w * ILP; k0 < nLive; k0 += VWAVES * ILP) {
+                Batch B;
+                load_batch(B, s0, k0, nLive);
+                process_batch(B, running);
             }
-#pragma unroll
-            for (uint32_t k = 0; k < ILP; ++k) {
-                if (!((mm[k] >> lane) & 1ull)) continue;
-                gsm::V3 pos = gsm::DecodeRawT<POSFMT>(raw[k], (uint64_t)sidx[k] * gsm::vecStrideT<POSFMT>());
-                if (chunked && (sidx[k] >> 8) <= lastChunk) {              // LoadSplatPos' chunk de-normalisation (ChunkLerpPos), same expressions
-                    pos.x = gsm::lerpf(gsm::u2f(bx[k].x), gsm::u2f(bx[k].y), pos.x);
-                    pos.y = gsm::lerpf(gsm::u2f(bx[k].z), gsm::u2f(bx[k].w), pos.y);
-                    pos.z = gsm::lerpf(gsm::u2f(bz[k].x), gsm::u2f(bz[k].y), pos.z);
-                }
-                const uint32_t key = gsm::SortKeyOf(pos, m20, m21, m22, m23);
-                const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(mm[k] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm[k], 0u));
-                const uint32_t p = off[k] + below;
-                outKeys[p] = key;
-                outIdx[p] = sidx[k];
-                if (HIST) {
-                    lds_hist_add(s_h, key & 255u);
-                    lds_hist_add(s_h + 256, (key >> 8) & 255u);
-                    lds_hist_add(s_h + 512, (key >> 16) & 255u);
-                    lds_hist_add(s_h + 768, key >> 24);
-                }
-            }
+            running += sub & 0xfffffu;
         }
     }
-    if (HIST) {
-        // two neighbouring bins per 64-bit atomic (a bin never reaches 2^32: no carry into its neighbour): every block holds every value
-        // of the low digits, so the ~700 blocks queue on each bin's address (~12 ns per same-address atomic)
+    if (HIST && total != 0u) {
+        // two neighbouring bins per 64-bit atomic (a bin never reaches 2^32: no carry into its neighbour), into one of the copies
         __syncthreads();
         unsigned long long* myHist = (unsigned long long*)(hist + (blockIdx.x % (uint32_t)kHistReplicas) * (uint32_t)kHistStride);      // SortControl::hist: one of the copies
         for (int j = tid; j < 2 * 256; j += VTHREADS) {
