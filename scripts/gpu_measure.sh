@@ -11,8 +11,8 @@ c3) timeout 600 python bench.py --config C3 > $O/bench_c3.json 2> $O/bench_c3.er
 c4) timeout 900 python bench.py --config C4 --steps 20 > $O/bench_c4.json 2> $O/bench_c4.err; tail -c 300 $O/bench_c4.json;;
 c5) timeout 600 python bench.py --config C5 --steps 20 > $O/bench_c5.json 2> $O/bench_c5.err; tail -c 300 $O/bench_c5.json;;
 c2d) timeout 600 python bench.py --config C2d --steps 20 > $O/bench_c2d.json 2> $O/bench_c2d.err; tail -c 300 $O/bench_c2d.json;;
-prof) bash scripts/profile_round.sh C2 20 visible > $O/profile_round.log 2>&1; tail -5 $O/profile_round.log;;
-proff) bash scripts/profile_round.sh C2 20 full > $O/profile_round_full.log 2>&1; tail -5 $O/profile_round_full.log;;
+prof) bash scripts/profile_round.sh C2 50 visible > $O/profile_round.log 2>&1; tail -5 $O/profile_round.log;;
+proff) bash scripts/profile_round.sh C2 50 full > $O/profile_round_full.log 2>&1; tail -5 $O/profile_round_full.log;;
 prof4) bash scripts/profile_round.sh C4 6 visible > $O/profile_round_c4.log 2>&1; tail -5 $O/profile_round_c4.log;;
 sq) bash scripts/pmc_sq.sh C2 > $O/pmc_sq.log 2>&1; tail -3 $O/pmc_sq.log;;
 esac

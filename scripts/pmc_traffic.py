@@ -78,7 +78,7 @@ for k in sorted(set(bf) | set(bw)):
 os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
 tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
 entry = {"config": config, "sort_mode": mode, "tile_pairs_P": bench_P, "visible_splats": bench_V,
-         "source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on `bench.py --config {config} --sort-mode {mode} --warmup 5`, {tag}",
+         "source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on `bench.py --config {config} --sort-mode {mode} --steps 50 --warmup 10`, {tag}",
          "units": "counters are KiB; true bytes = counter * factor * 1024, factors calibrated on 1-GiB kernels of the same access width in the same session",
          "calibration": cal, "kernels": kernels}
 allcfg = {}
@@ -103,7 +103,7 @@ for f in glob.glob(os.path.join(P, "stats", "*", "*_kernel_trace.csv")):
         t[3] = max(t[3], int(r.get("Grid_Size", 0) or r.get("Grid_Size_X", 0) or 0))
 outp = os.path.join(ROOT, "profiles", f"{tag}_rocprof_kernel_stats_{key.lower()}.txt")
 with open(outp, "w") as o:
-    o.write(f"# rocprofv3 --kernel-trace --stats -- python bench.py --config {config} --sort-mode {mode} --steps 20 --warmup 5 --cpu-baseline off --repeats 1   ({tag}; P = {bench_P}, visible = {bench_V})\n")
+    o.write(f"# rocprofv3 --kernel-trace --stats -- python bench.py --config {config} --sort-mode {mode} --steps 50 --warmup 10 --cpu-baseline off --repeats 1   ({tag}; P = {bench_P}, visible = {bench_V})\n")
     o.write(f"{'kernel':34s} {'calls':>6s} {'total_us':>11s} {'avg_us':>9s} {'min_us':>9s} {'max_us':>9s} {'pct':>6s} {'vgpr':>5s} {'sgpr':>5s} {'lds':>6s} {'grid':>9s}\n")
     for r in sorted(rows, key=lambda r: -float(r["TotalDurationNs"])):
         n = short(r["Name"]); t = trace.get(n, [0, 0, 0, 0])

@@ -3,11 +3,11 @@
 # On the GPU box: kernel-trace stats of the default bench, then separate PMC passes (FETCH_SIZE, WRITE_SIZE) for the bench
 # and for the calibration probe.  Usage: profile_round.sh [C2|C4|...] [steps] [visible|full].  Outputs under gpurun_out/prof_<config>[_visible]/.
 cd /tmp && export TMPDIR=/tmp
-CFG=${1:-C2}; STEPS=${2:-20}; MODE=${3:-visible}
+CFG=${1:-C2}; STEPS=${2:-50}; MODE=${3:-visible}      # 50 steps after 10 warm-up frames = the default bench.py run: the same frames, the same pair count
 SUF=""; [ $MODE = visible ] && SUF=_visible
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof_${CFG}${SUF}; rm -rf $O; mkdir -p $O
 export PYTHONPATH=$R
-BENCH="python $R/bench.py --config $CFG --steps $STEPS --warmup 5 --cpu-baseline off --sort-mode $MODE --repeats 1"
+BENCH="python $R/bench.py --config $CFG --steps $STEPS --warmup 10 --cpu-baseline off --sort-mode $MODE --repeats 1"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- $BENCH > $O/bench_stats.json 2> $O/bench_stats.err
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_$c -- $BENCH > $O/bench_$c.json 2> $O/bench_$c.err
