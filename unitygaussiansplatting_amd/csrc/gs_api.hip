@@ -390,6 +390,8 @@ static int32_t enqueue_full_sort(gs_renderer* r, const float m[16]) {
 
 int32_t gs_renderer_calc_view(gs_renderer* r, const gs_frame_params* p) {
     if (!r || !p) return fail(GS_ERR_INVALID_ARGUMENT, "null argument");
+    if (!(p->screen_w >= 1.0f && p->screen_w <= 65535.0f && p->screen_h >= 1.0f && p->screen_h <= 65535.0f))      // (pixel rectangles are packed in 16-bit fields)
+        return fail(GS_ERR_INVALID_ARGUMENT, "screen_w / screen_h must be in [1, 65535]");
     GS_TRY(bind_device(r->ctx));
     rec_ev(r, 7);
     gsm::EditView e;

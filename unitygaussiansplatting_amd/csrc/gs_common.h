@@ -71,6 +71,7 @@ struct SortState {
     uint32_t maxCount = 0;
     uint32_t maxParts = 0;
     uint32_t partMin = 8192;                // keys in the smallest partition a pass may use (gs_sort.hip: shape A, or shape C for a depth sort)
+    uint32_t histCopies = 1;                // copies of SortControl::hist the producer of the current histograms spread its flushes over (hist_copies()); the passes sum them
     uint32_t epoch = 0;                     // last epoch used on `status` / `groupIncl` (18 bits, never 0)
 };
 
@@ -80,6 +81,8 @@ struct SortState {
 // and the one reader (every Onesweep workgroup, once per pass) sums the copies.
 constexpr int kHistReplicas = 8;
 constexpr int kHistStride = 4 * 256;      // words between two copies
+// how many of the copies a sort's producer spreads its flushes over (and its Onesweep passes sum): a property of the producer's grid
+uint32_t hist_copies(int producerBlocks);
 // small per-sort control block (zeroed by one memset before each sort)
 struct SortControl {
     uint32_t hist[kHistReplicas * kHistStride];   // digit histograms [copy][pass][digit]: raw counts

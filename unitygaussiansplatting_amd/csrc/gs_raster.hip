@@ -215,7 +215,7 @@ __global__ __launch_bounds__(kBinThreads) void bin_emit_kernel(const uint2* __re
                                                                 uint32_t capacity, BinControl* ctl, unsigned long long* binStatus, unsigned long long* binGroupAgg, unsigned long long* binGroupBase,
                                                                 uint32_t* pairHist, unsigned long long* __restrict__ groupAgg, uint32_t groupAggWords,
                                                                 uint32_t* __restrict__ nextArena, uint32_t nextArenaWords, uint32_t digitBits,
-                                                                const uint32_t* __restrict__ schedCost, uint32_t schedTiles, uint32_t* __restrict__ schedOut) {
+                                                                const uint32_t* __restrict__ schedCost, uint32_t schedTiles, uint32_t* __restrict__ schedOut, uint32_t histCopies) {
     constexpr int SUB = 4;                                   // k's per emission batch: 256 positions per wave
     __shared__ uint32_t s_hist[3 * 256];
     __shared__ uint32_t s_tile[TILECNT ? kBinTileCounters : 1];
@@ -469,7 +469,7 @@ __global__ __launch_bounds__(kBinThreads) void bin_emit_kernel(const uint2* __re
         __syncthreads();
     }
     if (tid == 0 && visAcc) atomicAdd(&ctl->visible, visAcc);
-    uint32_t* myHist = pairHist + (bid % (uint32_t)kHistReplicas) * (uint32_t)kHistStride;      // SortControl::hist: one of the copies
+    uint32_t* myHist = pairHist + (bid % histCopies) * (uint32_t)kHistStride;      // SortControl::hist: one of the copies
     for (int j = tid; j < PASSES * 256; j += kBinThreads) {
         const uint32_t c = s_hist[j];
         if (c) atomicAdd(&myHist[j], c);
@@ -644,7 +644,7 @@ __global__ __launch_bounds__(kEmitThreads) void vis_emit_kernel(const uint32_t* 
                                                                 const VisControl* __restrict__ vis, uint32_t nImm, const BinControl* __restrict__ ctl,
                                                                 uint32_t tilesX, uint32_t tileShift, uint32_t* __restrict__ pairKeys, uint32_t* __restrict__ pairVals,
                                                                 uint32_t* pairHist, uint32_t digitBits,
-                                                                const uint32_t* __restrict__ schedCost, uint32_t schedTiles, uint32_t* __restrict__ schedOut) {
+                                                                const uint32_t* __restrict__ schedCost, uint32_t schedTiles, uint32_t* __restrict__ schedOut, uint32_t histCopies) {
     constexpr int NPOS = kEmitBatches * kEmitThreads;
     __shared__ uint32_t s_hist[3 * 256];
     __shared__ uint32_t s_tile[TILECNT ? kBinTileCounters : 1];
@@ -761,7 +761,7 @@ __global__ __launch_bounds__(kEmitThreads) void vis_emit_kernel(const uint32_t* 
         }
         __syncthreads();
     }
-    uint32_t* myHist = pairHist + (bid % (uint32_t)kHistReplicas) * (uint32_t)kHistStride;      // SortControl::hist: one of the copies
+    uint32_t* myHist = pairHist + (bid % histCopies) * (uint32_t)kHistStride;      // SortControl::hist: one of the copies
     for (int j = tid; j < PASSES * 256; j += kEmitThreads) {
         const uint32_t c = s_hist[j];
         if (c) atomicAdd(&myHist[j], c);
@@ -1389,6 +1389,7 @@ int32_t bin_and_sort(gs_renderer* r, const gs_frame_params* p, gs_target* rt, co
     const uint32_t binCap = max((uint32_t)ctx->cuCount * kBinBlocksPerCu / kBinTicketClasses * kBinTicketClasses, kBinTicketClasses);
     const uint32_t binGrid = min(div_up(div_up(count, kBinPart), kBinTicketClasses) * kBinTicketClasses, binCap);
     const bool schedInBin = haveCosts && !forceOrderKernel;     // one extra workgroup makes the blend's tile schedule meanwhile
+    r->pairSort.histCopies = hist_copies((int)binGrid);
     if (vis) {
         // GS_SORT_VISIBLE: offsets + output-partitioned emission (see vis_offsets_kernel)
         const uint32_t capChunks = div_up(cap, kEmitChunk) + 1u;
@@ -1410,15 +1411,16 @@ int32_t bin_and_sort(gs_renderer* r, const gs_frame_params* p, gs_target* rt, co
         hipLaunchKernelGGL(vis_offsets_kernel, dim3(vcGrid), dim3(kVcThreads), 0, st, vis, count, cap, binCtl, (const unsigned long long*)binStatus, (const unsigned long long*)binGroupAgg,
                            r->visPairOffset, r->visChunkStart, capChunks);
         const uint32_t emitGrid = (uint32_t)ctx->cuCount * (tileCnt ? 4u : 5u);      // resident at once (36 / 28 KB of LDS)
+        r->pairSort.histCopies = hist_copies((int)emitGrid);
         auto emitKernel = passes == 1 ? (tileCnt ? vis_emit_kernel<1, true> : vis_emit_kernel<1, false>)
                         : (passes == 2 ? (tileCnt ? vis_emit_kernel<2, true> : vis_emit_kernel<2, false>) : vis_emit_kernel<3, false>);
         hipLaunchKernelGGL(emitKernel, dim3(emitGrid + (schedInBin ? 1u : 0u)), dim3(kEmitThreads), 0, st, order, (const uint32_t*)r->visRectX, (const uint32_t*)r->visRectY,
                            (const uint32_t*)r->visPairOffset, (const uint32_t*)r->visChunkStart, vis, count, (const BinControl*)binCtl, rc.tilesX, shapeKey, r->pairKeys, r->pairVals,
-                           pairCtl->hist, (uint32_t)bits, o.costRead, numTiles, schedInBin ? o.tileOrder : (uint32_t*)nullptr);
+                           pairCtl->hist, (uint32_t)bits, o.costRead, numTiles, schedInBin ? o.tileOrder : (uint32_t*)nullptr, r->pairSort.histCopies);
     } else
     hipLaunchKernelGGL(binKernel, dim3(binGrid + (schedInBin ? 1u : 0u)), dim3(binThreads), 0, st, r->rects, wave_flags_of(r->visMask, r->n), order, count, rc.tilesX, shapeKey, r->pairKeys,
                        r->pairVals, cap, binCtl, binStatus, binGroupAgg, binGroupBase, pairCtl->hist, r->pairSort.groupAgg, sort_group_words(r->pairSort, cap, passes), (uint32_t*)nextArena, (uint32_t)(r->frameArenaBytes / 4), (uint32_t)bits,
-                       o.costRead, numTiles, schedInBin ? o.tileOrder : (uint32_t*)nullptr);
+                       o.costRead, numTiles, schedInBin ? o.tileOrder : (uint32_t*)nullptr, r->pairSort.histCopies);
     GS_TRY(mark_order_use(r));                                  // the next frame's depth sort may overwrite order[] from here on
     prof_record(r, 4);
     // the host only knows the capacity; the pair count of the last finished frame (pinned report) picks the sort's pass shape

@@ -102,7 +102,7 @@ __global__ __launch_bounds__(1024) void set_indices_kernel(uint32_t* order, uint
 // stand-alone histogram (gs_sorter path): `passes` digit histograms of keys[0..n)
 __global__ __launch_bounds__(256) void histogram_kernel(const uint32_t* __restrict__ keys, uint32_t nImm, const uint32_t* nPtr,
                                                         int passes, uint32_t lastMask, uint32_t* __restrict__ hist,
-                                                        unsigned long long* __restrict__ groupAgg, uint32_t groupAggWords) {
+                                                        unsigned long long* __restrict__ groupAgg, uint32_t groupAggWords, uint32_t copies) {
     __shared__ uint32_t s_h[4 * RADIX];
     for (int j = threadIdx.x; j < 4 * RADIX; j += 256) s_h[j] = 0;
     for (uint32_t j = blockIdx.x * 256u + threadIdx.x; j < groupAggWords; j += gridDim.x * 256u) groupAgg[j] = 0ull;
@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void histogram_kernel(const uint32_t* __restri
         for (int p = 0; p < passes; ++p) lds_hist_add(s_h + p * RADIX, (key >> (8 * p)) & (p == passes - 1 ? lastMask : 255u));
     }
     __syncthreads();
-    uint32_t* myHist = hist + (blockIdx.x % (uint32_t)kHistReplicas) * (uint32_t)kHistStride;      // SortControl::hist: one of the copies
+    uint32_t* myHist = hist + (blockIdx.x % copies) * (uint32_t)kHistStride;      // SortControl::hist: one of the copies
     for (int j = threadIdx.x; j < passes * RADIX; j += 256) {
         const uint32_t c = s_h[j];
         if (c) atomicAdd(&myHist[j], c);
@@ -131,7 +131,7 @@ template <int POSFMT>
 __global__ __launch_bounds__(1024) void sort_keys_kernel(gsm::AssetView a, float m20, float m21, float m22, float m23,
                                                          uint32_t* __restrict__ keyBySplat, uint32_t* __restrict__ hist, uint32_t n,
                                                          unsigned long long* __restrict__ groupAgg, uint32_t groupAggWords,
-                                                         uint32_t* __restrict__ nextControl) {
+                                                         uint32_t* __restrict__ nextControl, uint32_t copies) {
     __shared__ uint32_t s_h[4 * RADIX];
     for (int j = threadIdx.x; j < 4 * RADIX; j += 1024) s_h[j] = 0;
     for (uint32_t j = blockIdx.x * 1024u + threadIdx.x; j < groupAggWords; j += gridDim.x * 1024u) groupAgg[j] = 0ull;   // the sort passes accumulate into it
@@ -195,7 +195,7 @@ __global__ __launch_bounds__(1024) void sort_keys_kernel(gsm::AssetView a, float
         }
     }
     __syncthreads();
-    uint32_t* myHist = hist + (blockIdx.x % (uint32_t)kHistReplicas) * (uint32_t)kHistStride;      // SortControl::hist: one of the copies
+    uint32_t* myHist = hist + (blockIdx.x % copies) * (uint32_t)kHistStride;      // SortControl::hist: one of the copies
     for (int j = threadIdx.x; j < 4 * RADIX; j += 1024) {
         const uint32_t c = s_h[j];
         if (c) atomicAdd(&myHist[j], c);
@@ -216,7 +216,7 @@ __global__ __launch_bounds__(THREADS, KPT == KPT_B ? 4 : kMinWavesA) void oneswe
                                                            uint32_t* __restrict__ keysOut, uint32_t* __restrict__ valsOut,
                                                            const uint32_t* __restrict__ hist, uint32_t* status,
                                                            unsigned long long* groupAgg, unsigned long long* groupIncl, uint32_t* ticket, uint32_t* error,
-                                                           uint32_t nImm, const uint32_t* nPtr, uint32_t shift, uint32_t epoch, uint32_t digitMask) {
+                                                           uint32_t nImm, const uint32_t* nPtr, uint32_t shift, uint32_t epoch, uint32_t digitMask, uint32_t histCopies) {
     constexpr int PART = THREADS * KPT;              // keys per partition
     constexpr int RDX = 1 << BITS;                   // digits of this pass
     constexpr int DW = (RDX + 63) / 64;              // waves that own digits
@@ -248,7 +248,7 @@ __global__ __launch_bounds__(THREADS, KPT == KPT_B ? 4 : kMinWavesA) void oneswe
     if (tid < RDX) {
         uint32_t c = 0;
 #pragma unroll
-        for (int rp = 0; rp < kHistReplicas; ++rp) c += hist[rp * kHistStride + tid];      // the copies of SortControl::hist (independent loads)
+        for (int rp = 0; rp < kHistReplicas; ++rp) c += (uint32_t)rp < histCopies ? hist[rp * kHistStride + tid] : 0u;      // the copies of SortControl::hist in use (independent loads)
         digitLive = c != 0u;
         const uint32_t incl = wave_incl_scan(c, lane);
         if (lane == 63) s_htot[w] = incl;
@@ -258,7 +258,7 @@ __global__ __launch_bounds__(THREADS, KPT == KPT_B ? 4 : kMinWavesA) void oneswe
     if (tid < RDX / 4) {
         uint32_t any = 0;
 #pragma unroll
-        for (int rp = 0; rp < kHistReplicas; ++rp) { const uint4 h4 = ((const uint4*)(hist + rp * kHistStride))[tid]; any |= h4.x | h4.y | h4.z | h4.w; }
+        for (int rp = 0; rp < kHistReplicas; ++rp) if ((uint32_t)rp < histCopies) { const uint4 h4 = ((const uint4*)(hist + rp * kHistStride))[tid]; any |= h4.x | h4.y | h4.z | h4.w; }
         quadLive = any != 0u;
     }
     __syncthreads();
@@ -581,6 +581,14 @@ int32_t enqueue_set_indices(gs_context* ctx, uint32_t* order, uint32_t n) {
     return GS_OK;
 }
 
+// Copies of the digit histograms a producer with `producerBlocks` flushing workgroups spreads over: every copy is 32 lines that queue same-line
+// atomics at the memory side, but every Onesweep workgroup has to sum the copies in use.  GSPLAT_HIST_COPIES pins it (A/B).
+uint32_t hist_copies(int producerBlocks) {
+    static const int forced = [] { const char* e = getenv("GSPLAT_HIST_COPIES"); const int v = e ? atoi(e) : 0; return (v >= 1 && v <= kHistReplicas) ? v : 0; }();
+    if (forced) return (uint32_t)forced;
+    return producerBlocks > 512 ? (uint32_t)kHistReplicas : (producerBlocks > 256 ? 4u : 1u);
+}
+
 uint32_t sort_group_words(const SortState& st, uint32_t nUpper, int passes) { return (uint32_t)passes * div_up(div_up(max(nUpper, 1u), st.partMin), (uint32_t)GROUP) * RADIX; }
 
 int32_t enqueue_sort_keys(gs_context* ctx, hipStream_t stream, const gsm::AssetView& a, const float* m, uint32_t* keyBySplat,
@@ -588,8 +596,9 @@ int32_t enqueue_sort_keys(gs_context* ctx, hipStream_t stream, const gsm::AssetV
     // `control` was zeroed by the previous sort's launch of this kernel (or at creation); this launch zeroes `nextControl`
     const uint32_t chunks = div_up(n, 256u);
     const uint32_t grid = max(1u, min(div_up(chunks, 4u * kKeysIlp), (uint32_t)ctx->cuCount));      // one 1024-thread workgroup per CU
+    st.histCopies = hist_copies((int)grid);
 #define GS_LAUNCH_KEYS(F) hipLaunchKernelGGL(sort_keys_kernel<F>, dim3(grid), dim3(1024), 0, stream, a, m[8], m[9], m[10], m[11], keyBySplat, \
-                                             control->hist, n, st.groupAgg, sort_group_words(st, n, 4), (uint32_t*)nextControl)
+                                             control->hist, n, st.groupAgg, sort_group_words(st, n, 4), (uint32_t*)nextControl, st.histCopies)
     switch (a.posFmt) { case 0: GS_LAUNCH_KEYS(0); break; case 1: GS_LAUNCH_KEYS(1); break; case 2: GS_LAUNCH_KEYS(2); break; default: GS_LAUNCH_KEYS(3); break; }
 #undef GS_LAUNCH_KEYS
     GS_HIP(hipGetLastError());
@@ -600,7 +609,8 @@ int32_t enqueue_histogram(gs_context* ctx, hipStream_t stream, const uint32_t* k
                           SortState& st) {
     GS_HIP(hipMemsetAsync(control, 0, sizeof(SortControl), stream));
     const uint32_t grid = max(1u, min(div_up(n, 256), (uint32_t)ctx->cuCount * 4u));
-    hipLaunchKernelGGL(histogram_kernel, dim3(grid), dim3(256), 0, stream, keys, n, nPtr, passes, lastMask, control->hist, st.groupAgg, sort_group_words(st, n, passes));
+    st.histCopies = hist_copies((int)grid);
+    hipLaunchKernelGGL(histogram_kernel, dim3(grid), dim3(256), 0, stream, keys, n, nPtr, passes, lastMask, control->hist, st.groupAgg, sort_group_words(st, n, passes), st.histCopies);
     GS_HIP(hipGetLastError());
     return GS_OK;
 }
@@ -608,6 +618,7 @@ int32_t enqueue_histogram(gs_context* ctx, hipStream_t stream, const uint32_t* k
 int32_t enqueue_sort_passes(gs_context* ctx, hipStream_t stream, SortState& st, SortControl* control, uint32_t* keys, uint32_t* vals, uint32_t nUpper,
                             const uint32_t* nPtr, int passes, uint32_t lastMask, gs_renderer* profR, int evFirst, int bits, const uint32_t* gatherKeys,
                             bool skipLastKeys, uint32_t expected) {
+    const uint32_t histCopies = min(max(st.histCopies, 1u), (uint32_t)kHistReplicas);
     if (passes < 1 || passes > 4) return fail(GS_ERR_INVALID_ARGUMENT, "sort passes");
     if (bits < 6 || bits > 8 || (gatherKeys && bits != 8)) return fail(GS_ERR_INVALID_ARGUMENT, "sort digit width");
     if (nUpper > st.maxCount) return fail(GS_ERR_INVALID_ARGUMENT, "sort count exceeds sorter capacity");
@@ -655,7 +666,7 @@ int32_t enqueue_sort_passes(gs_context* ctx, hipStream_t stream, SortState& st, 
         }
 #define GS_LAUNCH_ONESWEEP_K(B, G, KIN, K) \
         hipExtLaunchKernelGGL((onesweep_kernel<B, G, K>), dim3(grid), dim3(THREADS), 0, stream, evStart, evStop, 0, (const uint32_t*)(KIN), (const uint32_t*)vs, kdst, vd, \
-                              (const uint32_t*)hist, st.status, agg, st.groupIncl, (uint32_t*)control->tickets[p], &control->error, nUpper, nPtr, shift, epoch, mask)
+                              (const uint32_t*)hist, st.status, agg, st.groupIncl, (uint32_t*)control->tickets[p], &control->error, nUpper, nPtr, shift, epoch, mask, histCopies)
 #define GS_LAUNCH_ONESWEEP(B, G, KIN) do { if (shapeB) GS_LAUNCH_ONESWEEP_K(B, G, KIN, KPT_B); else GS_LAUNCH_ONESWEEP_K(B, G, KIN, KPT_A); } while (0)
         if (p == 0 && gatherKeys) GS_LAUNCH_ONESWEEP(8, true, gatherKeys);
         else if (shapeC) GS_LAUNCH_ONESWEEP_K(8, false, ks, KPT_C);

@@ -61,7 +61,7 @@ __global__ __launch_bounds__(VTHREADS, 6) void visible_keys_kernel(gsm::AssetVie
                                                                 const unsigned long long* __restrict__ visMask, uint32_t words, uint32_t blockWords,
                                                                 uint32_t* __restrict__ outKeys, uint32_t* __restrict__ outIdx, uint32_t* __restrict__ hist,
                                                                 VisControl* vc, uint32_t* __restrict__ nextVc,
-                                                                unsigned long long* __restrict__ groupAgg, uint32_t groupAggWords, uint32_t* __restrict__ nextControl) {
+                                                                unsigned long long* __restrict__ groupAgg, uint32_t groupAggWords, uint32_t* __restrict__ nextControl, uint32_t copies) {
     __shared__ uint32_t s_h[4 * 256];
     __shared__ unsigned long long s_m[VTHREADS];
     __shared__ uint32_t s_off[VTHREADS];
@@ -209,7 +209,7 @@ __global__ __launch_bounds__(VTHREADS, 6) void visible_keys_kernel(gsm::AssetVie
     if (HIST && total != 0u) {
         // two neighbouring bins per 64-bit atomic (a bin never reaches 2^32: no carry into its neighbour), into one of the copies
         __syncthreads();
-        unsigned long long* myHist = (unsigned long long*)(hist + (blockIdx.x % (uint32_t)kHistReplicas) * (uint32_t)kHistStride);      // SortControl::hist: one of the copies
+        unsigned long long* myHist = (unsigned long long*)(hist + (blockIdx.x % copies) * (uint32_t)kHistStride);      // SortControl::hist: one of the copies
         for (int j = tid; j < 2 * 256; j += VTHREADS) {
             const unsigned long long c = (unsigned long long)s_h[2 * j] | ((unsigned long long)s_h[2 * j + 1] << 32);
             if (c) atomicAdd(myHist + j, c);
@@ -409,10 +409,11 @@ int32_t enqueue_visible_sort(gs_renderer* r) {
     const bool sorted = r->visHistDepth > 0;                       // nothing was ever sorted: CSSetIndices' order = the index order of the compaction
     static const float zeroRow[4] = { 0.f, 0.f, 0.f, 0.f };
     const float* row = sorted ? r->visHist[0] : zeroRow;
+    r->depthSort.histCopies = hist_copies((int)grid);
     prof_record(r, 0, st);
 #define GS_LAUNCH_VK(F, HI) hipLaunchKernelGGL((visible_keys_kernel<F, HI>), dim3(grid), dim3(VTHREADS), 0, st, a, row[0], row[1], row[2], row[3], \
                                                (const unsigned long long*)r->visMask, words, blockWords, r->visKeys, r->visIdx, control->hist, vc, (uint32_t*)nextVc, \
-                                               r->depthSort.groupAgg, sort_group_words(r->depthSort, n, 4), (uint32_t*)nextControl)
+                                               r->depthSort.groupAgg, sort_group_words(r->depthSort, n, 4), (uint32_t*)nextControl, r->depthSort.histCopies)
 #define GS_LAUNCH_VKF(F) do { if (sorted) GS_LAUNCH_VK(F, true); else GS_LAUNCH_VK(F, false); } while (0)
     switch (a.posFmt) { case 0: GS_LAUNCH_VKF(0); break; case 1: GS_LAUNCH_VKF(1); break; case 2: GS_LAUNCH_VKF(2); break; default: GS_LAUNCH_VKF(3); break; }
 #undef GS_LAUNCH_VKF
