@@ -29,6 +29,7 @@ def run_sequence(gpu_ctx, asset, cams, sort_every=1, expect_overflow=False, chec
     rv.sortMode = SortMode.Visible
     rv.OnEnable()
     rf = GaussianSplatRenderer(gpu_ctx, asset)
+    rf.sortMode = SortMode.Full
     rf.OnEnable()
     assert rv.SortModeActive() and not rf.SortModeActive()
     orc = O.Oracle(asset)
@@ -98,6 +99,7 @@ def test_no_sort_yet_draws_in_index_order(gpu_ctx):
     r.sortMode = SortMode.Visible
     r.OnEnable()
     rf = GaussianSplatRenderer(gpu_ctx, a)
+    rf.sortMode = SortMode.Full
     rf.OnEnable()
     cam = default_camera()
     rt, rt2 = RenderTarget(gpu_ctx, cam.pixelWidth, cam.pixelHeight), RenderTarget(gpu_ctx, cam.pixelWidth, cam.pixelHeight)

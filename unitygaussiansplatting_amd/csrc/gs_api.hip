@@ -649,6 +649,7 @@ int32_t gs_renderer_download_distances(gs_renderer* r, uint32_t* out, size_t cou
     if (!r || !out || count > r->n) return fail(GS_ERR_INVALID_ARGUMENT, "bad argument");
     GS_TRY(join_sort(r));
     GS_TRY(bind_device(r->ctx));
+    if (vis_active(r)) GS_TRY(materialise_full_order(r));      // GS_SORT_VISIBLE: the reference's buffers are rebuilt from the kept matrices first (as gs_renderer_download_order does)
     GS_TRY(materialise_distances(r));      // the sorted keys, materialised on demand
     return download(r->ctx, out, r->distances, count * 4);
 }

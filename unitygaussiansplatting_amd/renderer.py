@@ -11,6 +11,7 @@ from __future__ import annotations
 import atexit
 import ctypes as C
 import enum
+import os
 import weakref
 from typing import List, Optional, Tuple
 
@@ -210,7 +211,9 @@ class GaussianSplatRenderer:
         self.m_Cutouts: Optional[List[Optional[GaussianCutout]]] = None      # :244
         self.m_FrameCounter = 0
         self.blendMode = 0            # 0 exact (fp16 ROP rounding), 1 fast (fp32 accumulate)
-        self.sortMode = SortMode.Full # applied to the native renderer when its resources are created (SetSortMode changes it later)
+        # applied to the native renderer when its resources are created (SetSortMode changes it later).  GSPLAT_SORT_MODE=visible makes the visible-only
+        # mode the default of this host layer -- how the whole GPU test suite is run through it (profiles/r05_pytest_gpu_visible.log)
+        self.sortMode = SortMode.Visible if os.environ.get("GSPLAT_SORT_MODE", "") == "visible" else SortMode.Full
         self._asset_h = C.c_void_p()
         self._r_h = C.c_void_p()
         self._keep: list = []
