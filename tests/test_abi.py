@@ -111,6 +111,16 @@ def test_header_is_plain_c99_and_the_dotnet_binding_covers_it():
     names = set(re.findall(r"\b(gs_[a-z0-9_]+)\s*\(", open(hdr).read()))
     cs = open(os.path.join(root, "unitygaussiansplatting_amd", "dotnet", "GaussianSplatNative.cs")).read()
     assert set(re.findall(r"extern\s+\w+\s+(gs_[a-z0-9_]+)\s*\(", cs)) == names
+    # ... and its error / sort-mode enums carry the header's values (CamelCase of the header's names)
+    htxt = open(hdr).read()
+    camel = lambda n: "".join(w.capitalize() for w in n.split("_"))
+    want_err = {camel(n): int(v) for n, v in re.findall(r"\bGS_ERR_([A-Z_]+)\s*=\s*(-?\d+)", htxt)}
+    want_err["Ok"] = 0
+    have_err = {n: int(v) for n, v in re.findall(r"(\w+)\s*=\s*(-?\d+)", re.search(r"enum Error \{([^}]*)\}", cs).group(1))}
+    assert have_err == want_err
+    want_mode = {camel(n): int(v) for n, v in re.findall(r"\bGS_SORT_([A-Z_]+)\s*=\s*(\d+)", htxt)}
+    have_mode = {n: int(v) for n, v in re.findall(r"(\w+)\s*=\s*(\d+)", re.search(r"enum SortMode \{([^}]*)\}", cs).group(1))}
+    assert have_mode == want_mode and want_mode == {"Full": 0, "Visible": 1}
 
 
 def test_plain_c_program_links_and_runs(tmp_path):

@@ -15,7 +15,8 @@ namespace GaussianSplatting.Runtime
     {
         const string Lib = "gsplat_hip";
 
-        public enum Error { Ok = 0, InvalidArgument = -1, Hip = -2, UnsupportedFormat = -3, OutOfMemory = -4, InvalidAsset = -5, PairOverflow = -6, SortTimeout = -7, NoDevice = -8, Comm = -9 }
+        public enum Error { Ok = 0, InvalidArgument = -1, Hip = -2, UnsupportedFormat = -3, OutOfMemory = -4, InvalidAsset = -5, PairOverflow = -6, SortTimeout = -7, NoDevice = -8, Comm = -9, TieOverflow = -10 }
+        public enum SortMode { Full = 0, Visible = 1 }       // gs_sort_mode: Full = SortPoints as the reference runs it; Visible = cull first, sort what is drawn
 
         [StructLayout(LayoutKind.Sequential)]
         public struct AssetDesc
