@@ -115,14 +115,21 @@ def respawn_under_torchrun(n: int) -> int:
 VALU_PEAK_GWI = 687.0     # G wave-instructions / s, whole chip, plain v_fma_f32 at 8 waves per SIMD: MEASURED on MI355X, profiles/r05_valu_issue.txt
 
 
-def load_stored(name, config):
-    """profiles/<name>: figures that need rocprofv3 passes of their own (PMC counters), STORED by the builder's measurement call."""
+def load_stored(name, config, P=None):
+    """profiles/<name>: figures that need rocprofv3 passes of their own (PMC counters), STORED by the builder's measurement call.  A configuration may
+    hold several entries -- "<config>" and "<config>@<label>", collected on different frames (the default run; the driver's `--steps 20 --warmup 5`):
+    the one whose pair count is closest to this frame's P is returned (the caller still refuses to use it beyond 2 %)."""
     path = os.path.join(ROOT, "profiles", name)
     try:
-        d = json.load(open(path))
-        return d.get("configs", {}).get(config, {})
+        d = json.load(open(path)).get("configs", {})
     except Exception:
         return {}
+    cands = [v for k, v in d.items() if k == config or k.startswith(config + "@")]
+    if not cands:
+        return {}
+    if P is None:
+        return d.get(config, cands[0])
+    return min(cands, key=lambda v: abs((v.get("tile_pairs_P") or 0) - P))
 
 
 def dry_run(args, rank, world):
@@ -457,8 +464,8 @@ def main():
         kbytes = {"onesweep_kernel": depth_keys * (16 * 4 - (0 if vmode else 4)) + P * 16 * passes_pair, "blend_kernel": sb["blend"], "calc_view_kernel": sb["calc_view"],
                   bin_kernel: sb["bin"], key_kernel: sb["calc_distances"]}
         frame_bytes = sum(sb.values())
-        tj = load_stored("hbm_traffic.json", args.config + ("_visible" if vmode else ""))
-        vj = load_stored("valu_insts.json", args.config)
+        tj = load_stored("hbm_traffic.json", args.config + ("_visible" if vmode else ""), P)
+        vj = load_stored("valu_insts.json", args.config, P)
 
         def roof_hbm(k):
             """HBM roofline of kernel k: algorithmic bytes per launch / its mean launch duration against the 8 TB/s spec peak."""

@@ -2,14 +2,20 @@
   profiles/<tag>_rocprof_kernel_stats_<cfg>.txt   per-kernel time summary (--kernel-trace --stats)
   profiles/hbm_traffic.json                       HBM bytes per launch per kernel from the FETCH_SIZE / WRITE_SIZE PMC passes,
                                                   corrected with factors calibrated on known-byte-count kernels in the same session
-Usage: python scripts/pmc_traffic.py <tag> [config] [visible|full]     (the sort mode the bench ran in; stored under "<config>_visible" / "<config>")"""
+Usage: python scripts/pmc_traffic.py <tag> [config] [visible|full] [key suffix] [steps] [warmup]
+(the sort mode the bench ran in; stored under "<config>_visible" / "<config>" + the suffix, e.g. "C2_visible@s20w5" for the frames of the driver's
+`bench.py --steps 20 --warmup 5`; bench.py picks the entry whose pair count matches its frame).  If the run directory also holds an SQ_INSTS_VALU pass,
+profiles/valu_insts.json gets the matching entry."""
 import csv, glob, json, os, re, sys
 from collections import defaultdict
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 config = sys.argv[2] if len(sys.argv) > 2 else "C2"
 mode = sys.argv[3] if len(sys.argv) > 3 else "visible"
-key = config + ("_visible" if mode == "visible" else "")
+ksuf = sys.argv[4] if len(sys.argv) > 4 else ""
+steps = sys.argv[5] if len(sys.argv) > 5 else "50"
+warm = sys.argv[6] if len(sys.argv) > 6 else "10"
+key = config + ("_visible" if mode == "visible" else "") + ksuf
 P = os.path.join(ROOT, "gpurun_out", "prof_" + key)
 if not os.path.isdir(P): P = os.path.join(ROOT, "gpurun_out", "prof")
 # the frame the counters were collected on (bench.py refuses to pair a stored traffic with a frame whose pair count differs by > 2 %)
@@ -78,7 +84,7 @@ for k in sorted(set(bf) | set(bw)):
 os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
 tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
 entry = {"config": config, "sort_mode": mode, "tile_pairs_P": bench_P, "visible_splats": bench_V,
-         "source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on `bench.py --config {config} --sort-mode {mode} --steps 50 --warmup 10`, {tag}",
+         "source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on `bench.py --config {config} --sort-mode {mode} --steps {steps} --warmup {warm}`, {tag}",
          "units": "counters are KiB; true bytes = counter * factor * 1024, factors calibrated on 1-GiB kernels of the same access width in the same session",
          "calibration": cal, "kernels": kernels}
 allcfg = {}
@@ -101,9 +107,9 @@ for f in glob.glob(os.path.join(P, "stats", "*", "*_kernel_trace.csv")):
         t = trace[short(r["Kernel_Name"])]
         t[0] = max(t[0], int(r.get("VGPR_Count", 0) or 0)); t[1] = max(t[1], int(r.get("SGPR_Count", 0) or 0)); t[2] = max(t[2], int(r.get("LDS_Block_Size", 0) or 0))
         t[3] = max(t[3], int(r.get("Grid_Size", 0) or r.get("Grid_Size_X", 0) or 0))
-outp = os.path.join(ROOT, "profiles", f"{tag}_rocprof_kernel_stats_{key.lower()}.txt")
+outp = os.path.join(ROOT, "profiles", f"{tag}_rocprof_kernel_stats_{key.lower().replace('@', '_')}.txt")
 with open(outp, "w") as o:
-    o.write(f"# rocprofv3 --kernel-trace --stats -- python bench.py --config {config} --sort-mode {mode} --steps 50 --warmup 10 --cpu-baseline off --repeats 1   ({tag}; P = {bench_P}, visible = {bench_V})\n")
+    o.write(f"# rocprofv3 --kernel-trace --stats -- python bench.py --config {config} --sort-mode {mode} --steps {steps} --warmup {warm} --cpu-baseline off --repeats 1   ({tag}; P = {bench_P}, visible = {bench_V})\n")
     o.write(f"{'kernel':34s} {'calls':>6s} {'total_us':>11s} {'avg_us':>9s} {'min_us':>9s} {'max_us':>9s} {'pct':>6s} {'vgpr':>5s} {'sgpr':>5s} {'lds':>6s} {'grid':>9s}\n")
     for r in sorted(rows, key=lambda r: -float(r["TotalDurationNs"])):
         n = short(r["Name"]); t = trace.get(n, [0, 0, 0, 0])
@@ -123,3 +129,20 @@ with open(outp, "w") as o:
     o.write("\n# calibration (1 GiB each)\n")
     for k, v in cal.items(): o.write(f"{k:26s} {v}\n")
 print(open(outp).read())
+
+# ---- SQ_INSTS_VALU of the VALU-bound kernels on the same frames (profile_round.sh's last pass) -> profiles/valu_insts.json
+sq = counters("pmc_SQ_INSTS_VALU")
+ks = {}
+for k, v in by_base(sq).items():
+    if k in ("blend_kernel", "calc_view_kernel") and v:
+        ks[k] = {"valu_wave_insts": int(sum(v) / len(v)), "launches_sampled": len(v)}
+if ks:
+    vpath = os.path.join(ROOT, "profiles", "valu_insts.json")
+    allv = {}
+    if os.path.exists(vpath):
+        try: allv = json.load(open(vpath)).get("configs", {})
+        except Exception: allv = {}
+    allv[config + ksuf] = {"config": config, "tile_pairs_P": bench_P, "visible_splats": bench_V, "kernels": ks,
+                           "source": f"rocprofv3 --pmc SQ_INSTS_VALU on `bench.py --config {config} --sort-mode {mode} --steps {steps} --warmup {warm}` (scripts/profile_round.sh), {tag}: mean wave-level VALU instructions per launch"}
+    json.dump({"configs": allv}, open(vpath, "w"), indent=1)
+    print("valu_insts.json:", config + ksuf, ks)
