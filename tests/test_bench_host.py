@@ -27,6 +27,8 @@ def test_stored_counters_exist_for_the_default_and_the_driver_frames():
         for k in ("blend_kernel", "calc_view_kernel", "onesweep_kernel"):
             assert t["kernels"][k]["hbm_bytes_per_launch"] > 0
         assert v["kernels"]["blend_kernel"]["valu_wave_insts"] > 5e7
+    # the reference-shaped full-sort mode (`--headline full`) on the driver's frames
+    assert b.load_stored("hbm_traffic.json", "C2", P_DRIVER).get("tile_pairs_P") == P_DRIVER
 
 
 def test_entry_selection_is_by_pair_count_and_never_crosses_configurations(tmp_path, monkeypatch):
