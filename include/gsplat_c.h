@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GS_ABI_VERSION 7
+#define GS_ABI_VERSION 8
 
 typedef enum gs_error {
     GS_OK = 0,
@@ -41,9 +41,8 @@ typedef enum gs_error {
     GS_ERR_PAIR_OVERFLOW = -6,      /* tile-pair buffer too small for this frame; the renderer grew it -- draw again */
     GS_ERR_SORT_TIMEOUT = -7,       /* a bounded spin in the sort's look-back expired (never expected; reported instead of hanging) */
     GS_ERR_NO_DEVICE = -8,
-    GS_ERR_COMM = -9,               /* RCCL: library not loadable, or a collective failed; gs_last_error_string() has the detail */
-    GS_ERR_TIE_OVERFLOW = -10       /* GS_SORT_VISIBLE: this frame held a run of > 64 visible splats with equal sort keys that the history had to order
-                                       (left in index order); the renderer has switched to full sorts -- draw again */
+    GS_ERR_COMM = -9                /* RCCL: library not loadable, or a collective failed; gs_last_error_string() has the detail */
+    /* (-10 was GS_ERR_TIE_OVERFLOW of ABI 7: GS_SORT_VISIBLE no longer has a case it cannot order) */
 } gs_error;
 
 /* GaussianSplatAsset.cs:31-37 / :51-57 / :70-81 */
@@ -129,10 +128,10 @@ typedef struct gs_frame_stats {
     uint32_t tiles_x, tiles_y;
     uint32_t sort_error;        /* != 0 => GS_ERR_SORT_TIMEOUT was raised */
     uint32_t tile_w, tile_h;    /* the compositor tile of the last draw, pixels (16x16, 32x16 or 32x32: gs_renderer_set_tile_shape); 0 x 0 before the first draw */
-    uint32_t sort_mode;         /* gs_sort_mode the last draw's order came from (GS_SORT_VISIBLE only while that mode is active) */
-    uint32_t tie_exhausted;     /* GS_SORT_VISIBLE, once more than 32 distinct sort matrices have been seen since gs_renderer_reset_order: tied pairs of
-                                   visible splats with different positions that none of the 32 kept matrices separates (ordered by index; an older
-                                   matrix might have ordered them otherwise).  0 = the order is the reference's, provably */
+    uint32_t sort_mode;         /* gs_sort_mode the last draw's order came from */
+    uint32_t tie_long_runs;     /* GS_SORT_VISIBLE, statistics only: runs of more than 64 visible splats with equal sort keys in the last draw (ordered by the
+                                   fix-up's workgroup-wide sorting network instead of a thread / a wave) ... */
+    uint32_t tie_longest_run;   /* ... and the longest of them (0 if none) */
 } gs_frame_stats;
 
 /* hipEvent-timed stage durations of the last frame, ms (the four ProfilerMarkers of
@@ -221,21 +220,25 @@ int32_t gs_renderer_reset_order(gs_renderer* r);
  * the C# does), then GpuSorting.Dispatch on (distances, order). */
 int32_t gs_renderer_sort(gs_renderer* r, const float matrix_sort[16]);
 /* GS_SORT_FULL (default) or GS_SORT_VISIBLE.  In visible mode gs_renderer_sort only records the matrix; the sort itself runs inside
- * gs_renderer_draw over the splats gs_renderer_calc_view found visible (V of N): keys of those splats in index order, four plain Onesweep
- * passes over V pairs, then a fix-up of runs of equal keys -- the reference's sort is stable through EVERY earlier sort, so tied splats
- * keep the order the previous sort matrices gave them: the fix-up re-evaluates the tied splats' keys under the last 32 distinct matrices
- * (most recent first) and falls back to the splat index (= CSSetIndices' initial order).  The frame is the reference's frame, and the
- * visible subsequence of its order buffer, bit for bit, unless a tied pair with different positions stays tied under all 32 kept matrices
- * AND an older, dropped matrix separated it (gs_frame_stats.tie_exhausted counts such pairs; 0 = exact).  A frame that skips
- * gs_renderer_sort (m_SortNthFrame > 1) orders its own visible set with the stale matrix, as the reference's stale order buffer does.
- * A run of more than 64 equal keys that the history would have to order (coplanar / duplicated geometry seen from a new direction) is left
- * in index order and reported (GS_ERR_TIE_OVERFLOW from gs_renderer_frame_stats); the renderer then rebuilds the full order buffer from the
- * kept matrices and stays on full sorts until gs_renderer_reset_order.  The mode only takes effect while the order buffer is CSSetIndices'
- * identity plus sorts made in this mode: after gs_renderer_upload_order, or after sorts in GS_SORT_FULL, call gs_renderer_reset_order.
- * Switching back to GS_SORT_FULL rebuilds the order buffer the reference would hold (one full sort per kept matrix). */
+ * gs_renderer_draw over the splats gs_renderer_calc_view found visible (V of N): keys of those splats in index order, Onesweep passes over
+ * V pairs, then a fix-up of runs of equal keys -- the reference's sort is stable through EVERY earlier sort, so after sorts M_1 .. M_k of a
+ * base order B its buffer is sorted lexicographically by (key under M_k, ..., key under M_1, rank in B), and the fix-up orders tied splats by
+ * exactly that chain: their keys under the recorded matrices, most recent first, then the base order.  What is drawn is the visible
+ * subsequence of the reference's order buffer, bit for bit, BY CONSTRUCTION: no matrix is ever dropped (when 128 are recorded the library
+ * carries them out on all N once -- one reference-shaped sort + the same fix-up over N, ~0.25 ms for 6 M splats -- and that buffer becomes
+ * the new base), and a run of equal keys of any length is ordered (2..4 by a thread, ..64 by a wave, longer ones by a workgroup-wide sorting
+ * network).  The base is whatever the order buffer holds when the mode is set or gs_renderer_upload_order / gs_renderer_reset_order is
+ * called; the mode is active whenever it is set.  A frame that skips gs_renderer_sort (m_SortNthFrame > 1) orders its own visible set with
+ * the stale matrix, as the reference's stale order buffer does.  Switching back to GS_SORT_FULL, gs_renderer_download_order and
+ * gs_renderer_download_distances carry the recorded sorts out first and so see the reference's buffers. */
 int32_t gs_renderer_set_sort_mode(gs_renderer* r, int32_t mode);
-/* *mode = what was set; *active != 0 = the visible-only path is what the next draw uses */
+/* *mode = what was set; *active != 0 = the visible-only path is what the next draw uses (ABI 8: whenever it is set) */
 int32_t gs_renderer_sort_mode(const gs_renderer* r, int32_t* mode, int32_t* active);
+/* GS_SORT_VISIBLE tuning / introspection.  rows in [2, 128]: matrices recorded before the library carries them out on all N (default 128;
+ * a smaller limit shortens the longest possible tie chain and consolidates more often -- the drawn order is the same either way).
+ * gs_renderer_sort_history: any pointer may be NULL; *rows = matrices recorded since the base, *consolidations = how often they were carried out. */
+int32_t gs_renderer_set_sort_history_limit(gs_renderer* r, uint32_t rows);
+int32_t gs_renderer_sort_history(const gs_renderer* r, uint32_t* rows, uint32_t* limit, uint64_t* consolidations);
 /* CalcViewData (GaussianSplatRenderer.cs:579-610): CSCalcViewData.  The reference's output, the N x 40 B m_GpuView
  * buffer, is only read by its own vertex shader; here the compositor reads compact per-splat records instead, so by
  * default the kernel evaluates colour (SH) only for the splats that reach the screen and does not write m_GpuView.
@@ -293,8 +296,8 @@ int32_t gs_renderer_download_distances(gs_renderer* r, uint32_t* out, size_t cou
                                                                                            (also after a later upload_order / reset_order, as in the reference) */
 int32_t gs_renderer_upload_order(gs_renderer* r, const uint32_t* in, size_t count);
 /* GS_SORT_VISIBLE parity hook: the depth-ordered splat indices the last draw was binned from (the visible subsequence of the reference's
- * _OrderBuffer); *count = V, at most `capacity` entries are written.  (gs_renderer_download_order in this mode rebuilds the whole
- * reference buffer from the kept matrices first: one full sort per matrix.)  Blocks. */
+ * _OrderBuffer); *count = V, at most `capacity` entries are written.  (gs_renderer_download_order in this mode carries the recorded sorts
+ * out on all N first: one full sort + the chain fix-up.)  Blocks. */
 int32_t gs_renderer_download_visible_order(gs_renderer* r, uint32_t* out, size_t capacity, uint32_t* count);
 int32_t gs_renderer_download_view(gs_renderer* r, void* out, size_t bytes);             /* N x 40 B SplatViewData */
 /* What the last gs_renderer_calc_view left for the compositor (the per-frame launch, NOT the on-demand full kernel), in

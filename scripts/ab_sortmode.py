@@ -71,5 +71,5 @@ for rep in range(reps):
         r.SetProfiling(0)
         out = {k.replace("_ms", ""): round(getattr(t, k), 4) for k, _ in t._fields_ if k.endswith("_ms") and k not in ("resolve_ms",)}
         out.update(cfg=key, sort_mode=name, active=bool(r.SortModeActive()), tile=f"{st.tile_w}x{st.tile_h}", wall_min=round(min(walls), 4), wall_med=round(sorted(walls)[1], 4),
-                   P=int(st.tile_pairs), V=int(st.visible_splats), tie_exhausted=int(st.tie_exhausted), lib=os.path.basename(os.environ.get("GSPLAT_LIB", "default")))
+                   P=int(st.tile_pairs), V=int(st.visible_splats), tie_long_runs=int(getattr(st, 'tie_long_runs', 0)), lib=os.path.basename(os.environ.get("GSPLAT_LIB", "default")))
         print(json.dumps(out), flush=True)

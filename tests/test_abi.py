@@ -32,8 +32,8 @@ def test_every_declared_symbol_is_exported_and_bound():
 
 def test_version_and_error_strings():
     lib = _lib.lib()
-    assert lib.gs_abi_version() == 7
-    for code in range(0, -11, -1):
+    assert lib.gs_abi_version() == 8
+    for code in range(0, -10, -1):
         assert lib.gs_error_string(code) not in (None, b"", b"unknown error")
     assert lib.gs_error_string(-99) == b"unknown error"
 
@@ -41,7 +41,7 @@ def test_version_and_error_strings():
 def test_struct_layouts_match_the_header():
     assert C.sizeof(_abi.gs_asset_desc) == 6 * 4 + 5 * 16
     assert C.sizeof(_abi.gs_frame_params) == (64 + 2 + 2 + 3 + 2 + 2 + 2) * 4
-    assert C.sizeof(_abi.gs_frame_stats) == 48
+    assert C.sizeof(_abi.gs_frame_stats) == 56
     assert C.sizeof(_abi.gs_cutout) == 68            # GaussianCutout.ShaderData: float4x4 + uint
     assert C.sizeof(_abi.gs_stage_times) == 56
     assert _abi.VIEW_DTYPE.itemsize == 40
@@ -58,6 +58,8 @@ def test_argument_validation_without_a_device():
     assert lib.gs_renderer_set_deleted_bits(None, None, 0) == _abi.GS_ERR_INVALID_ARGUMENT
     assert lib.gs_renderer_set_sort_mode(None, _abi.GS_SORT_VISIBLE) == _abi.GS_ERR_INVALID_ARGUMENT
     assert lib.gs_renderer_download_visible_order(None, None, 0, None) == _abi.GS_ERR_INVALID_ARGUMENT
+    assert lib.gs_renderer_set_sort_history_limit(None, 8) == _abi.GS_ERR_INVALID_ARGUMENT
+    assert lib.gs_renderer_sort_history(None, None, None, None) == _abi.GS_ERR_INVALID_ARGUMENT
     assert lib.gs_target_create(None, 65536, 16, None) == _abi.GS_ERR_INVALID_ARGUMENT     # pixel rectangles are packed in 16-bit fields
     assert lib.gs_context_destroy(None) == 0 and lib.gs_asset_destroy(None) == 0      # destroying null is a no-op
     if not os.path.exists("/dev/kfd"):

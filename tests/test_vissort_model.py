@@ -12,8 +12,8 @@ from unitygaussiansplatting_amd import camera, creator, scenes
 from vissort_model import VisibleSortModel, visible_bits
 
 
-def tie_heavy_asset(kind: str, n: int = 6000, seed: int = 3):
-    """fp32 positions (VeryHigh: exact, no chunk quantisation) arranged so that MANY splats share a sort key."""
+def tie_heavy_asset(kind: str, n: int = 6000, seed: int = 3, quality: str = "VeryHigh"):
+    """Positions arranged so that MANY splats share a sort key (VeryHigh: fp32, exact; Medium: the same geometry on Norm11 lattices per chunk)."""
     raw = scenes.make_splats(n, seed, 3.0)
     rng = np.random.default_rng(seed)
     pos = raw.pos.copy()
@@ -25,8 +25,11 @@ def tie_heavy_asset(kind: str, n: int = 6000, seed: int = 3):
     elif kind == "duplicates":       # every position three times
         base = pos[: n // 3]
         pos = np.concatenate([base, base, base, pos[: n - 3 * (n // 3)]])[:n]
+    elif kind == "colocated":        # 150 splats at each of 8 points (runs of > 64 equal keys that NO matrix separates), the rest random
+        pts = pos[:8].copy()
+        pos[: 8 * 150] = np.repeat(pts, 150, axis=0)[rng.permutation(8 * 150)]
     raw = creator.InputSplatData(pos.astype(np.float32), raw.dc0, raw.sh, raw.opacity, raw.scale, raw.rot)
-    return creator.CreateAssetFromSplats(raw, "VeryHigh", name=f"ties_{kind}")
+    return creator.CreateAssetFromSplats(raw, quality, name=f"ties_{kind}_{quality}")
 
 
 def cams_for(kind: str):
@@ -40,7 +43,7 @@ def cams_for(kind: str):
     return [default_camera(az=a) for a in (0.0, 5.0, 5.0, 10.0, 0.0, 15.0)]
 
 
-@pytest.mark.parametrize("kind", ["lattice", "planes", "duplicates", "random"])
+@pytest.mark.parametrize("kind", ["lattice", "planes", "duplicates", "colocated", "random"])
 def test_visible_subsequence_of_the_full_order_is_the_chain_sort(kind):
     a = tie_heavy_asset(kind)
     orc = O.Oracle(a)
@@ -61,8 +64,32 @@ def test_visible_subsequence_of_the_full_order_is_the_chain_sort(kind):
     assert len(model.hist) < len(cams_for(kind))                     # the sequences repeat matrices: kept once
     if kind == "lattice":
         assert 5 <= longest                                          # columns of tied splats: the history decides
-    if kind == "planes":
-        assert longest > 64                                          # whole planes tie: beyond the in-kernel fix-up (GS_ERR_TIE_OVERFLOW on the GPU)
+    if kind in ("planes", "colocated"):
+        assert longest > 64                                          # beyond a wave: the workgroup-wide sorting network on the GPU
+
+
+@pytest.mark.parametrize("kind", ["lattice", "planes", "duplicates", "random"])
+@pytest.mark.parametrize("every", [1, 2, 3])
+def test_consolidation_is_one_stable_sort_plus_the_chain_fix_up(kind, every):
+    """What gs_api.hip's vis_consolidate does every `limit` sorts: the reference's buffer after sorts M_1 .. M_k of a base B == ONE stable
+    sort of B by M_k, then every run of equal keys re-ordered by (key under M_k-1, ..., key under M_1, position) -- and the visible chain
+    sort on the new base (ranks in it instead of indices) keeps giving the visible subsequence of the reference's buffer."""
+    a = tie_heavy_asset(kind)
+    orc = O.Oracle(a)
+    model = VisibleSortModel(a, depth=10 ** 9)
+    l2w = np.eye(4, dtype=np.float32)
+    rng = np.random.default_rng(5)
+    cams = cams_for(kind) + cams_for(kind)[::-1]
+    for k, cam in enumerate(cams):
+        m = camera.sort_matrix(cam, l2w)
+        orc.sort(m)
+        model.push(m)
+        if k % every == every - 1:
+            model.consolidate()
+            assert np.array_equal(model.base, orc.order), f"{kind}: consolidation at sort {k}"
+            assert len(model.hist) == 1
+        visible = rng.random(a.splatCount) < 0.4
+        assert np.array_equal(model.visible_order(visible), orc.order[visible[orc.order]]), f"{kind}: frame {k}"
 
 
 def test_truncated_history_is_exact_unless_a_dropped_matrix_decides():

@@ -15,7 +15,6 @@ GS_ERR_PAIR_OVERFLOW = -6
 GS_ERR_SORT_TIMEOUT = -7
 GS_ERR_NO_DEVICE = -8
 GS_ERR_COMM = -9
-GS_ERR_TIE_OVERFLOW = -10
 GS_SORT_FULL = 0
 GS_SORT_VISIBLE = 1
 
@@ -62,7 +61,7 @@ class gs_import_formats(C.Structure):
 class gs_frame_stats(C.Structure):
     _fields_ = [("tile_pairs", C.c_uint64), ("pair_capacity", C.c_uint64), ("visible_splats", C.c_uint32),
                 ("tiles_x", C.c_uint32), ("tiles_y", C.c_uint32), ("sort_error", C.c_uint32), ("tile_w", C.c_uint32), ("tile_h", C.c_uint32),
-                ("sort_mode", C.c_uint32), ("tie_exhausted", C.c_uint32)]
+                ("sort_mode", C.c_uint32), ("tie_long_runs", C.c_uint32), ("tie_longest_run", C.c_uint32)]
 
 
 class gs_stage_times(C.Structure):

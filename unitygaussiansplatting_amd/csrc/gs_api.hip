@@ -74,7 +74,6 @@ const char* gs_error_string(int32_t err) {
         case GS_ERR_SORT_TIMEOUT: return "sort look-back timed out";
         case GS_ERR_NO_DEVICE: return "no HIP device";
         case GS_ERR_COMM: return "RCCL communication error";
-        case GS_ERR_TIE_OVERFLOW: return "visible-only sort: a run of more than 64 equal keys needed the sort history (the renderer switched to full sorts; render the frame again)";
         default: return "unknown error";
     }
 }
@@ -299,65 +298,59 @@ static int32_t materialise_distances(gs_renderer* r) {
     return GS_OK;
 }
 
+static int32_t enqueue_full_sort(gs_renderer* r, const float m[16], bool consolidating);
+
+// order[] is about to stop being what the visible-only mode calls its base (reset, upload, a sort in GS_SORT_FULL)
+static void vis_base_changed(gs_renderer* r, bool identity) {
+    r->visBaseIdentity = identity; r->visRankValid = false; r->visHistDepth = 0; r->visOrderValid = false;
+}
+
 int32_t gs_renderer_reset_order(gs_renderer* r) {
     if (!r) return fail(GS_ERR_INVALID_ARGUMENT, "renderer is null");
     GS_TRY(bind_device(r->ctx));
     GS_TRY(join_sort(r));
+    // m_GpuSortDistances keeps the sorted keys of the last SortPoints across CSSetIndices: in the visible-only mode they only exist once
+    // the sorts recorded since the base have been carried out on all N
+    if (vis_active(r)) GS_TRY(vis_consolidate(r));
     GS_TRY(materialise_distances(r));
     GS_TRY(enqueue_set_indices(r->ctx, r->order, r->n));
-    // CSSetIndices: the order buffer is the identity again and the stable-sort history starts over -- which is also what lets
-    // GS_SORT_VISIBLE (re)start (gs_renderer_set_sort_mode)
-    r->visBaseIdentity = true; r->visFallback = false; r->visHistDepth = 0; r->visHistDropped = 0; r->visOrderValid = false;
+    vis_base_changed(r, true);                                   // CSSetIndices: the order buffer is the identity again and the stable-sort history starts over
     return mark_order_use(r);
 }
 
 static void rec_ev(gs_renderer* r, int k) { gs::prof_record(r, k); }
 
-static int32_t enqueue_full_sort(gs_renderer* r, const float m[16]);
-
-// The order buffer the reference would hold after the sorts recorded in visHist: CSSetIndices' identity stably sorted by every kept
-// matrix, oldest first (one full sort each).  Exact unless rows have fallen off the history (visHistDropped).
-static int32_t materialise_full_order(gs_renderer* r) {
+// GS_SORT_VISIBLE keeps the sorts made since its base order[] as a list of matrix rows (gs_vissort.hip).  This carries them out on ALL N
+// splats: the reference's order buffer now = the base stably sorted by every row, oldest first = ONE stable sort of the base by the most
+// recent row (ties are left in base order) + the chain fix-up over N (every run of equal keys re-ordered by the older rows; where they tie
+// too the base order stands).  Exact at any history length, the cost of one reference-shaped sort.  Afterwards order[] is that buffer (the
+// new base), distances[] its sorted keys, and the history is its head alone (sorting the new base by it again changes nothing).
+// Called when the history is full, when the buffer itself is asked for (gs_renderer_download_order / _distances, reset) and when the
+// renderer goes back to GS_SORT_FULL.
+extern "C++" int32_t gs::vis_consolidate(gs_renderer* r) {
+    if (r->visHistDepth == 0) return GS_OK;                      // no sort since the base: order[] is the reference's buffer already
+    float m[16] = { 0.f };
+    memcpy(m + 8, r->visHist[0], 16);
     GS_TRY(join_sort(r));
-    GS_TRY(enqueue_set_indices(r->ctx, r->order, r->n));
+    GS_TRY(enqueue_full_sort(r, m, true));
+    GS_TRY(enqueue_tie_fix_full(r, r->distances, r->order));
     GS_TRY(mark_order_use(r));
-    r->distancesStale = false;
-    for (int j = r->visHistDepth - 1; j >= 0; --j) {
-        float m[16] = { 0.f };
-        memcpy(m + 8, r->visHist[j], 16);
-        GS_TRY(enqueue_full_sort(r, m));
-    }
-    return join_sort(r);                                         // (overlap: the sorts ran on the second queue)
-}
-
-// The visible sort's fix-up met a run of equal keys it cannot order (VIS_TIE_OVERFLOW in the report of a draw binned from visIdx): from
-// here on the renderer sorts all N like the reference -- starting from the order buffer the reference would hold now.
-static int32_t vis_fall_back(gs_renderer* r) {
-    if (!vis_active(r)) return GS_OK;
-    GS_TRY(materialise_full_order(r));
-    r->visFallback = true;
-    r->visBaseIdentity = r->visHistDepth == 0;
-    r->visOrderValid = false;
+    r->visHistDepth = 1; r->visBaseIdentity = false; r->visRankValid = false;
+    r->visConsolidations++;
     return GS_OK;
-}
-static bool vis_overflow_reported(const gs_renderer* r) {
-    return r->visDrawn && r->frameInFlight && r->hostReport && (*(volatile uint32_t*)&r->hostReport->tieFlags & VIS_TIE_OVERFLOW) != 0u;
 }
 
 int32_t gs_renderer_sort(gs_renderer* r, const float m[16]) {
     if (!r || !m) return fail(GS_ERR_INVALID_ARGUMENT, "null argument");
     GS_TRY(bind_device(r->ctx));
-    if (vis_active(r)) {
-        // GS_SORT_VISIBLE: SortPoints only says which matrix the order is sorted by from now on; the sort itself runs in gs_renderer_draw,
-        // over the splats that are drawn (gs_vissort.hip)
-        vis_push_matrix(r, m);
-        return GS_OK;
-    }
-    r->visBaseIdentity = false;                                  // the order buffer now holds a sort made outside the visible-only mode
-    return enqueue_full_sort(r, m);
+    // GS_SORT_VISIBLE: SortPoints only says which matrix the order is sorted by from now on; the sort itself runs in gs_renderer_draw,
+    // over the splats that are drawn (gs_vissort.hip)
+    if (vis_active(r)) return vis_push_matrix(r, m);
+    vis_base_changed(r, false);                                  // the order buffer now holds this sort
+    return enqueue_full_sort(r, m, false);
 }
 
-static int32_t enqueue_full_sort(gs_renderer* r, const float m[16]) {
+static int32_t enqueue_full_sort(gs_renderer* r, const float m[16], bool consolidating) {
     gs_context* ctx = r->ctx;
     // SortPoints depends on nothing else the frame computes (the C# merely records it before CalcViewData, :120-126), and
     // nothing but the draw's bin_emit reads its result.  With overlap on, the whole sort (keys + the four Onesweep passes)
@@ -365,23 +358,26 @@ static int32_t enqueue_full_sort(gs_renderer* r, const float m[16]) {
     // previous draw's bin_emit), i.e. beside the previous frame's pair sort / blend / resolve and this frame's calc_view
     // -- latency-bound kernels with little VALU work next to the VALU-bound ones -- and is joined by the first consumer of
     // order[] (gs_renderer_draw, or any readback).  The second queue is in-order, so consecutive sorts serialise there.
+    // (A consolidation of the visible-only mode is not a frame's SortPoints: main queue, sorted keys kept for the fix-up, no stage events.)
     hipStream_t st = ctx->stream;
-    if (ctx->overlap) {
+    const bool aux = ctx->overlap && !consolidating;
+    if (aux) {
         st = ctx->aux;
         GS_HIP(hipStreamWaitEvent(st, r->evOrderFree, 0));
     }
-    gs::prof_record(r, 0, st);
+    gs_renderer* profR = consolidating ? nullptr : r;
+    if (profR) gs::prof_record(r, 0, st);
     r->depthControlIdx ^= 1;
     SortControl* control = r->depthControl + r->depthControlIdx;
     // CSCalcDistances: keys of all splats in index order (+ the digit histograms); the gather through the previous order
     // (_SplatSortKeys, SplatUtilities.compute:76) is the first Onesweep pass's key load
     GS_TRY(enqueue_sort_keys(ctx, st, r->asset->view, m, r->keyBySplat, control, r->depthControl + (r->depthControlIdx ^ 1), r->n, r->depthSort));
-    gs::prof_record(r, 1, st);
+    if (profR) gs::prof_record(r, 1, st);
     // (skipLastKeys: the last depth pass writes only the order -- nothing on the frame's path reads the sorted keys; materialise_distances)
-    GS_TRY(enqueue_sort_passes(ctx, st, r->depthSort, control, r->distances, r->order, r->n, nullptr, 4, 255u, r, 10, 8, r->keyBySplat, true));
-    r->distancesStale = true;
-    gs::prof_record(r, 2, st);
-    if (ctx->overlap) {
+    GS_TRY(enqueue_sort_passes(ctx, st, r->depthSort, control, r->distances, r->order, r->n, nullptr, 4, 255u, profR, 10, 8, r->keyBySplat, !consolidating));
+    r->distancesStale = !consolidating;
+    if (profR) gs::prof_record(r, 2, st);
+    if (aux) {
         GS_HIP(hipEventRecord(r->evSortDone, st));
         r->sortPending = true;
     }
@@ -430,7 +426,6 @@ int32_t gs_renderer_draw(gs_renderer* r, const gs_frame_params* p, gs_target* rt
     GS_TRY(bind_device(r->ctx));
     if (r->renderMode == GS_RENDER_DEBUG_POINTS || r->renderMode == GS_RENDER_DEBUG_POINT_INDICES) return enqueue_debug_points(r, p, rt);
     GS_TRY(maybe_grow_pairs(r));
-    if (vis_overflow_reported(r)) GS_TRY(vis_fall_back(r));      // noticed within the pipeline depth, like a pair overflow
     if (r->renderMode == GS_RENDER_DEBUG_BOXES) return enqueue_debug_boxes(r, p, rt, false);
     if (r->renderMode == GS_RENDER_DEBUG_CHUNK_BOUNDS) return enqueue_debug_boxes(r, p, rt, true);
     return enqueue_draw(r, p, rt);
@@ -606,17 +601,24 @@ static int32_t download(gs_context* ctx, void* dst, const void* src, size_t byte
 
 int32_t gs_renderer_download_order(gs_renderer* r, uint32_t* out, size_t count) {
     if (!r || !out || count > r->n) return fail(GS_ERR_INVALID_ARGUMENT, "bad argument");
+    GS_TRY(bind_device(r->ctx));
     GS_TRY(join_sort(r));
-    if (vis_active(r)) { GS_TRY(bind_device(r->ctx)); GS_TRY(materialise_full_order(r)); }      // the reference's whole buffer, rebuilt from the kept matrices
+    if (vis_active(r)) GS_TRY(vis_consolidate(r));               // the reference's whole buffer: the recorded sorts carried out on all N (one sort + the chain fix-up)
     return download(r->ctx, out, r->order, count * 4);
 }
 int32_t gs_renderer_download_visible_order(gs_renderer* r, uint32_t* out, size_t capacity, uint32_t* count) {
     if (!r || !count || (capacity && !out)) return fail(GS_ERR_INVALID_ARGUMENT, "bad argument");
     *count = 0;
-    if (!vis_active(r)) return fail(GS_ERR_INVALID_ARGUMENT, "the visible-only sort mode is not active (gs_renderer_set_sort_mode / gs_renderer_reset_order)");
+    if (!vis_active(r)) return fail(GS_ERR_INVALID_ARGUMENT, "the visible-only sort mode is not set (gs_renderer_set_sort_mode)");
     if (!r->viewValid) return fail(GS_ERR_INVALID_ARGUMENT, "gs_renderer_calc_view has not run");
     GS_TRY(bind_device(r->ctx));
-    if (!r->visOrderValid) GS_TRY(enqueue_visible_sort(r));
+    if (!r->visOrderValid) {                                     // (not part of a draw: no stage events)
+        const bool prof = r->profiling;
+        r->profiling = false;
+        const int32_t rc = enqueue_visible_sort(r);
+        r->profiling = prof;
+        GS_TRY(rc);
+    }
     uint32_t v = 0;
     GS_TRY(download(r->ctx, &v, &vis_control(r)->count, 4));
     *count = v;
@@ -629,13 +631,16 @@ int32_t gs_renderer_set_sort_mode(gs_renderer* r, int32_t mode) {
     if (mode == r->sortMode) return GS_OK;
     GS_TRY(bind_device(r->ctx));
     if (mode == GS_SORT_VISIBLE) {
+        // whatever order[] holds -- CSSetIndices' identity, full sorts, an uploaded order -- is the base the mode's sorts start from
         GS_TRY(vis_alloc(r));
-        r->sortMode = mode;                                      // active while the order buffer is CSSetIndices' identity (+ sorts made in this mode)
-        r->visOrderValid = false;
+        GS_TRY(join_sort(r));
+        r->sortMode = mode;
+        r->visHistDepth = 0; r->visRankValid = false; r->visOrderValid = false;
         return GS_OK;
     }
     // back to the reference's SortPoints: it continues from the order buffer the reference would hold now
-    if (vis_active(r) && r->visHistDepth > 0) { GS_TRY(materialise_full_order(r)); r->visBaseIdentity = false; }
+    GS_TRY(vis_consolidate(r));
+    r->visHistDepth = 0;
     r->sortMode = mode;
     return GS_OK;
 }
@@ -645,11 +650,25 @@ int32_t gs_renderer_sort_mode(const gs_renderer* r, int32_t* mode, int32_t* acti
     if (active) *active = vis_active(r) ? 1 : 0;
     return GS_OK;
 }
+int32_t gs_renderer_set_sort_history_limit(gs_renderer* r, uint32_t rows) {
+    if (!r || rows < 2 || rows > (uint32_t)kVisHistory) return fail(GS_ERR_INVALID_ARGUMENT, "sort history limit must be in [2, 128]");
+    GS_TRY(bind_device(r->ctx));
+    if ((uint32_t)r->visHistDepth > rows) GS_TRY(vis_consolidate(r));
+    r->visHistLimit = (int)rows;
+    return GS_OK;
+}
+int32_t gs_renderer_sort_history(const gs_renderer* r, uint32_t* rows, uint32_t* limit, uint64_t* consolidations) {
+    if (!r) return fail(GS_ERR_INVALID_ARGUMENT, "renderer is null");
+    if (rows) *rows = (uint32_t)r->visHistDepth;
+    if (limit) *limit = (uint32_t)r->visHistLimit;
+    if (consolidations) *consolidations = r->visConsolidations;
+    return GS_OK;
+}
 int32_t gs_renderer_download_distances(gs_renderer* r, uint32_t* out, size_t count) {
     if (!r || !out || count > r->n) return fail(GS_ERR_INVALID_ARGUMENT, "bad argument");
-    GS_TRY(join_sort(r));
     GS_TRY(bind_device(r->ctx));
-    if (vis_active(r)) GS_TRY(materialise_full_order(r));      // GS_SORT_VISIBLE: the reference's buffers are rebuilt from the kept matrices first (as gs_renderer_download_order does)
+    GS_TRY(join_sort(r));
+    if (vis_active(r)) GS_TRY(vis_consolidate(r));               // GS_SORT_VISIBLE: the sorted keys of all N exist once the recorded sorts have been carried out
     GS_TRY(materialise_distances(r));      // the sorted keys, materialised on demand
     return download(r->ctx, out, r->distances, count * 4);
 }
@@ -657,10 +676,11 @@ int32_t gs_renderer_upload_order(gs_renderer* r, const uint32_t* in, size_t coun
     if (!r || !in || count != r->n) return fail(GS_ERR_INVALID_ARGUMENT, "bad argument");
     GS_TRY(bind_device(r->ctx));
     GS_TRY(join_sort(r));
+    if (vis_active(r)) GS_TRY(vis_consolidate(r));               // (distances[]: the last SortPoints' sorted keys, as in reset_order)
     GS_TRY(materialise_distances(r));      // before order[] stops being the sort's output
     GS_HIP(hipMemcpyAsync(r->order, in, count * 4, hipMemcpyHostToDevice, r->ctx->stream));
     GS_HIP(hipStreamSynchronize(r->ctx->stream));
-    r->visBaseIdentity = false; r->visOrderValid = false;        // a custom order: GS_SORT_VISIBLE waits for the next gs_renderer_reset_order
+    vis_base_changed(r, false);                                  // a custom order: the new base of the visible-only mode
     return GS_OK;
 }
 int32_t gs_renderer_download_view(gs_renderer* r, void* out, size_t bytes) {
@@ -709,17 +729,11 @@ int32_t gs_renderer_frame_stats(gs_renderer* r, gs_frame_stats* out) {
             GS_HIP(hipMemcpy(&visErr, &vis_control(r)->error, 4, hipMemcpyDeviceToHost));
             out->sort_error |= visErr;
             out->sort_mode = GS_SORT_VISIBLE;
-            // pairs no kept matrix separates are in index order -- which IS the reference's order while the history is complete; only once
-            // rows have been dropped can an older matrix have ordered them differently
-            out->tie_exhausted = r->visHistDropped ? r->hostReport->tieExhausted : 0u;
+            out->tie_long_runs = r->hostReport->tieLongRuns;
+            out->tie_longest_run = r->hostReport->tieLongest;
         }
     } else out->sort_error = depthErr;
     if (out->sort_error) return fail(GS_ERR_SORT_TIMEOUT, "a bounded look-back spin expired");
-    if (vis_overflow_reported(r)) {
-        r->visDrawn = false;                                     // reported once
-        GS_TRY(vis_fall_back(r));
-        return fail(GS_ERR_TIE_OVERFLOW, "a run of more than 64 equal sort keys needed the sort history; the renderer now sorts all splats -- render the frame again");
-    }
     if (r->frameInFlight && out->tile_pairs > r->pairCapacity) {
         const unsigned long long want = out->tile_pairs + out->tile_pairs / 4;
         r->frameInFlight = false;                                    // reported once, whatever the growth below does
@@ -740,8 +754,11 @@ int32_t gs_renderer_frame_times(gs_renderer* r, float* out_ms, int32_t capacity,
     const int slots = r->profCompleted < r->profCapacity ? r->profCompleted : r->profCapacity;
     for (int sidx = 0; sidx < slots && *count < capacity; ++sidx) {
         const int base = sidx * kEvPerFrame;
-        // first event of the frame: key generation if the frame sorted, else calc_view; last: after the blend
-        const int first = (r->evValid[base + 0] && !r->visDrawn) ? 0 : 7;      // (a visible-sort frame starts with calc_view: its sort runs inside the draw)
+        // first event of the frame: key generation if the frame sorted before its calc_view (GS_SORT_FULL), else calc_view (a GS_SORT_VISIBLE
+        // frame's sort runs inside the draw) -- decided per slot by the events themselves, so a ring that mixes the modes is timed correctly
+        int first = 7;
+        float lead = -1.f;
+        if (r->evValid[base + 0] && (!r->evValid[base + 7] || (hipEventElapsedTime(&lead, r->ev[base + 0], r->ev[base + 7]) == hipSuccess && lead >= 0.f))) first = 0;
         float ms = 0.f;
         if (r->evValid[base + first] && r->evValid[base + 6] && hipEventElapsedTime(&ms, r->ev[base + first], r->ev[base + 6]) == hipSuccess)
             out_ms[(*count)++] = ms;

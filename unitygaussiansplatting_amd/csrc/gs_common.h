@@ -95,19 +95,23 @@ struct SortControl {
 struct FrameReport {
     unsigned long long pairCount;
     uint32_t binError, pairSortError, visible, tileShape;   // tileShape: log2 tile width | log2 tile height << 8 of the draw that reported
-    uint32_t tieFlags, tieExhausted;                        // GS_SORT_VISIBLE draws: VisControl::tieFlags / tieExhausted of the draw's visible sort (else 0)
+    uint32_t tieLongRuns, tieLongest;                       // GS_SORT_VISIBLE draws: VisControl::tieLongRuns / tieLongest of the draw's visible sort (else 0)
 };
 
 // ---- GS_SORT_VISIBLE (gs_vissort.hip): the depth sort of the VISIBLE splats only --------------------------------------------------
-constexpr int kVisHistory = 32;            // distinct sort matrices (row 2) kept, most recent first: the tie-break chain of the stable sort history
+// The reference's order buffer after sorts M_1 .. M_k of a base order B is sorted lexicographically by (key under M_k, ..., key under M_1,
+// rank in B).  The mode keeps B in gs_renderer::order (CSSetIndices' identity at first) and the rows of the sorts made SINCE B in
+// gs_renderer::visHist, most recent first.  When the history is full the base is CONSOLIDATED: one full sort of B by the most recent row +
+// the chain fix-up over all N give the reference's whole buffer, which becomes the new B (history: that one row) -- so the chain is exact at
+// any length and its walk is bounded.
+constexpr int kVisHistory = 128;           // sort-matrix rows (row 2) kept since the base order, most recent first; kernel argument: 2 KB
 constexpr uint32_t kVisMaxBlocks = 1024;   // workgroups of visible_keys_kernel (one status word each)
-constexpr uint32_t kVisTieWaveMax = 64;    // longest run of equal keys the in-kernel fix-up orders (one wave); longer: VIS_TIE_OVERFLOW -> full path
-constexpr uint32_t VIS_TIE_OVERFLOW = 1u;  // VisControl::tieFlags bit
+constexpr uint32_t kVisTieWaveMax = 64;    // longest run of equal keys a wave ranks by counting; longer runs: the workgroup's sorting network
 // small per-sort control block, two copies used alternately: each visible_keys launch zeroes the other one for the next sort
 struct VisControl {
     uint32_t count;                // V: visible splats compacted this frame (the depth sort's device-side key count)
-    uint32_t tieFlags;             // VIS_TIE_OVERFLOW: a run of equal keys longer than kVisTieWaveMax was left in index order
-    uint32_t tieExhausted;         // pairs of tied splats with different positions that no kept matrix separates (ordered by index)
+    uint32_t tieLongRuns;          // statistic: runs of more than kVisTieWaveMax equal keys the fix-up ordered (workgroup path)
+    uint32_t tieLongest;           // statistic: the longest of them
     uint32_t error;                // bounded spin expired
     uint32_t pad[28];
     // visible count of block b, + 1 (0 = not published yet), one word per 64 bytes: block b polls the words of ALL blocks before it with
@@ -117,6 +121,10 @@ struct VisControl {
 };
 constexpr uint32_t kVisStatusStride = 16;
 struct TieHistory { float row[kVisHistory][4]; uint32_t depth; };   // row[0] = the matrix the keys were made with; depth >= 1
+// what ends the chain of a tied pair that no kept row separates: the base order
+enum TieBase { TB_INDEX = 0,      // base = identity: the splat index
+               TB_RANK = 1,       // base = gs_renderer::order: rank[splat] (its inverse, gs_renderer::visBaseRank)
+               TB_POSITION = 2 }; // the input is a stable sort OF the base: the position inside the run (consolidation over all N)
 
 // The two words every workgroup hits with an atomic (ticket, visible) sit in their own 128-B lines: same-address
 // atomics serialise in one L2 channel (~11 ns each), so they must not also queue behind each other.
@@ -124,7 +132,7 @@ struct BinControl {
     unsigned long long pairCount; // P: total pairs this frame (may exceed capacity => overflow)
     uint32_t pairCountClamped;    // min(P, capacity), what the pair sort / ranges / blend see
     uint32_t error;
-    uint32_t tieFlags, tieExhausted;   // copied from the visible sort's VisControl by bin_emit (GS_SORT_VISIBLE draws), for the report
+    uint32_t tieLongRuns, tieLongest;  // copied from the visible sort's VisControl by vis_count (GS_SORT_VISIBLE draws), for the report
     uint32_t pad0[26];
     uint32_t visible;
     uint32_t pad1[31];
@@ -256,13 +264,17 @@ struct gs_renderer {
     unsigned long long truncPairs = 0, truncCapacity = 0;
     // ---- GS_SORT_VISIBLE (gs_renderer_set_sort_mode; gs_vissort.hip) ----
     int sortMode = 0;                       // gs_sort_mode
-    bool visBaseIdentity = true;            // order[] is (logically) CSSetIndices' identity: the reference's order = identity stably sorted by visHist, oldest first
-    bool visFallback = false;               // a tie run the fix-up cannot order was seen: full sorts until gs_renderer_reset_order
-    bool visOrderValid = false;             // visIdx holds the sorted visible order of the last calc_view under visHist[0]
-    bool visDrawn = false;                  // the draw in flight was binned from visIdx (its report carries tie flags)
-    float visHist[gs::kVisHistory][4];      // distinct sort-matrix rows (m[8..11]), most recent first
+    // order[] is the BASE of the visible-only sort: the reference's order buffer as of the last full sort / consolidation / upload / reset;
+    // the reference's buffer NOW = order[] stably sorted by visHist, oldest first
+    bool visBaseIdentity = true;            // order[] is CSSetIndices' identity (rank[s] = s: no rank array needed)
+    bool visRankValid = false;              // visBaseRank holds the inverse of order[]
+    uint32_t* visBaseRank = nullptr;        // N x u32, allocated when first needed
+    bool visOrderValid = false;             // visIdx holds the sorted visible order of the last calc_view under the current history
+    bool visDrawn = false;                  // the draw in flight was binned from visIdx
+    float visHist[gs::kVisHistory][4];      // sort-matrix rows (m[8..11]) since the base, most recent first, no row twice
     int visHistDepth = 0;
-    uint32_t visHistDropped = 0;            // rows that fell off the end of visHist since the last reset (the chain is then truncated)
+    int visHistLimit = gs::kVisHistory;     // rows kept before the base is consolidated (gs_renderer_set_sort_history_limit; GSPLAT_VIS_HISTORY)
+    unsigned long long visConsolidations = 0;
     uint32_t* visKeys = nullptr;            // N x u32 each, allocated on first use: compacted (key, splat index) of the visible splats, sorted in place
     uint32_t* visIdx = nullptr;
     uint32_t* visRectX = nullptr;           // N x u32 each: the pixel rectangle (rects[visIdx[i]].x / .y) by SORTED position (vis_offsets_kernel's gather)
@@ -302,10 +314,15 @@ int32_t enqueue_gather_keys(gs_context* ctx, const uint32_t* keyBySplat, const u
 constexpr uint32_t kSortMaxCount = 1u << 30;   // 32-bit byte offsets inside the sort kernels
 int32_t enqueue_set_indices(gs_context* ctx, uint32_t* order, uint32_t n);
 // visible-only depth sort (gs_vissort.hip)
-inline bool vis_active(const gs_renderer* r) { return r->sortMode == GS_SORT_VISIBLE && r->visBaseIdentity && !r->visFallback; }
+inline bool vis_active(const gs_renderer* r) { return r->sortMode == GS_SORT_VISIBLE; }
 int32_t vis_alloc(gs_renderer* r);                                   // visKeys / visIdx / visControl, on first use
 void vis_free(gs_renderer* r);
-void vis_push_matrix(gs_renderer* r, const float* matrixSort);       // gs_renderer_sort in visible mode: history bookkeeping only
+int32_t vis_push_matrix(gs_renderer* r, const float* matrixSort);    // gs_renderer_sort in visible mode: history bookkeeping (+ a consolidation when the history is full)
+// order[] := the reference's whole order buffer now (one full sort of the base by the most recent row + the chain fix-up over N); the history shrinks
+// to that row.  Also what hands the buffer to GS_SORT_FULL / gs_renderer_download_order.  (gs_api.hip)
+int32_t vis_consolidate(gs_renderer* r);
+// the chain fix-up over a stable sort of the base (keys = sorted keys, idx = the order), rows 1.. of the history
+int32_t enqueue_tie_fix_full(gs_renderer* r, const uint32_t* keys, uint32_t* idx);
 // visMask (calc_view's or box_setup's visibility bits) -> r->visIdx = the visible items in the reference's depth order, count in visControl
 int32_t enqueue_visible_sort(gs_renderer* r);
 inline const VisControl* vis_control(const gs_renderer* r) { return r->visControl + r->visControlIdx; }

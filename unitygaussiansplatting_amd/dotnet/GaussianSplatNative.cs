@@ -15,7 +15,7 @@ namespace GaussianSplatting.Runtime
     {
         const string Lib = "gsplat_hip";
 
-        public enum Error { Ok = 0, InvalidArgument = -1, Hip = -2, UnsupportedFormat = -3, OutOfMemory = -4, InvalidAsset = -5, PairOverflow = -6, SortTimeout = -7, NoDevice = -8, Comm = -9, TieOverflow = -10 }
+        public enum Error { Ok = 0, InvalidArgument = -1, Hip = -2, UnsupportedFormat = -3, OutOfMemory = -4, InvalidAsset = -5, PairOverflow = -6, SortTimeout = -7, NoDevice = -8, Comm = -9 }
         public enum SortMode { Full = 0, Visible = 1 }       // gs_sort_mode: Full = SortPoints as the reference runs it; Visible = cull first, sort what is drawn
 
         [StructLayout(LayoutKind.Sequential)]
@@ -45,7 +45,7 @@ namespace GaussianSplatting.Runtime
         }
 
         [StructLayout(LayoutKind.Sequential)]
-        public struct FrameStats { public ulong tilePairs, pairCapacity; public uint visibleSplats, tilesX, tilesY, sortError, tileW, tileH, sortMode, tieExhausted; }
+        public struct FrameStats { public ulong tilePairs, pairCapacity; public uint visibleSplats, tilesX, tilesY, sortError, tileW, tileH, sortMode, tieLongRuns, tieLongestRun; }
 
         [StructLayout(LayoutKind.Sequential)]
         public struct StageTimes { public float calcDistancesMs, sortMs, calcViewMs, binMs, pairSortMs, blendMs, resolveMs, totalMs; public uint frames; public float onesweepDepthMs, onesweepPairsMs; public uint onesweepPairLaunches; public float onesweepDepthKernelMs, onesweepPairsKernelMs; }
@@ -101,6 +101,8 @@ namespace GaussianSplatting.Runtime
         // gs_sort_mode: 0 = GS_SORT_FULL (SortPoints as the reference runs it), 1 = GS_SORT_VISIBLE (cull first, sort what is drawn)
         [DllImport(Lib)] public static extern int gs_renderer_set_sort_mode(IntPtr renderer, int mode);
         [DllImport(Lib)] public static extern int gs_renderer_sort_mode(IntPtr renderer, out int mode, out int active);
+        [DllImport(Lib)] public static extern int gs_renderer_set_sort_history_limit(IntPtr renderer, uint rows);
+        [DllImport(Lib)] public static extern int gs_renderer_sort_history(IntPtr renderer, out uint rows, out uint limit, out ulong consolidations);
         [DllImport(Lib)] public static extern int gs_renderer_download_visible_order(IntPtr renderer, uint[] dst, UIntPtr capacity, out uint count);
         [DllImport(Lib)] public static extern int gs_renderer_set_render_mode(IntPtr renderer, int mode, float pointDisplaySize);
         [DllImport(Lib)] public static extern int gs_renderer_download_view(IntPtr renderer, IntPtr dst, UIntPtr bytes);

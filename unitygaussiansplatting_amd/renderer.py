@@ -18,7 +18,7 @@ from typing import List, Optional, Tuple
 import numpy as np
 
 from . import _lib
-from ._abi import (GS_ERR_PAIR_OVERFLOW, GS_ERR_TIE_OVERFLOW, GS_SORT_FULL, GS_SORT_VISIBLE, VIEW_DTYPE, gs_frame_params, gs_frame_stats, gs_stage_times,
+from ._abi import (GS_ERR_PAIR_OVERFLOW, GS_SORT_FULL, GS_SORT_VISIBLE, VIEW_DTYPE, gs_frame_params, gs_frame_stats, gs_stage_times,
                    make_asset_desc)
 from ._lib import GsError, check
 from .asset import GaussianSplatAsset, kCurrentVersion
@@ -377,11 +377,21 @@ class GaussianSplatRenderer:
             check(_lib.lib().gs_renderer_set_sort_mode(self._r_h, int(self.sortMode)), "gs_renderer_set_sort_mode")
 
     def SortModeActive(self) -> bool:
-        """True while the visible-only path is what the next Draw uses (the mode is set, the order buffer is CSSetIndices' identity plus sorts
-        made in this mode, and no tie overflow has sent the renderer back to full sorts)."""
+        """True while the visible-only path is what the next Draw uses (ABI 8: whenever the mode is set -- whatever the order buffer holds
+        is the base its sorts start from)."""
         m, a = C.c_int32(), C.c_int32()
         check(_lib.lib().gs_renderer_sort_mode(self._r_h, C.byref(m), C.byref(a)), "gs_renderer_sort_mode")
         return bool(a.value)
+
+    def SetSortHistoryLimit(self, rows: int) -> None:
+        """SortMode.Visible: sort matrices recorded before the library carries them out on all N (2..128, default 128).  Same drawn order either way."""
+        check(_lib.lib().gs_renderer_set_sort_history_limit(self._r_h, int(rows)), "gs_renderer_set_sort_history_limit")
+
+    def SortHistory(self):
+        """(matrices recorded since the base order, limit, consolidations so far)"""
+        rows, limit, cons = C.c_uint32(), C.c_uint32(), C.c_uint64()
+        check(_lib.lib().gs_renderer_sort_history(self._r_h, C.byref(rows), C.byref(limit), C.byref(cons)), "gs_renderer_sort_history")
+        return rows.value, limit.value, cons.value
 
     def DownloadVisibleOrder(self) -> np.ndarray:
         """SortMode.Visible: the depth-ordered indices of the visible splats (the visible subsequence of the reference's _OrderBuffer)."""
@@ -538,9 +548,9 @@ class GaussianSplatRenderSystem:
                 try:
                     gs.FrameStats()
                 except GsError as e:
-                    if e.code not in (GS_ERR_PAIR_OVERFLOW, GS_ERR_TIE_OVERFLOW):
+                    if e.code != GS_ERR_PAIR_OVERFLOW:
                         raise
-                    overflowed = True                         # the buffer has been grown / the renderer has fallen back to full sorts by the call
+                    overflowed = True                         # the buffer has been grown by the call
             if overflowed:                                     # same frame again: the order is already sorted, only the draws repeat
                 rt.Clear()
                 for gs in self.m_ActiveSplats:
