@@ -149,14 +149,15 @@ typedef struct gs_stage_times {
     uint32_t frames;           /* number of frames the averages cover */
     /* the Onesweep launches alone (the kernel with the largest time share): sort_ms / pair_sort_ms minus the
      * histogram-scan, copy-back and tile-range kernels that share those stages */
-    float onesweep_depth_ms;   /* sum of the 4 depth-sort launches of one frame */
+    float onesweep_depth_ms;   /* sum of the depth-sort launches of one frame */
     float onesweep_pairs_ms;   /* sum of the pair-sort launches of one frame */
     uint32_t onesweep_pair_launches;   /* 1..3, by tile count */
     /* the same launches by their OWN start / stop timestamps (the dispatch's completion signal, as rocprofv3 --kernel-trace reports
      * them): no event packets and no kernel boundaries inside, so <= the bracketed figures above.  0 unless the frames were recorded
      * with gs_renderer_set_kernel_timing(r, 1). */
-    float onesweep_depth_kernel_ms;    /* sum over the 4 depth-sort launches */
+    float onesweep_depth_kernel_ms;    /* sum over the depth-sort launches */
     float onesweep_pairs_kernel_ms;    /* sum over the pair-sort launches */
+    uint32_t onesweep_depth_launches;  /* of the last frame: 4 (8-bit passes), or 3 (GS_SORT_VISIBLE: 9-bit passes over keys reduced to a window around the last frame's range) */
 } gs_stage_times;
 
 int32_t gs_abi_version(void);

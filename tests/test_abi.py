@@ -43,7 +43,7 @@ def test_struct_layouts_match_the_header():
     assert C.sizeof(_abi.gs_frame_params) == (64 + 2 + 2 + 3 + 2 + 2 + 2) * 4
     assert C.sizeof(_abi.gs_frame_stats) == 56
     assert C.sizeof(_abi.gs_cutout) == 68            # GaussianCutout.ShaderData: float4x4 + uint
-    assert C.sizeof(_abi.gs_stage_times) == 56
+    assert C.sizeof(_abi.gs_stage_times) == 60
     assert _abi.VIEW_DTYPE.itemsize == 40
 
 

@@ -1,7 +1,6 @@
-"""bench.py host logic that needs no GPU: the STORED counter files (PMC traffic, SQ_INSTS_VALU: rocprofv3 passes of their own) are keyed per set of
-frames, and a bench line only pairs them with a frame whose pair count matches."""
+"""bench.py host logic that needs no GPU: how the per-dispatch records of the run's own rocprofv3 --pmc children are folded into per-launch figures
+(the timed region's frames only, template instantiations of a kernel together), and the algorithmic byte formulas of the stages."""
 import importlib.util
-import json
 import os
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -14,32 +13,42 @@ def _bench():
     return m
 
 
-# last-frame pair counts of the headline workload (C2): the default run (`--steps 50 --warmup 10`) and the driver's (`--steps 20 --warmup 5`)
-P_DEFAULT, P_DRIVER = 5207981, 5735437
-
-
-def test_stored_counters_exist_for_the_default_and_the_driver_frames():
+def test_kernel_names_are_folded_over_template_arguments():
     b = _bench()
-    for P in (P_DEFAULT, P_DRIVER):
-        t = b.load_stored("hbm_traffic.json", "C2_visible", P)
-        v = b.load_stored("valu_insts.json", "C2", P)
-        assert t.get("tile_pairs_P") == P and v.get("tile_pairs_P") == P, (P, t.get("tile_pairs_P"), v.get("tile_pairs_P"))
-        for k in ("blend_kernel", "calc_view_kernel", "onesweep_kernel"):
-            assert t["kernels"][k]["hbm_bytes_per_launch"] > 0
-        assert v["kernels"]["blend_kernel"]["valu_wave_insts"] > 5e7
-    # the reference-shaped full-sort mode (`--headline full`) on the driver's frames
-    assert b.load_stored("hbm_traffic.json", "C2", P_DRIVER).get("tile_pairs_P") == P_DRIVER
+    assert b.short_kernel("void gs::(anonymous namespace)::blend_kernel<0, false, 5, 4>(unsigned int const*, float)") == "blend_kernel"
+    assert b.short_kernel("gs::(anonymous namespace)::onesweep_kernel<8, false, 8>(unsigned int const*)") == "onesweep_kernel"
+    assert b.short_kernel("void gs::tie_fix_kernel<1>(gsm::AssetView)") == "tie_fix_kernel"
 
 
-def test_entry_selection_is_by_pair_count_and_never_crosses_configurations(tmp_path, monkeypatch):
+def test_counter_rows_of_the_timed_frames_only():
+    """A child runs W warm-up frames and then the K timed ones; per kernel the mean is over the dispatches of the last K frames."""
     b = _bench()
-    prof = tmp_path / "profiles"
-    prof.mkdir()
-    json.dump({"configs": {"C2": {"tile_pairs_P": 100}, "C2@x": {"tile_pairs_P": 200}, "C2d": {"tile_pairs_P": 150}, "C2_visible": {"tile_pairs_P": 151}}},
-              open(prof / "f.json", "w"))
-    monkeypatch.setattr(b, "ROOT", str(tmp_path))
-    assert b.load_stored("f.json", "C2", 149)["tile_pairs_P"] == 100
-    assert b.load_stored("f.json", "C2", 151)["tile_pairs_P"] == 200        # "C2d" / "C2_visible" are other configurations, not entries of "C2"
-    assert b.load_stored("f.json", "C2d", 1)["tile_pairs_P"] == 150
-    assert b.load_stored("f.json", "C2")["tile_pairs_P"] == 100             # no pair count given: the plain key
-    assert b.load_stored("f.json", "C3", 1) == {} and b.load_stored("missing.json", "C2", 1) == {}
+    W, K = 3, 4
+    rows = []
+    did = 0
+    for f in range(W + K):
+        for inst, val in (("blend_kernel<0, false, 5, 4>", 100.0 if f < W else 10.0 + f), ("onesweep_kernel<8, false, 8>", 1.0), ("onesweep_kernel<6, false, 16>", 3.0)):
+            did += 1
+            rows.append({"Kernel_Name": f"void gs::(anonymous namespace)::{inst}(int)", "Counter_Name": "FETCH_SIZE", "Counter_Value": str(val), "Dispatch_Id": str(did)})
+    rows.append({"Kernel_Name": "void gs::set_indices_kernel(unsigned int*, unsigned int)", "Counter_Name": "FETCH_SIZE", "Counter_Value": "7", "Dispatch_Id": "0"})
+    rows.append({"Kernel_Name": "void gs::x_kernel(int)", "Counter_Name": "OTHER", "Counter_Value": "9", "Dispatch_Id": "999"})
+    k = b.fold_counter_rows({}, rows[::-1], "FETCH_SIZE", W + K, K)          # (order in the file does not matter: sorted by dispatch id)
+    assert k["blend_kernel"]["dispatches"] == K and abs(k["blend_kernel"]["FETCH_SIZE_KiB"] - (10.0 + (3 + 4 + 5 + 6) / 4.0)) < 1e-9
+    assert k["onesweep_kernel"]["dispatches"] == 2 * K and k["onesweep_kernel"]["FETCH_SIZE_KiB"] == 2.0
+    assert k["set_indices_kernel"]["dispatches"] == 1 and "x_kernel" not in k
+    k = b.fold_counter_rows(k, [dict(r, Counter_Name="SQ_INSTS_VALU") for r in rows[:3 * (W + K)]], "SQ_INSTS_VALU", W + K, K)
+    assert "SQ_INSTS_VALU" in k["blend_kernel"] and "FETCH_SIZE_KiB" in k["blend_kernel"]
+
+
+def test_stage_bytes_follow_the_survey_formulas():
+    from unitygaussiansplatting_amd.asset import GaussianSplatAsset  # noqa: F401  (the module imports)
+    from common import small_asset
+    b = _bench()
+    a = small_asset(20000, 5, "Medium")
+    n, P, V, W, H = 1_000_000, 900_000, 300_000, 1200, 797
+    full = b.stage_bytes(n, P, V, W, H, a, 2, "full")
+    vis = b.stage_bytes(n, P, V, W, H, a, 2, "visible")
+    assert full["blend"] == vis["blend"] == P * 36 + W * H * 8               # SURVEY 8(d): 4 + 32 B per pair, the RGBA16F target written once
+    assert full["sort"] == n * 60 and vis["sort"] == V * 68
+    assert abs(full["calc_distances"] - n * 8.25) < 1 and vis["calc_distances"] < full["calc_distances"]
+    assert b.VALU_SPEC_GWI == 256 * 4 * 2.4 / 2

@@ -162,6 +162,37 @@ def test_rccl_asset_broadcast_single_rank(gpu_ctx):
 
 
 @pytest.mark.gpu
+def test_two_gpus_broadcast_and_render_their_own_views(gpu_ctx, tmp_path):
+    """The multi-GPU path itself, on the day a node with >= 2 GPUs runs this suite (skipped on the 1-GPU boxes): two processes, one GPU each,
+    gs_comm_create(nranks = 2) + gs_asset_broadcast over RCCL / xGMI, each rank renders its own camera -- the frame of rank k == the frame a
+    single GPU renders from camera k."""
+    import subprocess
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (no multi-GPU node was available in any round: no scaling curve was measured)")
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from common import small_asset
+    from two_gpu_worker import view_camera
+    from unitygaussiansplatting_amd import parallel
+    from unitygaussiansplatting_amd.renderer import GaussianSplatRenderer, RenderTarget
+    uid = parallel.Comm.UniqueId().hex()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "two_gpu_worker.py"), str(k), "2", uid, str(tmp_path / f"view{k}.npy")], env=env)
+             for k in range(2)]
+    for p in procs:
+        assert p.wait(timeout=300) == 0
+    a = small_asset(20000, 5, "Medium")
+    for k in range(2):
+        cam = view_camera(k)
+        r = GaussianSplatRenderer(gpu_ctx, a)
+        r.OnEnable()
+        rt = RenderTarget(gpu_ctx, cam.pixelWidth, cam.pixelHeight)
+        r.SortPoints(cam); r.CalcViewData(cam); rt.Clear(); r.Draw(cam, rt)
+        assert np.array_equal(np.load(tmp_path / f"view{k}.npy"), rt.Download()), f"view {k}"
+        r.OnDisable(); rt.Dispose()
+
+
+@pytest.mark.gpu
 def test_asset_replica_through_the_receive_half_of_the_broadcast(gpu_ctx):
     """gs_asset_replicate = the non-root branch of gs_asset_broadcast (header -> padded allocations -> blobs -> view) with a
     device copy in place of ncclBroadcast: the replica (on a second context of the same GPU) renders the same frame, owns its

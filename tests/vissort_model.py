@@ -23,6 +23,7 @@ class VisibleSortModel:
         self._keyer = O.Oracle(asset)       # its order stays the identity: calc_distances gives the keys BY SPLAT INDEX
         self.base = np.arange(asset.splatCount, dtype=np.uint32)      # the order the recorded sorts start from
         self.rank = self.base.copy()        # its inverse
+        self._keys = {}
 
     def reset(self):
         self.hist, self.dropped = [], 0
@@ -58,7 +59,12 @@ class VisibleSortModel:
             self.dropped += 1
 
     def keys_by_index(self, m16: np.ndarray) -> np.ndarray:
-        return self._keyer.calc_distances(m16).copy()
+        k = np.ascontiguousarray(m16, np.float32).tobytes()
+        if k not in self._keys:                                         # (a long history asks for the same rows every frame)
+            if len(self._keys) > 512:
+                self._keys.clear()
+            self._keys[k] = self._keyer.calc_distances(m16).copy()
+        return self._keys[k]
 
     def visible_order(self, visible: np.ndarray) -> np.ndarray:
         """visible: bool[N].  The visible splat indices in the order the mode draws them."""

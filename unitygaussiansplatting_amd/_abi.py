@@ -68,7 +68,7 @@ class gs_stage_times(C.Structure):
     _fields_ = [(n, C.c_float) for n in ("calc_distances_ms", "sort_ms", "calc_view_ms", "bin_ms", "pair_sort_ms",
                                          "blend_ms", "resolve_ms", "total_ms")] + [("frames", C.c_uint32)] + \
                [("onesweep_depth_ms", C.c_float), ("onesweep_pairs_ms", C.c_float), ("onesweep_pair_launches", C.c_uint32),
-                ("onesweep_depth_kernel_ms", C.c_float), ("onesweep_pairs_kernel_ms", C.c_float)]
+                ("onesweep_depth_kernel_ms", C.c_float), ("onesweep_pairs_kernel_ms", C.c_float), ("onesweep_depth_launches", C.c_uint32)]
 
 
 VIEW_DTYPE = np.dtype([("pos", "<f4", (4,)), ("axis1", "<f4", (2,)), ("axis2", "<f4", (2,)), ("color", "<u4", (2,))])

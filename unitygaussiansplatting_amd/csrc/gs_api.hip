@@ -376,7 +376,7 @@ static int32_t enqueue_full_sort(gs_renderer* r, const float m[16], bool consoli
     // (skipLastKeys: the last depth pass writes only the order -- nothing on the frame's path reads the sorted keys; materialise_distances)
     GS_TRY(enqueue_sort_passes(ctx, st, r->depthSort, control, r->distances, r->order, r->n, nullptr, 4, 255u, profR, 10, 8, r->keyBySplat, !consolidating));
     r->distancesStale = !consolidating;
-    if (profR) gs::prof_record(r, 2, st);
+    if (profR) { gs::prof_record(r, 2, st); r->lastDepthPasses = 4; }
     if (aux) {
         GS_HIP(hipEventRecord(r->evSortDone, st));
         r->sortPending = true;
@@ -794,6 +794,7 @@ int32_t gs_renderer_stage_times(gs_renderer* r, gs_stage_times* out) {
     out->onesweep_depth_ms = avg(10, 11);
     out->onesweep_pairs_ms = avg(12, 13);
     out->onesweep_pair_launches = r->lastPairPasses;
+    out->onesweep_depth_launches = r->lastDepthPasses;
     for (int ps = 0; ps < 4; ++ps) out->onesweep_depth_kernel_ms += avg(14 + 2 * ps, 15 + 2 * ps);
     for (int ps = 0; ps < (int)r->lastPairPasses && ps < 3; ++ps) out->onesweep_pairs_kernel_ms += avg(22 + 2 * ps, 23 + 2 * ps);
     out->total_ms = out->calc_distances_ms + out->sort_ms + out->calc_view_ms + out->bin_ms + out->pair_sort_ms + out->blend_ms;

@@ -48,7 +48,7 @@ namespace GaussianSplatting.Runtime
         public struct FrameStats { public ulong tilePairs, pairCapacity; public uint visibleSplats, tilesX, tilesY, sortError, tileW, tileH, sortMode, tieLongRuns, tieLongestRun; }
 
         [StructLayout(LayoutKind.Sequential)]
-        public struct StageTimes { public float calcDistancesMs, sortMs, calcViewMs, binMs, pairSortMs, blendMs, resolveMs, totalMs; public uint frames; public float onesweepDepthMs, onesweepPairsMs; public uint onesweepPairLaunches; public float onesweepDepthKernelMs, onesweepPairsKernelMs; }
+        public struct StageTimes { public float calcDistancesMs, sortMs, calcViewMs, binMs, pairSortMs, blendMs, resolveMs, totalMs; public uint frames; public float onesweepDepthMs, onesweepPairsMs; public uint onesweepPairLaunches; public float onesweepDepthKernelMs, onesweepPairsKernelMs; public uint onesweepDepthLaunches; }
 
         [DllImport(Lib)] public static extern int gs_abi_version();
         [DllImport(Lib)] public static extern IntPtr gs_error_string(int err);
