@@ -70,8 +70,10 @@ def parse():
     ap.add_argument("--sort-nth-frame", type=int, default=1)
     ap.add_argument("--repeats", type=int, default=5, help="the timed region (exactly --steps frames) is run this many times back to back; ms_per_step / value are the MEDIAN region")
     ap.add_argument("--broadcast", action="store_true", help="go through gs_comm_create / gs_asset_broadcast even with one rank")
-    ap.add_argument("--sort-mode", default="all", choices=["all", "both", "full", "visible", "reference_shaped"], help="which modes to measure (both = full + visible)")
-    ap.add_argument("--headline", default="auto", choices=["auto", "full", "visible"], help="which measured mode `value` reports (auto: visible if its end-of-orbit check holds)")
+    ap.add_argument("--sort-mode", default="all", choices=["all", "both", "full", "visible", "reference_shaped", "visible_in_flight"], help="which modes to measure (both = full + visible)")
+    ap.add_argument("--headline", default="auto", choices=["auto", "full", "visible", "visible_in_flight", "reference_shaped"],
+                    help="which measured mode `value` reports (auto: the fastest of visible_in_flight / visible whose end-of-orbit check holds, else full)")
+    ap.add_argument("--in-flight", type=int, default=2, help="renderers (contexts = streams) the visible_in_flight mode deals its frames / views to")
     ap.add_argument("--pmc", default="auto", choices=["auto", "off"], help="auto: at N = 1 spawn rocprofv3 --pmc children of this script for HBM traffic and VALU instruction counts")
     ap.add_argument("--pmc-child", default="", help="(internal) path of the pickled asset: run the frames of one mode and exit -- what the rocprofv3 children execute")
     ap.add_argument("--child-mode", default="visible", help="(internal) mode of a --pmc-child run")
@@ -422,18 +424,49 @@ def main():
 
     sort_log = []                                            # every SortPoints matrix of the measurement in progress, in call order (the oracle replays it)
 
+    # A lane = a renderer on a context (= a HIP stream) of its own with its own targets; lane 0 is `r`.  The sequential modes use lane 0 only.  The
+    # visible_in_flight mode deals its frames (C5: its views) round-robin to --in-flight lanes that SHARE the asset's device blobs: in GS_SORT_VISIBLE
+    # gs_renderer_sort is bookkeeping, so every lane is told every matrix and each draws its frames from the reference's order -- the same frames, one
+    # lane's streaming / latency-bound kernels under another's VALU-bound blend.
+    class Lane:
+        def __init__(self, ctx_, r_, rts_):
+            self.ctx, self.r, self.rts = ctx_, r_, rts_
+    lanes = [Lane(ctx, r, rts)]
+    active = [lanes[0]]
+
+    def lane(k):
+        while len(lanes) <= k:
+            c2 = GpuContext(local_rank)
+            r2 = GaussianSplatRenderer(c2, r.m_Asset)
+            r2.m_SortNthFrame = r.m_SortNthFrame
+            r2.sortMode = SortMode.Visible
+            r2.ShareResourcesOf(r)
+            r2.blendMode = r.blendMode
+            r2.UpdateCutoutsBuffer()
+            check(_lib.lib().gs_renderer_set_blend_mode(r2._r_h, int(r2.blendMode)), "gs_renderer_set_blend_mode")
+            lanes.append(Lane(c2, r2, [RenderTarget(c2, W, H) for _ in my_views]))
+        return lanes[k]
+
     def frame(i, cam=None):
-        for (m16, p), t in zip(prepared[i], rts):
+        nl = len(active)
+        for vi, (m16, p) in enumerate(prepared[i]):
             if i % r.m_SortNthFrame == 0:
-                r.SortPointsPrepared(m16)
+                for X in active:
+                    X.r.SortPointsPrepared(m16)
                 sort_log.append(m16)
-            r.CalcViewDataPrepared(p)
+            X = active[(i * len(my_views) + vi) % nl]
+            t = X.rts[vi]
+            X.r.CalcViewDataPrepared(p)
             t.Clear()
-            r.DrawPrepared(p, t)
+            X.r.DrawPrepared(p, t)
             check(lib_.gs_target_resolve(t._h, bgp, None, None), "gs_target_resolve")
 
+    def sync_lanes():
+        for X in active:
+            X.ctx.Synchronize()
+
     def full_sync():
-        ctx.Synchronize()
+        sync_lanes()
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
@@ -446,7 +479,7 @@ def main():
         t0 = time.perf_counter()
         for k in range(args.steps):
             frame(first + k)
-        ctx.Synchronize()                                   # every kernel of the region (the context's own stream)
+        sync_lanes()                                        # every kernel of the region (the contexts' own streams)
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
@@ -485,38 +518,43 @@ def main():
         """One mode: warm-up (sizes the pair buffer: an overflowing frame grows it and is re-run), `repeats` un-instrumented regions of
         exactly K frames, then the same K frames with the per-stage hipEvents, then once more with the Onesweep launches' own timestamps.
         Afterwards the renderer is left as the last frame left it (the end-of-orbit state the checks read)."""
-        r.SetSortMode(SortMode.Full)
-        r.ResetOrder()                                       # every mode starts from CSSetIndices' order
-        r.SetSortMode(SortMode.Visible if mode == "visible" else SortMode.Full)
+        piped = mode == "visible_in_flight"
+        active[:] = [lane(k) for k in range(max(1, args.in_flight))] if piped else [lanes[0]]
+        for X in active:
+            X.r.SetSortMode(SortMode.Full)
+            X.r.ResetOrder()                                 # every mode starts from CSSetIndices' order
+            X.r.SetSortMode(SortMode.Visible if mode in ("visible", "visible_in_flight") else SortMode.Full)
         r.SetViewBufferMode(mode == "reference_shaped")     # the reference's CSCalcViewData: colour + 40-byte record of every splat in front of the camera, every frame
         del sort_log[:]
         fi = 0
         first_frame_ms = first_again_ms = None
         for _ in range(frames_warm):
             if fi == 0:                       # the very first frame (identity order: keys in Morton order, cold buffers), timed on its own
-                ctx.Synchronize()
+                sync_lanes()
                 t_first = time.perf_counter()
             frame(fi)
             if fi == 0:
-                ctx.Synchronize()
+                sync_lanes()
                 first_frame_ms = (time.perf_counter() - t_first) * 1e3
                 # ... and the same frame once more (same matrix: the sort changes nothing, the history does not grow): what is left of the
                 # "first frame" once the code objects are loaded, the pair buffer sized and every buffer touched
                 t_first = time.perf_counter()
                 frame(fi)
-                ctx.Synchronize()
+                sync_lanes()
                 first_again_ms = (time.perf_counter() - t_first) * 1e3
-            try:
-                r.FrameStats()
-            except GsError as e:
-                if e.code != -6:
-                    raise
-                frame(fi)
-                r.FrameStats()
+            for X in active:
+                try:
+                    X.r.FrameStats()
+                except GsError as e:
+                    if e.code != -6:
+                        raise
+                    frame(fi)
+                    X.r.FrameStats()
             fi += 1
         # the orbit over the timed region may need more pairs than the warm-up saw: leave 50 % headroom
         st = r.FrameStats()
-        r.ReservePairs(int(st.tile_pairs * 1.5) + (1 << 20))
+        for X in active:
+            X.r.ReservePairs(int(st.tile_pairs * 1.5) + (1 << 20))
         # The un-instrumented region -- exactly K frames between barrier + synchronize -- is run `repeats` times back to back over the same
         # frames; ms_per_step and value are the MEDIAN region's (min / max / every region reported next to them): one 14 ms region alone is a
         # coin-flip inside +-4 % on these boxes.
@@ -527,6 +565,16 @@ def main():
         gc.disable()
         regions = [run_region(fi, gather=True) for _ in range(max(repeats, 1))]
         per_rank = list(per_rank_s)
+        if piped:                                            # frames in flight side by side: per-kernel brackets mean nothing; the sequential visible mode has them
+            gc.enable()
+            for X in active:
+                X.r.FrameStats()
+            # the lane that drew the orbit's last frame (view) holds the end-of-orbit state
+            last_lane = active[((fi + args.steps - 1) * len(my_views) + len(my_views) - 1) % len(active)]
+            rows, limit, cons = last_lane.r.SortHistory()
+            return dict(mode=mode, fi=fi, regions=regions, per_rank=per_rank, elapsed=float(np.median(regions)), elapsed_instr=None, resolve_ms=None, st=last_lane.r.FrameStats(),
+                        frame_ms=None, stage=None, stage_k=None, first_frame_ms=first_frame_ms, first_again_ms=first_again_ms, sorts=list(sort_log),
+                        history=dict(rows=int(rows), limit=int(limit), consolidations=int(cons)), lane=last_lane, lanes=len(active))
         # ---- the same K frames again with the per-stage hipEvents recorded (14 per frame, on the stream each kernel is
         #      launched on).  The events themselves cost ~50 us of a 0.6 ms frame (every record is a barrier + signal packet
         #      between two kernels), so the headline time comes from the regions above and the per-kernel durations from this one.
@@ -558,18 +606,24 @@ def main():
 
     def end_state(x):
         """What the mode's last frame left: the target, the order buffer the reference would hold (GS_SORT_VISIBLE: the recorded sorts carried out on
-        all N by the library), and in the visible-only mode the order the frame was drawn from."""
-        x["img"] = rts[-1].Download()
-        if x["mode"] == "visible":
-            x["vis_order"] = r.DownloadVisibleOrder()
-            x["vis_stats"] = r.FrameStats()
-        x["order"] = r.DownloadOrder()
+        all N by the library), and in the visible-only modes the order the frame was drawn from."""
+        L = x.get("lane", lanes[0])
+        x["img"] = L.rts[-1].Download()
+        if x["mode"] in ("visible", "visible_in_flight"):
+            x["vis_order"] = L.r.DownloadVisibleOrder()
+            x["vis_stats"] = L.r.FrameStats()
+        x["order"] = L.r.DownloadOrder()
 
-    modes = {"all": ["full", "reference_shaped", "visible"], "both": ["full", "visible"]}.get(args.sort_mode, [args.sort_mode])
+    modes = {"all": ["full", "reference_shaped", "visible", "visible_in_flight"], "both": ["full", "visible"]}.get(args.sort_mode, [args.sort_mode])
+    if world > 1:
+        modes = [m for m in modes if m != "visible_in_flight"] or ["visible"]      # (one camera per GPU: nothing to deal)
+    if "visible_in_flight" in modes and "visible" not in modes:
+        modes.insert(modes.index("visible_in_flight"), "visible")                  # the per-kernel figures come from one frame at a time
     res = {}
     for m in modes:
         res[m] = measure(m, args.repeats if m != "reference_shaped" else min(args.repeats, 3), instrument=(m != "reference_shaped"))
         end_state(res[m])
+    active[:] = [lanes[0]]
     r.SetViewBufferMode(False)
 
     # ---- GPU-internal end-of-orbit cross-check: the visible-only mode and the full mode ran the SAME sequence of SortPoints (warm-up + every region);
@@ -578,9 +632,9 @@ def main():
     cross = None
     if "visible" in res and "full" in res:
         V_, F_ = res["visible"], res["full"]
-        same_log = len(V_["sorts"]) == len(F_["sorts"]) and all(a is b or np.array_equal(a, b) for a, b in zip(V_["sorts"], F_["sorts"]))
-        _, _, vbits = r.DownloadRasterRecords()
-        gmask = np.unpackbits(vbits.view(np.uint8), bitorder="little")[:n].astype(bool)
+        same_log = same_sorts(V_["sorts"], F_["sorts"])
+        gmask = np.zeros(n, bool)
+        gmask[V_["vis_order"]] = True                        # the visible set of the last frame
         cross = {"same_sort_sequence": bool(same_log), "sorts_replayed": len(V_["sorts"]),
                  "consolidated_order_equals_full_mode_order": bool(np.array_equal(V_["order"], F_["order"])),
                  "visible_order_is_subsequence_of_full_mode_order": bool(np.array_equal(V_["vis_order"], F_["order"][gmask[F_["order"]]])),
@@ -590,6 +644,12 @@ def main():
         cross["ok"] = all(cross[k] for k in ("same_sort_sequence", "consolidated_order_equals_full_mode_order", "visible_order_is_subsequence_of_full_mode_order", "frames_bit_identical"))
         if "reference_shaped" in res:
             cross["reference_shaped_frame_bit_identical"] = bool(np.array_equal(res["reference_shaped"]["img"], F_["img"]))
+        if "visible_in_flight" in res:
+            X_ = res["visible_in_flight"]
+            cross["in_flight"] = {"lanes": X_["lanes"], "same_sort_sequence": bool(same_sorts(X_["sorts"], F_["sorts"])), "consolidated_order_equals_full_mode_order": bool(np.array_equal(X_["order"], F_["order"])),
+                                  "visible_order_identical_to_sequential": bool(np.array_equal(X_["vis_order"], V_["vis_order"])),
+                                  "frame_bit_identical": bool(np.array_equal(X_["img"], F_["img"]))}
+            cross["in_flight"]["ok"] = all(v for k, v in cross["in_flight"].items() if k != "lanes")
     if world > 1 and cross is not None:
         ok = [None] * world
         dist.all_gather_object(ok, bool(cross["ok"]))
@@ -604,24 +664,35 @@ def main():
     headline = args.headline
     headline_reason = "pinned by --headline"
     if headline == "auto":
-        if "visible" not in res:
-            headline, headline_reason = ("full" if "full" in res else modes[0]), "the visible-only mode was not measured"
-        elif parity is not None and "visible_mode" in parity:
-            okv = parity["visible_mode"]["ok"]
-            headline = "visible" if okv else ("full" if "full" in res else modes[0])
-            headline_reason = ("the oracle's end-of-orbit replay holds for the visible-only mode" if okv else "THE ORACLE'S END-OF-ORBIT CHECK OF THE VISIBLE-ONLY MODE FAILED")
-        elif cross is not None:
-            okv = cross.get("ok_all_ranks", cross["ok"])
-            headline = "visible" if okv else "full"
-            headline_reason = ("no oracle in this run; the GPU-internal end-of-orbit cross-check against the full mode holds" if okv else "THE END-OF-ORBIT CROSS-CHECK OF THE VISIBLE-ONLY MODE FAILED")
+        def verified(mode):
+            """(ok, how) of a visible-only mode's end-of-orbit check: the oracle's replay when this run has it, else the GPU-internal cross-check."""
+            key = "visible_mode" if mode == "visible" else "visible_in_flight"
+            if parity is not None and key in parity:
+                return bool(parity[key]["ok"]), "the oracle's end-of-orbit replay"
+            if cross is not None:
+                c = cross if mode == "visible" else cross.get("in_flight")
+                if c is not None:
+                    return bool(c.get("ok_all_ranks", c["ok"])), "the GPU-internal end-of-orbit cross-check against the full mode (no oracle in this run)"
+            return True, "no check in this run (only this mode was measured)"
+        cands = [m for m in ("visible_in_flight", "visible") if m in res]
+        good = [(m,) + verified(m) for m in cands]
+        failed = [m for m, ok, _ in good if not ok]
+        good = [(m, how) for m, ok, how in good if ok]
+        if good:
+            headline, how = min(good, key=lambda t: res[t[0]]["elapsed"])
+            headline_reason = f"the fastest mode that draws the reference's frame from the reference's order; verified by {how}"
         else:
-            headline, headline_reason = "visible", "only the visible-only mode was measured (no check in this run)"
-        if headline != "visible" and "visible" in res and rank == 0:
-            print(f"bench.py: WARNING: {headline_reason}; the headline is the {headline} mode", file=sys.stderr, flush=True)
+            headline = "full" if "full" in res else modes[0]
+            headline_reason = "the visible-only modes were not measured" if not cands else "THE END-OF-ORBIT CHECK OF THE VISIBLE-ONLY MODES FAILED"
+        if failed and rank == 0:
+            print(f"bench.py: WARNING: the end-of-orbit check FAILED for {failed}; the headline is the {headline} mode", file=sys.stderr, flush=True)
     if headline not in res:
         headline = modes[0]
     R = res[headline]
-    stage, stage_k, st, resolve_ms, frame_ms = R["stage"], R["stage_k"], R["st"], R["resolve_ms"], R["frame_ms"]
+    # per-kernel durations, stage brackets and counters are taken with ONE frame at a time: with frames in flight side by side a kernel's bracket
+    # holds other frames' kernels too
+    K = res["visible"] if headline == "visible_in_flight" else R
+    stage, stage_k, st, resolve_ms, frame_ms = K["stage"], K["stage_k"], R["st"], K["resolve_ms"], K["frame_ms"]
     elapsed = R["elapsed"]
     ms_per_step = elapsed / args.steps * 1e3
     msplats = n * args.steps * num_views / elapsed / 1e6
@@ -631,7 +702,7 @@ def main():
         numTiles = st.tiles_x * st.tiles_y
         passes_pair = 1 if numTiles <= 256 else (2 if numTiles <= 65536 else 3)
         vis = int(st.visible_splats)
-        vmode = headline == "visible"
+        vmode = headline in ("visible", "visible_in_flight")
         sb = stage_bytes(n, P, vis, W, H, r.m_Asset, passes_pair, "visible" if vmode else "full", depth_passes=(int(stage.onesweep_depth_launches) or 4))
         times = {"calc_distances": stage.calc_distances_ms, "sort": stage.sort_ms, "calc_view": stage.calc_view_ms,
                  "bin": stage.bin_ms, "pair_sort": stage.pair_sort_ms, "blend": stage.blend_ms, "resolve": resolve_ms}
@@ -659,7 +730,7 @@ def main():
         # ---- counters of THIS run: rocprofv3 --pmc children over the headline mode's own frames
         pmc = None
         if args.pmc == "auto" and world == 1:
-            pmc = pmc_children(args, asset, headline, R["fi"], frames_warm)
+            pmc = pmc_children(args, asset, "visible" if vmode else headline, R["fi"], frames_warm)
         pk = (pmc or {}).get("kernels", {})
         probe = run_valu_probe()
         valu_measured = float(probe["gwi_per_s"]) if probe and probe.get("gwi_per_s") else VALU_MEASURED_GWI_STORED
@@ -725,7 +796,7 @@ def main():
         stream_dom = max((k for k in ktime if k not in ("blend_kernel", "calc_view_kernel")), key=lambda k: ktime[k])
         roofline_streaming = roof(stream_dom)
         roofline.update({"frames_averaged": int(stage.frames),
-                    "instrumented_ms_per_step": round(R["elapsed_instr"] / args.steps * 1e3, 4),
+                    "instrumented_ms_per_step": round(K["elapsed_instr"] / args.steps * 1e3, 4),
                     "instrumented_frame_gpu_ms": ({"median": round(float(np.median(frame_ms)), 4), "p95": round(float(np.percentile(frame_ms, 95)), 4),
                                                    "max": round(float(frame_ms.max()), 4), "frames": int(len(frame_ms))} if len(frame_ms) else None),
                     "timing": "onesweep_kernel: the launches' own start/stop timestamps (hipExtLaunchKernelGGL events = rocprofv3's kernel durations) from a third pass over the same K frames; `stages` and the other kernels: hipEventRecord brackets on the launching stream from a second pass (the events add ~50 us/frame, so ms_per_step is timed without either)",
@@ -747,6 +818,13 @@ def main():
 
         def mode_summary(x):
             s_, k_ = x["stage"], x["stage_k"]
+            if s_ is None:
+                return {"ms_per_step": round(x["elapsed"] / args.steps * 1e3, 4), "value_Msplats_s": round(n * args.steps * num_views / x["elapsed"] / 1e6, 2),
+                        "regions_ms_per_step": [round(v / args.steps * 1e3, 4) for v in x["regions"]], "renderers_in_flight": x["lanes"],
+                        "tile_pairs_P": int(x["st"].tile_pairs), "visible_splats": int(x["st"].visible_splats), "sort_history": x["history"],
+                        "note": "GS_SORT_VISIBLE with the frames (C5: the views) dealt round-robin to this many renderers on contexts (streams) of their own over ONE copy of the asset; "
+                                "every renderer is told every SortPoints matrix, each draws its frames from the reference's order (checked: sort_mode_cross_check.in_flight, end_of_orbit_check); "
+                                "throughput with frames in flight, not the latency of one frame"}
             return {"ms_per_step": round(x["elapsed"] / args.steps * 1e3, 4), "value_Msplats_s": round(n * args.steps * num_views / x["elapsed"] / 1e6, 2),
                     "regions_ms_per_step": [round(v / args.steps * 1e3, 4) for v in x["regions"]],
                     "tile_pairs_P": int(x["st"].tile_pairs), "visible_splats": int(x["st"].visible_splats),
@@ -776,7 +854,11 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": cfg.label + (f" [splat count overridden to {n}]" if args.splats else ""),
                        "sort_mode": headline, "headline_reason": headline_reason,
-                       "sort_mode_note": ("visible = GS_SORT_VISIBLE: cull first, key + sort + bin the V visible splats only, ties ordered by the chain of every recorded sort matrix and the base "
+                       "frames_in_flight": (R.get("lanes", 1) if headline == "visible_in_flight" else 1),
+                       "one_frame_at_a_time_ms": (round(res["visible"]["elapsed"] / args.steps * 1e3, 4) if "visible" in res else None),
+                       "sort_mode_note": ("visible_in_flight = GS_SORT_VISIBLE with the frames (C5: the views) dealt round-robin to --in-flight renderers on contexts (streams) of their own over ONE copy of "
+                                          "the asset: one frame's latency-bound sort / binning kernels run under another's VALU-bound blend; throughput, each frame the same bits; per-kernel figures "
+                                          "(`roofline`, `stages`) are taken one frame at a time (modes.visible); visible = GS_SORT_VISIBLE: cull first, key + sort + bin the V visible splats only, ties ordered by the chain of every recorded sort matrix and the base "
                                           "order -- the same frame and the same order among the drawn splats as the reference's full sort (tests/test_gpu_vissort.py; this run: `end_of_orbit_check`, "
                                           "`sort_mode_cross_check`); full = SortPoints as the reference runs it (all N), colours only for visible splats; reference_shaped = full + the reference's "
                                           "whole CSCalcViewData (colour + 40-byte view record of every splat in front of the camera) every frame: the like-for-like figure; all are in `modes`"),
@@ -803,6 +885,19 @@ def main():
         dist.destroy_process_group()
 
 
+def same_sorts(a, b):
+    """Two SortPoints logs describe the same sequence of sorts: equal once immediate repetitions of a matrix are dropped (a stable sort of a
+    sequence already sorted by that matrix changes nothing -- a warm-up frame that is drawn again after a pair-buffer overflow logs its matrix twice)."""
+    def dedup(log):
+        out = []
+        for m in log:
+            if not out or not (out[-1] is m or np.array_equal(out[-1], m)):
+                out.append(m)
+        return out
+    a, b = dedup(a), dedup(b)
+    return len(a) == len(b) and all(x is y or np.array_equal(x, y) for x, y in zip(a, b))
+
+
 def cpu_baseline_and_replay(asset, r, res, cam, n, W, H, blend_mode):
     """The oracle (CPU restatement of the reference shaders, oracle/gs_oracle.cpp) as the run's checker and as the reported CPU baseline.
 
@@ -818,7 +913,7 @@ def cpu_baseline_and_replay(asset, r, res, cam, n, W, H, blend_mode):
     orc = O.Oracle(asset)
     cores = int(O.lib().gso_num_threads())
     P = r.FrameParams(cam)
-    ref_mode = next((m for m in ("visible", "full", "reference_shaped") if m in res), None)
+    ref_mode = next((m for m in ("visible", "full", "reference_shaped", "visible_in_flight") if m in res), None)
     sorts = res[ref_mode]["sorts"]
     t_replay = time.perf_counter()
     replayed = 0
@@ -856,7 +951,7 @@ def cpu_baseline_and_replay(asset, r, res, cam, n, W, H, blend_mode):
     fm = "full" if "full" in res else ("reference_shaped" if "reference_shaped" in res else None)
     if fm:
         x = res[fm]
-        same = len(x["sorts"]) == len(sorts) and all(a is b or np.array_equal(a, b) for a, b in zip(x["sorts"], sorts))
+        same = same_sorts(x["sorts"], sorts)
         parity.update({"order_bit_exact": bool(same and np.array_equal(x["order"], orc.order)), **frame_check(x["img"]),
                        "tile_pairs_equal": bool(int(x["st"].tile_pairs) == int(orc.pairs(P, x["st"])))})
     if "visible" in res:
@@ -869,6 +964,15 @@ def cpu_baseline_and_replay(asset, r, res, cam, n, W, H, blend_mode):
             v["frame_bit_identical_to_full_mode"] = bool(np.array_equal(x["img"], res[fm]["img"]))
         v["ok"] = bool(v["order_is_visible_subsequence_of_oracle_order"] and v["consolidated_order_equals_oracle_order"] and v["within_bar"] and v["tile_pairs_equal"])
         parity["visible_mode"] = v
+    if "visible_in_flight" in res:
+        x = res["visible_in_flight"]
+        same = same_sorts(x["sorts"], sorts)
+        v = {"renderers_in_flight": x["lanes"], "same_sort_sequence": bool(same),
+             "order_is_visible_subsequence_of_oracle_order": bool(np.array_equal(x["vis_order"], orc.order[mask[orc.order]])),
+             "consolidated_order_equals_oracle_order": bool(np.array_equal(x["order"], orc.order)), **frame_check(x["img"]),
+             "tile_pairs_equal": bool(int(x["st"].tile_pairs) == int(orc.pairs(P, x["st"])))}
+        v["ok"] = bool(same and v["order_is_visible_subsequence_of_oracle_order"] and v["consolidated_order_equals_oracle_order"] and v["within_bar"] and v["tile_pairs_equal"])
+        parity["visible_in_flight"] = v
     cpu = {"value": round(n / total / 1e6, 3), "unit": "Msplats/s", "cores": cores, "kind": "port",
            "sample": f"1 whole frame of the same workload ({n} splats, {W}x{H}): sort {t_sort or 0.0:.2f}s + view {t2 - t1:.2f}s + "
                      f"composite {t3 - t2:.2f}s + resolve {t4 - t3:.2f}s = {total:.2f}s on {cores} OpenMP threads (the sort = the last of the {replayed} replayed)",

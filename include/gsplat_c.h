@@ -211,7 +211,10 @@ int32_t gs_asset_replicate(gs_context* dst_ctx, const gs_asset* src, gs_asset** 
 
 /* ---- renderer (per GaussianSplatRenderer component) ---------------------------------------------- */
 /* allocates m_GpuView (N x 40 B), m_GpuSortDistances, m_GpuSortKeys, the sorter's SupportResources and the
- * tile-binning buffers; runs CSSetIndices (GaussianSplatRenderer.cs:407,423-445). */
+ * tile-binning buffers; runs CSSetIndices (GaussianSplatRenderer.cs:407,423-445).  `asset` may belong to another context of the SAME GPU
+ * (its blobs are immutable): several renderers on several contexts = several frames / views in flight on several streams over one copy
+ * of the asset (in GS_SORT_VISIBLE every such renderer is told every SortPoints matrix -- gs_renderer_sort is bookkeeping there -- and draws
+ * the frames dealt to it: each draws from the reference's order).  The asset must outlive its renderers. */
 int32_t gs_renderer_create(gs_context* ctx, gs_asset* asset, gs_renderer** out);
 int32_t gs_renderer_destroy(gs_renderer* r);
 /* CSSetIndices (SplatUtilities.compute:59-67): order[i] = i */

@@ -288,3 +288,40 @@ def test_debug_boxes_through_the_visible_order(gpu_ctx):
         r.OnDisable(); rt.Dispose()
     for x, y in zip(*frames):
         assert np.array_equal(x, y) and x.any()
+
+
+def test_frames_dealt_to_two_renderers_sharing_one_asset(gpu_ctx):
+    """Frames in flight: two renderers on two contexts (streams) over ONE copy of the asset's device blobs (ShareResourcesOf), the frames dealt
+    alternately, every renderer told every SortPoints matrix (bookkeeping in this mode): each frame is drawn from the reference's order -- the
+    visible subsequence of the oracle's buffer -- and is the same bits as the frame of one renderer drawing every frame."""
+    from unitygaussiansplatting_amd.renderer import GpuContext
+    a = tie_heavy_asset("lattice", quality="Medium")
+    seq = GaussianSplatRenderer(gpu_ctx, a)
+    seq.sortMode = SortMode.Visible
+    seq.OnEnable()
+    ctx2 = GpuContext(0)
+    lanes = [GaussianSplatRenderer(gpu_ctx, a), GaussianSplatRenderer(ctx2, a)]
+    for L in lanes:
+        L.sortMode = SortMode.Visible
+    lanes[0].OnEnable()
+    lanes[1].ShareResourcesOf(lanes[0])
+    lanes[1].SetSortHistoryLimit(3)                              # (the lanes need not agree on when they consolidate)
+    orc = O.Oracle(a)
+    rts = [RenderTarget(gpu_ctx, 320, 200), RenderTarget(ctx2, 320, 200)]
+    rt_seq = RenderTarget(gpu_ctx, 320, 200)
+    cams = orbit(6, step=5.0, elev=20.0) + flight(6)
+    for k, cam in enumerate(cams):
+        orc.sort(camera.sort_matrix(cam, seq.transform.localToWorldMatrix))
+        seq.SortPoints(cam); seq.CalcViewData(cam); rt_seq.Clear(); seq.Draw(cam, rt_seq)
+        for L in lanes:
+            L.SortPoints(cam)
+        L, rt = lanes[k % 2], rts[k % 2]
+        L.CalcViewData(cam); rt.Clear(); L.Draw(cam, rt)
+        P = L.FrameParams(cam); orc.calc_view(P); vis = visible_bits(orc, P)
+        assert np.array_equal(L.DownloadVisibleOrder(), orc.order[vis[orc.order]]), f"frame {k}"
+        assert np.array_equal(rt.Download(), rt_seq.Download()), f"frame {k}"
+    for L in lanes:
+        assert np.array_equal(L.DownloadOrder(), orc.order)
+    lanes[1].OnDisable(); lanes[0].OnDisable(); seq.OnDisable()
+    for t in rts + [rt_seq]:
+        t.Dispose()

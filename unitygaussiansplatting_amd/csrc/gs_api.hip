@@ -239,7 +239,9 @@ int32_t gs_asset_device_blobs(const gs_asset* a, void* ptrs[5], uint64_t sizes[5
 int32_t gs_renderer_create(gs_context* ctx, gs_asset* asset, gs_renderer** out) {
     if (!ctx || !asset || !out) return fail(GS_ERR_INVALID_ARGUMENT, "null argument");
     *out = nullptr;
-    if (asset->ctx != ctx) return fail(GS_ERR_INVALID_ARGUMENT, "asset belongs to another context");
+    // the asset's blobs are immutable: renderers of OTHER contexts on the same GPU may read them too (several frames / views in flight on
+    // several streams, one copy of the asset); the caller keeps the asset alive, as for any renderer
+    if (asset->ctx != ctx && asset->ctx->device != ctx->device) return fail(GS_ERR_INVALID_ARGUMENT, "asset lives on another GPU (gs_asset_replicate / gs_asset_broadcast)");
     GS_TRY(bind_device(ctx));
     gs_renderer* r = new (std::nothrow) gs_renderer();
     if (!r) return fail(GS_ERR_OUT_OF_MEMORY, "host allocation");

@@ -71,7 +71,6 @@ struct SortState {
     uint32_t maxCount = 0;
     uint32_t maxParts = 0;
     uint32_t partMin = 8192;                // keys in the smallest partition a pass may use (gs_sort.hip: shape A, or shape C for a depth sort)
-    uint32_t digitsMax = 256;               // digits per pass the status / group words are sized for (512: the sort may run 9-bit passes)
     uint32_t histCopies = 1;                // copies of SortControl::hist the producer of the current histograms spread its flushes over (hist_copies()); the passes sum them
     uint32_t epoch = 0;                     // last epoch used on `status` / `groupIncl` (18 bits, never 0)
 };
@@ -81,7 +80,7 @@ struct SortState {
 // 512 atomics = 12,000 per line, most of its 26 us).  So there are kHistReplicas copies, 4 KB apart; workgroup b adds to copy b % kHistReplicas
 // and the one reader (every Onesweep workgroup, once per pass) sums the copies.
 constexpr int kHistReplicas = 8;
-constexpr int kHistStride = 4 * 512;      // words between two copies: [pass][digit], four 8-bit passes (256 apart) or three 9-bit ones (512 apart)
+constexpr int kHistStride = 4 * 256;      // words between two copies
 // how many of the copies a sort's producer spreads its flushes over (and its Onesweep passes sum): a property of the producer's grid
 uint32_t hist_copies(int producerBlocks);
 // small per-sort control block (zeroed by one memset before each sort)
@@ -97,7 +96,6 @@ struct FrameReport {
     unsigned long long pairCount;
     uint32_t binError, pairSortError, visible, tileShape;   // tileShape: log2 tile width | log2 tile height << 8 of the draw that reported
     uint32_t tieLongRuns, tieLongest;                       // GS_SORT_VISIBLE draws: VisControl::tieLongRuns / tieLongest of the draw's visible sort (else 0)
-    uint32_t keyNotMin, keyMax;                             // ... and the range of its raw sort keys (keyMax >= ~keyNotMin: valid)
 };
 
 // ---- GS_SORT_VISIBLE (gs_vissort.hip): the depth sort of the VISIBLE splats only --------------------------------------------------
@@ -115,8 +113,7 @@ struct VisControl {
     uint32_t tieLongRuns;          // statistic: runs of more than kVisTieWaveMax equal keys the fix-up ordered (workgroup path)
     uint32_t tieLongest;           // statistic: the longest of them
     uint32_t error;                // bounded spin expired
-    uint32_t keyNotMin, keyMax;    // ~min / max of the visible splats' RAW sort keys (both start at 0): the next frame's key window is laid around them
-    uint32_t pad[26];
+    uint32_t pad[28];
     // visible count of block b, + 1 (0 = not published yet), one word per 64 bytes: block b polls the words of ALL blocks before it with
     // agent-scope loads, and loads of one 128-byte line queue behind each other at the memory side (749 blocks: 280,000 loads on 24 lines
     // when the words were packed)
@@ -124,11 +121,6 @@ struct VisControl {
 };
 constexpr uint32_t kVisStatusStride = 16;
 struct TieHistory { float row[kVisHistory][4]; uint32_t depth; };   // row[0] = the matrix the keys were made with; depth >= 1
-// The visible-only depth sort runs THREE 9-bit passes over keys reduced to a window of 2^(18 + b) values laid around the previous frame's key
-// range: key' = clamp(key - base, 0, 2^(18 + b) - 1) -- monotone, ties preserved.  Keys outside the window (the camera moved further than the
-// margins) land on its two end values and form a run there, which the tie fix-up orders by the chain STARTING at row 0 -- the true key -- so
-// the order is the reference's whatever the window is; it only decides how many keys take that slower road (none on a steady orbit).
-constexpr uint32_t kVisWideBits = 9;
 // what ends the chain of a tied pair that no kept row separates: the base order
 enum TieBase { TB_INDEX = 0,      // base = identity: the splat index
                TB_RANK = 1,       // base = gs_renderer::order: rank[splat] (its inverse, gs_renderer::visBaseRank)
@@ -141,8 +133,7 @@ struct BinControl {
     uint32_t pairCountClamped;    // min(P, capacity), what the pair sort / ranges / blend see
     uint32_t error;
     uint32_t tieLongRuns, tieLongest;  // copied from the visible sort's VisControl by vis_count (GS_SORT_VISIBLE draws), for the report
-    uint32_t keyNotMin, keyMax;
-    uint32_t pad0[24];
+    uint32_t pad0[26];
     uint32_t visible;
     uint32_t pad1[31];
     uint32_t tickets[16 * 32];    // kBinTicketClasses partition-ticket counters, one per 128-B line
@@ -301,19 +292,19 @@ int32_t join_sort(gs_renderer* r);          // make ctx->stream wait for a sort 
 int32_t mark_order_use(gs_renderer* r);     // the main queue has just been given work that reads / writes order[]: the next sort waits for it
 void prof_end_frame(gs_renderer* r);
 // sort entry points (gs_sort.hip)
-int32_t sort_state_create(gs_context* ctx, SortState& st, uint32_t maxCount, bool smallPartitions = false);   // smallPartitions: the depth sort's state (shape C, 9-bit passes)
+int32_t sort_state_create(gs_context* ctx, SortState& st, uint32_t maxCount, bool smallPartitions = false);
 void sort_state_destroy(SortState& st);
 // keys of all splats in index order (CSCalcDistances' arithmetic) + the four digit histograms; the gather through the
 // previous order is done by the first sort pass (enqueue_sort_passes with gatherKeys)
 int32_t enqueue_sort_keys(gs_context* ctx, hipStream_t st, const gsm::AssetView& a, const float* matSort, uint32_t* keyBySplat,
                           SortControl* control, SortControl* nextControl, uint32_t n, SortState& sort);
-uint32_t sort_group_words(const SortState& st, uint32_t nUpper, int passes, int bits = 8);   // 8-byte words of SortState::groupAgg a sort of nUpper keys uses (to be zeroed before the passes)
+uint32_t sort_group_words(const SortState& st, uint32_t nUpper, int passes);   // 8-byte words of SortState::groupAgg a sort of nUpper keys uses (to be zeroed before the passes)
 int32_t enqueue_histogram(gs_context* ctx, hipStream_t st, const uint32_t* keys, uint32_t n, const uint32_t* nPtr, int passes, uint32_t lastMask,
                           SortControl* control, SortState& sort);
 // `passes` Onesweep passes.  The raw digit histograms must already be in control->hist and sort.groupAgg zeroed.  Result ends in (keys, vals) when
 // passes is even, otherwise it is copied back.
 // profR/evFirst: optional hipEvent slots (evFirst = just before the first Onesweep launch, evFirst + 1 = after the last)
-// bitsPerPass: digit width (6..9; the histograms in control->hist must have been taken with the same width, pass p at hist + p * max(256, 2^bits)).
+// bitsPerPass: digit width (6..8; the histograms in control->hist must have been taken with the same width).
 // gatherKeys != null (8-bit passes, an even number of them): the first pass reads its keys as gatherKeys[vals[i]].
 int32_t enqueue_sort_passes(gs_context* ctx, hipStream_t stream, SortState& st, SortControl* control, uint32_t* keys, uint32_t* vals,
                             uint32_t nUpper, const uint32_t* nPtr, int passes, uint32_t lastMask = 255u,

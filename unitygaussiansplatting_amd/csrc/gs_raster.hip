@@ -108,7 +108,6 @@ __device__ __forceinline__ void write_report(const BinControl* binCtl, const uin
     report->pairSortError = *pairSortError;
     report->tileShape = tileShape;                  // log2 tile width | log2 tile height << 8: what pairCount counts
     report->tieLongRuns = binCtl->tieLongRuns; report->tieLongest = binCtl->tieLongest;      // (GS_SORT_VISIBLE draws; else 0)
-    report->keyNotMin = binCtl->keyNotMin; report->keyMax = binCtl->keyMax;
 }
 
 // Scheduling order of the blend's workgroups: tiles by descending expected cost (the hardware hands out workgroups in
@@ -525,7 +524,7 @@ __global__ __launch_bounds__(kVcThreads) void vis_count_kernel(const uint2* __re
     for (uint32_t j = blockIdx.x * (uint32_t)kVcThreads + tid; j < groupAggWords; j += gridDim.x * (uint32_t)kVcThreads) groupAgg[j] = 0ull;      // for the pair sort's look-back
     for (uint32_t j = blockIdx.x * (uint32_t)kVcThreads + tid; j < nextArenaWords; j += gridDim.x * (uint32_t)kVcThreads) nextArena[j] = 0u;       // the NEXT draw's zeroed arena
     const uint32_t V = min(vis->count, nImm);
-    if (blockIdx.x == 0u && tid == 0) { ctl->tieLongRuns = vis->tieLongRuns; ctl->tieLongest = vis->tieLongest; ctl->keyNotMin = vis->keyNotMin; ctl->keyMax = vis->keyMax; }      // the visible sort's statistics, for the draw's report
+    if (blockIdx.x == 0u && tid == 0) { ctl->tieLongRuns = vis->tieLongRuns; ctl->tieLongest = vis->tieLongest; }      // the visible sort's fix-up statistics, for the draw's report
     const uint32_t shx = tileShift & 0xffu, shy = tileShift >> 8;
     const uint32_t waves = gridDim.x * (uint32_t)(kVcThreads / 64);
     for (uint32_t wb = blockIdx.x * (uint32_t)(kVcThreads / 64) + (uint32_t)(tid >> 6); (unsigned long long)wb * kVcBlock < V; wb += waves) {      // (wave-uniform)

@@ -220,10 +220,6 @@ __global__ __launch_bounds__(THREADS, KPT == KPT_B ? 4 : kMinWavesA) void oneswe
     constexpr int PART = THREADS * KPT;              // keys per partition
     constexpr int RDX = 1 << BITS;                   // digits of this pass
     constexpr int DW = (RDX + 63) / 64;              // waves that own digits
-    constexpr int GSTRIDE = RDX > RADIX ? RDX : RADIX;   // words per group in groupAgg / groupIncl
-    constexpr int DPB = BITS > 8 ? 16 : 8;           // bits a digit takes in dpack
-    constexpr int DPR = 32 / DPB;                    // digits per dpack register
-    static_assert(RDX <= THREADS, "a digit is owned by one thread");
     __shared__ uint32_t s_hist[WAVES * RDX];         // per-wave digit counts -> wave-exclusive offsets
     __shared__ uint32_t s_lbase[RDX];                // exclusive digit offsets inside the partition
     __shared__ uint32_t s_gbase[RDX];                // global index of local slot j with digit d = s_gbase[d] + j
@@ -388,7 +384,7 @@ __global__ __launch_bounds__(THREADS, KPT == KPT_B ? 4 : kMinWavesA) void oneswe
             // (group, digit) = members published << 40 | sum of their counts, so a reader sees a consistent pair.  A digit that
             // no key of the whole input holds is never looked up by anyone: nothing is published for it.
             if (digitLive)
-                __hip_atomic_fetch_add(groupAgg + (size_t)(part / GROUP) * GSTRIDE + tid, (1ull << 40) | (unsigned long long)total, __ATOMIC_RELAXED,
+                __hip_atomic_fetch_add(groupAgg + (size_t)(part / GROUP) * RADIX + tid, (1ull << 40) | (unsigned long long)total, __ATOMIC_RELAXED,
                                        __HIP_MEMORY_SCOPE_AGENT);
             const uint32_t incl = wave_incl_scan(total, lane);
             if (lane == 63) s_wtot[w] = incl;
@@ -478,8 +474,8 @@ __global__ __launch_bounds__(THREADS, KPT == KPT_B ? 4 : kMinWavesA) void oneswe
 #pragma unroll
                     for (int b = 0; b < GB; ++b) {
                         const int jj = j - b;
-                        incl[b] = jj >= 0 ? ld_word64(groupIncl + (size_t)jj * GSTRIDE + tid) : 0ull;
-                        agg[b] = jj >= 0 ? ld_word64(groupAgg + (size_t)jj * GSTRIDE + tid) : 0ull;
+                        incl[b] = jj >= 0 ? ld_word64(groupIncl + (size_t)jj * RADIX + tid) : 0ull;
+                        agg[b] = jj >= 0 ? ld_word64(groupAgg + (size_t)jj * RADIX + tid) : 0ull;
                     }
                     int consumed = 0;
 #pragma unroll
@@ -504,13 +500,13 @@ __global__ __launch_bounds__(THREADS, KPT == KPT_B ? 4 : kMinWavesA) void oneswe
             // the last partition of a group that knows its prefix publishes the group's inclusive prefix: a shortcut for
             // every later group's level 2 (those that find it stop there; those that do not use the aggregates)
             if ((part % GROUP) == (uint32_t)(GROUP - 1) && total > 0 && digitLive)
-                st_word64(groupIncl + (size_t)(part / GROUP) * GSTRIDE + tid, ((unsigned long long)epoch << 32) | (unsigned long long)(exclPrefix + total));
+                st_word64(groupIncl + (size_t)(part / GROUP) * RADIX + tid, ((unsigned long long)epoch << 32) | (unsigned long long)(exclPrefix + total));
             s_gbase[tid] = histExcl + exclPrefix - lbase;
         }
         __syncthreads();
-        uint32_t dpack[(KPT + DPR - 1) / DPR];
+        uint32_t dpack[(KPT + 3) / 4];
 #pragma unroll
-        for (int k = 0; k < (KPT + DPR - 1) / DPR; ++k) dpack[k] = 0;
+        for (int k = 0; k < (KPT + 3) / 4; ++k) dpack[k] = 0;
 #pragma unroll
         for (int k = 0; k < KPT; ++k) {
             const uint32_t j = (uint32_t)tid + (uint32_t)k * THREADS;
@@ -518,7 +514,7 @@ __global__ __launch_bounds__(THREADS, KPT == KPT_B ? 4 : kMinWavesA) void oneswe
                 const uint32_t kk = s_buf[j];
                 const uint32_t d = (kk >> shift) & digitMask;
                 if (keysOut) stg32(keysOut, s_gbase[d] + j, kk);       // (null: the last pass of a depth sort whose sorted keys nobody reads)
-                dpack[k / DPR] |= d << (DPB * (k % DPR));
+                dpack[k >> 2] |= d << (8 * (k & 3));
             }
         }
         __syncthreads();
@@ -528,7 +524,7 @@ __global__ __launch_bounds__(THREADS, KPT == KPT_B ? 4 : kMinWavesA) void oneswe
 #pragma unroll
         for (int k = 0; k < KPT; ++k) {
             const uint32_t j = (uint32_t)tid + (uint32_t)k * THREADS;
-            if (j < valid) stg32(valsOut, s_gbase[(dpack[k / DPR] >> (DPB * (k % DPR))) & (uint32_t)(RDX - 1)] + j, s_buf[j]);
+            if (j < valid) stg32(valsOut, s_gbase[(dpack[k >> 2] >> (8 * (k & 3))) & 255u] + j, s_buf[j]);
         }
     }
 }
@@ -548,16 +544,15 @@ int32_t sort_state_create(gs_context* ctx, SortState& st, uint32_t maxCount, boo
     if (maxCount > kSortMaxCount) return fail(GS_ERR_INVALID_ARGUMENT, "sort capacity above 2^30 keys");
     st.maxCount = maxCount;
     st.partMin = smallPartitions ? (uint32_t)PART_MIN : (uint32_t)PART_A;       // the smallest partition a pass of this sort may use: sizes the status / group words
-    st.digitsMax = smallPartitions ? 512u : (uint32_t)RADIX;                    // the depth sort may run 9-bit passes
     st.maxParts = div_up(maxCount > 0 ? maxCount : 1, st.partMin);
     GS_HIP(hipMalloc((void**)&st.altKeys, ((size_t)maxCount + 16) * 4));
     GS_HIP(hipMalloc((void**)&st.altVals, ((size_t)maxCount + 16) * 4));
-    GS_HIP(hipMalloc((void**)&st.status, (size_t)st.maxParts * st.digitsMax * 4));
-    GS_HIP(hipMemsetAsync(st.status, 0, (size_t)st.maxParts * st.digitsMax * 4, ctx->stream));
+    GS_HIP(hipMalloc((void**)&st.status, (size_t)st.maxParts * RADIX * 4));
+    GS_HIP(hipMemsetAsync(st.status, 0, (size_t)st.maxParts * RADIX * 4, ctx->stream));
     st.maxGroups = div_up(st.maxParts, (uint32_t)GROUP);
-    GS_HIP(hipMalloc((void**)&st.groupAgg, (size_t)4 * st.maxGroups * st.digitsMax * 8));
-    GS_HIP(hipMalloc((void**)&st.groupIncl, (size_t)st.maxGroups * st.digitsMax * 8));
-    GS_HIP(hipMemsetAsync(st.groupIncl, 0, (size_t)st.maxGroups * st.digitsMax * 8, ctx->stream));
+    GS_HIP(hipMalloc((void**)&st.groupAgg, (size_t)4 * st.maxGroups * RADIX * 8));
+    GS_HIP(hipMalloc((void**)&st.groupIncl, (size_t)st.maxGroups * RADIX * 8));
+    GS_HIP(hipMemsetAsync(st.groupIncl, 0, (size_t)st.maxGroups * RADIX * 8, ctx->stream));
     return GS_OK;
 }
 
@@ -594,9 +589,7 @@ uint32_t hist_copies(int producerBlocks) {
     return producerBlocks > 512 ? (uint32_t)kHistReplicas : (producerBlocks > 256 ? 4u : 1u);
 }
 
-uint32_t sort_group_words(const SortState& st, uint32_t nUpper, int passes, int bits) {
-    return (uint32_t)passes * div_up(div_up(max(nUpper, 1u), st.partMin), (uint32_t)GROUP) * max((uint32_t)RADIX, 1u << bits);
-}
+uint32_t sort_group_words(const SortState& st, uint32_t nUpper, int passes) { return (uint32_t)passes * div_up(div_up(max(nUpper, 1u), st.partMin), (uint32_t)GROUP) * RADIX; }
 
 int32_t enqueue_sort_keys(gs_context* ctx, hipStream_t stream, const gsm::AssetView& a, const float* m, uint32_t* keyBySplat,
                           SortControl* control, SortControl* nextControl, uint32_t n, SortState& st) {
@@ -627,7 +620,7 @@ int32_t enqueue_sort_passes(gs_context* ctx, hipStream_t stream, SortState& st, 
                             bool skipLastKeys, uint32_t expected) {
     const uint32_t histCopies = min(max(st.histCopies, 1u), (uint32_t)kHistReplicas);
     if (passes < 1 || passes > 4) return fail(GS_ERR_INVALID_ARGUMENT, "sort passes");
-    if (bits < 6 || bits > 9 || (gatherKeys && bits != 8) || (1u << bits) > st.digitsMax || (bits == 9 && passes > 3)) return fail(GS_ERR_INVALID_ARGUMENT, "sort digit width");
+    if (bits < 6 || bits > 8 || (gatherKeys && bits != 8)) return fail(GS_ERR_INVALID_ARGUMENT, "sort digit width");
     if (nUpper > st.maxCount) return fail(GS_ERR_INVALID_ARGUMENT, "sort count exceeds sorter capacity");
     if (nUpper == 0) return GS_OK;
     // shape by the expected key count (the pair sort knows only an upper bound on the host: the caller passes the last frame's count);
@@ -635,30 +628,28 @@ int32_t enqueue_sort_passes(gs_context* ctx, hipStream_t stream, SortState& st, 
     static const int forcedShape = [] { const char* e = getenv("GSPLAT_SORT_SHAPE");
                                         return !e ? 0 : (e[0] == 'a' || e[0] == 'A') ? 1 : (e[0] == 'b' || e[0] == 'B') ? 2 : (e[0] == 'c' || e[0] == 'C') ? 3 : 0; }();
     const uint32_t expect = min(expected ? expected : nUpper, nUpper);
-    const bool canC = bits >= 8 && !gatherKeys && st.partMin <= (uint32_t)PART_C;      // shape C exists for the plain 8- / 9-bit passes of a sort sized for it
+    const bool canC = bits == 8 && !gatherKeys && st.partMin <= (uint32_t)PART_C;      // shape C exists for the plain 8-bit passes of a sort sized for it
     const bool shapeC = canC && (forcedShape ? forcedShape == 3 : expect <= kSmallSortKeys);
     const bool shapeB = !shapeC && (forcedShape ? forcedShape == 2 : expect > kBigSortKeys);
     const uint32_t parts = div_up(nUpper, shapeC ? (uint32_t)PART_C : shapeB ? (uint32_t)PART_B : (uint32_t)PART_A);
     // persistent grid: no more workgroups than are resident at once (3 per CU at <= 80 VGPRs / 43 KB LDS, 2 at <= 128 / 52 KB), a
     // multiple of the ticket classes so that every class is served
-    // (a 9-bit pass in shape A holds 55 KB of LDS and 105 VGPRs: two workgroups per CU, like shape B)
-    const uint32_t capacity = max(((uint32_t)ctx->cuCount * ((shapeB || (bits == 9 && !shapeC)) ? 2u : 3u) / TICKET_CLASSES) * TICKET_CLASSES, TICKET_CLASSES);
+    const uint32_t capacity = max(((uint32_t)ctx->cuCount * (shapeB ? 2u : 3u) / TICKET_CLASSES) * TICKET_CLASSES, TICKET_CLASSES);
     const uint32_t grid = min(div_up(parts, TICKET_CLASSES) * TICKET_CLASSES, capacity);
     uint32_t *ks = keys, *vs = vals, *kd = st.altKeys, *vd = st.altVals;
     const uint32_t groups = div_up(div_up(nUpper, st.partMin), (uint32_t)GROUP);             // per-pass stride of the group words: sort_group_words()
     const uint32_t fullMask = (1u << bits) - 1u;
-    const uint32_t digitStride = max((uint32_t)RADIX, 1u << bits);                             // of the histograms and the group words, per pass
     // st.groupAgg[passes][groups][256] accumulates: it was zeroed by the kernel that produced the keys / their histograms
     if (profR && evFirst >= 0) prof_record(profR, evFirst, stream);
     for (int p = 0; p < passes; ++p) {
         uint32_t epoch = (++st.epoch) & EPOCH_MASK;
         if (epoch == 0) {   // 18-bit epoch wrapped: wipe the tagged words (they may hold every old epoch), restart at 1
-            GS_HIP(hipMemsetAsync(st.status, 0, (size_t)st.maxParts * st.digitsMax * 4, stream));
-            GS_HIP(hipMemsetAsync(st.groupIncl, 0, (size_t)st.maxGroups * st.digitsMax * 8, stream));
+            GS_HIP(hipMemsetAsync(st.status, 0, (size_t)st.maxParts * RADIX * 4, stream));
+            GS_HIP(hipMemsetAsync(st.groupIncl, 0, (size_t)st.maxGroups * RADIX * 8, stream));
             st.epoch = epoch = 1;
         }
-        const uint32_t* hist = control->hist + digitStride * p;
-        unsigned long long* agg = st.groupAgg + (size_t)p * groups * digitStride;
+        const uint32_t* hist = control->hist + RADIX * p;
+        unsigned long long* agg = st.groupAgg + (size_t)p * groups * RADIX;
         const uint32_t mask = p == passes - 1 ? (lastMask & fullMask) : fullMask;
         const uint32_t shift = (uint32_t)(bits * p);
         uint32_t* kdst = (skipLastKeys && p == passes - 1) ? (uint32_t*)nullptr : kd;      // the payload (order) is all the caller wants
@@ -678,9 +669,7 @@ int32_t enqueue_sort_passes(gs_context* ctx, hipStream_t stream, SortState& st, 
                               (const uint32_t*)hist, st.status, agg, st.groupIncl, (uint32_t*)control->tickets[p], &control->error, nUpper, nPtr, shift, epoch, mask, histCopies)
 #define GS_LAUNCH_ONESWEEP(B, G, KIN) do { if (shapeB) GS_LAUNCH_ONESWEEP_K(B, G, KIN, KPT_B); else GS_LAUNCH_ONESWEEP_K(B, G, KIN, KPT_A); } while (0)
         if (p == 0 && gatherKeys) GS_LAUNCH_ONESWEEP(8, true, gatherKeys);
-        else if (shapeC && bits == 9) GS_LAUNCH_ONESWEEP_K(9, false, ks, KPT_C);
         else if (shapeC) GS_LAUNCH_ONESWEEP_K(8, false, ks, KPT_C);
-        else if (bits == 9) GS_LAUNCH_ONESWEEP(9, false, ks);
         else if (bits == 8) GS_LAUNCH_ONESWEEP(8, false, ks);
         else if (bits == 7) GS_LAUNCH_ONESWEEP(7, false, ks);
         else GS_LAUNCH_ONESWEEP(6, false, ks);

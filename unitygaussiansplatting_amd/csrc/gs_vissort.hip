@@ -63,24 +63,18 @@ __global__ __launch_bounds__(VTHREADS, 6) void visible_keys_kernel(gsm::AssetVie
                                                                 const unsigned long long* __restrict__ visMask, uint32_t words, uint32_t blockWords,
                                                                 uint32_t* __restrict__ outKeys, uint32_t* __restrict__ outIdx, uint32_t* __restrict__ hist,
                                                                 VisControl* vc, uint32_t* __restrict__ nextVc,
-                                                                unsigned long long* __restrict__ groupAgg, uint32_t groupAggWords, uint32_t* __restrict__ nextControl, uint32_t copies,
-                                                                uint32_t wide, uint32_t keyBase, uint32_t keyClamp) {
-    // wide != 0: three 9-bit digit histograms of the REDUCED key clamp(key - keyBase, 0, keyClamp) (gs_common.h: kVisWideBits), which is also what is written;
-    // else four 8-bit ones of the raw key
-    constexpr int kBins = 3 * 512;                                // >= 4 * 256
-    __shared__ uint32_t s_h[kBins];
-    __shared__ uint32_t s_kmin, s_kmax;
+                                                                unsigned long long* __restrict__ groupAgg, uint32_t groupAggWords, uint32_t* __restrict__ nextControl, uint32_t copies) {
+    __shared__ uint32_t s_h[4 * 256];
     __shared__ unsigned long long s_m[VTHREADS];
     __shared__ uint32_t s_off[VTHREADS];
     __shared__ uint32_t s_live[VTHREADS];
     __shared__ uint32_t s_w[VWAVES], s_w2[VWAVES];
     __shared__ uint32_t s_bcast[2];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    if (tid == 0) { s_bcast[1] = 0; s_kmin = 0xffffffffu; s_kmax = 0u; }      // (read after the barriers of the first scan)
-    uint32_t tmin = 0xffffffffu, tmax = 0u;                        // raw keys this thread made
+    if (tid == 0) s_bcast[1] = 0;                                 // (read after the barriers of the first scan)
     // housekeeping for the sort passes that follow and for the NEXT sort (the control blocks alternate: no memset launch per frame)
     if (HIST) {
-        for (int j = tid; j < kBins; j += VTHREADS) s_h[j] = 0;
+        for (int j = tid; j < 4 * 256; j += VTHREADS) s_h[j] = 0;
         for (uint32_t j = blockIdx.x * (uint32_t)VTHREADS + tid; j < groupAggWords; j += gridDim.x * (uint32_t)VTHREADS) groupAgg[j] = 0ull;
     }
     for (uint32_t j = blockIdx.x * (uint32_t)VTHREADS + tid; j < (uint32_t)(sizeof(SortControl) / 4); j += gridDim.x * (uint32_t)VTHREADS) nextControl[j] = 0u;
@@ -128,21 +122,13 @@ __global__ __launch_bounds__(VTHREADS, 6) void visible_keys_kernel(gsm::AssetVie
             }
             const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(B.mm[k] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)B.mm[k], 0u));
             const uint32_t p = firstSlot + B.off[k] + below;
-            if (HIST && !RANKKEY) { tmin = min(tmin, key); tmax = max(tmax, key); }
-            if (wide) key = min(max(key, keyBase) - keyBase, keyClamp);
             outKeys[p] = key;
             outIdx[p] = B.sidx[k];
             if (HIST) {
-                if (wide) {                                          // (wave-uniform)
-                    lds_hist_add(s_h, key & 511u);
-                    lds_hist_add(s_h + 512, (key >> 9) & 511u);
-                    lds_hist_add(s_h + 1024, key >> 18);
-                } else {
-                    lds_hist_add(s_h, key & 255u);
-                    lds_hist_add(s_h + 256, (key >> 8) & 255u);
-                    lds_hist_add(s_h + 512, (key >> 16) & 255u);
-                    lds_hist_add(s_h + 768, key >> 24);
-                }
+                lds_hist_add(s_h, key & 255u);
+                lds_hist_add(s_h + 256, (key >> 8) & 255u);
+                lds_hist_add(s_h + 512, (key >> 16) & 255u);
+                lds_hist_add(s_h + 768, key >> 24);
             }
         }
     };
@@ -228,16 +214,13 @@ __global__ __launch_bounds__(VTHREADS, 6) void visible_keys_kernel(gsm::AssetVie
         }
     }
     if (HIST && total != 0u) {
-        if (!RANKKEY && tmin <= tmax) { atomicMin(&s_kmin, tmin); atomicMax(&s_kmax, tmax); }
         // two neighbouring bins per 64-bit atomic (a bin never reaches 2^32: no carry into its neighbour), into one of the copies
         __syncthreads();
         unsigned long long* myHist = (unsigned long long*)(hist + (blockIdx.x % copies) * (uint32_t)kHistStride);      // SortControl::hist: one of the copies
-        for (int j = tid; j < (wide ? kBins / 2 : 2 * 256); j += VTHREADS) {
+        for (int j = tid; j < 2 * 256; j += VTHREADS) {
             const unsigned long long c = (unsigned long long)s_h[2 * j] | ((unsigned long long)s_h[2 * j + 1] << 32);
             if (c) atomicAdd(myHist + j, c);
         }
-        // the range of this frame's raw keys: where the NEXT frame's key window goes (one pair of atomics per block)
-        if (!RANKKEY && tid == 0 && s_kmin <= s_kmax) { atomicMax(&vc->keyNotMin, ~s_kmin); atomicMax(&vc->keyMax, s_kmax); }
     }
 }
 
@@ -260,12 +243,10 @@ __device__ __forceinline__ int tie_chain(const float* rows, uint32_t first, uint
 // does splat A precede splat B in the reference's order buffer, given that their keys under row 0 are equal?  The chain ends in the base
 // order: the splat index (TB_INDEX), rank[splat] (TB_RANK) or the position the stable sort of the base left the splat at (TB_POSITION) --
 // ta / tb carry the index or the position.
-// first: the row the chain starts at -- 1 (the keys under row 0 are equal), or 0 for a run on one of the two end values of a reduced-key window, whose
-// members' TRUE keys under row 0 may differ (kVisWideBits).
 template <int TB>
-__device__ __forceinline__ bool tie_precedes(const float* rows, uint32_t first, uint32_t depth, const TiePos& pa, uint32_t ea, uint32_t ta, const TiePos& pb, uint32_t eb, uint32_t tb,
+__device__ __forceinline__ bool tie_precedes(const float* rows, uint32_t depth, const TiePos& pa, uint32_t ea, uint32_t ta, const TiePos& pb, uint32_t eb, uint32_t tb,
                                              const uint32_t* __restrict__ rank) {
-    const int c = tie_chain(rows, first, depth, pa, pb);
+    const int c = tie_chain(rows, 1u, depth, pa, pb);
     if (c) return c < 0;
     if (TB == TB_RANK) return rank[ea] < rank[eb];
     return ta < tb;
@@ -283,10 +264,10 @@ constexpr int TIE_XL_ILP = 4;                                     // compare-exc
 // stable sort left the splat at.  Rare by construction (a real scene's depth keys do not tie 65 deep): built to be exact, not fast.
 template <int TB>
 __device__ void tie_sort_long_run(const gsm::AssetView& a, const float* rows, uint32_t depth, const uint32_t* __restrict__ keys, uint32_t* idx, uint32_t n, uint32_t i,
-                                  const uint32_t* __restrict__ rank, uint32_t* k1, uint32_t* tpos, VisControl* vc, uint32_t* s_len, uint32_t keyClamp) {
+                                  const uint32_t* __restrict__ rank, uint32_t* k1, uint32_t* tpos, VisControl* vc, uint32_t* s_len) {
     const int tid = threadIdx.x;
     const uint32_t kc = keys[i];
-    const uint32_t first = (kc == 0u || kc == keyClamp) ? 0u : 1u;      // (block-uniform) a run on an end value of the key window: the chain starts at the true key
+    constexpr uint32_t first = 1u;                                // the chain starts behind the row the keys were made with
     if (tid == 0) *s_len = 0xffffffffu;
     __syncthreads();
     for (uint32_t b = i + 64u;; b += (uint32_t)TIE_THREADS * 4u) {          // (positions i .. i + 64 are known to be equal)
@@ -380,7 +361,7 @@ __device__ void tie_sort_long_run(const gsm::AssetView& a, const float* rows, ui
 template <int TB>
 __global__ __launch_bounds__(TIE_THREADS) void tie_fix_kernel(gsm::AssetView a, TieHistory H, const uint32_t* __restrict__ keys, uint32_t* idx,
                                                               const uint32_t* __restrict__ nPtr, uint32_t nImm, VisControl* vc,
-                                                              const uint32_t* __restrict__ rank, uint32_t* k1BySplat, uint32_t* tBySplat, uint32_t keyClamp) {
+                                                              const uint32_t* __restrict__ rank, uint32_t* k1BySplat, uint32_t* tBySplat) {
     __shared__ float s_rows[kVisHistory * 4];
     __shared__ uint32_t s_start[TIE_SEG / 2];                     // a run has >= 2 positions
     __shared__ uint32_t s_long[TIE_SEG / 5 + 8];
@@ -415,7 +396,6 @@ __global__ __launch_bounds__(TIE_THREADS) void tie_fix_kernel(gsm::AssetView a, 
             const bool m2 = i + 2u < n && k2 == kc, m3 = m2 && i + 3u < n && k3 == kc, m4 = m3 && i + 4u < n && k4 == kc;
             const uint32_t L = m4 ? 5u : (m3 ? 4u : (m2 ? 3u : 2u));
             if (L > 4u) { s_long[atomicAdd(&s_nLong, 1u)] = i; continue; }
-            const uint32_t first = (kc == 0u || kc == keyClamp) ? 0u : 1u;
             // ---- runs of 2..4: rank by counting with the chain comparison, in registers
             TiePos p[4];
 #pragma unroll
@@ -429,7 +409,7 @@ __global__ __launch_bounds__(TIE_THREADS) void tie_fix_kernel(gsm::AssetView a, 
 #pragma unroll
                 for (int y = x + 1; y < 4; ++y)
                     if ((uint32_t)y < L) {
-                        const bool xy = tie_precedes<TB>(s_rows, first, depth, p[x], e[x], TB == TB_POSITION ? (uint32_t)x : e[x], p[y], e[y], TB == TB_POSITION ? (uint32_t)y : e[y], rank);
+                        const bool xy = tie_precedes<TB>(s_rows, depth, p[x], e[x], TB == TB_POSITION ? (uint32_t)x : e[x], p[y], e[y], TB == TB_POSITION ? (uint32_t)y : e[y], rank);
                         rk[xy ? y : x] += 1u;
                     }
             // (the run arrives in the base order -- by index from the visible compaction, by position from a sort of the base -- so most
@@ -457,7 +437,6 @@ __global__ __launch_bounds__(TIE_THREADS) void tie_fix_kernel(gsm::AssetView a, 
                 continue;
             }
             const bool mine = (uint32_t)lane < L;
-            const uint32_t first = (kc == 0u || kc == keyClamp) ? 0u : 1u;
             const uint32_t e = idx[min(i + (uint32_t)lane, n - 1u)];
             const gsm::V3 pq = gsm::LoadSplatPos(a, mine ? e : idx[i]);
             const TiePos p = { pq.x, pq.y, pq.z };
@@ -468,7 +447,7 @@ __global__ __launch_bounds__(TIE_THREADS) void tie_fix_kernel(gsm::AssetView a, 
                 const TiePos pj = { __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p.x), (int)j)), __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p.y), (int)j)),
                                     __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p.z), (int)j)) };
                 if (mine && j != (uint32_t)lane) {
-                    const bool jFirst = tie_precedes<TB>(s_rows, first, depth, pj, ej, TB == TB_POSITION ? j : ej, p, e, t, rank);
+                    const bool jFirst = tie_precedes<TB>(s_rows, depth, pj, ej, TB == TB_POSITION ? j : ej, p, e, t, rank);
                     rk += jFirst ? 1u : 0u;
                 }
             }
@@ -476,7 +455,7 @@ __global__ __launch_bounds__(TIE_THREADS) void tie_fix_kernel(gsm::AssetView a, 
         }
         __syncthreads();
         const uint32_t nXl = s_nXl;
-        for (uint32_t q = 0; q < nXl; ++q) tie_sort_long_run<TB>(a, s_rows, depth, keys, idx, n, s_xl[q], rank, k1BySplat, tBySplat, vc, &s_len, keyClamp);
+        for (uint32_t q = 0; q < nXl; ++q) tie_sort_long_run<TB>(a, s_rows, depth, keys, idx, n, s_xl[q], rank, k1BySplat, tBySplat, vc, &s_len);
     }
 }
 
@@ -560,7 +539,7 @@ int32_t enqueue_tie_fix_full(gs_renderer* r, const uint32_t* keys, uint32_t* idx
     const uint32_t n = r->n;
     const uint32_t tgrid = max(1u, min(div_up(n, (uint32_t)TIE_SEG), (uint32_t)r->ctx->cuCount * 8u));
     hipLaunchKernelGGL(tie_fix_kernel<TB_POSITION>, dim3(tgrid), dim3(TIE_THREADS), 0, r->ctx->stream, r->asset->view, H, keys, idx, (const uint32_t*)nullptr, n,
-                       (VisControl*)nullptr, (const uint32_t*)nullptr, r->depthSort.altKeys, r->depthSort.altVals, 0xffffffffu);      // (the sort's ping-pong buffers are free again: per-splat scratch; raw keys: no window)
+                       (VisControl*)nullptr, (const uint32_t*)nullptr, r->depthSort.altKeys, r->depthSort.altVals);      // (the sort's ping-pong buffers are free again: per-splat scratch)
     GS_HIP(hipGetLastError());
     return GS_OK;
 }
@@ -596,33 +575,12 @@ int32_t enqueue_visible_sort(gs_renderer* r) {
     const bool sorted = byMatrix || byRank;                        // neither: CSSetIndices' order = the index order of the compaction
     static const float zeroRow[4] = { 0.f, 0.f, 0.f, 0.f };
     const float* row = byMatrix ? r->visHist[0] : zeroRow;
-    // Three 9-bit passes over keys reduced to a window around the key range of the last visible draw that reported (pinned memory: no stream
-    // query; it may be a frame or two old), four 8-bit passes over the raw keys while there is none or it is too wide.  A hint only: keys that
-    // leave the window are ordered by the fix-up's chain from row 0 (kVisWideBits), so the drawn order does not depend on it.
-    static const int wideOff = [] { const char* e = getenv("GSPLAT_VIS_WIDE"); return e && e[0] == '0' ? 1 : 0; }();
-    uint32_t wide = 0, keyBase = 0, keyClamp = 0xffffffffu, topBits = 0;
-    if (byMatrix && !wideOff && r->hostReport && r->frameInFlight) {
-        const uint32_t kmin = ~*(volatile uint32_t*)&r->hostReport->keyNotMin, kmax = *(volatile uint32_t*)&r->hostReport->keyMax;
-        if (kmax >= kmin && (kmax | ~kmin) != 0u) {
-            // window = 2^(18 + b) values, b in [1, 9]: at least 1.5 x the range, centred on it
-            const unsigned long long range = (unsigned long long)kmax - kmin + 1ull, want = range + range / 2ull + (1ull << 16);
-            uint32_t b = 1;
-            while (b < kVisWideBits && (1ull << (18u + b)) < want) ++b;
-            if ((1ull << (18u + b)) >= want) {
-                const unsigned long long win = 1ull << (18u + b), slack = (win - range) / 2ull;
-                const unsigned long long base = (unsigned long long)kmin > slack ? (unsigned long long)kmin - slack : 0ull;
-                wide = 1; topBits = b; keyClamp = (uint32_t)(win - 1ull);
-                keyBase = (uint32_t)min(base, 0x100000000ull - win);
-            }
-        }
-    }
-    const int bits = wide ? (int)kVisWideBits : 8, passes = wide ? 3 : 4;
     r->depthSort.histCopies = hist_copies((int)grid);
-    r->lastDepthPasses = sorted ? (uint32_t)passes : 0u;
+    r->lastDepthPasses = sorted ? 4u : 0u;
     prof_record(r, 0, st);
 #define GS_LAUNCH_VK(F, HI, RK) hipLaunchKernelGGL((visible_keys_kernel<F, HI, RK>), dim3(grid), dim3(VTHREADS), 0, st, a, row[0], row[1], row[2], row[3], (const uint32_t*)r->visBaseRank, \
                                                (const unsigned long long*)r->visMask, words, blockWords, r->visKeys, r->visIdx, control->hist, vc, (uint32_t*)nextVc, \
-                                               r->depthSort.groupAgg, sort_group_words(r->depthSort, n, passes, bits), (uint32_t*)nextControl, r->depthSort.histCopies, wide, keyBase, keyClamp)
+                                               r->depthSort.groupAgg, sort_group_words(r->depthSort, n, 4), (uint32_t*)nextControl, r->depthSort.histCopies)
 #define GS_LAUNCH_VKF(F) do { if (byRank) GS_LAUNCH_VK(F, true, true); else if (sorted) GS_LAUNCH_VK(F, true, false); else GS_LAUNCH_VK(F, false, false); } while (0)
     switch (a.posFmt) { case 0: GS_LAUNCH_VKF(0); break; case 1: GS_LAUNCH_VKF(1); break; case 2: GS_LAUNCH_VKF(2); break; default: GS_LAUNCH_VKF(3); break; }
 #undef GS_LAUNCH_VKF
@@ -633,9 +591,9 @@ int32_t enqueue_visible_sort(gs_renderer* r) {
         // the pass shape follows the visible count of the last draw that reported (the host only knows the bound N)
         const uint32_t lastVisible = (r->hostReport && r->frameInFlight) ? *(volatile uint32_t*)&r->hostReport->visible : 0u;
         // the fix-up reads the sorted keys.  Not needed while ties are already in the base order: one matrix on the identity (a stable sort of
-        // the index-ordered compaction) with raw keys, or ranks as keys (no ties at all)
-        const bool needFix = byMatrix && (r->visHistDepth > 1 || !r->visBaseIdentity || wide);
-        GS_TRY(enqueue_sort_passes(ctx, st, r->depthSort, control, r->visKeys, r->visIdx, n, &vc->count, passes, wide ? (1u << topBits) - 1u : 255u, r, 10, bits, nullptr, !needFix,
+        // the index-ordered compaction), or ranks as keys (no ties at all)
+        const bool needFix = byMatrix && (r->visHistDepth > 1 || !r->visBaseIdentity);
+        GS_TRY(enqueue_sort_passes(ctx, st, r->depthSort, control, r->visKeys, r->visIdx, n, &vc->count, 4, 255u, r, 10, 8, nullptr, !needFix,
                                    lastVisible ? lastVisible : max(n / 3u, 1u)));
         if (needFix) {
             TieHistory H;
@@ -643,10 +601,10 @@ int32_t enqueue_visible_sort(gs_renderer* r) {
             const uint32_t tgrid = max(1u, min(div_up(n, (uint32_t)TIE_SEG), (uint32_t)ctx->cuCount * 8u));
             if (r->visBaseIdentity)
                 hipLaunchKernelGGL(tie_fix_kernel<TB_INDEX>, dim3(tgrid), dim3(TIE_THREADS), 0, st, a, H, (const uint32_t*)r->visKeys, r->visIdx, (const uint32_t*)&vc->count, n, vc,
-                                   (const uint32_t*)nullptr, r->depthSort.altKeys, (uint32_t*)nullptr, keyClamp);
+                                   (const uint32_t*)nullptr, r->depthSort.altKeys, (uint32_t*)nullptr);
             else
                 hipLaunchKernelGGL(tie_fix_kernel<TB_RANK>, dim3(tgrid), dim3(TIE_THREADS), 0, st, a, H, (const uint32_t*)r->visKeys, r->visIdx, (const uint32_t*)&vc->count, n, vc,
-                                   (const uint32_t*)r->visBaseRank, r->depthSort.altKeys, (uint32_t*)nullptr, keyClamp);
+                                   (const uint32_t*)r->visBaseRank, r->depthSort.altKeys, (uint32_t*)nullptr);
             GS_HIP(hipGetLastError());
         }
     }

@@ -259,14 +259,29 @@ class GaussianSplatRenderer:
         if self.sortMode != SortMode.Full:
             check(_lib.lib().gs_renderer_set_sort_mode(self._r_h, int(self.sortMode)), "gs_renderer_set_sort_mode")
 
+    def ShareResourcesOf(self, other: "GaussianSplatRenderer") -> None:
+        """A second renderer over the SAME device blobs as `other` (no copy; `other` must outlive this one), on this renderer's own context =
+        its own stream: frames / views in flight side by side.  In SortMode.Visible tell every such renderer every SortPoints matrix and let
+        each draw the frames dealt to it."""
+        assert other._asset_h and not self._r_h
+        self.m_Asset = other.m_Asset
+        self._asset_h, self._asset_borrowed = other._asset_h, True
+        check(_lib.lib().gs_renderer_create(self.ctx._h, self._asset_h, C.byref(self._r_h)), "gs_renderer_create")
+        self.m_SplatCount = other.m_SplatCount
+        self.m_PrevAsset, self.m_PrevHash = other.m_PrevAsset, other.m_PrevHash
+        if self.sortMode != SortMode.Full:
+            check(_lib.lib().gs_renderer_set_sort_mode(self._r_h, int(self.sortMode)), "gs_renderer_set_sort_mode")
+
     def DisposeResourcesForAsset(self) -> None:     # :527-565
         l = _lib.lib()
         if self._r_h:
             l.gs_renderer_destroy(self._r_h)
             self._r_h = C.c_void_p()
         if self._asset_h:
-            l.gs_asset_destroy(self._asset_h)
+            if not getattr(self, "_asset_borrowed", False):
+                l.gs_asset_destroy(self._asset_h)
             self._asset_h = C.c_void_p()
+            self._asset_borrowed = False
         self.m_SplatCount = 0
 
     def OnEnable(self) -> None:                     # :475-485
