@@ -566,6 +566,7 @@ def main():
         regions = [run_region(fi, gather=True) for _ in range(max(repeats, 1))]
         per_rank = list(per_rank_s)
         if piped:                                            # frames in flight side by side: per-kernel brackets mean nothing; the sequential visible mode has them
+            run_region(fi); run_region(fi)                   # (the two instrumented passes of the other modes, as plain regions: every mode logs the SAME sequence of sorts)
             gc.enable()
             for X in active:
                 X.r.FrameStats()

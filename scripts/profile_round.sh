@@ -9,7 +9,7 @@ CFG=${1:-C2}; STEPS=${2:-50}; MODE=${3:-visible}; WARM=${4:-10}; KSUF=${5:-}    
 SUF=""; [ $MODE = visible ] && SUF=_visible
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof_${CFG}${SUF}${KSUF}; rm -rf $O; mkdir -p $O
 export PYTHONPATH=$R
-BENCH="python $R/bench.py --config $CFG --steps $STEPS --warmup $WARM --cpu-baseline off --sort-mode $MODE --repeats 1"
+BENCH="python $R/bench.py --config $CFG --steps $STEPS --warmup $WARM --cpu-baseline off --pmc off --sort-mode $MODE --repeats 1"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- $BENCH > $O/bench_stats.json 2> $O/bench_stats.err
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_$c -- $BENCH > $O/bench_$c.json 2> $O/bench_$c.err

@@ -15,7 +15,7 @@ HEADERS = ["gs_common.h", "gs_device_math.h", os.path.join("..", "..", "include"
 # -fno-slp-vectorize: v_pk_*_f32 is no faster than two scalar VALU ops on gfx950 and the packing costs v_movs (and hides
 # the fp16 mixed-precision FMA patterns of the blend kernel).
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize",
-         "-fgpu-rdc=0" if False else "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
+         "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
 
 
 def hipcc() -> str:
