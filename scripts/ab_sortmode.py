@@ -4,7 +4,7 @@
 Per mode and repetition one JSON line: hipEvent stage means over `frames` profiled frames and the un-instrumented wall time per frame
 (min / median of three regions).  The two renderers share the context; each is warmed up (pair buffers grown, tile schedule history,
 automatic tile shape settled) before it is measured.  GSPLAT_LIB selects a variant build."""
-import json, os, sys, time
+import json, os, sys, time, zlib
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from unitygaussiansplatting_amd import camera, creator, scenes
@@ -67,9 +67,10 @@ for rep in range(reps):
             frame(r, f)
         ctx.Synchronize()
         st = r.FrameStats()
+        crc = zlib.crc32(rt.Download().tobytes())
         t = r.StageTimes()
         r.SetProfiling(0)
         out = {k.replace("_ms", ""): round(getattr(t, k), 4) for k, _ in t._fields_ if k.endswith("_ms") and k not in ("resolve_ms",)}
         out.update(cfg=key, sort_mode=name, active=bool(r.SortModeActive()), tile=f"{st.tile_w}x{st.tile_h}", wall_min=round(min(walls), 4), wall_med=round(sorted(walls)[1], 4),
-                   P=int(st.tile_pairs), V=int(st.visible_splats), tie_long_runs=int(getattr(st, 'tie_long_runs', 0)), lib=os.path.basename(os.environ.get("GSPLAT_LIB", "default")))
+                   P=int(st.tile_pairs), V=int(st.visible_splats), frame_crc=crc, tie_long_runs=int(getattr(st, 'tie_long_runs', 0)), lib=os.path.basename(os.environ.get("GSPLAT_LIB", "default")))
         print(json.dumps(out), flush=True)

@@ -18,8 +18,8 @@
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 
-enum Kind { FMA = 0, PKFMA = 1, EXP = 2, MIX = 3, MIXLO = 4, NKIND = 5 };
-static const char* kKindName[NKIND] = { "v_fma_f32", "v_pk_fma_f32", "v_exp_f32", "v_fma_mix_f32", "v_fma_mixlo_f16" };
+enum Kind { FMA = 0, PKFMA = 1, EXP = 2, MIX = 3, MIXLO = 4, CVTPK = 5, NKIND = 6 };
+static const char* kKindName[NKIND] = { "v_fma_f32", "v_pk_fma_f32", "v_exp_f32", "v_fma_mix_f32", "v_fma_mixlo_f16", "v_cvt_pk_f16_f32" };
 constexpr int UNROLL = 8;              // instructions per loop iteration (8 accumulators when independent)
 
 // one instruction of KIND on accumulator a (b, c: loop-invariant operands)
@@ -28,6 +28,7 @@ template <int KIND> __device__ __forceinline__ void op(float& a, float b, float 
     else if (KIND == EXP) asm volatile("v_exp_f32 %0, %0" : "+v"(a));
     else if (KIND == MIX) asm volatile("v_fma_mix_f32 %0, %0, %1, %2 op_sel_hi:[0,0,0]" : "+v"(a) : "v"(b), "v"(c));
     else if (KIND == MIXLO) asm volatile("v_fma_mixlo_f16 %0, %1, %2, %0 op_sel_hi:[0,0,1]" : "+v"(a) : "v"(b), "v"(c));
+    else if (KIND == CVTPK) asm volatile("v_cvt_pk_f16_f32 %0, %0, %1" : "+v"(a) : "v"(b));
 }
 __device__ __forceinline__ void op_pk(v2f& a, v2f b, v2f c) { asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(a) : "v"(b), "v"(c)); }
 
@@ -86,7 +87,7 @@ static int run(int kind, int dep, int wps, int cus, int iters, float* sink, unsi
     for (int rep = 0; rep < 2; ++rep) {               // rep 0 warms up (clocks, code)
         CK(hipEventRecord(e0, 0));
 #define L(K) do { if (dep) launch<K, true>(grid, block, sink, iters, cyc, rt, rs); else launch<K, false>(grid, block, sink, iters, cyc, rt, rs); } while (0)
-        switch (kind) { case FMA: L(FMA); break; case PKFMA: L(PKFMA); break; case EXP: L(EXP); break; case MIX: L(MIX); break; default: L(MIXLO); break; }
+        switch (kind) { case FMA: L(FMA); break; case PKFMA: L(PKFMA); break; case EXP: L(EXP); break; case MIX: L(MIX); break; case CVTPK: L(CVTPK); break; default: L(MIXLO); break; }
 #undef L
         CK(hipEventRecord(e1, 0));
         CK(hipEventSynchronize(e1));
