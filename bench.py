@@ -616,8 +616,6 @@ def main():
         x["order"] = L.r.DownloadOrder()
 
     modes = {"all": ["full", "reference_shaped", "visible", "visible_in_flight"], "both": ["full", "visible"]}.get(args.sort_mode, [args.sort_mode])
-    if world > 1:
-        modes = [m for m in modes if m != "visible_in_flight"] or ["visible"]      # (one camera per GPU: nothing to deal)
     if "visible_in_flight" in modes and "visible" not in modes:
         modes.insert(modes.index("visible_in_flight"), "visible")                  # the per-kernel figures come from one frame at a time
     res = {}
@@ -653,8 +651,10 @@ def main():
             cross["in_flight"]["ok"] = all(v for k, v in cross["in_flight"].items() if k != "lanes")
     if world > 1 and cross is not None:
         ok = [None] * world
-        dist.all_gather_object(ok, bool(cross["ok"]))
-        cross["ok_all_ranks"] = all(ok)
+        dist.all_gather_object(ok, (bool(cross["ok"]), bool(cross.get("in_flight", {}).get("ok", True))))
+        cross["ok_all_ranks"] = all(a for a, _ in ok)
+        if "in_flight" in cross:
+            cross["in_flight"]["ok_all_ranks"] = all(b for _, b in ok)
 
     # ---- the oracle's end-of-orbit check + the CPU baseline (rank 0, N = 1): the oracle replays EVERY SortPoints of the measurement
     cpu = parity = None

@@ -125,15 +125,27 @@ def test_header_is_plain_c99_and_the_dotnet_binding_covers_it():
     assert have_mode == want_mode and want_mode == {"Full": 0, "Visible": 1}
 
 
-def test_plain_c_program_links_and_runs(tmp_path):
-    """tests/abi_smoke.c: a C99 translation unit that includes the header, links libgsplat_hip.so and uses the ABI."""
+def _run_plain_c_program(tmp_path):
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     _lib.lib()                                     # makes sure the library is built
     libdir = os.path.dirname(_lib.LIB_PATH)
     exe = str(tmp_path / "abi_smoke")
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", os.path.join(root, "tests", "abi_smoke.c"), "-o", exe,
-                           "-L" + libdir, "-l:" + os.path.basename(_lib.LIB_PATH), "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
-    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+                           "-L" + libdir, "-l:" + os.path.basename(_lib.LIB_PATH), "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-lm"])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr
     assert "abi_smoke ok" in out.stdout
+    return out.stdout
+
+
+def test_plain_c_program_links_and_runs(tmp_path):
+    """tests/abi_smoke.c: a C99 translation unit that includes the header, links libgsplat_hip.so and uses the ABI."""
+    _run_plain_c_program(tmp_path)
+
+
+@pytest.mark.gpu
+def test_plain_c_program_renders_through_the_abi(tmp_path):
+    """The same program on a GPU box: frames through nothing but the C-ABI -- importer -> gs_asset_create -> three renderers in GS_SORT_VISIBLE,
+    two of them on contexts of their own sharing the asset with the frames dealt alternately (history limit 2): same bits, same order."""
+    assert "GPU present" in _run_plain_c_program(tmp_path)
