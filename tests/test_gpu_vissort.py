@@ -325,3 +325,28 @@ def test_frames_dealt_to_two_renderers_sharing_one_asset(gpu_ctx):
     lanes[1].OnDisable(); lanes[0].OnDisable(); seq.OnDisable()
     for t in rts + [rt_seq]:
         t.Dispose()
+
+
+def test_views_in_flight_helper_gives_the_sequential_frames(gpu_ctx):
+    """renderer.ViewsInFlight: the 8 cameras of a C5-style batch dealt to two lanes, twice (the second batch continues the sort history): every
+    target == the target a single renderer drawing the cameras one after the other produces, bit for bit."""
+    from unitygaussiansplatting_amd.renderer import ViewsInFlight
+    a = small_asset(40_000, 12, "Medium")
+    seq = GaussianSplatRenderer(gpu_ctx, a)
+    seq.sortMode = SortMode.Visible
+    seq.OnEnable()
+    main = GaussianSplatRenderer(gpu_ctx, a)
+    main.OnEnable()
+    vif = ViewsInFlight(main, lanes=2)
+    rt = RenderTarget(gpu_ctx, 320, 200)
+    for batch in range(2):
+        cams = [default_camera(az=45.0 * k + 7.0 * batch, elev=12.0) for k in range(8)]
+        want = []
+        for cam in cams:
+            seq.SortPoints(cam); seq.CalcViewData(cam); rt.Clear(); seq.Draw(cam, rt)
+            want.append(rt.Download())
+        got = [t.Download() for t in vif.Render(cams)]
+        for k in range(8):
+            assert np.array_equal(got[k], want[k]) and want[k].any(), f"batch {batch}, view {k}"
+    assert np.array_equal(vif.lanes[1].DownloadOrder(), seq.DownloadOrder())
+    vif.Dispose(); main.OnDisable(); seq.OnDisable(); rt.Dispose()
