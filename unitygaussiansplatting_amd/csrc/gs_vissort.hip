@@ -7,16 +7,18 @@
 //   1. visible_keys_kernel   keys of the V visible splats (CSCalcDistances' arithmetic, the matrix of the last gs_renderer_sort) compacted
 //                            in SPLAT-INDEX order into (visKeys, visIdx), the four digit histograms of those keys, V itself;
 //   2. four plain Onesweep passes (gs_sort.hip) over V pairs -- no gather pass, no keys of culled splats;
-//   3. tie_fix_kernel        the reference's order among EQUAL keys.  Its sort is stable and its input is the previous frame's order,
-//                            so the order buffer is sorted lexicographically by (key under M_k, key under M_k-1, ..., key under M_1,
-//                            index): tied splats keep what the earlier sort matrices gave them.  A stable sort of an index-ordered
-//                            compaction leaves ties in index order; the fix-up re-orders every run of equal keys by that chain,
-//                            re-evaluating the tied splats' keys under the kept matrices (gs_renderer::visHist, most recent first;
-//                            a matrix that occurs twice only counts where it occurs first, so a static camera keeps ONE).  Runs of
-//                            2..4 are ordered by the thread that finds them, 5..64 by a wave; a longer run that the history would have to
-//                            order is reported (VIS_TIE_OVERFLOW) and the renderer falls back to full sorts (gs_api.hip).
-// The draw (gs_raster.hip: vis_offsets_kernel + vis_emit_kernel) then bins the V sorted entries instead of walking N positions of the full order.
-// Host-side bookkeeping (the matrix history) lives at the end of this file; the API around it in gs_api.hip.
+//   3. tie_fix_kernel<TB>    the reference's order among EQUAL keys.  Its sort is stable and its input is the previous frame's order, so
+//                            after sorts M_1 .. M_k of a base order B its buffer is sorted lexicographically by (key under M_k, ..., key under
+//                            M_1, rank in B): tied splats keep what the earlier sort matrices gave them.  A stable sort of an index-ordered
+//                            compaction leaves ties in index order; the fix-up re-orders every run of equal keys by that chain, re-evaluating
+//                            the tied splats' keys under the rows recorded since B (gs_renderer::visHist, most recent first; a matrix that
+//                            occurs twice only counts where it occurs first, so a static camera keeps ONE) and ending in B: the index while B
+//                            is CSSetIndices' identity, else rank[] = the inverse of gs_renderer::order (invert_order_kernel).  Runs of 2..4 are
+//                            ordered by the thread that finds them, 5..64 by a wave, longer ones by the workgroup (a bitonic network in place).
+// Nothing is ever dropped from the chain: when the history is full (kVisHistory rows) gs_api.hip's vis_consolidate carries the recorded sorts
+// out on all N -- one reference-shaped sort of B by the most recent row + tie_fix_kernel<TB_POSITION> over N -- and that buffer is the new B.
+// The draw (gs_raster.hip: vis_count / vis_offsets / vis_emit) then bins the V sorted entries instead of walking N positions of the full order.
+// Host-side bookkeeping (the matrix history) lives at the end of this file; the API around it in gs_api.hip.  DESIGN.md section 4.4.
 #include "gs_common.h"
 #include <cstdlib>
 
