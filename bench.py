@@ -662,31 +662,9 @@ def main():
         last = res[modes[-1]]["fi"] + args.steps - 1
         cpu, parity = cpu_baseline_and_replay(asset, r, res, cam_at(last, my_views[-1]), n, W, H, r.blendMode)
 
-    headline = args.headline
-    headline_reason = "pinned by --headline"
-    if headline == "auto":
-        def verified(mode):
-            """(ok, how) of a visible-only mode's end-of-orbit check: the oracle's replay when this run has it, else the GPU-internal cross-check."""
-            key = "visible_mode" if mode == "visible" else "visible_in_flight"
-            if parity is not None and key in parity:
-                return bool(parity[key]["ok"]), "the oracle's end-of-orbit replay"
-            if cross is not None:
-                c = cross if mode == "visible" else cross.get("in_flight")
-                if c is not None:
-                    return bool(c.get("ok_all_ranks", c["ok"])), "the GPU-internal end-of-orbit cross-check against the full mode (no oracle in this run)"
-            return True, "no check in this run (only this mode was measured)"
-        cands = [m for m in ("visible_in_flight", "visible") if m in res]
-        good = [(m,) + verified(m) for m in cands]
-        failed = [m for m, ok, _ in good if not ok]
-        good = [(m, how) for m, ok, how in good if ok]
-        if good:
-            headline, how = min(good, key=lambda t: res[t[0]]["elapsed"])
-            headline_reason = f"the fastest mode that draws the reference's frame from the reference's order; verified by {how}"
-        else:
-            headline = "full" if "full" in res else modes[0]
-            headline_reason = "the visible-only modes were not measured" if not cands else "THE END-OF-ORBIT CHECK OF THE VISIBLE-ONLY MODES FAILED"
-        if failed and rank == 0:
-            print(f"bench.py: WARNING: the end-of-orbit check FAILED for {failed}; the headline is the {headline} mode", file=sys.stderr, flush=True)
+    headline, headline_reason, failed = pick_headline(args.headline, {m: x["elapsed"] for m, x in res.items()}, parity, cross, modes)
+    if failed and rank == 0:
+        print(f"bench.py: WARNING: the end-of-orbit check FAILED for {failed}; the headline is the {headline} mode", file=sys.stderr, flush=True)
     if headline not in res:
         headline = modes[0]
     R = res[headline]
@@ -884,6 +862,33 @@ def main():
         comm.Dispose()
     if dist is not None:
         dist.destroy_process_group()
+
+
+def pick_headline(want, elapsed, parity, cross, modes):
+    """Which measured mode `value` reports.  want: --headline.  elapsed: {mode: seconds of its median region}.  A visible-only mode qualifies only if its
+    end-of-orbit check holds -- the oracle's replay when this run has it (parity), else the GPU-internal cross-check against the full mode (cross) -- and the
+    fastest qualifying one wins; if none qualifies the headline is the reference-shaped full sort.  Returns (mode, reason, modes whose check FAILED)."""
+    if want != "auto":
+        return (want if want in elapsed else modes[0]), "pinned by --headline", []
+
+    def verified(mode):
+        key = "visible_mode" if mode == "visible" else "visible_in_flight"
+        if parity is not None and key in parity:
+            return bool(parity[key]["ok"]), "the oracle's end-of-orbit replay"
+        if cross is not None:
+            c = cross if mode == "visible" else cross.get("in_flight")
+            if c is not None:
+                return bool(c.get("ok_all_ranks", c["ok"])), "the GPU-internal end-of-orbit cross-check against the full mode (no oracle in this run)"
+        return True, "no check in this run (only this mode was measured)"
+    cands = [m for m in ("visible_in_flight", "visible") if m in elapsed]
+    checked = [(m,) + verified(m) for m in cands]
+    failed = [m for m, ok, _ in checked if not ok]
+    good = [(m, how) for m, ok, how in checked if ok]
+    if good:
+        mode, how = min(good, key=lambda t: elapsed[t[0]])
+        return mode, f"the fastest mode that draws the reference's frame from the reference's order; verified by {how}", failed
+    mode = "full" if "full" in elapsed else modes[0]
+    return mode, ("the visible-only modes were not measured" if not cands else "THE END-OF-ORBIT CHECK OF THE VISIBLE-ONLY MODES FAILED"), failed
 
 
 def same_sorts(a, b):

@@ -52,3 +52,28 @@ def test_stage_bytes_follow_the_survey_formulas():
     assert full["sort"] == n * 60 and vis["sort"] == V * 68
     assert abs(full["calc_distances"] - n * 8.25) < 1 and vis["calc_distances"] < full["calc_distances"]
     assert b.VALU_SPEC_GWI == 256 * 4 * 2.4 / 2
+
+
+def test_headline_is_gated_on_the_end_of_orbit_check():
+    """`value` reports a visible-only mode only if ITS end-of-orbit check holds: the oracle's replay when the run has one, else the cross-check against the
+    full mode; a failed check falls back loudly (the failed modes are returned for the warning), never silently."""
+    b = _bench()
+    el = {"full": 0.62, "reference_shaped": 0.67, "visible": 0.56, "visible_in_flight": 0.44}
+    modes = list(el)
+    ok = {"visible_mode": {"ok": True}, "visible_in_flight": {"ok": True}}
+    assert b.pick_headline("auto", el, ok, None, modes)[0] == "visible_in_flight"
+    m, why, failed = b.pick_headline("auto", el, {"visible_mode": {"ok": True}, "visible_in_flight": {"ok": False}}, None, modes)
+    assert m == "visible" and failed == ["visible_in_flight"] and "oracle" in why
+    m, why, failed = b.pick_headline("auto", el, {"visible_mode": {"ok": False}, "visible_in_flight": {"ok": False}}, None, modes)
+    assert m == "full" and set(failed) == {"visible", "visible_in_flight"} and "FAILED" in why
+    # no oracle in the run (N > 1, 50 M splats): the GPU-internal cross-check, every rank's
+    cross = {"ok": True, "ok_all_ranks": False, "in_flight": {"ok": True, "ok_all_ranks": True}}
+    m, why, failed = b.pick_headline("auto", el, None, cross, modes)
+    assert m == "visible_in_flight" and failed == ["visible"] and "cross-check" in why
+    assert b.pick_headline("auto", {"full": 0.6}, None, None, ["full"])[0] == "full"
+    assert b.pick_headline("visible", el, None, None, modes)[:2] == ("visible", "pinned by --headline")
+    assert b.pick_headline("visible", {"full": 0.6}, None, None, ["full"])[0] == "full"
+    # the sort logs of two modes describe the same sequence once immediate repetitions are dropped
+    import numpy as np
+    a, c = np.arange(16, dtype=np.float32), np.arange(16, dtype=np.float32) + 1
+    assert b.same_sorts([a, a, c], [a, c, c]) and not b.same_sorts([a, c], [c, a]) and not b.same_sorts([a, c, a], [a, c])
