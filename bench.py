@@ -200,7 +200,7 @@ def pmc_children(args, asset, mode, first, frames_warm):
             d = os.path.join(out_root, counter)
             tp = time.perf_counter()
             pr = subprocess.run([rocprof, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--"] + child, cwd="/tmp", env=env,
-                                capture_output=True, text=True, timeout=300)
+                                capture_output=True, text=True, timeout=120)
             rows = []
             for fcsv in glob.glob(os.path.join(d, "*", "*_counter_collection.csv")):
                 rows += list(csv.DictReader(open(fcsv)))
