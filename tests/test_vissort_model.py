@@ -107,3 +107,46 @@ def test_truncated_history_is_exact_unless_a_dropped_matrix_decides():
         orc.sort(m); full.push(m); short.push(m)
     assert np.array_equal(full.visible_order(vis), orc.order)
     assert short.dropped == 2 and not np.array_equal(short.visible_order(vis), orc.order)      # the pitched view (dropped) ordered the planes' splats
+
+
+def bitonic_pairs(L: int):
+    """The compare-exchange schedule of gs_vissort.hip's tie_sort_long_run, restated: the all-ascending bitonic network over 2^lp >= L positions --
+    per merge level lk a FLIP step (position o of the lower half of every block of 2^lk meets its mirror image in the upper half), then half-cleaners
+    of strides 2^(lk-2) .. 1 -- with every pair whose upper position does not exist (>= L) left out.  Yields the steps as lists of (x, y), x < y."""
+    lp = 0
+    while (1 << lp) < L:
+        lp += 1
+    half = (1 << (lp - 1)) if lp else 0
+    for lk in range(1, lp + 1):
+        step = []
+        for p in range(half):
+            blk, o = p >> (lk - 1), p & ((1 << (lk - 1)) - 1)
+            x, y = (blk << lk) + o, (blk << lk) + (1 << lk) - 1 - o
+            if y < L:
+                step.append((x, y))
+        yield step
+        for lj in range(lk - 2, -1, -1):
+            step = []
+            for p in range(half):
+                x = ((p >> lj) << (lj + 1)) | (p & ((1 << lj) - 1))
+                y = x + (1 << lj)
+                if y < L:
+                    step.append((x, y))
+            yield step
+
+
+@pytest.mark.parametrize("L", list(range(1, 70)) + [127, 128, 129, 150, 255, 257, 1000, 3001])
+def test_the_long_run_network_sorts_any_length(L):
+    """Positions beyond the run act as +infinity that never moves (every exchange puts the smaller element at the lower position), so the network
+    for the next power of two sorts ANY length with the missing pairs simply skipped; within a step no position occurs twice (the kernel's threads
+    exchange concurrently between two barriers)."""
+    rng = np.random.default_rng(L)
+    for trial in range(3):
+        v = rng.permutation(L) if trial else np.arange(L)[::-1].copy()
+        for step in bitonic_pairs(L):
+            flat = [i for xy in step for i in xy]
+            assert len(flat) == len(set(flat)) and all(x < y < L for x, y in step)
+            for x, y in step:
+                if v[y] < v[x]:
+                    v[x], v[y] = v[y], v[x]
+        assert np.array_equal(v, np.arange(L)), L
