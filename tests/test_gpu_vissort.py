@@ -350,3 +350,11 @@ def test_views_in_flight_helper_gives_the_sequential_frames(gpu_ctx):
             assert np.array_equal(got[k], want[k]) and want[k].any(), f"batch {batch}, view {k}"
     assert np.array_equal(vif.lanes[1].DownloadOrder(), seq.DownloadOrder())
     vif.Dispose(); main.OnDisable(); seq.OnDisable(); rt.Dispose()
+
+
+def test_a_run_of_tens_of_thousands(gpu_ctx):
+    """60,000 splats on two planes facing the camera, after a pitched view: two runs of ~30,000 equal keys each, ordered by the network through
+    global memory in the frame that meets them (slow by design -- milliseconds -- but the reference's order)."""
+    a = tie_heavy_asset("planes", n=60_000)
+    s = run_sequence(gpu_ctx, a, cams_for("planes")[:3], use_model=False, check_frames=False)
+    assert s["longest"] > 20_000 and s["long_runs"] >= 2
