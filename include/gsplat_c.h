@@ -177,6 +177,15 @@ int32_t gs_context_synchronize(gs_context* ctx);
  * blend / resolve and this frame's gs_renderer_calc_view.  Results are identical either way.  Default OFF: on MI355X every
  * kernel of the frame already fills the chip and the frame is not shorter.  Blocks until both queues are idle. */
 int32_t gs_context_set_overlap(gs_context* ctx, int32_t enabled);
+/* May OTHER kernels that wait on their own workgroups run on this GPU at the same time as this context's GS_SORT_FULL sorts -- another process using this
+ * library, or another context of this process sorting concurrently?  Every kernel of the library takes its partitions in dependency order -- a running
+ * workgroup only ever waits on workgroups that were started before it, so it makes progress whatever holds the other wave slots -- with ONE exception kept for
+ * speed: the first pass of the full depth sort deals blocks of partitions to the XCDs (its random key gather then meets in one L2: 25 us per sort of 6 M
+ * keys), which is only deadlock-free if the workgroups still waiting for a slot get one eventually.  shared > 0 makes that pass dependency-ordered too, 0 keeps
+ * the XCD deal, < 0 (the default) decides per sort: shared while this process holds more than one context on the device.  Another PROCESS on the GPU is
+ * something only the host knows: set 1 (or GSPLAT_SHARED_GPU=1 in the environment) there.  (A stall is never a hang: every spin is bounded and surfaces as
+ * GS_ERR_SORT_TIMEOUT.)  GS_SORT_VISIBLE is unaffected: it has no such pass. */
+int32_t gs_context_set_shared_gpu(gs_context* ctx, int32_t shared);
 int32_t gs_context_device_info(gs_context* ctx, char* name_out, size_t name_cap, int32_t* cu_count, uint64_t* hbm_bytes);
 
 /* ---- asset (replaces CreateResourcesForAsset's buffer uploads, GaussianSplatRenderer.cs:373-405) - */

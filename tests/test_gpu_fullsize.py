@@ -86,3 +86,34 @@ def test_garden_like_veryhigh_1080p_properties(gpu_ctx):
         assert 0 < st.visible_splats < n and st.tile_pairs >= st.visible_splats and st.tile_pairs != prev_pairs
         prev_pairs = st.tile_pairs
     r.OnDisable()
+
+
+def test_two_contexts_full_sorting_at_the_same_time(gpu_ctx, c2):
+    """Two contexts of one process, each with a renderer in GS_SORT_FULL over the C2 asset, their sorts enqueued back to back without a host sync:
+    6 M keys are ~1,500 partitions per pass, more than fit the part beside another kernel's, so workgroups of both kernels wait for slots while the
+    resident ones look back.  With a second context alive the gather pass is dealt in dependency order (gs_context_set_shared_gpu's automatic form):
+    no bounded spin may expire (frame_stats would say GS_ERR_SORT_TIMEOUT) and both order buffers are the oracle's after every frame's sort."""
+    from unitygaussiansplatting_amd.renderer import GpuContext
+    cfg, a = c2
+    ctx2 = GpuContext(0)
+    rs = [GaussianSplatRenderer(gpu_ctx, a), GaussianSplatRenderer(ctx2, a)]
+    rs[0].OnEnable()
+    rs[1].ShareResourcesOf(rs[0])
+    orc = O.Oracle(a)
+    rts = [RenderTarget(gpu_ctx, 320, 200), RenderTarget(ctx2, 320, 200)]
+    for f in range(6):
+        cam = camera.Camera(position=scenes.orbit_eye(cfg.eye_radius, cfg.eye_elev_deg, 7.0 * f), pixelWidth=320, pixelHeight=200, fieldOfView=cfg.fov_y)
+        for rep in range(3):                                      # the same sort three times per context, all six in flight together
+            for r in rs:
+                r.SortPoints(cam)
+        for _ in range(3):
+            orc.sort(camera.sort_matrix(cam, rs[0].transform.localToWorldMatrix))
+        for r, rt in zip(rs, rts):
+            r.CalcViewData(cam); rt.Clear(); r.Draw(cam, rt)
+            r.FrameStats()                                        # raises on GS_ERR_SORT_TIMEOUT
+            assert np.array_equal(r.DownloadOrder(), orc.order), f
+        assert np.array_equal(rts[0].Download(), rts[1].Download())
+    rs[1].OnDisable(); rs[0].OnDisable()
+    for t in rts:
+        t.Dispose()
+    ctx2.Dispose()

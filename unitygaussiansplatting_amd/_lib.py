@@ -31,6 +31,7 @@ SIGNATURES = {
     "gs_context_create": (C.c_int32, [C.c_int32, _P, _PP]),
     "gs_context_destroy": (C.c_int32, [_P]),
     "gs_context_synchronize": (C.c_int32, [_P]),
+    "gs_context_set_shared_gpu": (C.c_int32, [_P, C.c_int32]),
     "gs_context_set_overlap": (C.c_int32, [_P, C.c_int32]),
     "gs_context_device_info": (C.c_int32, [_P, C.c_char_p, C.c_size_t, C.POINTER(C.c_int32), C.POINTER(C.c_uint64)]),
     "gs_asset_create": (C.c_int32, [_P, C.POINTER(gs_asset_desc), _PP]),

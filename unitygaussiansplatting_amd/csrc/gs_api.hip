@@ -4,6 +4,7 @@
 #include <stdarg.h>
 #include <stdlib.h>
 
+#include <atomic>
 #include <new>
 
 #include "gs_common.h"
@@ -58,6 +59,15 @@ static int32_t bind_device(gs_context* ctx) {
     return GS_OK;
 }
 
+// live contexts of this process per device: two of them may sort at the same time (gs_shared_gpu)
+static constexpr int kMaxTrackedDevices = 64;
+static std::atomic<int> g_liveContexts[kMaxTrackedDevices];
+
+bool gs_shared_gpu(const gs_context* ctx) {
+    if (ctx->sharedGpu >= 0) return ctx->sharedGpu != 0;
+    return g_liveContexts[ctx->device % kMaxTrackedDevices].load(std::memory_order_relaxed) > 1;
+}
+
 extern "C" {
 
 int32_t gs_abi_version(void) { return GS_ABI_VERSION; }
@@ -106,6 +116,12 @@ int32_t gs_context_create(int32_t device, void* hip_stream, gs_context** out) {
     // The default is therefore off; GSPLAT_OVERLAP=1 or gs_context_set_overlap(ctx, 1) turns it on.
     const char* ov = getenv("GSPLAT_OVERLAP");
     ctx->overlap = ov && ov[0] == '1';
+    // -1 = automatic: shared as soon as this process holds a second context on the device (gs_shared_gpu); GSPLAT_SHARED_GPU=1 / 0 or
+    // gs_context_set_shared_gpu pin it (another PROCESS on the GPU is something only the host knows)
+    const char* sh = getenv("GSPLAT_SHARED_GPU");
+    ctx->sharedGpu = (sh && (sh[0] == '0' || sh[0] == '1')) ? (sh[0] - '0') : -1;
+    g_liveContexts[device % kMaxTrackedDevices].fetch_add(1, std::memory_order_relaxed);
+    ctx->counted = true;
     *out = ctx;
     return GS_OK;
 }
@@ -116,6 +132,7 @@ int32_t gs_context_destroy(gs_context* ctx) {
     if (ctx->aux) { (void)hipStreamSynchronize(ctx->aux); (void)hipStreamDestroy(ctx->aux); }
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->ownStream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    if (ctx->counted) g_liveContexts[ctx->device % kMaxTrackedDevices].fetch_sub(1, std::memory_order_relaxed);
     delete ctx;
     return GS_OK;
 }
@@ -134,6 +151,12 @@ int32_t gs_context_set_overlap(gs_context* ctx, int32_t enabled) {
     GS_HIP(hipStreamSynchronize(ctx->aux));
     GS_HIP(hipStreamSynchronize(ctx->stream));                  // no order[] use of the main queue is outstanding when the mode changes
     ctx->overlap = enabled != 0;
+    return GS_OK;
+}
+
+int32_t gs_context_set_shared_gpu(gs_context* ctx, int32_t shared) {
+    if (!ctx) return fail(GS_ERR_INVALID_ARGUMENT, "ctx is null");
+    ctx->sharedGpu = shared < 0 ? -1 : (shared != 0);
     return GS_OK;
 }
 

@@ -9,6 +9,20 @@
 #include "../../include/gsplat_c.h"
 #include "gs_device_math.h"
 
+// Issue priority of the frame's latency-bound kernels (the sort passes, the key / binning / fix-up kernels, resolve): with frames in flight they share their SIMDs
+// with another frame's blend, whose heaviest tiles raise their own priority (gs_raster.hip); a chain kernel's few instructions between two waits then queue behind
+// the blend's.  -DGS_CHAIN_PRIO=n / -DGS_VIEW_PRIO=n: experiment builds (scripts/build_variants.py).
+#ifdef GS_CHAIN_PRIO
+#define GS_CHAIN_PRIORITY() __builtin_amdgcn_s_setprio(GS_CHAIN_PRIO)
+#else
+#define GS_CHAIN_PRIORITY() do { } while (0)
+#endif
+#ifdef GS_VIEW_PRIO
+#define GS_VIEW_PRIORITY() __builtin_amdgcn_s_setprio(GS_VIEW_PRIO)
+#else
+#define GS_VIEW_PRIORITY() do { } while (0)
+#endif
+
 namespace gs {
 
 // thread-local error detail -------------------------------------------------------------------------
@@ -149,9 +163,15 @@ struct gs_context {
     // here, forked from / joined to `stream` with events, and the two latency-bound kernels share the GPU
     hipStream_t aux = nullptr;
     bool overlap = false;
+    // other kernels that spin on their own workgroups may share this GPU (another process running this library, another context of this process sorting
+    // at the same time): the depth sort's gather pass then hands its partitions out in dependency order instead of in XCD blocks (gs_sort.hip)
+    // -1 automatic (shared iff the process holds more than one context on the device), 0 / 1 pinned by the host
+    int sharedGpu = -1;
+    bool counted = false;                 // this context is in the live count of its device
     int cuCount = 0;
     hipDeviceProp_t props;
 };
+bool gs_shared_gpu(const gs_context* ctx);      // may another kernel that waits on its own workgroups run beside this context's? (gs_api.hip)
 
 struct gs_asset {
     gs_context* ctx = nullptr;

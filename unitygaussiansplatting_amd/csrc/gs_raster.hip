@@ -216,6 +216,7 @@ __global__ __launch_bounds__(kBinThreads) void bin_emit_kernel(const uint2* __re
                                                                 uint32_t* pairHist, unsigned long long* __restrict__ groupAgg, uint32_t groupAggWords,
                                                                 uint32_t* __restrict__ nextArena, uint32_t nextArenaWords, uint32_t digitBits,
                                                                 const uint32_t* __restrict__ schedCost, uint32_t schedTiles, uint32_t* __restrict__ schedOut, uint32_t histCopies) {
+    GS_CHAIN_PRIORITY();
     constexpr int SUB = 4;                                   // k's per emission batch: 256 positions per wave
     __shared__ uint32_t s_hist[3 * 256];
     __shared__ uint32_t s_tile[TILECNT ? kBinTileCounters : 1];
@@ -246,16 +247,14 @@ __global__ __launch_bounds__(kBinThreads) void bin_emit_kernel(const uint2* __re
     const uint32_t numParts = (n + kBinPart - 1) / kBinPart;
     const uint32_t digitMask = (1u << digitBits) - 1u;          // the pair sort's digit width (6..8 bits by tile count)
     uint32_t visAcc = 0;                                         // thread 0: visible splats of this workgroup's partitions
-    // Persistent grid, partitions drawn from kBinTicketClasses counters in separate 128-B lines (one counter would
-    // serialise ~1500 same-address atomics, 12 ns each, at the start of the kernel): ticket t of class c = partition
-    // t * classes + c; see the same scheme in gs_sort.hip for why a workgroup still only waits on running partitions.
-    for (;;) {
+    // Persistent grid.  A partition's scan waits on the totals of every partition before it, so -- as in gs_sort.hip -- partitions are taken in dependency
+    // order: binning workgroup b takes partition b first (no atomic: it only waits on workgroups the dispatcher started before it), afterwards whoever is
+    // running claims the lowest unclaimed partition from ONE counter (the later requests are spread over the kernel; the 16 ticket classes of rounds 1-5,
+    // which spread the ~1300 simultaneous requests at the head of the kernel, stall when a class has no running workgroup: gs_sort.hip).
+    for (uint32_t round = 0;; ++round) {
     __syncthreads();                                             // s_part / s_wtot / s_base of the previous partition are no longer read
-    if (tid == 0) {
-        const uint32_t cls = bid % kBinTicketClasses;
-        const uint32_t t = __hip_atomic_fetch_add(&ctl->tickets[cls * 32u], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_part = t * kBinTicketClasses + cls;     // (XCD blocks as in the sort's gather pass were measured here too: 0.133 vs 0.102 ms -- the scan then waits on blocks other XCDs have not reached)
-    }
+    if (tid == 0)
+        s_part = round == 0u ? bid : binBlocks + __hip_atomic_fetch_add(&ctl->tickets[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     const uint32_t part = s_part;
     if (part >= numParts) break;
@@ -520,6 +519,7 @@ __global__ __launch_bounds__(kVcThreads) void vis_count_kernel(const uint2* __re
                                                                unsigned long long* groupSum, uint32_t* __restrict__ pairOffset,
                                                                uint32_t* __restrict__ rectX, uint32_t* __restrict__ rectY,
                                                                unsigned long long* __restrict__ groupAgg, uint32_t groupAggWords, uint32_t* __restrict__ nextArena, uint32_t nextArenaWords) {
+    GS_CHAIN_PRIORITY();
     const int tid = threadIdx.x, lane = tid & 63;
     for (uint32_t j = blockIdx.x * (uint32_t)kVcThreads + tid; j < groupAggWords; j += gridDim.x * (uint32_t)kVcThreads) groupAgg[j] = 0ull;      // for the pair sort's look-back
     for (uint32_t j = blockIdx.x * (uint32_t)kVcThreads + tid; j < nextArenaWords; j += gridDim.x * (uint32_t)kVcThreads) nextArena[j] = 0u;       // the NEXT draw's zeroed arena
@@ -577,6 +577,7 @@ __global__ __launch_bounds__(kVcThreads) void vis_count_kernel(const uint2* __re
 __global__ __launch_bounds__(kVcThreads) void vis_offsets_kernel(const VisControl* __restrict__ vis, uint32_t nImm, uint32_t capacity, BinControl* ctl,
                                                                  const unsigned long long* __restrict__ blockSum, const unsigned long long* __restrict__ groupSum,
                                                                  uint32_t* pairOffset, uint32_t* __restrict__ chunkStart, uint32_t capChunks) {
+    GS_CHAIN_PRIORITY();
     constexpr int NW = kVcThreads / 64;
     constexpr unsigned long long PAIRS = (1ull << 44) - 1ull;
     __shared__ unsigned long long s_w64[2 * NW];
@@ -645,6 +646,7 @@ __global__ __launch_bounds__(kEmitThreads) void vis_emit_kernel(const uint32_t* 
                                                                 uint32_t tilesX, uint32_t tileShift, uint32_t* __restrict__ pairKeys, uint32_t* __restrict__ pairVals,
                                                                 uint32_t* pairHist, uint32_t digitBits,
                                                                 const uint32_t* __restrict__ schedCost, uint32_t schedTiles, uint32_t* __restrict__ schedOut, uint32_t histCopies) {
+    GS_CHAIN_PRIORITY();
     constexpr int NPOS = kEmitBatches * kEmitThreads;
     __shared__ uint32_t s_hist[3 * 256];
     __shared__ uint32_t s_tile[TILECNT ? kBinTileCounters : 1];
@@ -773,6 +775,7 @@ __global__ __launch_bounds__(kEmitThreads) void vis_emit_kernel(const uint32_t* 
 // key before and the one after them.
 __global__ __launch_bounds__(256) void tile_ranges_kernel(const uint32_t* __restrict__ pairKeys, const uint32_t* nPtr,
                                                           uint32_t* __restrict__ tileStart, uint32_t* __restrict__ tileEnd, uint32_t numTiles) {
+    GS_CHAIN_PRIORITY();
     const uint32_t n = *nPtr;
     const uint32_t octs = (n + 7u) >> 3;
     for (uint32_t q = blockIdx.x * 256u + threadIdx.x; q < octs; q += gridDim.x * 256u) {
@@ -896,6 +899,19 @@ typedef uint32_t u4v __attribute__((ext_vector_type(4)));
 // ZTest LEqual, ZWrite Off against the camera's depth buffer (RenderGaussianSplats.shader:10; the RT is bound with the
 // current depth, GaussianSplatRenderer.cs:195), and all four vertices of a quad carry the centre's depth (:56-60), so a
 // fragment survives iff the splat's view depth clip.w <= the opaque scene's view depth at that pixel.
+#ifdef GS_BLEND_STATS
+// instrumented build only (scripts/blend_stats.py): where the blend's wave-instructions go.  [0] wave x batch stagings, [1] wave x 64-record chunks tested,
+// [2] bounding-box hits, [3] survivors walked (wave x record), [4] live fragments blended (lane x record), [5] workgroups that had a list
+__device__ unsigned long long g_blendStats[8];
+#define GS_STAT(i, v) do { if (lane == 0) atomicAdd(&g_blendStats[i], (unsigned long long)(v)); } while (0)
+#else
+#define GS_STAT(i, v) do { } while (0)
+#endif
+#ifdef GS_BLEND_TL
+// instrumented build only: per workgroup (in dispatch order): start, end (100 MHz wall clock), batches walked, the most survivors one wave walked, list length,
+// tile, HW_ID | XCC_ID << 32, 0.  Two clock reads and one 64-byte store per workgroup: the launch is not slowed measurably (unlike GS_BLEND_STATS' atomics).
+__device__ unsigned long long g_blendTl[8192 * 8];
+#endif
 template <int MODE, bool DEPTH, int TWL, int THL>
 __global__ __launch_bounds__(64 << (TWL + THL - 6)) void blend_kernel(const uint32_t* __restrict__ pairVals, const uint32_t* __restrict__ tileStart,
                                                     const uint32_t* __restrict__ tileEnd, const uint32_t* __restrict__ tileOrder,
@@ -916,13 +932,18 @@ __global__ __launch_bounds__(64 << (TWL + THL - 6)) void blend_kernel(const uint
     uint32_t survWalked = 0;                                      // survivors this wave walked (wave-uniform)
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+#ifdef GS_BLEND_TL
+    const unsigned long long tl0 = wall_clock64();
+#endif
     if (blockIdx.x == 0 && tid == 0) write_report(binCtl, pairSortError, report, (uint32_t)TWL | ((uint32_t)THL << 8));      // the first workgroup to run: before any tile is blended
     const uint32_t tile = tileOrder[blockIdx.x];
     // tiles are dispatched heaviest first (tileOrder); the heaviest also get the higher issue priority on their SIMD, so that the longest
     // survivor chains -- the launch lasts as long as they do -- are not slowed by the light tiles beside them (measured: -1 %)
+#ifndef GS_BLEND_NOPRIO
     if (blockIdx.x < SLOTS / 8u) __builtin_amdgcn_s_setprio(3);
     else if (blockIdx.x < 3u * SLOTS / 8u) __builtin_amdgcn_s_setprio(2);
     else if (blockIdx.x < 6u * SLOTS / 8u) __builtin_amdgcn_s_setprio(1);
+#endif
     const uint32_t tx = tile % rc.tilesX, ty = tile / rc.tilesX;
     const uint32_t start = tileStart[tile], end = tileEnd[tile];
     const int qx0 = (int)tx * TW + (w % NWX) * 8, qy0 = (int)ty * TH + (w / NWX) * 8;
@@ -931,6 +952,9 @@ __global__ __launch_bounds__(64 << (TWL + THL - 6)) void blend_kernel(const uint
     uint2* dst = (uint2*)(rt + ((size_t)py * rc.width + (size_t)px) * 4);
     if (start >= end) {                                        // nothing lands on this tile: target unchanged ...
         if (threadIdx.x == 0) tileCost[tile] = 0;
+#ifdef GS_BLEND_TL
+        if (threadIdx.x == 0 && blockIdx.x < 8192u) { unsigned long long* q = g_blendTl + blockIdx.x * 8u; q[0] = tl0; q[1] = wall_clock64(); q[2] = 0; q[3] = 0; q[4] = 0; q[5] = tile; q[6] = 0; }
+#endif
         if (dstIsZero && inside) *dst = make_uint2(0u, 0u);    // ... or cleared here, when this draw also performs the pending clear
         return;
     }
@@ -966,6 +990,7 @@ __global__ __launch_bounds__(64 << (TWL + THL - 6)) void blend_kernel(const uint
         __syncthreads();
         if (s_done == NW) break;
         ++batchesWalked;
+        GS_STAT(0, 1);
         const uint32_t cnt = min((uint32_t)NT, end - bs);
         if ((uint32_t)tid < cnt) {
             const float inv1 = 1.0f / gsm::dot2f(r0.z, r0.w, r0.z, r0.w);
@@ -991,22 +1016,22 @@ __global__ __launch_bounds__(64 << (TWL + THL - 6)) void blend_kernel(const uint
             for (uint32_t c = 0; c < cnt; c += 64u) {
                 const uint32_t j = c + lane;
                 bool hit = false;
+                GS_STAT(1, 1);
                 if (j < cnt) {
                     const float4 ra = s_a[j];
                     const float4 re = s_e[j];
                     hit = (ra.x + re.x >= qminx) && (ra.x - re.x <= qmaxx) && (ra.y + re.y >= qminy) && (ra.y - re.y <= qmaxy);
+#ifdef GS_BLEND_STATS
+                    { const unsigned long long bb = __ballot(hit); if (__ffsll((long long)__ballot(true)) - 1 == lane) atomicAdd(&g_blendStats[2], (unsigned long long)__popcll(bb)); }
+#endif
                     // oriented test: 30 % of the bounding-box survivors cannot put a live fragment on this 8x8 quadrant
                     const uint4 rb = s_b[j];
                     hit = hit && gsm::BlockMayTouch((float)qx0 + 4.0f, (float)qy0 + 4.0f, 3.5f, ra.x, ra.y, ra.z, gsm::u2f(rb.x), ra.w, gsm::u2f(rb.y), re.z);
                 }
                 unsigned long long mask = __ballot(hit);
                 survWalked += (uint32_t)__popcll(mask);
-                while (mask) {
-                    const int b = __ffsll((long long)mask) - 1;
-                    mask &= ~(1ull << b);                              // one s_bitset0_b64 instead of a 64-bit subtract + and
-                    const float4 A4 = s_a[c + b];                      // wave-uniform address: LDS broadcast
-                    u4v B4 = *(const u4v*)&s_b[c + b];
-                    asm volatile("" : "+v"(B4));                       // keep it ONE ds_read_b128 (no piece sunk into the branch)
+                // one survivor: the fragment of record `rec` (its staged dwords A4, B4) at this lane's pixel
+                auto fragment = [&](const float4 A4, const u4v B4, const uint32_t rec) {
                     // q_k = dx u_kx + dy u_ky for both axes at once: three packed fp32 instructions (v_pk_add / v_pk_mul / v_pk_fma)
                     // instead of six scalar ones, element by element the same operations
                     const gsm::F2 d = fxy - gsm::F2{ A4.x, A4.y };
@@ -1031,10 +1056,53 @@ __global__ __launch_bounds__(64 << (TWL + THL - 6)) void blend_kernel(const uint
                     } else {
                         live = (inQuad & (int)(alpha >= 1.0f / 255.0f)) != 0;
                     }
-                    if (DEPTH) live = live && (s_e[c + b].w <= sceneZ);                  // ZTest LEqual on the quad's (single) depth
+                    if (DEPTH) live = live && (s_e[rec].w <= sceneZ);                  // ZTest LEqual on the quad's (single) depth
                     if (MODE == 1) live = live && !acc.saturated();
+#ifdef GS_BLEND_STATS
+                    { const unsigned long long lv = __ballot(live); GS_STAT(4, __popcll(lv)); }
+#endif
                     if (live) acc.blend(B4.z, B4.w, alpha);
+                };
+#ifdef GS_BLEND_PREFETCH
+                // the survivors' records one ahead: the ds_reads of the next survivor are issued before this one's arithmetic, so a wave that has its SIMD
+                // almost to itself (the heavy tiles at the end of the launch: the launch lasts as long as their chains) does not sit out an LDS round trip per
+                // survivor.  Two copies of the body alternate between two register sets (no moves).
+                if (mask) {
+                    int b0 = __ffsll((long long)mask) - 1;
+                    mask &= ~(1ull << b0);
+                    float4 A0 = s_a[c + b0];
+                    u4v B0 = *(const u4v*)&s_b[c + b0];
+                    for (;;) {
+                        // (the next record is loaded unconditionally -- the last survivor's own record again when there is no next one -- so that the number of
+                        // LDS loads in flight at the first use of this one's is known at compile time: s_waitcnt lgkmcnt(2), not (0))
+                        const bool more1 = mask != 0;
+                        const int b1 = more1 ? __ffsll((long long)mask) - 1 : b0;
+                        mask &= ~(1ull << b1);
+                        const float4 A1 = s_a[c + b1];
+                        u4v B1 = *(const u4v*)&s_b[c + b1];
+                        asm volatile("" : "+v"(B0));
+                        fragment(A0, B0, c + (uint32_t)b0);
+                        if (!more1) break;
+                        const bool more0 = mask != 0;
+                        b0 = more0 ? __ffsll((long long)mask) - 1 : b1;
+                        mask &= ~(1ull << b0);
+                        A0 = s_a[c + b0];
+                        B0 = *(const u4v*)&s_b[c + b0];
+                        asm volatile("" : "+v"(B1));
+                        fragment(A1, B1, c + (uint32_t)b1);
+                        if (!more0) break;
+                    }
                 }
+#else
+                while (mask) {
+                    const int b = __ffsll((long long)mask) - 1;
+                    mask &= ~(1ull << b);                              // one s_bitset0_b64 instead of a 64-bit subtract + and
+                    const float4 A4 = s_a[c + b];                      // wave-uniform address: LDS broadcast
+                    u4v B4 = *(const u4v*)&s_b[c + b];
+                    asm volatile("" : "+v"(B4));                       // keep it ONE ds_read_b128 (no piece sunk into the branch)
+                    fragment(A4, B4, c + (uint32_t)b);
+                }
+#endif
                 if (__all(!inside || acc.finished())) {
                     waveDone = true;
                     if (lane == 0) atomicAdd(&s_done, 1);
@@ -1049,8 +1117,18 @@ __global__ __launch_bounds__(64 << (TWL + THL - 6)) void blend_kernel(const uint
     // C2 / C3 -- survivors per batch vary tenfold between tiles; the measured duration of the tile schedules worse than either, 0.189 vs
     // 0.185 ms: it depends on who the tile shared its SIMDs with.)
     if (lane == 0) atomicMax(&s_cost, survWalked);
+    GS_STAT(3, survWalked);
+    if (w == 0) GS_STAT(5, 1);
     __syncthreads();
     if (threadIdx.x == 0) tileCost[tile] = min(254u, (s_cost + batchesWalked * (uint32_t)(NT / 8)) / 4u);
+#ifdef GS_BLEND_TL
+    if (threadIdx.x == 0 && blockIdx.x < 8192u) {
+        unsigned long long* q = g_blendTl + blockIdx.x * 8u;
+        uint32_t hwid; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        uint32_t xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        q[0] = tl0; q[1] = wall_clock64(); q[2] = batchesWalked; q[3] = s_cost; q[4] = end - start; q[5] = tile; q[6] = hwid | ((unsigned long long)xcc << 32);
+    }
+#endif
 }
 
 // View depth (centerClipPos.w, SplatUtilities.compute:199-200) of every visible splat, for the scene-depth test of the blend:
@@ -1224,6 +1302,7 @@ __global__ __launch_bounds__(256) void debug_points_resolve_kernel(gsm::AssetVie
 // GaussianComposite.shader:25-39 + "Blend SrcAlpha OneMinusSrcAlpha" over a constant background
 __global__ __launch_bounds__(256) void resolve_kernel(const uint16_t* __restrict__ rt, uint32_t numPix, float bgr, float bgg, float bgb,
                                                       float bga, float* __restrict__ out32, uint8_t* __restrict__ out8) {
+    GS_CHAIN_PRIORITY();
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= numPix) return;
     const uint2 d = ((const uint2*)rt)[i];
@@ -1636,3 +1715,20 @@ int32_t enqueue_resolve(gs_target* t, const float bg[4], bool want8) {
 }
 
 } // namespace gs
+
+#ifdef GS_BLEND_TL
+extern "C" int32_t gs_debug_blend_timeline(void* out, size_t bytes) {
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(gs::g_blendTl), bytes) == hipSuccess ? 0 : -1;
+}
+#endif
+#ifdef GS_BLEND_STATS
+extern "C" int32_t gs_debug_blend_stats(uint64_t* out8, int32_t reset) {
+    unsigned long long h[8];
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(gs::g_blendStats), sizeof(h)) != hipSuccess) return -1;
+    for (int i = 0; i < 8; ++i) out8[i] = h[i];
+    if (reset) { memset(h, 0, sizeof(h)); if (hipMemcpyToSymbol(HIP_SYMBOL(gs::g_blendStats), h, sizeof(h)) != hipSuccess) return -1; }
+    return 0;
+}
+#endif

@@ -103,6 +103,7 @@ __global__ __launch_bounds__(1024) void set_indices_kernel(uint32_t* order, uint
 __global__ __launch_bounds__(256) void histogram_kernel(const uint32_t* __restrict__ keys, uint32_t nImm, const uint32_t* nPtr,
                                                         int passes, uint32_t lastMask, uint32_t* __restrict__ hist,
                                                         unsigned long long* __restrict__ groupAgg, uint32_t groupAggWords, uint32_t copies) {
+    GS_CHAIN_PRIORITY();
     __shared__ uint32_t s_h[4 * RADIX];
     for (int j = threadIdx.x; j < 4 * RADIX; j += 256) s_h[j] = 0;
     for (uint32_t j = blockIdx.x * 256u + threadIdx.x; j < groupAggWords; j += gridDim.x * 256u) groupAgg[j] = 0ull;
@@ -216,7 +217,8 @@ __global__ __launch_bounds__(THREADS, KPT == KPT_B ? 4 : kMinWavesA) void oneswe
                                                            uint32_t* __restrict__ keysOut, uint32_t* __restrict__ valsOut,
                                                            const uint32_t* __restrict__ hist, uint32_t* status,
                                                            unsigned long long* groupAgg, unsigned long long* groupIncl, uint32_t* ticket, uint32_t* error,
-                                                           uint32_t nImm, const uint32_t* nPtr, uint32_t shift, uint32_t epoch, uint32_t digitMask, uint32_t histCopies) {
+                                                           uint32_t nImm, const uint32_t* nPtr, uint32_t shift, uint32_t epoch, uint32_t digitMask, uint32_t histCopies, uint32_t gatherXcd) {
+    GS_CHAIN_PRIORITY();
     constexpr int PART = THREADS * KPT;              // keys per partition
     constexpr int RDX = 1 << BITS;                   // digits of this pass
     constexpr int DW = (RDX + 63) / 64;              // waves that own digits
@@ -265,37 +267,37 @@ __global__ __launch_bounds__(THREADS, KPT == KPT_B ? 4 : kMinWavesA) void oneswe
     if (tid < RDX)
         for (int k = 0; k < w; ++k) histExcl += s_htot[k];
 
-    // (uniform) the grid covers every partition: workgroup b takes partition b without an atomic.  Only in the plain passes, where the
-    // static mapping is the identity -- a partition then only ever waits on partitions of workgroups with a SMALLER blockIdx, which the
-    // dispatcher started before it, so forward progress does not depend on how many workgroups are resident (another process on the GPU,
-    // a part with less LDS).  The gather pass permutes partitions over XCDs (workgroup 1 would wait on workgroups 8, 16, ...): it keeps
-    // the atomic tickets, which hand partitions out in dependency order to whoever is running.
-    const bool oneRound = !GATHER && gridDim.x >= numParts;
+    // Which partition a workgroup takes.  A partition waits (look-back) on EVERY partition before it, so forward progress needs the lowest unfinished
+    // partition to be held by a workgroup that is RUNNING -- whatever else shares the GPU (another process, another context of this one: kernels that
+    // may themselves be spinning on workgroups of theirs that cannot be dispatched while ours hold the slots).  The dispatcher starts workgroups in
+    // blockIdx order, so:
+    //   round 0   workgroup b takes partition b (no atomic): it only ever waits on workgroups started before it;
+    //   later     the next partition in dependency order from ONE counter: whoever is running can claim the lowest unclaimed partition.  (The requests
+    //             of the later rounds are spread over the pass -- a partition finishes behind its predecessors -- so one counter does not queue them the
+    //             way it queued the ~768 simultaneous requests at the head of the kernel, which is what the 16 ticket classes of rounds 1-5 were for.
+    //             Per-class counters deadlock under sharing: a class whose workgroups are all still waiting for a slot is served by nobody, and every
+    //             running workgroup ends up spinning on a partition of that class -- two such kernels hold each other's slots until the bounded spins
+    //             expire: found in round 6 by two processes on one GPU.)
+    // The GATHER pass of a frame's depth sort may instead deal whole blocks of consecutive partitions to the XCDs (gatherXcd != 0: 16 counters, two per XCD) so
+    // that the 16 keys of a gathered 64-byte sector meet in one L2 -- 25 us faster per sort at C2, but only deadlock-free while no other kernel that spins
+    // shares the GPU; gs_context_set_shared_gpu / GSPLAT_SHARED_GPU=1 selects the dependency-ordered form for it too.
+    const bool oneRound = !(GATHER && gatherXcd) && gridDim.x >= numParts;      // (the XCD deal is not the identity: its first tickets need not cover every partition)
     for (uint32_t round = 0;; ++round) {
         if (oneRound && round) break;
         __syncthreads();                                    // previous partition's LDS reads are finished
-        // Partition tickets.  One counter would serialise every workgroup of the grid on a single L2 channel (~12 ns per
-        // same-address atomic: the 768th workgroup starts 9 us late in a 35 us pass), so there are TICKET_CLASSES counters
-        // in separate 128-B lines; workgroup b draws from counter b % TICKET_CLASSES and ticket t of class c is partition
-        // t * TICKET_CLASSES + c.  The grid is persistent and every class has resident workgroups, so the lowest partition
-        // that is not finished has either been drawn or will be drawn by a workgroup of its class that is free to do so:
-        // a workgroup still only waits on partitions that are running or will run without needing a new slot.
         if (tid == 0) {
-            const uint32_t cls = blockIdx.x % TICKET_CLASSES;
-            // One round (the grid covers every partition -- a 6 M-key pass): the ticket a workgroup would draw is known, blockIdx / classes
-            // (partition = blockIdx), so the atomic's round trip (~1.2 us at the head of a ~31 us pass) is skipped.
-            const uint32_t t = oneRound ? blockIdx.x / TICKET_CLASSES : __hip_atomic_fetch_add(ticket + cls * 32u, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            uint32_t p = t * TICKET_CLASSES + cls;
-            if (GATHER) {                  // (XCD blocks in the plain passes too -- do neighbouring partitions' runs merge in a shared L2? -- measured: no change, r04 call 4)
-                // The gathered key array does not fit one XCD's L2, but the 16 keys of a 64-byte sector belong to spatial
-                // neighbours (the asset is in Morton order), which are close in the previous depth order too: they are asked for
-                // within a few partitions of each other.  Workgroup b runs on XCD b % 8 (MI355X_MICROARCH.md) = cls % 8, so
-                // instead of dealing partitions round-robin, every XCD takes whole blocks of `xb` consecutive partitions (block
-                // j belongs to XCD j % 8; the two ticket classes of an XCD alternate inside its blocks): the other 15 requests
-                // for a sector then arrive at the L2 that already holds it.  Still monotonic per class, still a bijection.
+            uint32_t p;
+            if (GATHER && gatherXcd) {
+                // Workgroup b runs on XCD b % 8 (MI355X_MICROARCH.md) = cls % 8: every XCD takes whole blocks of `xb` consecutive partitions (block j belongs
+                // to XCD j % 8; the two ticket classes of an XCD alternate inside its blocks): the other 15 requests for a sector then arrive at the L2 that
+                // already holds it.  Monotonic per class, a bijection.
+                const uint32_t cls = blockIdx.x % TICKET_CLASSES;
+                const uint32_t t = __hip_atomic_fetch_add(ticket + cls * 32u, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const uint32_t xb = xcdBlock;
                 const uint32_t x = cls & 7u, u = t * 2u + (cls >> 3);       // u-th partition of XCD x
                 p = ((u / xb) * 8u + x) * xb + (u % xb);
+            } else {
+                p = round == 0u ? blockIdx.x : gridDim.x + __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             s_part = p;
         }
@@ -666,7 +668,7 @@ int32_t enqueue_sort_passes(gs_context* ctx, hipStream_t stream, SortState& st, 
         }
 #define GS_LAUNCH_ONESWEEP_K(B, G, KIN, K) \
         hipExtLaunchKernelGGL((onesweep_kernel<B, G, K>), dim3(grid), dim3(THREADS), 0, stream, evStart, evStop, 0, (const uint32_t*)(KIN), (const uint32_t*)vs, kdst, vd, \
-                              (const uint32_t*)hist, st.status, agg, st.groupIncl, (uint32_t*)control->tickets[p], &control->error, nUpper, nPtr, shift, epoch, mask, histCopies)
+                              (const uint32_t*)hist, st.status, agg, st.groupIncl, (uint32_t*)control->tickets[p], &control->error, nUpper, nPtr, shift, epoch, mask, histCopies, (gatherKeys && !gs_shared_gpu(ctx)) ? 1u : 0u)
 #define GS_LAUNCH_ONESWEEP(B, G, KIN) do { if (shapeB) GS_LAUNCH_ONESWEEP_K(B, G, KIN, KPT_B); else GS_LAUNCH_ONESWEEP_K(B, G, KIN, KPT_A); } while (0)
         if (p == 0 && gatherKeys) GS_LAUNCH_ONESWEEP(8, true, gatherKeys);
         else if (shapeC) GS_LAUNCH_ONESWEEP_K(8, false, ks, KPT_C);

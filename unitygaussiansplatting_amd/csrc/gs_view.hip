@@ -58,6 +58,7 @@ constexpr int cmax(int a, int b) { return a > b ? a : b; }
 // FULL = true on demand, so the parity surface is unchanged.  VALU-bound either way (~1200 instructions per splat FULL).
 template <int SHMODE, bool FULL>
 __global__ __launch_bounds__(256) void calc_view_kernel(gsm::AssetView a, gsm::FrameConsts P, gsm::EditView E, ViewOutputs O) {
+    GS_VIEW_PRIORITY();
     gsm::ViewData* __restrict__ out = O.view;
     SplatRec* __restrict__ recs = O.recs;
     uint2* __restrict__ rects = O.rects;

@@ -66,6 +66,7 @@ __global__ __launch_bounds__(VTHREADS, 6) void visible_keys_kernel(gsm::AssetVie
                                                                 uint32_t* __restrict__ outKeys, uint32_t* __restrict__ outIdx, uint32_t* __restrict__ hist,
                                                                 VisControl* vc, uint32_t* __restrict__ nextVc,
                                                                 unsigned long long* __restrict__ groupAgg, uint32_t groupAggWords, uint32_t* __restrict__ nextControl, uint32_t copies) {
+    GS_CHAIN_PRIORITY();
     __shared__ uint32_t s_h[4 * 256];
     __shared__ unsigned long long s_m[VTHREADS];
     __shared__ uint32_t s_off[VTHREADS];
@@ -364,6 +365,7 @@ template <int TB>
 __global__ __launch_bounds__(TIE_THREADS) void tie_fix_kernel(gsm::AssetView a, TieHistory H, const uint32_t* __restrict__ keys, uint32_t* idx,
                                                               const uint32_t* __restrict__ nPtr, uint32_t nImm, VisControl* vc,
                                                               const uint32_t* __restrict__ rank, uint32_t* k1BySplat, uint32_t* tBySplat) {
+    GS_CHAIN_PRIORITY();
     __shared__ float s_rows[kVisHistory * 4];
     __shared__ uint32_t s_start[TIE_SEG / 2];                     // a run has >= 2 positions
     __shared__ uint32_t s_long[TIE_SEG / 5 + 8];

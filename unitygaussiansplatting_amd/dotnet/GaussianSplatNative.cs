@@ -58,6 +58,7 @@ namespace GaussianSplatting.Runtime
         [DllImport(Lib)] public static extern int gs_context_destroy(IntPtr ctx);
         [DllImport(Lib)] public static extern int gs_context_synchronize(IntPtr ctx);
         [DllImport(Lib)] public static extern int gs_context_set_overlap(IntPtr ctx, int enabled);
+        [DllImport(Lib)] public static extern int gs_context_set_shared_gpu(IntPtr ctx, int shared);
         [DllImport(Lib)] public static extern int gs_context_device_info(IntPtr ctx, byte[] nameOut, UIntPtr nameCap, out int cuCount, out ulong hbmBytes);
 
         [DllImport(Lib)] public static extern int gs_asset_create(IntPtr ctx, ref AssetDesc desc, out IntPtr asset);

@@ -73,6 +73,11 @@ class GpuContext:
     def Synchronize(self) -> None:
         check(_lib.lib().gs_context_synchronize(self._h), "gs_context_synchronize")
 
+    def SetSharedGpu(self, shared) -> None:
+        """Other kernels that wait on their own workgroups (another process / context sorting in GS_SORT_FULL) may share the GPU: gs_context_set_shared_gpu.
+        True / False pin it, None = automatic (shared while this process holds more than one context on the device)."""
+        check(_lib.lib().gs_context_set_shared_gpu(self._h, -1 if shared is None else int(bool(shared))), "gs_context_set_shared_gpu")
+
     def SetOverlap(self, enabled: bool) -> None:
         """Run SortPoints concurrently with CalcViewData on the context's second queue (default off: no gain on MI355X)."""
         check(_lib.lib().gs_context_set_overlap(self._h, int(bool(enabled))), "gs_context_set_overlap")
