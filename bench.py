@@ -74,6 +74,9 @@ def parse():
     ap.add_argument("--headline", default="auto", choices=["auto", "full", "visible", "visible_in_flight", "reference_shaped"],
                     help="which measured mode `value` reports (auto: the fastest of visible_in_flight / visible whose end-of-orbit check holds, else full)")
     ap.add_argument("--in-flight", type=int, default=2, help="renderers (contexts = streams) the visible_in_flight mode deals its frames / views to")
+    ap.add_argument("--in-flight-impl", default="library", choices=["library", "host"],
+                    help="library: ONE renderer on one context, gs_renderer_set_frames_in_flight deals the frames to lanes inside the library (the reference's calls unchanged); "
+                         "host: the host holds --in-flight renderers on contexts of their own over one asset and deals the frames itself")
     ap.add_argument("--pmc", default="auto", choices=["auto", "off"], help="auto: at N = 1 spawn rocprofv3 --pmc children of this script for HBM traffic and VALU instruction counts")
     ap.add_argument("--pmc-child", default="", help="(internal) path of the pickled asset: run the frames of one mode and exit -- what the rocprofv3 children execute")
     ap.add_argument("--child-mode", default="visible", help="(internal) mode of a --pmc-child run")
@@ -431,6 +434,7 @@ def main():
     class Lane:
         def __init__(self, ctx_, r_, rts_):
             self.ctx, self.r, self.rts = ctx_, r_, rts_
+            self.rt_sets, self.last_rt = None, rts_[-1]
     lanes = [Lane(ctx, r, rts)]
     active = [lanes[0]]
 
@@ -455,7 +459,10 @@ def main():
                     X.r.SortPointsPrepared(m16)
                 sort_log.append(m16)
             X = active[(i * len(my_views) + vi) % nl]
-            t = X.rts[vi]
+            # lanes inside the library: the host alternates as many sets of targets as it has frames in flight (a swap chain: the reference's
+            # _GaussianSplatRT is a temporary of the frame) -- a frame's blend then waits for ITS target's last use, not for the frame before it
+            t = (X.rt_sets[(i * len(my_views) + vi) % len(X.rt_sets)] if X.rt_sets else X.rts)[vi]
+            X.last_rt = t
             X.r.CalcViewDataPrepared(p)
             t.Clear()
             X.r.DrawPrepared(p, t)
@@ -519,7 +526,13 @@ def main():
         exactly K frames, then the same K frames with the per-stage hipEvents, then once more with the Onesweep launches' own timestamps.
         Afterwards the renderer is left as the last frame left it (the end-of-orbit state the checks read)."""
         piped = mode == "visible_in_flight"
-        active[:] = [lane(k) for k in range(max(1, args.in_flight))] if piped else [lanes[0]]
+        lib_lanes = piped and args.in_flight_impl == "library"
+        active[:] = [lane(k) for k in range(max(1, args.in_flight))] if (piped and not lib_lanes) else [lanes[0]]
+        r.SetFramesInFlight(max(1, args.in_flight) if lib_lanes else 1)      # the lanes live inside the library, behind r
+        if lib_lanes and lanes[0].rt_sets is None:
+            lanes[0].rt_sets = [rts] + [[RenderTarget(ctx, W, H) for _ in my_views] for _ in range(max(1, args.in_flight) - 1)]
+        if not lib_lanes and lanes[0].rt_sets is not None:
+            lanes[0].rt_sets = None
         for X in active:
             X.r.SetSortMode(SortMode.Full)
             X.r.ResetOrder()                                 # every mode starts from CSSetIndices' order
@@ -575,7 +588,8 @@ def main():
             rows, limit, cons = last_lane.r.SortHistory()
             return dict(mode=mode, fi=fi, regions=regions, per_rank=per_rank, elapsed=float(np.median(regions)), elapsed_instr=None, resolve_ms=None, st=last_lane.r.FrameStats(),
                         frame_ms=None, stage=None, stage_k=None, first_frame_ms=first_frame_ms, first_again_ms=first_again_ms, sorts=list(sort_log),
-                        history=dict(rows=int(rows), limit=int(limit), consolidations=int(cons)), lane=last_lane, lanes=len(active))
+                        history=dict(rows=int(rows), limit=int(limit), consolidations=int(cons)), lane=last_lane, lanes=(max(1, args.in_flight) if lib_lanes else len(active)),
+                        impl=args.in_flight_impl)
         # ---- the same K frames again with the per-stage hipEvents recorded (14 per frame, on the stream each kernel is
         #      launched on).  The events themselves cost ~50 us of a 0.6 ms frame (every record is a barrier + signal packet
         #      between two kernels), so the headline time comes from the regions above and the per-kernel durations from this one.
@@ -609,7 +623,7 @@ def main():
         """What the mode's last frame left: the target, the order buffer the reference would hold (GS_SORT_VISIBLE: the recorded sorts carried out on
         all N by the library), and in the visible-only modes the order the frame was drawn from."""
         L = x.get("lane", lanes[0])
-        x["img"] = L.rts[-1].Download()
+        x["img"] = L.last_rt.Download()
         if x["mode"] in ("visible", "visible_in_flight"):
             x["vis_order"] = L.r.DownloadVisibleOrder()
             x["vis_stats"] = L.r.FrameStats()
@@ -623,6 +637,7 @@ def main():
         res[m] = measure(m, args.repeats if m != "reference_shaped" else min(args.repeats, 3), instrument=(m != "reference_shaped"))
         end_state(res[m])
     active[:] = [lanes[0]]
+    r.SetFramesInFlight(1)
     r.SetViewBufferMode(False)
 
     # ---- GPU-internal end-of-orbit cross-check: the visible-only mode and the full mode ran the SAME sequence of SortPoints (warm-up + every region);
@@ -800,6 +815,8 @@ def main():
             if s_ is None:
                 return {"ms_per_step": round(x["elapsed"] / args.steps * 1e3, 4), "value_Msplats_s": round(n * args.steps * num_views / x["elapsed"] / 1e6, 2),
                         "regions_ms_per_step": [round(v / args.steps * 1e3, 4) for v in x["regions"]], "renderers_in_flight": x["lanes"],
+                        "in_flight_impl": ("library: ONE renderer on one context and the reference's calls; gs_renderer_set_frames_in_flight deals the frames to lanes inside the library"
+                                           if x.get("impl") == "library" else "host: the host holds the renderers (one context each) and deals the frames itself"),
                         "tile_pairs_P": int(x["st"].tile_pairs), "visible_splats": int(x["st"].visible_splats), "sort_history": x["history"],
                         "note": "GS_SORT_VISIBLE with the frames (C5: the views) dealt round-robin to this many renderers on contexts (streams) of their own over ONE copy of the asset; "
                                 "every renderer is told every SortPoints matrix, each draws its frames from the reference's order (checked: sort_mode_cross_check.in_flight, end_of_orbit_check); "
@@ -834,6 +851,7 @@ def main():
             "config": {"workload": cfg.label + (f" [splat count overridden to {n}]" if args.splats else ""),
                        "sort_mode": headline, "headline_reason": headline_reason,
                        "frames_in_flight": (R.get("lanes", 1) if headline == "visible_in_flight" else 1),
+                       "frames_in_flight_impl": (R.get("impl") if headline == "visible_in_flight" else None),
                        "one_frame_at_a_time_ms": (round(res["visible"]["elapsed"] / args.steps * 1e3, 4) if "visible" in res else None),
                        "sort_mode_note": ("visible_in_flight = GS_SORT_VISIBLE with the frames (C5: the views) dealt round-robin to --in-flight renderers on contexts (streams) of their own over ONE copy of "
                                           "the asset: one frame's latency-bound sort / binning kernels run under another's VALU-bound blend; throughput, each frame the same bits; per-kernel figures "

@@ -32,7 +32,7 @@ def test_every_declared_symbol_is_exported_and_bound():
 
 def test_version_and_error_strings():
     lib = _lib.lib()
-    assert lib.gs_abi_version() == 8
+    assert lib.gs_abi_version() == 9
     for code in range(0, -10, -1):
         assert lib.gs_error_string(code) not in (None, b"", b"unknown error")
     assert lib.gs_error_string(-99) == b"unknown error"

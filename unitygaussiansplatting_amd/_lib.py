@@ -70,6 +70,8 @@ SIGNATURES = {
     "gs_renderer_sort_mode": (C.c_int32, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "gs_renderer_set_sort_history_limit": (C.c_int32, [_P, C.c_uint32]),
     "gs_renderer_sort_history": (C.c_int32, [_P, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]),
+    "gs_renderer_set_frames_in_flight": (C.c_int32, [_P, C.c_int32]),
+    "gs_renderer_frames_in_flight": (C.c_int32, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "gs_renderer_download_visible_order": (C.c_int32, [_P, _P, C.c_size_t, C.POINTER(C.c_uint32)]),
     "gs_renderer_download_view": (C.c_int32, [_P, _P, C.c_size_t]),
     "gs_renderer_download_raster_records": (C.c_int32, [_P, _P, _P, _P]),

@@ -139,6 +139,7 @@ int32_t gs_context_destroy(gs_context* ctx) {
 
 int32_t gs_context_synchronize(gs_context* ctx) {
     if (!ctx) return fail(GS_ERR_INVALID_ARGUMENT, "ctx is null");
+    for (gs_context* c : ctx->children) GS_TRY(gs_context_synchronize(c));      // lanes of this context's renderers (their frames may not have been joined by a draw)
     GS_TRY(bind_device(ctx));
     GS_HIP(hipStreamSynchronize(ctx->aux));
     GS_HIP(hipStreamSynchronize(ctx->stream));
@@ -259,6 +260,103 @@ int32_t gs_asset_device_blobs(const gs_asset* a, void* ptrs[5], uint64_t sizes[5
 }
 
 // ---- renderer --------------------------------------------------------------------------------------------
+// ---- frames in flight inside the library: lanes ---------------------------------------------------------------
+// (gs_renderer_set_frames_in_flight, gsplat_c.h.)  A lane is an ordinary renderer on a context of its own; the owner tells every lane every sort matrix
+// (bookkeeping in GS_SORT_VISIBLE) and every setting, deals the frames round-robin at gs_renderer_calc_view and answers the whole-buffer questions
+// (gs_renderer_download_order, _distances, _sort_history) from its own copy of the bookkeeping.
+static inline bool lanes_on(const gs_renderer* r) { return !r->lanes.empty() && r->sortMode == GS_SORT_VISIBLE && r->renderMode == GS_RENDER_SPLATS; }
+static inline gs_renderer* lane_cur(gs_renderer* r) { return lanes_on(r) && r->laneCur >= 0 ? r->lanes[(size_t)r->laneCur] : r; }
+
+static void lanes_destroy(gs_renderer* r) {
+    for (gs_renderer* L : r->lanes) {
+        gs_context* c = L->ctx;
+        (void)gs_renderer_destroy(L);
+        for (size_t k = 0; k < r->ctx->children.size(); ++k)
+            if (r->ctx->children[k] == c) { r->ctx->children.erase(r->ctx->children.begin() + (long)k); break; }
+        (void)gs_context_destroy(c);
+    }
+    r->lanes.clear();
+    r->laneCur = -1;
+}
+
+// The lanes take over the owner's order: its buffer as the reference holds it now (the recorded sorts carried out) becomes every lane's base, the
+// owner's remaining history (its head row at most) theirs.  Rare: when lanes are made, when the mode is switched to GS_SORT_VISIBLE, after reset / upload.
+static int32_t lanes_resync(gs_renderer* r) {
+    if (r->lanes.empty() || r->sortMode != GS_SORT_VISIBLE) return GS_OK;
+    GS_TRY(bind_device(r->ctx));
+    GS_TRY(vis_consolidate(r));
+    GS_HIP(hipStreamSynchronize(r->ctx->stream));
+    for (gs_renderer* L : r->lanes) {
+        GS_TRY(gs_renderer_set_sort_mode(L, GS_SORT_VISIBLE));
+        GS_HIP(hipStreamSynchronize(L->ctx->stream));
+        if (r->visBaseIdentity) GS_TRY(enqueue_set_indices(L->ctx, L->order, L->n));
+        else GS_HIP(hipMemcpyAsync(L->order, r->order, (size_t)r->n * 4, hipMemcpyDeviceToDevice, L->ctx->stream));
+        GS_HIP(hipStreamSynchronize(L->ctx->stream));
+        L->visBaseIdentity = r->visBaseIdentity; L->visRankValid = false; L->visOrderValid = false;
+        L->visHistDepth = r->visHistDepth;
+        memcpy(L->visHist, r->visHist, sizeof(r->visHist));
+        L->visHistLimit = r->visHistLimit;
+        L->distancesStale = false;
+    }
+    return GS_OK;
+}
+
+int32_t gs_renderer_set_frames_in_flight(gs_renderer* r, int32_t frames) {
+    if (!r || frames < 1 || frames > GS_MAX_FRAMES_IN_FLIGHT) return fail(GS_ERR_INVALID_ARGUMENT, "frames in flight must be in [1, GS_MAX_FRAMES_IN_FLIGHT]");
+    if (r->laneOf) return fail(GS_ERR_INVALID_ARGUMENT, "a lane has no lanes of its own");
+    const size_t want = frames > 1 ? (size_t)frames : 0u;       // one frame at a time: the renderer's own context, no lanes
+    if (r->lanes.size() == want) return GS_OK;
+    GS_TRY(gs_context_synchronize(r->ctx));
+    lanes_destroy(r);
+    for (size_t k = 0; k < want; ++k) {
+        gs_context* c = nullptr;
+        gs_renderer* L = nullptr;
+        int32_t rc = gs_context_create(r->ctx->device, nullptr, &c);
+        if (rc == GS_OK) rc = gs_renderer_create(c, r->asset, &L);
+        if (rc == GS_OK) {
+            L->laneOf = r;
+            hipError_t e = hipEventCreateWithFlags(&L->evTargetFree, hipEventDisableTiming);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&L->evBlendDone, hipEventDisableTiming);
+            if (e != hipSuccess) rc = fail_hip(e, "create lane events", __FILE__, __LINE__);
+        }
+        // the owner's settings as they are now; later changes are forwarded by the setters themselves
+        if (rc == GS_OK) {
+            L->blendMode = r->blendMode; L->alwaysWriteView = r->alwaysWriteView; L->kernelTiming = r->kernelTiming;
+            L->tileOverrideWL = r->tileOverrideWL; L->tileOverrideHL = r->tileOverrideHL; L->adaptTall = r->adaptTall;
+            L->visHistLimit = r->visHistLimit;
+            if (r->pairCapacity > L->pairCapacity) rc = gs_renderer_reserve_pairs(L, r->pairCapacity);
+        }
+        if (rc == GS_OK && r->cutoutCount) rc = gs_renderer_set_cutouts(L, (const gs_cutout*)r->cutoutsHost, r->cutoutCount);
+        if (rc == GS_OK && r->deletedBits) {
+            const size_t words = ((size_t)r->n + 31) / 32;
+            uint32_t* h = new (std::nothrow) uint32_t[words];
+            if (!h) rc = fail(GS_ERR_OUT_OF_MEMORY, "host allocation");
+            else {
+                rc = bind_device(r->ctx);
+                if (rc == GS_OK && hipMemcpy(h, r->deletedBits, words * 4, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(GS_ERR_HIP, "copy deleted bits");
+                if (rc == GS_OK) rc = gs_renderer_set_deleted_bits(L, h, words);
+                delete[] h;
+            }
+        }
+        if (rc != GS_OK) {
+            if (L) (void)gs_renderer_destroy(L);
+            if (c) (void)gs_context_destroy(c);
+            lanes_destroy(r);
+            return rc;
+        }
+        r->lanes.push_back(L);
+        r->ctx->children.push_back(c);
+    }
+    return lanes_resync(r);
+}
+
+int32_t gs_renderer_frames_in_flight(const gs_renderer* r, int32_t* frames, int32_t* active) {
+    if (!r) return fail(GS_ERR_INVALID_ARGUMENT, "renderer is null");
+    if (frames) *frames = r->lanes.empty() ? 1 : (int32_t)r->lanes.size();
+    if (active) *active = lanes_on(r) ? 1 : 0;
+    return GS_OK;
+}
+
 int32_t gs_renderer_create(gs_context* ctx, gs_asset* asset, gs_renderer** out) {
     if (!ctx || !asset || !out) return fail(GS_ERR_INVALID_ARGUMENT, "null argument");
     *out = nullptr;
@@ -291,9 +389,12 @@ int32_t gs_renderer_create(gs_context* ctx, gs_asset* asset, gs_renderer** out) 
 
 int32_t gs_renderer_destroy(gs_renderer* r) {
     if (!r) return GS_OK;
+    lanes_destroy(r);
     (void)hipSetDevice(r->ctx->device);
     (void)hipStreamSynchronize(r->ctx->aux);
     (void)hipStreamSynchronize(r->ctx->stream);
+    if (r->evTargetFree) (void)hipEventDestroy(r->evTargetFree);
+    if (r->evBlendDone) (void)hipEventDestroy(r->evBlendDone);
     if (r->evOrderFree) (void)hipEventDestroy(r->evOrderFree);
     if (r->evSortDone) (void)hipEventDestroy(r->evSortDone);
     if (r->view) (void)hipFree(r->view);
@@ -340,7 +441,8 @@ int32_t gs_renderer_reset_order(gs_renderer* r) {
     GS_TRY(materialise_distances(r));
     GS_TRY(enqueue_set_indices(r->ctx, r->order, r->n));
     vis_base_changed(r, true);                                   // CSSetIndices: the order buffer is the identity again and the stable-sort history starts over
-    return mark_order_use(r);
+    GS_TRY(mark_order_use(r));
+    return lanes_resync(r);
 }
 
 static void rec_ev(gs_renderer* r, int k) { gs::prof_record(r, k); }
@@ -370,7 +472,11 @@ int32_t gs_renderer_sort(gs_renderer* r, const float m[16]) {
     GS_TRY(bind_device(r->ctx));
     // GS_SORT_VISIBLE: SortPoints only says which matrix the order is sorted by from now on; the sort itself runs in gs_renderer_draw,
     // over the splats that are drawn (gs_vissort.hip)
-    if (vis_active(r)) return vis_push_matrix(r, m);
+    if (vis_active(r)) {
+        GS_TRY(vis_push_matrix(r, m));
+        for (gs_renderer* L : r->lanes) { GS_TRY(bind_device(L->ctx)); GS_TRY(vis_push_matrix(L, m)); }      // every lane is told every matrix
+        return GS_OK;
+    }
     vis_base_changed(r, false);                                  // the order buffer now holds this sort
     return enqueue_full_sort(r, m, false);
 }
@@ -413,6 +519,10 @@ int32_t gs_renderer_calc_view(gs_renderer* r, const gs_frame_params* p) {
     if (!r || !p) return fail(GS_ERR_INVALID_ARGUMENT, "null argument");
     if (!(p->screen_w >= 1.0f && p->screen_w <= 65535.0f && p->screen_h >= 1.0f && p->screen_h <= 65535.0f))      // (pixel rectangles are packed in 16-bit fields)
         return fail(GS_ERR_INVALID_ARGUMENT, "screen_w / screen_h must be in [1, 65535]");
+    if (lanes_on(r)) {                                           // a new frame (or view): the next lane's
+        r->laneCur = (r->laneCur + 1) % (int)r->lanes.size();
+        return gs_renderer_calc_view(r->lanes[(size_t)r->laneCur], p);
+    }
     GS_TRY(bind_device(r->ctx));
     rec_ev(r, 7);
     gsm::EditView e;
@@ -446,7 +556,12 @@ static int32_t maybe_grow_pairs(gs_renderer* r) {
 
 int32_t gs_renderer_draw(gs_renderer* r, const gs_frame_params* p, gs_target* rt) {
     if (!r || !p || !rt) return fail(GS_ERR_INVALID_ARGUMENT, "null argument");
-    if (rt->ctx != r->ctx) return fail(GS_ERR_INVALID_ARGUMENT, "target belongs to another context");
+    if (lanes_on(r)) {
+        if (rt->ctx != r->ctx) return fail(GS_ERR_INVALID_ARGUMENT, "target belongs to another context");
+        if (r->laneCur < 0) return fail(GS_ERR_INVALID_ARGUMENT, "gs_renderer_draw: call gs_renderer_calc_view with the same screen size / clip planes first");
+        return gs_renderer_draw(r->lanes[(size_t)r->laneCur], p, rt);
+    }
+    if (rt->ctx != r->ctx && !(r->laneOf && rt->ctx == r->laneOf->ctx)) return fail(GS_ERR_INVALID_ARGUMENT, "target belongs to another context");
     if ((uint32_t)p->screen_w != rt->width || (uint32_t)p->screen_h != rt->height) return fail(GS_ERR_INVALID_ARGUMENT, "screen_w/h do not match the target");
     GS_TRY(bind_device(r->ctx));
     if (r->renderMode == GS_RENDER_DEBUG_POINTS || r->renderMode == GS_RENDER_DEBUG_POINT_INDICES) return enqueue_debug_points(r, p, rt);
@@ -497,6 +612,7 @@ int32_t gs_renderer_set_cutouts(gs_renderer* r, const gs_cutout* cutouts, uint32
         }
     }
     r->cutoutCount = count;
+    for (gs_renderer* L : r->lanes) GS_TRY(gs_renderer_set_cutouts(L, cutouts, count));
     return GS_OK;
 }
 
@@ -506,6 +622,7 @@ int32_t gs_renderer_set_deleted_bits(gs_renderer* r, const uint32_t* words, size
     const size_t need = ((size_t)r->n + 31) / 32;
     if (!words) {                                           // _SplatBitsValid = 0
         if (r->deletedBits) { GS_HIP(hipStreamSynchronize(r->ctx->stream)); (void)hipFree(r->deletedBits); r->deletedBits = nullptr; }
+        for (gs_renderer* L : r->lanes) GS_TRY(gs_renderer_set_deleted_bits(L, nullptr, 0));
         return GS_OK;
     }
     if (word_count != need) return fail(GS_ERR_INVALID_ARGUMENT, "deleted bits: word_count must be ceil(splat_count / 32)");
@@ -513,12 +630,14 @@ int32_t gs_renderer_set_deleted_bits(gs_renderer* r, const uint32_t* words, size
     // an edit-time operation (EditDeleteSelected): stream-ordered copy, then block so `words` is only read during the call
     GS_HIP(hipMemcpyAsync(r->deletedBits, words, need * 4, hipMemcpyHostToDevice, r->ctx->stream));
     GS_HIP(hipStreamSynchronize(r->ctx->stream));
+    for (gs_renderer* L : r->lanes) GS_TRY(gs_renderer_set_deleted_bits(L, words, word_count));
     return GS_OK;
 }
 
 int32_t gs_renderer_set_view_buffer_mode(gs_renderer* r, int32_t every_frame) {
     if (!r) return fail(GS_ERR_INVALID_ARGUMENT, "renderer is null");
     r->alwaysWriteView = every_frame != 0;
+    for (gs_renderer* L : r->lanes) L->alwaysWriteView = r->alwaysWriteView;
     return GS_OK;
 }
 
@@ -533,11 +652,13 @@ int32_t gs_renderer_set_render_mode(gs_renderer* r, int32_t mode, float point_di
 int32_t gs_renderer_set_blend_mode(gs_renderer* r, int32_t mode) {
     if (!r || (mode != 0 && mode != 1)) return fail(GS_ERR_INVALID_ARGUMENT, "blend mode must be 0 or 1");
     r->blendMode = mode;
+    for (gs_renderer* L : r->lanes) L->blendMode = mode;
     return GS_OK;
 }
 
 int32_t gs_renderer_set_tile_shape(gs_renderer* r, uint32_t tile_w, uint32_t tile_h) {
     if (!r) return fail(GS_ERR_INVALID_ARGUMENT, "renderer is null");
+    for (gs_renderer* L : r->lanes) GS_TRY(gs_renderer_set_tile_shape(L, tile_w, tile_h));
     if (tile_w == 0 && tile_h == 0) { r->tileOverrideWL = r->tileOverrideHL = 0; return GS_OK; }
     if (!((tile_w == 16 && tile_h == 16) || (tile_w == 32 && tile_h == 16) || (tile_w == 32 && tile_h == 32)))
         return fail(GS_ERR_INVALID_ARGUMENT, "tile shape must be 16x16, 32x16, 32x32 or 0x0 (automatic)");
@@ -548,6 +669,7 @@ int32_t gs_renderer_set_tile_shape(gs_renderer* r, uint32_t tile_w, uint32_t til
 int32_t gs_renderer_tile_shape(const gs_renderer* r, uint32_t width, uint32_t height, uint32_t* tile_w, uint32_t* tile_h) {
     if (!tile_w || !tile_h) return fail(GS_ERR_INVALID_ARGUMENT, "null argument");
     uint32_t wl, hl;
+    if (r && lanes_on(r) && r->laneCur >= 0) r = r->lanes[(size_t)r->laneCur];      // (the adaptive choice follows the lane's own draws)
     pick_tile_shape(r, width, height, wl, hl);           // r may be null: the automatic choice
     *tile_w = 1u << wl; *tile_h = 1u << hl;
     return GS_OK;
@@ -555,6 +677,7 @@ int32_t gs_renderer_tile_shape(const gs_renderer* r, uint32_t width, uint32_t he
 
 int32_t gs_renderer_set_profiling(gs_renderer* r, int32_t frames) {
     if (!r || frames < 0 || frames > 4096) return fail(GS_ERR_INVALID_ARGUMENT, "frames must be in [0, 4096]");
+    for (gs_renderer* L : r->lanes) GS_TRY(gs_renderer_set_profiling(L, frames));
     GS_TRY(bind_device(r->ctx));
     if (frames > r->profCapacity) {
         GS_HIP(hipStreamSynchronize(r->ctx->stream));
@@ -581,11 +704,13 @@ int32_t gs_renderer_set_profiling(gs_renderer* r, int32_t frames) {
 int32_t gs_renderer_set_kernel_timing(gs_renderer* r, int32_t enabled) {
     if (!r) return fail(GS_ERR_INVALID_ARGUMENT, "renderer is null");
     r->kernelTiming = enabled != 0;
+    for (gs_renderer* L : r->lanes) L->kernelTiming = r->kernelTiming;
     return GS_OK;
 }
 
 int32_t gs_renderer_reserve_pairs(gs_renderer* r, uint64_t cap) {
     if (!r) return fail(GS_ERR_INVALID_ARGUMENT, "renderer is null");
+    for (gs_renderer* L : r->lanes) GS_TRY(gs_renderer_reserve_pairs(L, cap));
     if (cap <= r->pairCapacity) return GS_OK;
     if (cap > kSortMaxCount) cap = kSortMaxCount;          // 32-bit byte offsets inside the sort kernels
     if (cap <= r->pairCapacity) return fail(GS_ERR_PAIR_OVERFLOW, "the frame needs more than 2^30 (tile, splat) pairs");
@@ -602,11 +727,16 @@ int32_t gs_renderer_reserve_pairs(gs_renderer* r, uint64_t cap) {
     if (r->pairVals) (void)hipFree(r->pairVals);
     sort_state_destroy(r->pairSort);
     r->pairKeys = nk; r->pairVals = nv; r->pairSort = ns; r->pairCapacity = cap;
+    // a lane that had to grow: its siblings draw the same scene (a frame repeated after GS_ERR_PAIR_OVERFLOW goes to the next lane)
+    if (r->laneOf)
+        for (gs_renderer* S : r->laneOf->lanes)
+            if (S != r && S->pairCapacity < cap) GS_TRY(gs_renderer_reserve_pairs(S, cap));
     return GS_OK;
 }
 
 int32_t gs_renderer_poll_pairs(gs_renderer* r, uint64_t* tile_pairs, uint64_t* pair_capacity) {
     if (!r || !tile_pairs || !pair_capacity) return fail(GS_ERR_INVALID_ARGUMENT, "null argument");
+    r = lane_cur(r);
     if (r->truncPairs) {                                         // a truncated draw the library has already reacted to: handed out once
         *tile_pairs = r->truncPairs; *pair_capacity = r->truncCapacity;
         r->truncPairs = r->truncCapacity = 0;
@@ -633,6 +763,7 @@ int32_t gs_renderer_download_order(gs_renderer* r, uint32_t* out, size_t count) 
 }
 int32_t gs_renderer_download_visible_order(gs_renderer* r, uint32_t* out, size_t capacity, uint32_t* count) {
     if (!r || !count || (capacity && !out)) return fail(GS_ERR_INVALID_ARGUMENT, "bad argument");
+    r = lane_cur(r);
     *count = 0;
     if (!vis_active(r)) return fail(GS_ERR_INVALID_ARGUMENT, "the visible-only sort mode is not set (gs_renderer_set_sort_mode)");
     if (!r->viewValid) return fail(GS_ERR_INVALID_ARGUMENT, "gs_renderer_calc_view has not run");
@@ -661,7 +792,7 @@ int32_t gs_renderer_set_sort_mode(gs_renderer* r, int32_t mode) {
         GS_TRY(join_sort(r));
         r->sortMode = mode;
         r->visHistDepth = 0; r->visRankValid = false; r->visOrderValid = false;
-        return GS_OK;
+        return lanes_resync(r);                                  // (lanes: the same base)
     }
     // back to the reference's SortPoints: it continues from the order buffer the reference would hold now
     GS_TRY(vis_consolidate(r));
@@ -677,6 +808,8 @@ int32_t gs_renderer_sort_mode(const gs_renderer* r, int32_t* mode, int32_t* acti
 }
 int32_t gs_renderer_set_sort_history_limit(gs_renderer* r, uint32_t rows) {
     if (!r || rows < 2 || rows > (uint32_t)kVisHistory) return fail(GS_ERR_INVALID_ARGUMENT, "sort history limit must be in [2, 128]");
+    GS_TRY(bind_device(r->ctx));
+    for (gs_renderer* L : r->lanes) GS_TRY(gs_renderer_set_sort_history_limit(L, rows));
     GS_TRY(bind_device(r->ctx));
     if ((uint32_t)r->visHistDepth > rows) GS_TRY(vis_consolidate(r));
     r->visHistLimit = (int)rows;
@@ -706,10 +839,11 @@ int32_t gs_renderer_upload_order(gs_renderer* r, const uint32_t* in, size_t coun
     GS_HIP(hipMemcpyAsync(r->order, in, count * 4, hipMemcpyHostToDevice, r->ctx->stream));
     GS_HIP(hipStreamSynchronize(r->ctx->stream));
     vis_base_changed(r, false);                                  // a custom order: the new base of the visible-only mode
-    return GS_OK;
+    return lanes_resync(r);
 }
 int32_t gs_renderer_download_view(gs_renderer* r, void* out, size_t bytes) {
     if (!r || !out || bytes > (size_t)r->n * sizeof(gsm::ViewData)) return fail(GS_ERR_INVALID_ARGUMENT, "bad argument");
+    r = lane_cur(r);
     if (r->viewValid && !r->viewMaterialised) {
         // m_GpuView is materialised on demand: the per-frame launch skips it (nothing in this renderer reads it); re-run the
         // frame's launch as the reference's full kernel.  rec/rect/visibility are rewritten with identical values.
@@ -724,6 +858,7 @@ int32_t gs_renderer_download_view(gs_renderer* r, void* out, size_t bytes) {
 
 int32_t gs_renderer_download_raster_records(gs_renderer* r, void* recs, uint32_t* rects, uint64_t* vis_mask) {
     if (!r) return fail(GS_ERR_INVALID_ARGUMENT, "renderer is null");
+    r = lane_cur(r);
     if (!r->viewValid) return fail(GS_ERR_INVALID_ARGUMENT, "gs_renderer_calc_view has not run");
     GS_TRY(bind_device(r->ctx));
     hipStream_t st = r->ctx->stream;
@@ -736,6 +871,7 @@ int32_t gs_renderer_download_raster_records(gs_renderer* r, void* recs, uint32_t
 
 int32_t gs_renderer_frame_stats(gs_renderer* r, gs_frame_stats* out) {
     if (!r || !out) return fail(GS_ERR_INVALID_ARGUMENT, "null argument");
+    r = lane_cur(r);                                             // the frame in progress (the lane that drew last)
     GS_TRY(bind_device(r->ctx));
     GS_TRY(join_sort(r));
     GS_HIP(hipStreamSynchronize(r->ctx->stream));
@@ -772,6 +908,7 @@ int32_t gs_renderer_frame_stats(gs_renderer* r, gs_frame_stats* out) {
 int32_t gs_renderer_frame_times(gs_renderer* r, float* out_ms, int32_t capacity, int32_t* count) {
     if (!r || !out_ms || !count || capacity < 0) return fail(GS_ERR_INVALID_ARGUMENT, "bad argument");
     *count = 0;
+    r = lane_cur(r);                                             // (with lanes: the ring of the lane that drew last -- every lane times its own frames)
     if (!r->ev) return fail(GS_ERR_INVALID_ARGUMENT, "profiling was never enabled");
     GS_TRY(bind_device(r->ctx));
     GS_HIP(hipStreamSynchronize(r->ctx->aux));
@@ -794,6 +931,7 @@ int32_t gs_renderer_frame_times(gs_renderer* r, float* out_ms, int32_t capacity,
 int32_t gs_renderer_stage_times(gs_renderer* r, gs_stage_times* out) {
     if (!r || !out) return fail(GS_ERR_INVALID_ARGUMENT, "null argument");
     memset(out, 0, sizeof(*out));
+    r = lane_cur(r);
     if (!r->ev) return fail(GS_ERR_INVALID_ARGUMENT, "profiling was never enabled");
     GS_TRY(bind_device(r->ctx));
     GS_HIP(hipStreamSynchronize(r->ctx->aux));
@@ -848,13 +986,14 @@ int32_t gs_target_create(gs_context* ctx, uint32_t w, uint32_t h, gs_target** ou
 int32_t gs_target_destroy(gs_target* t) {
     if (!t) return GS_OK;
     (void)hipSetDevice(t->ctx->device);
-    (void)hipStreamSynchronize(t->ctx->stream);
+    (void)hipStreamSynchronize(t->ctx->stream);        // (a lane's blend into the target is joined into this stream by its draw)
     if (t->rgba16f) (void)hipFree(t->rgba16f);
     if (t->resolved) (void)hipFree(t->resolved);
     if (t->resolved8) (void)hipFree(t->resolved8);
     if (t->sceneDepthOwned) (void)hipFree(t->sceneDepthOwned);
     if (t->zbuf) (void)hipFree(t->zbuf);
     if (t->rev) { for (int k = 0; k < 2 * gs_target::kResolveRing; ++k) if (t->rev[k]) (void)hipEventDestroy(t->rev[k]); delete[] t->rev; }
+    if (t->evLastUse) (void)hipEventDestroy(t->evLastUse);
     delete t;
     return GS_OK;
 }
@@ -934,6 +1073,7 @@ int32_t gs_target_resolve_time(gs_target* t, float* mean_ms, int32_t* count) {
 int32_t gs_target_device_ptr(gs_target* t, void** rgba16f_dev, void** resolved_dev) {
     if (!t) return fail(GS_ERR_INVALID_ARGUMENT, "target is null");
     GS_TRY(flush_clear(t));                 // the caller is about to read the memory directly
+    t->exposed = true;                      // (lanes: from now on a draw into this target waits for everything the context's stream holds)
     if (rgba16f_dev) *rgba16f_dev = t->rgba16f;
     if (resolved_dev) *resolved_dev = t->resolved;
     return GS_OK;

@@ -5,6 +5,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
+#include <vector>
 
 #include "../../include/gsplat_c.h"
 #include "gs_device_math.h"
@@ -170,6 +171,8 @@ struct gs_context {
     bool counted = false;                 // this context is in the live count of its device
     int cuCount = 0;
     hipDeviceProp_t props;
+    // contexts the library made itself for renderers of THIS context (gs_renderer_set_frames_in_flight's lanes): gs_context_synchronize waits for them too
+    std::vector<gs_context*> children;
 };
 bool gs_shared_gpu(const gs_context* ctx);      // may another kernel that waits on its own workgroups run beside this context's? (gs_api.hip)
 
@@ -207,6 +210,12 @@ struct gs_target {
     hipEvent_t* rev = nullptr;              // 2 x kResolveRing events, or null (profiling off)
     bool profiling = false;
     int revCount = 0;                       // resolves recorded since the last read (may exceed the ring: the oldest are overwritten)
+    // Lanes (gs_renderer_set_frames_in_flight) draw into the target from streams of their own: a lane's blend waits for the target's LAST USE -- the resolve
+    // of the frame drawn into it before, a clear, another draw -- not for everything the context's stream holds (the other frames' blends into OTHER targets:
+    // a host that alternates two targets lets consecutive blends overlap).  Recorded only while the context has lanes (gs::target_touched).
+    hipEvent_t evLastUse = nullptr;
+    bool lastUseValid = false;
+    bool exposed = false;                   // gs_target_device_ptr handed the memory out: the host's own work on the context's stream may touch it
 };
 
 struct gs_renderer {
@@ -304,10 +313,19 @@ struct gs_renderer {
     uint32_t visChunkCap = 0;
     gs::VisControl* visControl = nullptr;   // two blocks, used alternately
     int visControlIdx = 0;
+    // ---- frames in flight inside the library (gs_renderer_set_frames_in_flight; gs_api.hip) ----
+    // lanes: renderers on contexts (= streams) of their own over this renderer's asset, owned by it; while GS_SORT_VISIBLE draws splats every gs_renderer_calc_view
+    // moves on to the next lane and the frame's kernels run there -- one frame's latency-bound chain under another's blend.  Empty: one frame at a time, on ctx.
+    std::vector<gs_renderer*> lanes;
+    int laneCur = -1;                       // the lane of the frame in progress (-1: none yet)
+    gs_renderer* laneOf = nullptr;          // a lane's owner
+    hipEvent_t evTargetFree = nullptr;      // a lane drawing into its owner's target: target's stream -> lane (before the blend) ...
+    hipEvent_t evBlendDone = nullptr;       // ... and lane -> target's stream (after it)
 };
 
 namespace gs {
 void prof_record(gs_renderer* r, int k, hipStream_t st = nullptr);   // gs_api.hip: record event k of the current profiling slot (on st, default ctx->stream)
+int32_t target_touched(gs_target* t, hipStream_t st);   // gs_raster.hip: the last operation on the target's memory has just been enqueued on st
 int32_t join_sort(gs_renderer* r);          // make ctx->stream wait for a sort still running on ctx->aux
 int32_t mark_order_use(gs_renderer* r);     // the main queue has just been given work that reads / writes order[]: the next sort waits for it
 void prof_end_frame(gs_renderer* r);

@@ -1605,6 +1605,19 @@ int32_t enqueue_draw(gs_renderer* r, const gs_frame_params* p, gs_target* rt) {
     const uint32_t numTiles = ds.numTiles;
     uint32_t *tileStart = ds.tileStart, *tileEnd = ds.tileEnd, *tileOrder = ds.tileOrder;
     const int dstIsZero = ds.dstIsZero;
+    // A lane (gs_renderer_set_frames_in_flight) draws into a target of its owner's context: everything up to here ran beside whatever that context's stream
+    // holds (the previous frame's blend and resolve, the host's own work on the target); the blend -- the first kernel to touch the target or its depth
+    // attachment -- waits for it, and the stream waits for the blend.
+    const bool foreignTarget = rt->ctx != r->ctx;
+    if (foreignTarget) {
+        // the target's last use (target_touched); everything the context's stream holds only if the host may have put work of its own on the memory there
+        // (it asked for the device pointers, or lent a depth buffer it fills itself)
+        const bool borrowedDepth = rt->sceneDepth && rt->sceneDepth != rt->sceneDepthOwned;
+        if (rt->exposed || borrowedDepth) {
+            GS_HIP(hipEventRecord(r->evTargetFree, rt->ctx->stream));
+            GS_HIP(hipStreamWaitEvent(st, r->evTargetFree, 0));
+        } else if (rt->lastUseValid) GS_HIP(hipStreamWaitEvent(st, rt->evLastUse, 0));
+    }
     if (rt->sceneDepth) {
         gsm::FrameConsts fc;
         flatten_params(p, fc);
@@ -1620,6 +1633,11 @@ int32_t enqueue_draw(gs_renderer* r, const gs_frame_params* p, gs_target* rt) {
 #undef GS_LAUNCH_BLEND_S
     prof_record(r, 6);
     GS_HIP(hipGetLastError());
+    if (foreignTarget) {
+        GS_HIP(hipEventRecord(r->evBlendDone, st));
+        GS_HIP(hipStreamWaitEvent(rt->ctx->stream, r->evBlendDone, 0));
+    }
+    GS_TRY(target_touched(rt, st));
     r->frameInFlight = true;
     prof_end_frame(r);
     return GS_OK;
@@ -1666,6 +1684,7 @@ int32_t enqueue_debug_boxes(gs_renderer* r, const gs_frame_params* p, gs_target*
 #undef GS_LAUNCH_BOX
     prof_record(r, 6);
     GS_HIP(hipGetLastError());
+    GS_TRY(target_touched(rt, st));
     r->frameInFlight = true;
     prof_end_frame(r);
     return GS_OK;
@@ -1690,6 +1709,7 @@ int32_t enqueue_debug_points(gs_renderer* r, const gs_frame_params* p, gs_target
                        rt->zbuf, rt->rgba16f);
     prof_record(r, 6);
     GS_HIP(hipGetLastError());
+    GS_TRY(target_touched(rt, st));
     prof_end_frame(r);
     return GS_OK;
 }
@@ -1699,6 +1719,14 @@ int32_t flush_clear(gs_target* t) {
     GS_HIP(hipSetDevice(t->ctx->device));
     GS_HIP(hipMemsetAsync(t->rgba16f, 0, (size_t)t->width * t->height * 8, t->ctx->stream));
     t->clearPending = false;
+    return target_touched(t, t->ctx->stream);
+}
+
+int32_t target_touched(gs_target* t, hipStream_t st) {
+    if (t->ctx->children.empty()) { t->lastUseValid = false; return GS_OK; }      // no lanes: the context's stream orders everything by itself
+    if (!t->evLastUse) GS_HIP(hipEventCreateWithFlags(&t->evLastUse, hipEventDisableTiming));
+    GS_HIP(hipEventRecord(t->evLastUse, st));
+    t->lastUseValid = true;
     return GS_OK;
 }
 
@@ -1711,7 +1739,7 @@ int32_t enqueue_resolve(gs_target* t, const float bg[4], bool want8) {
     hipLaunchKernelGGL(resolve_kernel, dim3(div_up(numPix, 256)), dim3(256), 0, t->ctx->stream, t->rgba16f, numPix, bg[0], bg[1], bg[2], bg[3],
                        t->resolved, want8 ? t->resolved8 : (uint8_t*)nullptr);      // the sRGB 8-bit image (3 powf per pixel) only when asked for
     GS_HIP(hipGetLastError());
-    return GS_OK;
+    return target_touched(t, t->ctx->stream);
 }
 
 } // namespace gs

@@ -104,6 +104,8 @@ namespace GaussianSplatting.Runtime
         [DllImport(Lib)] public static extern int gs_renderer_sort_mode(IntPtr renderer, out int mode, out int active);
         [DllImport(Lib)] public static extern int gs_renderer_set_sort_history_limit(IntPtr renderer, uint rows);
         [DllImport(Lib)] public static extern int gs_renderer_sort_history(IntPtr renderer, out uint rows, out uint limit, out ulong consolidations);
+        [DllImport(Lib)] public static extern int gs_renderer_set_frames_in_flight(IntPtr renderer, int frames);
+        [DllImport(Lib)] public static extern int gs_renderer_frames_in_flight(IntPtr renderer, out int frames, out int active);
         [DllImport(Lib)] public static extern int gs_renderer_download_visible_order(IntPtr renderer, uint[] dst, UIntPtr capacity, out uint count);
         [DllImport(Lib)] public static extern int gs_renderer_set_render_mode(IntPtr renderer, int mode, float pointDisplaySize);
         [DllImport(Lib)] public static extern int gs_renderer_download_view(IntPtr renderer, IntPtr dst, UIntPtr bytes);

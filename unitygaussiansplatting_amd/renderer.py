@@ -219,6 +219,7 @@ class GaussianSplatRenderer:
         # applied to the native renderer when its resources are created (SetSortMode changes it later).  GSPLAT_SORT_MODE=visible makes the visible-only
         # mode the default of this host layer -- how the whole GPU test suite is run through it (profiles/r05_pytest_gpu_visible.log)
         self.sortMode = SortMode.Visible if os.environ.get("GSPLAT_SORT_MODE", "") == "visible" else SortMode.Full
+        self.framesInFlight = max(1, int(os.environ.get("GSPLAT_FRAMES_IN_FLIGHT", "1") or 1))     # SetFramesInFlight
         self._asset_h = C.c_void_p()
         self._r_h = C.c_void_p()
         self._keep: list = []
@@ -263,6 +264,8 @@ class GaussianSplatRenderer:
         self.m_SplatCount = a.splatCount
         if self.sortMode != SortMode.Full:
             check(_lib.lib().gs_renderer_set_sort_mode(self._r_h, int(self.sortMode)), "gs_renderer_set_sort_mode")
+        if self.framesInFlight > 1:
+            check(_lib.lib().gs_renderer_set_frames_in_flight(self._r_h, int(self.framesInFlight)), "gs_renderer_set_frames_in_flight")
 
     def ShareResourcesOf(self, other: "GaussianSplatRenderer") -> None:
         """A second renderer over the SAME device blobs as `other` (no copy; `other` must outlive this one), on this renderer's own context =
@@ -395,6 +398,20 @@ class GaussianSplatRenderer:
         self.sortMode = SortMode(mode)
         if self._r_h:
             check(_lib.lib().gs_renderer_set_sort_mode(self._r_h, int(self.sortMode)), "gs_renderer_set_sort_mode")
+
+    def SetFramesInFlight(self, frames: int) -> None:
+        """Frames (or the views of a batch of cameras) in flight INSIDE the library, behind this one renderer: `frames` lanes on streams of their own, dealt
+        round-robin at every CalcViewData while SortMode.Visible draws splats -- one frame's latency-bound kernels under another's blend; the calls and the
+        frames stay what they are with one frame at a time (gs_renderer_set_frames_in_flight).  1 = off (default)."""
+        self.framesInFlight = int(frames)
+        if self._r_h:
+            check(_lib.lib().gs_renderer_set_frames_in_flight(self._r_h, int(frames)), "gs_renderer_set_frames_in_flight")
+
+    def FramesInFlight(self):
+        """(lanes set, True while the next CalcViewData goes to a lane)"""
+        f, a = C.c_int32(), C.c_int32()
+        check(_lib.lib().gs_renderer_frames_in_flight(self._r_h, C.byref(f), C.byref(a)), "gs_renderer_frames_in_flight")
+        return f.value, bool(a.value)
 
     def SortModeActive(self) -> bool:
         """True while the visible-only path is what the next Draw uses (ABI 8: whenever the mode is set -- whatever the order buffer holds
