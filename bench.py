@@ -77,6 +77,8 @@ def parse():
     ap.add_argument("--in-flight-impl", default="library", choices=["library", "host"],
                     help="library: ONE renderer on one context, gs_renderer_set_frames_in_flight deals the frames to lanes inside the library (the reference's calls unchanged); "
                          "host: the host holds --in-flight renderers on contexts of their own over one asset and deals the frames itself")
+    ap.add_argument("--in-flight-targets", type=int, default=1, help="library lanes: sets of targets the host draws into in rotation (1: every frame into the same target, as the "
+                                                                         "sequential modes do -- the library double-buffers a target's pixels itself while it has lanes)")
     ap.add_argument("--pmc", default="auto", choices=["auto", "off"], help="auto: at N = 1 spawn rocprofv3 --pmc children of this script for HBM traffic and VALU instruction counts")
     ap.add_argument("--pmc-child", default="", help="(internal) path of the pickled asset: run the frames of one mode and exit -- what the rocprofv3 children execute")
     ap.add_argument("--child-mode", default="visible", help="(internal) mode of a --pmc-child run")
@@ -459,8 +461,7 @@ def main():
                     X.r.SortPointsPrepared(m16)
                 sort_log.append(m16)
             X = active[(i * len(my_views) + vi) % nl]
-            # lanes inside the library: the host alternates as many sets of targets as it has frames in flight (a swap chain: the reference's
-            # _GaussianSplatRT is a temporary of the frame) -- a frame's blend then waits for ITS target's last use, not for the frame before it
+            # (lanes inside the library, --in-flight-targets > 1: the host alternates sets of targets, a swap chain)
             t = (X.rt_sets[(i * len(my_views) + vi) % len(X.rt_sets)] if X.rt_sets else X.rts)[vi]
             X.last_rt = t
             X.r.CalcViewDataPrepared(p)
@@ -529,8 +530,8 @@ def main():
         lib_lanes = piped and args.in_flight_impl == "library"
         active[:] = [lane(k) for k in range(max(1, args.in_flight))] if (piped and not lib_lanes) else [lanes[0]]
         r.SetFramesInFlight(max(1, args.in_flight) if lib_lanes else 1)      # the lanes live inside the library, behind r
-        if lib_lanes and lanes[0].rt_sets is None:
-            lanes[0].rt_sets = [rts] + [[RenderTarget(ctx, W, H) for _ in my_views] for _ in range(max(1, args.in_flight) - 1)]
+        if lib_lanes and args.in_flight_targets > 1 and lanes[0].rt_sets is None:
+            lanes[0].rt_sets = [rts] + [[RenderTarget(ctx, W, H) for _ in my_views] for _ in range(args.in_flight_targets - 1)]
         if not lib_lanes and lanes[0].rt_sets is not None:
             lanes[0].rt_sets = None
         for X in active:

@@ -259,8 +259,9 @@ int32_t gs_renderer_sort_history(const gs_renderer* r, uint32_t* rows, uint32_t*
  * reference's -- SortPoints, CalcViewData, the draw, the composite on ONE GaussianSplatRenderer (GaussianSplatRenderer.cs:108-169) -- and so do the results:
  * gs_renderer_sort is bookkeeping in that mode and every lane is told every matrix, so each frame is drawn from the reference's order, the same bits as with
  * one frame at a time.  The target stays the context's: a lane's blend waits for what the context's stream holds for the target when gs_renderer_draw is
- * called (the previous frame's resolve, the host's own work) and the stream waits for the blend, so gs_target_resolve / _download and anything the host
- * enqueues afterwards see the finished frame.  What is NOT ordered against the context's stream any more is the rest of the frame (it reads the asset and
+ * called -- its last use: a clear, a resolve, another draw; everything the stream holds once the host has taken the device pointers -- and the stream waits for the
+ * blend, so gs_target_resolve / _download and anything the host enqueues afterwards see the finished frame.  (A target of a context with lanes holds two pixel
+ * buffers and gs_target_clear moves on to the other one: drawing every frame into the same target does not queue a blend behind the previous frame's composite.)  What is NOT ordered against the context's stream any more is the rest of the frame (it reads the asset and
  * the renderer's settings only): change those through this API.  It is throughput, not latency; a host that blocks after every frame gains nothing.
  * GS_SORT_FULL and the debug render modes run on the renderer's own context as before (their state is one order buffer).  frames = 1 (the default) frees
  * the lanes.  Costs the per-frame buffers once more per lane (about 100 B per splat). */

@@ -1,7 +1,8 @@
 /* Plain-C consumer of include/gsplat_c.h: links libgsplat_hip.so like a non-C++ host would and walks the parts of the ABI
  * that need no GPU (version, error strings, argument validation, the native importer) and, where a GPU is present, the frame itself:
  * asset from the imported blobs, GS_SORT_VISIBLE on three renderers -- one drawing every frame, two on contexts of their own SHARING the
- * asset with the frames dealt alternately and a sort history of two rows -- every frame the same bits, the order buffers equal at the end.
+ * asset with the frames dealt alternately and a sort history of two rows -- and on a fourth with the frames in flight INSIDE the library
+ * (gs_renderer_set_frames_in_flight: one renderer, two targets in rotation): every frame the same bits, the order buffers equal at the end.
  * Built and run by tests/test_abi.py. */
 #include <math.h>
 #include <stdio.h>
@@ -71,6 +72,13 @@ int main(void) {
         CHECK(gs_target_create(cx[k], W, H, &rt[k]) == GS_OK);
     }
     CHECK(gs_renderer_set_sort_history_limit(r[2], 2) == GS_OK && gs_renderer_set_sort_history_limit(r[2], 1) == GS_ERR_INVALID_ARGUMENT);
+    gs_renderer* rl = NULL; gs_target* rtl[2];                  /* the same, behind ONE renderer: lanes inside the library */
+    CHECK(gs_renderer_create(ctx, asset, &rl) == GS_OK && gs_renderer_set_sort_mode(rl, GS_SORT_VISIBLE) == GS_OK);
+    CHECK(gs_renderer_set_frames_in_flight(rl, 0) == GS_ERR_INVALID_ARGUMENT && gs_renderer_set_frames_in_flight(rl, GS_MAX_FRAMES_IN_FLIGHT + 1) == GS_ERR_INVALID_ARGUMENT);
+    CHECK(gs_renderer_set_frames_in_flight(rl, 2) == GS_OK);
+    int32_t lanes_set = 0, lanes_active = 0;
+    CHECK(gs_renderer_frames_in_flight(rl, &lanes_set, &lanes_active) == GS_OK && lanes_set == 2 && lanes_active == 1);
+    CHECK(gs_target_create(ctx, W, H, &rtl[0]) == GS_OK && gs_target_create(ctx, W, H, &rtl[1]) == GS_OK);
     static uint16_t img0[W * H * 4], img1[W * H * 4];
     static uint32_t ord0[N], ord1[N], vis0[N], vis1[N];
     for (int f = 0; f < FRAMES; ++f) {
@@ -92,6 +100,8 @@ int main(void) {
         float S[16];                                             /* SortPoints' matrix: the view matrix with m20, m21, m22 negated (GaussianSplatRenderer.cs:617-629) */
         memcpy(S, V, sizeof S); S[8] = -S[8]; S[9] = -S[9]; S[10] = -S[10];
         for (int k = 0; k < 3; ++k) CHECK(gs_renderer_sort(r[k], S) == GS_OK);      /* every renderer learns every matrix */
+        CHECK(gs_renderer_sort(rl, S) == GS_OK);                 /* (the library tells its lanes) */
+        CHECK(gs_renderer_calc_view(rl, &p) == GS_OK && gs_target_clear(rtl[f & 1]) == GS_OK && gs_renderer_draw(rl, &p, rtl[f & 1]) == GS_OK);
         const int lane = 1 + (f & 1);
         const int who[2] = { 0, lane };
         for (int j = 0; j < 2; ++j) {
@@ -106,16 +116,23 @@ int main(void) {
         uint32_t c0 = 0, c1 = 0;
         CHECK(gs_renderer_download_visible_order(r[0], vis0, N, &c0) == GS_OK && gs_renderer_download_visible_order(r[lane], vis1, N, &c1) == GS_OK);
         CHECK(c0 == st0.visible_splats && c0 == c1 && memcmp(vis0, vis1, c0 * sizeof(uint32_t)) == 0);
+        /* the frame drawn on a lane inside the library: the same target bits (gs_target_download waits on the context's stream, which the draw made wait for
+         * the lane's blend), the same drawn order */
+        CHECK(gs_target_download(rtl[f & 1], img1, sizeof img1) == GS_OK && memcmp(img0, img1, sizeof img0) == 0);
+        CHECK(gs_renderer_download_visible_order(rl, vis1, N, &c1) == GS_OK && c1 == c0 && memcmp(vis0, vis1, c0 * sizeof(uint32_t)) == 0);
     }
+    CHECK(gs_renderer_download_order(rl, ord1, N) == GS_OK && gs_renderer_download_order(r[0], ord0, N) == GS_OK && memcmp(ord0, ord1, sizeof ord0) == 0);
+    CHECK(gs_renderer_set_frames_in_flight(rl, 1) == GS_OK && gs_renderer_frames_in_flight(rl, &lanes_set, &lanes_active) == GS_OK && lanes_set == 1 && lanes_active == 0);
+    CHECK(gs_renderer_destroy(rl) == GS_OK && gs_target_destroy(rtl[0]) == GS_OK && gs_target_destroy(rtl[1]) == GS_OK);
     uint32_t rows = 0, limit = 0; uint64_t cons = 0;
     CHECK(gs_renderer_sort_history(r[2], &rows, &limit, &cons) == GS_OK && limit == 2 && rows <= 2 && cons >= 2);
-    CHECK(gs_renderer_sort_history(r[0], &rows, &limit, &cons) == GS_OK && limit == 128 && rows == FRAMES && cons == 0);
+    CHECK(gs_renderer_sort_history(r[0], &rows, &limit, &cons) == GS_OK && limit == 128 && rows <= FRAMES && cons <= 1);      /* (download_order above consolidated once) */
     CHECK(gs_renderer_download_order(r[0], ord0, N) == GS_OK);   /* the reference's whole buffer: the recorded sorts carried out on all N */
     for (int k = 1; k < 3; ++k) { CHECK(gs_renderer_download_order(r[k], ord1, N) == GS_OK); CHECK(memcmp(ord0, ord1, sizeof ord0) == 0); }
     CHECK(gs_renderer_set_sort_mode(r[0], GS_SORT_FULL) == GS_OK && gs_renderer_download_order(r[0], ord1, N) == GS_OK && memcmp(ord0, ord1, sizeof ord0) == 0);
     for (int k = 2; k >= 0; --k) { CHECK(gs_renderer_destroy(r[k]) == GS_OK); CHECK(gs_target_destroy(rt[k]) == GS_OK); }
     CHECK(gs_asset_destroy(asset) == GS_OK);
     CHECK(gs_context_destroy(ctx2) == GS_OK && gs_context_destroy(ctx1) == GS_OK && gs_context_destroy(ctx) == GS_OK);
-    printf("abi_smoke ok (context: GPU present; %d frames on three renderers, two of them sharing the asset across contexts: same bits, same order)\n", FRAMES);
+    printf("abi_smoke ok (context: GPU present; %d frames on three renderers, two of them sharing the asset across contexts, and on one with two frames in flight inside the library: same bits, same order)\n", FRAMES);
     return 0;
 }

@@ -6,6 +6,7 @@
 
 #include <atomic>
 #include <new>
+#include <utility>
 
 #include "gs_common.h"
 
@@ -988,6 +989,8 @@ int32_t gs_target_destroy(gs_target* t) {
     (void)hipSetDevice(t->ctx->device);
     (void)hipStreamSynchronize(t->ctx->stream);        // (a lane's blend into the target is joined into this stream by its draw)
     if (t->rgba16f) (void)hipFree(t->rgba16f);
+    if (t->rgba16fAlt) (void)hipFree(t->rgba16fAlt);
+    if (t->evLastUseAlt) (void)hipEventDestroy(t->evLastUseAlt);
     if (t->resolved) (void)hipFree(t->resolved);
     if (t->resolved8) (void)hipFree(t->resolved8);
     if (t->sceneDepthOwned) (void)hipFree(t->sceneDepthOwned);
@@ -1001,6 +1004,17 @@ int32_t gs_target_destroy(gs_target* t) {
 int32_t gs_target_clear(gs_target* t) {
     if (!t) return fail(GS_ERR_INVALID_ARGUMENT, "target is null");
     t->clearPending = true;                 // the next draw writes every pixel (blend kernel); anything else clears first
+    // lanes on this context: the cleared frame goes into the target's other pixel buffer (gs_common.h), so that its blend does not wait for the composite of the
+    // frame before it.  Not once the host holds the device pointer.
+    if (!t->ctx->children.empty() && !t->exposed) {
+        if (!t->rgba16fAlt) {
+            GS_TRY(bind_device(t->ctx));
+            GS_HIP(hipMalloc((void**)&t->rgba16fAlt, (size_t)t->width * t->height * 8));
+        }
+        std::swap(t->rgba16f, t->rgba16fAlt);
+        std::swap(t->evLastUse, t->evLastUseAlt);
+        std::swap(t->lastUseValid, t->lastUseValidAlt);
+    }
     return GS_OK;
 }
 

@@ -213,9 +213,15 @@ struct gs_target {
     // Lanes (gs_renderer_set_frames_in_flight) draw into the target from streams of their own: a lane's blend waits for the target's LAST USE -- the resolve
     // of the frame drawn into it before, a clear, another draw -- not for everything the context's stream holds (the other frames' blends into OTHER targets:
     // a host that alternates two targets lets consecutive blends overlap).  Recorded only while the context has lanes (gs::target_touched).
-    hipEvent_t evLastUse = nullptr;
+    // A host that draws every frame into the SAME target would still queue every blend behind the previous frame's composite (which reads the pixels the blend is
+    // about to overwrite).  So while the context has lanes the target holds TWO pixel buffers and gs_target_clear -- after which nothing of the old content can be
+    // seen -- moves on to the other one: frame k + 1 is blended into one buffer while frame k's is being resolved from the other.  rgba16f is the current one.
+    hipEvent_t evLastUse = nullptr;         // of the current buffer (swapped with evLastUseAlt by the flip)
     bool lastUseValid = false;
-    bool exposed = false;                   // gs_target_device_ptr handed the memory out: the host's own work on the context's stream may touch it
+    uint16_t* rgba16fAlt = nullptr;         // the other buffer, allocated at the first flip
+    hipEvent_t evLastUseAlt = nullptr;
+    bool lastUseValidAlt = false;
+    bool exposed = false;                   // gs_target_device_ptr handed the memory out: the host's own work on the context's stream may touch it (and the pointer stays put)
 };
 
 struct gs_renderer {
