@@ -173,6 +173,8 @@ struct gs_context {
     hipDeviceProp_t props;
     // contexts the library made itself for renderers of THIS context (gs_renderer_set_frames_in_flight's lanes): gs_context_synchronize waits for them too
     std::vector<gs_context*> children;
+    bool internalLane = false;              // one of those: not in the live count of the device; its own (rare) full sorts -- consolidations -- always take the shared-GPU form
+    bool sortBesideSiblings = false;        // set around a consolidation of a renderer that has lanes: they consolidate at the same frame, on their own streams
 };
 bool gs_shared_gpu(const gs_context* ctx);      // may another kernel that waits on its own workgroups run beside this context's? (gs_api.hip)
 
@@ -291,6 +293,7 @@ struct gs_renderer {
     hipEvent_t evOrderFree = nullptr;       // main -> aux fork: the last operation of the main queue that reads or writes order[]
     bool distancesStale = false;      // the last depth pass skipped the sorted-key write: gs_renderer_download_distances gathers them
     bool sortPending = false;               // a sort on ctx->aux has not been joined into ctx->stream yet
+    bool sortRecorded = false;              // evSortDone has been recorded at least once (lanes wait on it)
     uint32_t lastTilesX = 0, lastTilesY = 0, lastPairPasses = 0, lastDepthPasses = 4;
     bool frameInFlight = false;
     float resolveMs = 0.f;

@@ -248,13 +248,14 @@ __global__ __launch_bounds__(kBinThreads) void bin_emit_kernel(const uint2* __re
     const uint32_t digitMask = (1u << digitBits) - 1u;          // the pair sort's digit width (6..8 bits by tile count)
     uint32_t visAcc = 0;                                         // thread 0: visible splats of this workgroup's partitions
     // Persistent grid.  A partition's scan waits on the totals of every partition before it, so -- as in gs_sort.hip -- partitions are taken in dependency
-    // order: binning workgroup b takes partition b first (no atomic: it only waits on workgroups the dispatcher started before it), afterwards whoever is
-    // running claims the lowest unclaimed partition from ONE counter (the later requests are spread over the kernel; the 16 ticket classes of rounds 1-5,
-    // which spread the ~1300 simultaneous requests at the head of the kernel, stall when a class has no running workgroup: gs_sort.hip).
+    // order: when the grid covers every partition binning workgroup b takes partition b (no atomic) and exits; otherwise EVERY partition comes from ONE
+    // counter, so that the lowest unclaimed partition is always taken by a workgroup that is running (a static first round would leave it with a workgroup
+    // that may not have been dispatched while another stream's kernels hold the wave slots: gs_sort.hip).
+    const bool oneRound = binBlocks >= numParts;
     for (uint32_t round = 0;; ++round) {
     __syncthreads();                                             // s_part / s_wtot / s_base of the previous partition are no longer read
     if (tid == 0)
-        s_part = round == 0u ? bid : binBlocks + __hip_atomic_fetch_add(&ctl->tickets[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_part = oneRound ? (round == 0u ? bid : numParts) : __hip_atomic_fetch_add(&ctl->tickets[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     const uint32_t part = s_part;
     if (part >= numParts) break;
@@ -1598,7 +1599,8 @@ int32_t enqueue_draw(gs_renderer* r, const gs_frame_params* p, gs_target* rt) {
         GS_TRY(bin_and_sort(r, p, rt, r->visIdx, r->n, ds, false, twl, thl, vis_control(r)));
         r->visDrawn = true;
     } else {
-        GS_TRY(bin_and_sort(r, p, rt, r->order, r->n, ds, false, twl, thl));
+        // (a lane of a renderer in GS_SORT_FULL bins from its owner's order buffer: join_sort above waited for the owner's last sort)
+        GS_TRY(bin_and_sort(r, p, rt, r->laneOf ? r->laneOf->order : r->order, r->n, ds, false, twl, thl));
         r->visDrawn = false;
     }
     const RasterConsts& rc = ds.rc;

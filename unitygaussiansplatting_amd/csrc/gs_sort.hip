@@ -268,16 +268,18 @@ __global__ __launch_bounds__(THREADS, KPT == KPT_B ? 4 : kMinWavesA) void oneswe
         for (int k = 0; k < w; ++k) histExcl += s_htot[k];
 
     // Which partition a workgroup takes.  A partition waits (look-back) on EVERY partition before it, so forward progress needs the lowest unfinished
-    // partition to be held by a workgroup that is RUNNING -- whatever else shares the GPU (another process, another context of this one: kernels that
-    // may themselves be spinning on workgroups of theirs that cannot be dispatched while ours hold the slots).  The dispatcher starts workgroups in
-    // blockIdx order, so:
-    //   round 0   workgroup b takes partition b (no atomic): it only ever waits on workgroups started before it;
-    //   later     the next partition in dependency order from ONE counter: whoever is running can claim the lowest unclaimed partition.  (The requests
-    //             of the later rounds are spread over the pass -- a partition finishes behind its predecessors -- so one counter does not queue them the
-    //             way it queued the ~768 simultaneous requests at the head of the kernel, which is what the 16 ticket classes of rounds 1-5 were for.
-    //             Per-class counters deadlock under sharing: a class whose workgroups are all still waiting for a slot is served by nobody, and every
-    //             running workgroup ends up spinning on a partition of that class -- two such kernels hold each other's slots until the bounded spins
-    //             expire: found in round 6 by two processes on one GPU.)
+    // partition to be held by a workgroup that is RUNNING -- whatever else shares the GPU (another frame in flight on another stream, another process: kernels
+    // that may themselves be spinning on workgroups of theirs that cannot be dispatched while ours hold the slots).
+    //   The grid covers every partition (one round: a 6 M-key depth pass, the pair sort of a 6 M-pair frame): workgroup b takes partition b, no atomic, and
+    //             exits when it is done.  The dispatcher starts workgroups in blockIdx order, so a workgroup only ever waits on workgroups started before it, and
+    //             those need nothing from anyone to finish.
+    //   Otherwise (a persistent grid walking more partitions than it has workgroups): EVERY partition, the first one too, comes from ONE counter -- whoever is
+    //             running claims the lowest unclaimed partition.  (A static first round is not safe here: a workgroup that has not been dispatched yet owns a
+    //             partition nobody else can take, the running ones never exit -- they claim further partitions and end up spinning on that one -- and two such
+    //             kernels on two streams can hold each other's wave slots for good.  Found with frames in flight at C3 / C5 / C2d / C4, whose pair sorts walk
+    //             more partitions than fit: bounded spins expired, GS_ERR_SORT_TIMEOUT.  Rounds 1-5 spread the ~768 simultaneous requests at the head of the
+    //             kernel over 16 counters; per-class counters stall the same way when a class has no running workgroup -- found by two processes on one GPU.
+    //             The requests are 12 ns apart on one address: the 768th workgroup starts 9 us late, behind a look-back chain that reaches it later still.)
     // The GATHER pass of a frame's depth sort may instead deal whole blocks of consecutive partitions to the XCDs (gatherXcd != 0: 16 counters, two per XCD) so
     // that the 16 keys of a gathered 64-byte sector meet in one L2 -- 25 us faster per sort at C2, but only deadlock-free while no other kernel that spins
     // shares the GPU; gs_context_set_shared_gpu / GSPLAT_SHARED_GPU=1 selects the dependency-ordered form for it too.
@@ -297,7 +299,7 @@ __global__ __launch_bounds__(THREADS, KPT == KPT_B ? 4 : kMinWavesA) void oneswe
                 const uint32_t x = cls & 7u, u = t * 2u + (cls >> 3);       // u-th partition of XCD x
                 p = ((u / xb) * 8u + x) * xb + (u % xb);
             } else {
-                p = round == 0u ? blockIdx.x : gridDim.x + __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                p = oneRound ? blockIdx.x : __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             s_part = p;
         }
