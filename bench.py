@@ -70,8 +70,7 @@ def parse():
     ap.add_argument("--sort-nth-frame", type=int, default=1)
     ap.add_argument("--repeats", type=int, default=5, help="the timed region (exactly --steps frames) is run this many times back to back; ms_per_step / value are the MEDIAN region")
     ap.add_argument("--broadcast", action="store_true", help="go through gs_comm_create / gs_asset_broadcast even with one rank")
-    ap.add_argument("--sort-mode", default="all", choices=["all", "both", "full", "visible", "reference_shaped", "visible_in_flight", "reference_shaped_in_flight", "full_in_flight"],
-                    help="which modes to measure (both = full + visible; all = full, reference_shaped, reference_shaped_in_flight, visible, visible_in_flight)")
+    ap.add_argument("--sort-mode", default="all", choices=["all", "both", "full", "visible", "reference_shaped", "visible_in_flight"], help="which modes to measure (both = full + visible)")
     ap.add_argument("--headline", default="auto", choices=["auto", "full", "visible", "visible_in_flight", "reference_shaped"],
                     help="which measured mode `value` reports (auto: the fastest of visible_in_flight / visible whose end-of-orbit check holds, else full)")
     ap.add_argument("--in-flight", type=int, default=2, help="renderers (contexts = streams) the visible_in_flight mode deals its frames / views to")
@@ -527,8 +526,8 @@ def main():
         """One mode: warm-up (sizes the pair buffer: an overflowing frame grows it and is re-run), `repeats` un-instrumented regions of
         exactly K frames, then the same K frames with the per-stage hipEvents, then once more with the Onesweep launches' own timestamps.
         Afterwards the renderer is left as the last frame left it (the end-of-orbit state the checks read)."""
-        piped = mode.endswith("_in_flight")
-        lib_lanes = piped and (args.in_flight_impl == "library" or mode != "visible_in_flight")      # (the reference's sort has ONE order buffer: only the library can deal its frames)
+        piped = mode == "visible_in_flight"
+        lib_lanes = piped and args.in_flight_impl == "library"
         active[:] = [lane(k) for k in range(max(1, args.in_flight))] if (piped and not lib_lanes) else [lanes[0]]
         r.SetFramesInFlight(max(1, args.in_flight) if lib_lanes else 1)      # the lanes live inside the library, behind r
         if lib_lanes and args.in_flight_targets > 1 and lanes[0].rt_sets is None:
@@ -539,7 +538,7 @@ def main():
             X.r.SetSortMode(SortMode.Full)
             X.r.ResetOrder()                                 # every mode starts from CSSetIndices' order
             X.r.SetSortMode(SortMode.Visible if mode in ("visible", "visible_in_flight") else SortMode.Full)
-        r.SetViewBufferMode(mode.startswith("reference_shaped"))     # the reference's CSCalcViewData: colour + 40-byte record of every splat in front of the camera, every frame
+        r.SetViewBufferMode(mode == "reference_shaped")     # the reference's CSCalcViewData: colour + 40-byte record of every splat in front of the camera, every frame
         del sort_log[:]
         fi = 0
         first_frame_ms = first_again_ms = None
@@ -631,12 +630,12 @@ def main():
             x["vis_stats"] = L.r.FrameStats()
         x["order"] = L.r.DownloadOrder()
 
-    modes = {"all": ["full", "reference_shaped", "reference_shaped_in_flight", "visible", "visible_in_flight"], "both": ["full", "visible"]}.get(args.sort_mode, [args.sort_mode])
+    modes = {"all": ["full", "reference_shaped", "visible", "visible_in_flight"], "both": ["full", "visible"]}.get(args.sort_mode, [args.sort_mode])
     if "visible_in_flight" in modes and "visible" not in modes:
         modes.insert(modes.index("visible_in_flight"), "visible")                  # the per-kernel figures come from one frame at a time
     res = {}
     for m in modes:
-        res[m] = measure(m, args.repeats if not m.startswith("reference_shaped") else min(args.repeats, 3), instrument=(m != "reference_shaped"))
+        res[m] = measure(m, args.repeats if m != "reference_shaped" else min(args.repeats, 3), instrument=(m != "reference_shaped"))
         end_state(res[m])
     active[:] = [lanes[0]]
     r.SetFramesInFlight(1)
@@ -660,12 +659,6 @@ def main():
         cross["ok"] = all(cross[k] for k in ("same_sort_sequence", "consolidated_order_equals_full_mode_order", "visible_order_is_subsequence_of_full_mode_order", "frames_bit_identical"))
         if "reference_shaped" in res:
             cross["reference_shaped_frame_bit_identical"] = bool(np.array_equal(res["reference_shaped"]["img"], F_["img"]))
-        for m_ in ("reference_shaped_in_flight", "full_in_flight"):
-            if m_ in res:                                    # the reference's sort with the frames in flight inside the library: the same order buffer, the same frame
-                X_ = res[m_]
-                cross[m_] = {"lanes": X_["lanes"], "same_sort_sequence": bool(same_sorts(X_["sorts"], F_["sorts"])), "order_equals_full_mode_order": bool(np.array_equal(X_["order"], F_["order"])),
-                             "frame_bit_identical": bool(np.array_equal(X_["img"], F_["img"]))}
-                cross[m_]["ok"] = all(v for k, v in cross[m_].items() if k != "lanes")
         if "visible_in_flight" in res:
             X_ = res["visible_in_flight"]
             cross["in_flight"] = {"lanes": X_["lanes"], "same_sort_sequence": bool(same_sorts(X_["sorts"], F_["sorts"])), "consolidated_order_equals_full_mode_order": bool(np.array_equal(X_["order"], F_["order"])),
@@ -826,12 +819,9 @@ def main():
                         "in_flight_impl": ("library: ONE renderer on one context and the reference's calls; gs_renderer_set_frames_in_flight deals the frames to lanes inside the library"
                                            if x.get("impl") == "library" else "host: the host holds the renderers (one context each) and deals the frames itself"),
                         "tile_pairs_P": int(x["st"].tile_pairs), "visible_splats": int(x["st"].visible_splats), "sort_history": x["history"],
-                        "note": ("GS_SORT_VISIBLE with the frames (C5: the views) dealt round-robin to this many renderers on contexts (streams) of their own over ONE copy of the asset; "
-                                 "every renderer is told every SortPoints matrix, each draws its frames from the reference's order (checked: sort_mode_cross_check.in_flight, end_of_orbit_check); "
-                                 "throughput with frames in flight, not the latency of one frame") if x["mode"] == "visible_in_flight" else
-                                ("the reference's frame -- SortPoints over all N" + (", the whole CSCalcViewData (colour + 40-byte view record of every splat in front of the camera)" if x["mode"].startswith("reference_shaped") else "") +
-                                 ", composite -- with this many frames in flight inside the library: the sorts follow one another on the renderer's second queue (one order buffer), "
-                                 "the lanes run the rest of each frame and bin from that buffer; no work skipped, the same order buffer and frame as one at a time (sort_mode_cross_check." + x["mode"] + ")")}
+                        "note": "GS_SORT_VISIBLE with the frames (C5: the views) dealt round-robin to this many renderers on contexts (streams) of their own over ONE copy of the asset; "
+                                "every renderer is told every SortPoints matrix, each draws its frames from the reference's order (checked: sort_mode_cross_check.in_flight, end_of_orbit_check); "
+                                "throughput with frames in flight, not the latency of one frame"}
             return {"ms_per_step": round(x["elapsed"] / args.steps * 1e3, 4), "value_Msplats_s": round(n * args.steps * num_views / x["elapsed"] / 1e6, 2),
                     "regions_ms_per_step": [round(v / args.steps * 1e3, 4) for v in x["regions"]],
                     "tile_pairs_P": int(x["st"].tile_pairs), "visible_splats": int(x["st"].visible_splats),

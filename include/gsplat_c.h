@@ -253,22 +253,19 @@ int32_t gs_renderer_sort_mode(const gs_renderer* r, int32_t* mode, int32_t* acti
 int32_t gs_renderer_set_sort_history_limit(gs_renderer* r, uint32_t rows);
 int32_t gs_renderer_sort_history(const gs_renderer* r, uint32_t* rows, uint32_t* limit, uint64_t* consolidations);
 /* Frames (or the views of a multi-view batch) in flight INSIDE the library, behind one renderer: frames > 1 makes that many lanes -- renderers on contexts
- * (= HIP streams) of their own over this renderer's asset, owned by it.  While the renderer draws splats, every gs_renderer_calc_view moves on to the next
- * lane and that frame's kernels (calc_view, the binning, the pair sort, the blend; in GS_SORT_VISIBLE the visible-only sort too) run on the lane's stream: one
- * frame's latency-bound chain under another frame's blend (C2: 0.56 -> 0.45 ms per frame with two).  The calls stay the reference's --
- * SortPoints, CalcViewData, the draw, the composite on ONE GaussianSplatRenderer (GaussianSplatRenderer.cs:108-169) -- and so do the results:
- *   GS_SORT_VISIBLE  gs_renderer_sort is bookkeeping and every lane is told every matrix, so each frame is drawn from the reference's order;
- *   GS_SORT_FULL     SortPoints stays this renderer's: all N, stable, through the previous order, one sort after the other on the context's second queue (its
- *                    order buffer is the one state every frame's sort mutates); the lanes bin from that buffer, and a sort starts as soon as the previous
- *                    frame's binning has read it -- beside that frame's pair sort and blend and the next frame's calc_view;
- * the same bits as with one frame at a time either way.  The target stays the context's: a lane's blend waits for what the context's stream holds for the target
- * when gs_renderer_draw is
- * called -- its last use: a clear, a resolve, another draw; everything the stream holds once the host has taken the device pointers -- and the stream waits for the
+ * (= HIP streams) of their own over this renderer's asset, owned by it.  While the renderer is in GS_SORT_VISIBLE and draws splats, every
+ * gs_renderer_calc_view moves on to the next lane and that frame's kernels (calc_view, the visible-only sort, the binning, the pair sort, the blend) run on
+ * the lane's stream: one frame's latency-bound chain under another frame's blend (C2: 0.56 -> 0.45 ms per frame with two).  The calls stay the
+ * reference's -- SortPoints, CalcViewData, the draw, the composite on ONE GaussianSplatRenderer (GaussianSplatRenderer.cs:108-169) -- and so do the results:
+ * gs_renderer_sort is bookkeeping in that mode and every lane is told every matrix, so each frame is drawn from the reference's order,
+ * the same bits as with one frame at a time.  The target stays the context's: a lane's blend waits for what the context's stream holds for the target when
+ * gs_renderer_draw is called -- its last use: a clear, a resolve, another draw; everything the stream holds once the host has taken the device pointers -- and the stream waits for the
  * blend, so gs_target_resolve / _download and anything the host enqueues afterwards see the finished frame.  (A target of a context with lanes holds two pixel
  * buffers and gs_target_clear moves on to the other one: drawing every frame into the same target does not queue a blend behind the previous frame's composite.)
  * What is NOT ordered against the context's stream any more is the rest of the frame (it reads the asset and the renderer's settings only): change those through
- * this API.  It is throughput, not latency; a host that blocks after every frame gains nothing.  The debug render modes run on the renderer's own context as
- * before.  frames = 1 (the default) frees the lanes.  Costs the per-frame buffers once more per lane (about 100 B per splat). */
+ * this API.  It is throughput, not latency; a host that blocks after every frame gains nothing.  GS_SORT_FULL and the debug render modes run on the renderer's
+ * own context as before (the reference's sort has one order buffer that every frame mutates; dealing its frames to lanes with the sorts on a second queue was
+ * built and measured slower -- the big sorts find no wave slots beside a blend: docs/experiments.md).  frames = 1 (the default) frees the lanes.  Costs the per-frame buffers once more per lane (about 100 B per splat). */
 #define GS_MAX_FRAMES_IN_FLIGHT 4
 int32_t gs_renderer_set_frames_in_flight(gs_renderer* r, int32_t frames);
 /* *frames = what was set; *active != 0 = the next gs_renderer_calc_view goes to a lane */

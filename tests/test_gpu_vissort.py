@@ -510,74 +510,3 @@ def test_library_lanes_get_every_setting(gpu_ctx):
         x.OnDisable()
     rt.Dispose(); rt_seq.Dispose()
 
-
-def test_frames_in_flight_inside_the_library_with_the_reference_sort(gpu_ctx):
-    """Lanes in GS_SORT_FULL: SortPoints stays the owner's (all N, stable, through the previous order: the one state every frame mutates), on the owner's
-    second queue, one after the other; the lanes run the rest of each frame and bin from the owner's buffer -- a sort starts as soon as the previous frame's
-    binning has read it.  Every order buffer == the oracle's, every frame == the one-at-a-time renderer's, frame by frame and over an unsynchronised burst;
-    with m_SortNthFrame = 2 (a frame drawn from a stale order), the reference's whole CSCalcViewData every frame, and across a switch to GS_SORT_VISIBLE and back."""
-    a = tie_heavy_asset("lattice", quality="Medium")
-    seq = GaussianSplatRenderer(gpu_ctx, a); seq.OnEnable()
-    lib = GaussianSplatRenderer(gpu_ctx, a); lib.OnEnable()
-    lib.SetFramesInFlight(2)
-    assert lib.FramesInFlight() == (2, True) and not lib.SortModeActive()
-    orc = O.Oracle(a)
-    W, H = 320, 200
-    rt_seq, rts = RenderTarget(gpu_ctx, W, H), [RenderTarget(gpu_ctx, W, H) for _ in range(2)]
-
-    def frame(k, cam, sort=True, check=True):
-        if sort:
-            orc.sort(camera.sort_matrix(cam, seq.transform.localToWorldMatrix)); lib.SortPoints(cam)
-            if check:
-                seq.SortPoints(cam)
-        rt = rts[k % 2]
-        lib.CalcViewData(cam); rt.Clear(); lib.Draw(cam, rt)
-        if check:
-            seq.CalcViewData(cam); rt_seq.Clear(); seq.Draw(cam, rt_seq)
-            st = lib.FrameStats()
-            assert st.sort_mode != GS_SORT_VISIBLE and st.tile_pairs == seq.FrameStats().tile_pairs
-            assert np.array_equal(lib.DownloadOrder(), orc.order), f"frame {k}"
-            assert np.array_equal(rt.Download(), rt_seq.Download()), f"frame {k}"
-
-    cams = orbit(6, step=5.0, elev=20.0) + flight(5)
-    for k, cam in enumerate(cams):
-        frame(k, cam, sort=(k % 2 == 0) or k < 4)                # the later frames: every second one is drawn from the previous frame's order
-    for x in (seq, lib):
-        x.SetViewBufferMode(True)                                # the reference's CSCalcViewData: colour + 40-byte record of every splat in front of the camera
-    for k, cam in enumerate(orbit(3, step=7.0, elev=-15.0)):
-        frame(20 + k, cam)
-        assert np.array_equal(lib.DownloadView().view(np.uint32), orc.calc_view(lib.FrameParams(cam)).view(np.uint32))
-    for x in (seq, lib):
-        x.SetViewBufferMode(False)
-    # a burst that is never synchronised: 8 frames, every one sorted; the last two targets and the final order buffer are checked
-    burst = orbit(8, step=4.0, elev=8.0)
-    for k, cam in enumerate(burst):
-        frame(40 + k, cam, check=False)
-    # (the sequential renderer replays the burst; its last two frames are the targets the burst left)
-    want = []
-    for k, cam in enumerate(burst):
-        seq.SortPoints(cam); seq.CalcViewData(cam); rt_seq.Clear(); seq.Draw(cam, rt_seq)
-        if k >= 6:
-            want.append(rt_seq.Download())
-    assert np.array_equal(rts[(40 + 6) % 2].Download(), want[0]) and np.array_equal(rts[(40 + 7) % 2].Download(), want[1])
-    assert np.array_equal(lib.DownloadOrder(), orc.order) and np.array_equal(seq.DownloadOrder(), orc.order)
-    assert np.array_equal(lib.DownloadDistances(), orc.keys)
-    # GS_SORT_VISIBLE and back
-    for x in (seq, lib):
-        x.SetSortMode(SortMode.Visible)
-    for k, cam in enumerate(orbit(3, step=6.0, elev=30.0)):
-        orc.sort(camera.sort_matrix(cam, seq.transform.localToWorldMatrix)); seq.SortPoints(cam); lib.SortPoints(cam)
-        lib.CalcViewData(cam); rts[0].Clear(); lib.Draw(cam, rts[0]); seq.CalcViewData(cam); rt_seq.Clear(); seq.Draw(cam, rt_seq)
-        assert lib.FrameStats().sort_mode == GS_SORT_VISIBLE and np.array_equal(rts[0].Download(), rt_seq.Download())
-    for x in (seq, lib):
-        x.SetSortMode(SortMode.Full)
-    assert np.array_equal(lib.DownloadOrder(), orc.order)
-    for k, cam in enumerate(flight(4, start=(0.2, -0.1, 6.5))):
-        frame(60 + k, cam)
-    lib.ResetOrder(); seq.ResetOrder(); orc.order[:] = np.arange(a.splatCount, dtype=np.uint32)
-    for k, cam in enumerate(orbit(3, step=-5.0, elev=12.0)):
-        frame(70 + k, cam)
-    for x in (lib, seq):
-        x.OnDisable()
-    for t in rts + [rt_seq]:
-        t.Dispose()

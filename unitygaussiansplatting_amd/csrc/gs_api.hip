@@ -34,22 +34,14 @@ void prof_record(gs_renderer* r, int k, hipStream_t st) {
     const int idx = r->profCur * kEvPerFrame + k;
     if (hipEventRecord(r->ev[idx], st ? st : r->ctx->stream) == hipSuccess) r->evValid[idx] = 1;
 }
-// A renderer with lanes (gs_renderer_set_frames_in_flight) in GS_SORT_FULL: SortPoints stays the owner's -- its order buffer is the one state every frame's sort
-// mutates -- and runs on the owner's second queue, one sort after the other; the lanes bin from the owner's buffer.  The two events are the owner's: a lane's
-// draw waits for the last sort recorded (evSortDone) and, once its binning has read order[], releases the next sort (evOrderFree).
 int32_t join_sort(gs_renderer* r) {
-    if (r->laneOf) {
-        if (r->laneOf->sortRecorded) GS_HIP(hipStreamWaitEvent(r->ctx->stream, r->laneOf->evSortDone, 0));
-        return GS_OK;
-    }
     if (!r->sortPending) return GS_OK;
     GS_HIP(hipStreamWaitEvent(r->ctx->stream, r->evSortDone, 0));
     r->sortPending = false;
     return GS_OK;
 }
 int32_t mark_order_use(gs_renderer* r) {
-    if (r->laneOf) { if (!vis_active(r)) GS_HIP(hipEventRecord(r->laneOf->evOrderFree, r->ctx->stream)); return GS_OK; }
-    if (r->ctx->overlap || !r->lanes.empty()) GS_HIP(hipEventRecord(r->evOrderFree, r->ctx->stream));
+    if (r->ctx->overlap) GS_HIP(hipEventRecord(r->evOrderFree, r->ctx->stream));
     return GS_OK;
 }
 void prof_end_frame(gs_renderer* r) {
@@ -274,7 +266,7 @@ int32_t gs_asset_device_blobs(const gs_asset* a, void* ptrs[5], uint64_t sizes[5
 // (gs_renderer_set_frames_in_flight, gsplat_c.h.)  A lane is an ordinary renderer on a context of its own; the owner tells every lane every sort matrix
 // (bookkeeping in GS_SORT_VISIBLE) and every setting, deals the frames round-robin at gs_renderer_calc_view and answers the whole-buffer questions
 // (gs_renderer_download_order, _distances, _sort_history) from its own copy of the bookkeeping.
-static inline bool lanes_on(const gs_renderer* r) { return !r->lanes.empty() && r->renderMode == GS_RENDER_SPLATS; }
+static inline bool lanes_on(const gs_renderer* r) { return !r->lanes.empty() && r->sortMode == GS_SORT_VISIBLE && r->renderMode == GS_RENDER_SPLATS; }
 static inline gs_renderer* lane_cur(gs_renderer* r) { return lanes_on(r) && r->laneCur >= 0 ? r->lanes[(size_t)r->laneCur] : r; }
 
 static void lanes_destroy(gs_renderer* r) {
@@ -294,17 +286,7 @@ static void lanes_destroy(gs_renderer* r) {
 static int32_t lanes_resync(gs_renderer* r) {
     if (r->lanes.empty()) return GS_OK;
     GS_TRY(bind_device(r->ctx));
-    if (r->sortMode != GS_SORT_VISIBLE) {
-        // GS_SORT_FULL: the lanes bin from the owner's order buffer; whatever has just been done to it on the owner's queues is finished before a lane reads it
-        GS_TRY(join_sort(r));
-        GS_HIP(hipStreamSynchronize(r->ctx->stream));
-        for (gs_renderer* L : r->lanes) {
-            GS_HIP(hipStreamSynchronize(L->ctx->stream));
-            L->visHistDepth = 0;                                 // (nothing to carry out: the lane's own buffer is not the one that is drawn from)
-            GS_TRY(gs_renderer_set_sort_mode(L, GS_SORT_FULL));
-        }
-        return GS_OK;
-    }
+    if (r->sortMode != GS_SORT_VISIBLE) return GS_OK;            // GS_SORT_FULL runs on the owner alone: the lanes idle until the mode comes back (and are resynchronised then)
     GS_TRY(vis_consolidate(r));
     GS_HIP(hipStreamSynchronize(r->ctx->stream));
     for (gs_renderer* L : r->lanes) {
@@ -519,7 +501,7 @@ static int32_t enqueue_full_sort(gs_renderer* r, const float m[16], bool consoli
     // order[] (gs_renderer_draw, or any readback).  The second queue is in-order, so consecutive sorts serialise there.
     // (A consolidation of the visible-only mode is not a frame's SortPoints: main queue, sorted keys kept for the fix-up, no stage events.)
     hipStream_t st = ctx->stream;
-    const bool aux = (ctx->overlap || !r->lanes.empty()) && !consolidating;      // (lanes: the sorts of consecutive frames follow one another on the second queue, beside the lanes' frames)
+    const bool aux = ctx->overlap && !consolidating;
     if (aux) {
         st = ctx->aux;
         GS_HIP(hipStreamWaitEvent(st, r->evOrderFree, 0));
@@ -539,7 +521,6 @@ static int32_t enqueue_full_sort(gs_renderer* r, const float m[16], bool consoli
     if (aux) {
         GS_HIP(hipEventRecord(r->evSortDone, st));
         r->sortPending = true;
-        r->sortRecorded = true;
     }
     return GS_OK;
 }
@@ -905,8 +886,7 @@ int32_t gs_renderer_frame_stats(gs_renderer* r, gs_frame_stats* out) {
     GS_TRY(join_sort(r));
     GS_HIP(hipStreamSynchronize(r->ctx->stream));
     uint32_t depthErr = 0;
-    const gs_renderer* sorter = (r->laneOf && !vis_active(r)) ? r->laneOf : r;      // (a lane in GS_SORT_FULL: the depth sort is its owner's; join_sort above waited for it)
-    GS_HIP(hipMemcpy(&depthErr, &sorter->depthControl[sorter->depthControlIdx].error, 4, hipMemcpyDeviceToHost));
+    GS_HIP(hipMemcpy(&depthErr, &r->depthControl[r->depthControlIdx].error, 4, hipMemcpyDeviceToHost));
     memset(out, 0, sizeof(*out));
     out->pair_capacity = r->pairCapacity;
     out->tiles_x = r->lastTilesX; out->tiles_y = r->lastTilesY;

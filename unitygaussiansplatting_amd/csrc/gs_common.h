@@ -293,7 +293,6 @@ struct gs_renderer {
     hipEvent_t evOrderFree = nullptr;       // main -> aux fork: the last operation of the main queue that reads or writes order[]
     bool distancesStale = false;      // the last depth pass skipped the sorted-key write: gs_renderer_download_distances gathers them
     bool sortPending = false;               // a sort on ctx->aux has not been joined into ctx->stream yet
-    bool sortRecorded = false;              // evSortDone has been recorded at least once (lanes wait on it)
     uint32_t lastTilesX = 0, lastTilesY = 0, lastPairPasses = 0, lastDepthPasses = 4;
     bool frameInFlight = false;
     float resolveMs = 0.f;

@@ -1599,8 +1599,7 @@ int32_t enqueue_draw(gs_renderer* r, const gs_frame_params* p, gs_target* rt) {
         GS_TRY(bin_and_sort(r, p, rt, r->visIdx, r->n, ds, false, twl, thl, vis_control(r)));
         r->visDrawn = true;
     } else {
-        // (a lane of a renderer in GS_SORT_FULL bins from its owner's order buffer: join_sort above waited for the owner's last sort)
-        GS_TRY(bin_and_sort(r, p, rt, r->laneOf ? r->laneOf->order : r->order, r->n, ds, false, twl, thl));
+        GS_TRY(bin_and_sort(r, p, rt, r->order, r->n, ds, false, twl, thl));
         r->visDrawn = false;
     }
     const RasterConsts& rc = ds.rc;
