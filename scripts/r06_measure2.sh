@@ -1,0 +1,22 @@
+#!/bin/bash
+# round 6, the measurement call on the final build (visible_in_flight = one renderer, lanes inside the library): the driver's command, the default run, every single-GPU
+# configuration, rocprofv3 stats + PMC passes of the driver's frames
+cd $GRAFT_REPO_ROOT; export PYTHONPATH=$PWD; O=$PWD/gpurun_out; mkdir -p $O
+T0=$(date +%s.%N)
+timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/r06_bench_driver_cmd.json 2> $O/r06_bench_driver_cmd.err
+T1=$(date +%s.%N); echo "driver command wall: $(echo "$T1 - $T0" | bc) s"
+timeout 600 python bench.py > $O/r06_bench_c2.json 2> $O/r06_bench_c2.err
+timeout 900 python bench.py --config C3 --steps 20 > $O/r06_bench_c3.json 2> $O/r06_bench_c3.err
+timeout 900 python bench.py --config C5 --steps 20 --cpu-baseline off > $O/r06_bench_c5.json 2> $O/r06_bench_c5.err
+timeout 600 python bench.py --config C2d --steps 20 > $O/r06_bench_c2d.json 2> $O/r06_bench_c2d.err
+timeout 900 python bench.py --config C4 --steps 20 > $O/r06_bench_c4.json 2> $O/r06_bench_c4.err
+bash scripts/profile_round.sh C2 20 visible 5 @s20w5 > $O/r06_profile_round.log 2>&1
+python - <<'PY'
+import json,glob
+for f in sorted(glob.glob('gpurun_out/r06_bench_*.json')):
+    try:
+        d=json.loads([l for l in open(f) if l.startswith('{')][-1])
+        print(f.split('/')[-1], d['value'], d['ms_per_step'], d['config']['sort_mode'], d['config'].get('frames_in_flight_impl'), {m:x['ms_per_step'] for m,x in d['modes'].items()}, (d.get('end_of_orbit_check') or {}).get('ok'), ((d.get('parity_vs_oracle') or {}).get('visible_in_flight') or {}).get('ok'), d['roofline']['frac'], d['roofline']['traffic'], 'P', d['modes']['visible']['tile_pairs_P'], 'V', d['modes']['visible']['visible_splats'])
+    except Exception as e: print(f, 'ERR', e)
+PY
+tail -3 $O/r06_profile_round.log
