@@ -18,8 +18,8 @@
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 
-enum Kind { FMA = 0, PKFMA = 1, EXP = 2, MIX = 3, MIXLO = 4, CVTPK = 5, NKIND = 6 };
-static const char* kKindName[NKIND] = { "v_fma_f32", "v_pk_fma_f32", "v_exp_f32", "v_fma_mix_f32", "v_fma_mixlo_f16", "v_cvt_pk_f16_f32" };
+enum Kind { FMA = 0, PKFMA = 1, EXP = 2, MIX = 3, MIXLO = 4, CVTPK = 5, CVT16 = 6, CVT16HI = 7, CVT32 = 8, NKIND = 9 };
+static const char* kKindName[NKIND] = { "v_fma_f32", "v_pk_fma_f32", "v_exp_f32", "v_fma_mix_f32", "v_fma_mixlo_f16", "v_cvt_pk_f16_f32", "v_cvt_f16_f32", "v_cvt_f16_f32_sdwa", "v_cvt_f32_f16" };
 constexpr int UNROLL = 8;              // instructions per loop iteration (8 accumulators when independent)
 
 // one instruction of KIND on accumulator a (b, c: loop-invariant operands)
@@ -29,6 +29,9 @@ template <int KIND> __device__ __forceinline__ void op(float& a, float b, float 
     else if (KIND == MIX) asm volatile("v_fma_mix_f32 %0, %0, %1, %2 op_sel_hi:[0,0,0]" : "+v"(a) : "v"(b), "v"(c));
     else if (KIND == MIXLO) asm volatile("v_fma_mixlo_f16 %0, %1, %2, %0 op_sel_hi:[0,0,1]" : "+v"(a) : "v"(b), "v"(c));
     else if (KIND == CVTPK) asm volatile("v_cvt_pk_f16_f32 %0, %0, %1" : "+v"(a) : "v"(b));
+    else if (KIND == CVT16) asm volatile("v_cvt_f16_f32 %0, %1" : "+v"(a) : "v"(b));                     // (the plain conversion: RTNE, what __float2half compiles to)
+    else if (KIND == CVT16HI) asm volatile("v_cvt_f16_f32_sdwa %0, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(a) : "v"(b));   // into the high half
+    else if (KIND == CVT32) asm volatile("v_cvt_f32_f16 %0, %0" : "+v"(a));
 }
 __device__ __forceinline__ void op_pk(v2f& a, v2f b, v2f c) { asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(a) : "v"(b), "v"(c)); }
 
@@ -87,7 +90,7 @@ static int run(int kind, int dep, int wps, int cus, int iters, float* sink, unsi
     for (int rep = 0; rep < 2; ++rep) {               // rep 0 warms up (clocks, code)
         CK(hipEventRecord(e0, 0));
 #define L(K) do { if (dep) launch<K, true>(grid, block, sink, iters, cyc, rt, rs); else launch<K, false>(grid, block, sink, iters, cyc, rt, rs); } while (0)
-        switch (kind) { case FMA: L(FMA); break; case PKFMA: L(PKFMA); break; case EXP: L(EXP); break; case MIX: L(MIX); break; case CVTPK: L(CVTPK); break; default: L(MIXLO); break; }
+        switch (kind) { case FMA: L(FMA); break; case PKFMA: L(PKFMA); break; case EXP: L(EXP); break; case MIX: L(MIX); break; case CVTPK: L(CVTPK); break; case CVT16: L(CVT16); break; case CVT16HI: L(CVT16HI); break; case CVT32: L(CVT32); break; default: L(MIXLO); break; }
 #undef L
         CK(hipEventRecord(e1, 0));
         CK(hipEventSynchronize(e1));
@@ -113,6 +116,7 @@ static int run(int kind, int dep, int wps, int cus, int iters, float* sink, unsi
 
 int main(int argc, char** argv) {
     const bool quick = argc > 1 && std::string(argv[1]) == "--quick";
+    const int firstKind = (argc > 2 && std::string(argv[1]) == "--from") ? atoi(argv[2]) : 0;       // --from 6: the conversion kinds only
     hipDeviceProp_t prop;
     CK(hipGetDeviceProperties(&prop, 0));
     const int cus = prop.multiProcessorCount;
@@ -139,7 +143,7 @@ int main(int argc, char** argv) {
            "# span = first start .. last end; launch = hipEvent bracket; MHz = median wave's cycles / its realtime; Gwi/s = wave-instr of the whole chip / span;\n"
            "# cyc/instr/SIMD = span x MHz x SIMDs / wave-instr (what the issue roof is at THAT clock; the guide: 2.0)\n");
     printf("# kind              dep w/SIMD | cyc/instr min med max     | dur us min med max          | spread us | span us | launch us |  MHz | Gwi/s | cyc/instr/SIMD\n");
-    for (int kind = 0; kind < NKIND; ++kind)
+    for (int kind = firstKind; kind < NKIND; ++kind)
         for (int dep = 0; dep < 2; ++dep)
             for (int wps : { 1, 2, 4, 6, 8 }) {
                 if (run(kind, dep, wps, cus, iters, sink, cyc, rt, rs, hc, hr, hs, e0, e1, R)) return 1;

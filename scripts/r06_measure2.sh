@@ -7,9 +7,7 @@ timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/r06_bench_driver
 T1=$(date +%s.%N); echo "driver command wall: $(echo "$T1 - $T0" | bc) s"
 timeout 600 python bench.py > $O/r06_bench_c2.json 2> $O/r06_bench_c2.err
 timeout 900 python bench.py --config C3 --steps 20 > $O/r06_bench_c3.json 2> $O/r06_bench_c3.err
-timeout 900 python bench.py --config C5 --steps 20 --cpu-baseline off > $O/r06_bench_c5.json 2> $O/r06_bench_c5.err
-timeout 600 python bench.py --config C2d --steps 20 > $O/r06_bench_c2d.json 2> $O/r06_bench_c2d.err
-timeout 900 python bench.py --config C4 --steps 20 > $O/r06_bench_c4.json 2> $O/r06_bench_c4.err
+# (C5 / C2d / C4 on this build: gpurun_out/r06_all_*.json of call 21, every mode back to back, no oracle replay, no counters)
 bash scripts/profile_round.sh C2 20 visible 5 @s20w5 > $O/r06_profile_round.log 2>&1
 python - <<'PY'
 import json,glob

@@ -214,7 +214,7 @@ __global__ __launch_bounds__(kBinThreads) void bin_emit_kernel(const uint2* __re
                                                                 uint32_t* __restrict__ pairKeys, uint32_t* __restrict__ pairVals,
                                                                 uint32_t capacity, BinControl* ctl, unsigned long long* binStatus, unsigned long long* binGroupAgg, unsigned long long* binGroupBase,
                                                                 uint32_t* pairHist, unsigned long long* __restrict__ groupAgg, uint32_t groupAggWords,
-                                                                uint32_t* __restrict__ nextArena, uint32_t nextArenaWords, uint32_t digitBits,
+                                                                uint32_t* __restrict__ nextArena, uint32_t nextArenaWords, uint32_t digitBitsAndFlags,
                                                                 const uint32_t* __restrict__ schedCost, uint32_t schedTiles, uint32_t* __restrict__ schedOut, uint32_t histCopies) {
     GS_CHAIN_PRIORITY();
     constexpr int SUB = 4;                                   // k's per emission batch: 256 positions per wave
@@ -245,17 +245,22 @@ __global__ __launch_bounds__(kBinThreads) void bin_emit_kernel(const uint2* __re
     // the zero-initialised per-draw arena of the NEXT draw (the two copies alternate: no memset launch per draw)
     for (uint32_t j = bid * (uint32_t)kBinThreads + (uint32_t)tid; j < nextArenaWords; j += binBlocks * (uint32_t)kBinThreads) nextArena[j] = 0u;
     const uint32_t numParts = (n + kBinPart - 1) / kBinPart;
+    const uint32_t digitBits = digitBitsAndFlags & 0xffu;
+    const bool staticFirst = (digitBitsAndFlags & 0x100u) != 0u;   // the context shares the GPU with nobody (gs_shared_gpu() false): see below
     const uint32_t digitMask = (1u << digitBits) - 1u;          // the pair sort's digit width (6..8 bits by tile count)
     uint32_t visAcc = 0;                                         // thread 0: visible splats of this workgroup's partitions
     // Persistent grid.  A partition's scan waits on the totals of every partition before it, so -- as in gs_sort.hip -- partitions are taken in dependency
     // order: when the grid covers every partition binning workgroup b takes partition b (no atomic) and exits; otherwise EVERY partition comes from ONE
     // counter, so that the lowest unclaimed partition is always taken by a workgroup that is running (a static first round would leave it with a workgroup
-    // that may not have been dispatched while another stream's kernels hold the wave slots: gs_sort.hip).
+    // that may not have been dispatched while another stream's kernels hold the wave slots: gs_sort.hip).  A context that shares the GPU with no other
+    // spinning kernel (staticFirst) keeps the static first round: the ~1280 simultaneous requests at the head of the kernel cost 16 us at C2.
     const bool oneRound = binBlocks >= numParts;
     for (uint32_t round = 0;; ++round) {
     __syncthreads();                                             // s_part / s_wtot / s_base of the previous partition are no longer read
     if (tid == 0)
-        s_part = oneRound ? (round == 0u ? bid : numParts) : __hip_atomic_fetch_add(&ctl->tickets[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_part = oneRound ? (round == 0u ? bid : numParts)
+               : (staticFirst && round == 0u) ? bid
+               : (staticFirst ? binBlocks : 0u) + __hip_atomic_fetch_add(&ctl->tickets[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     const uint32_t part = s_part;
     if (part >= numParts) break;
@@ -1499,8 +1504,8 @@ int32_t bin_and_sort(gs_renderer* r, const gs_frame_params* p, gs_target* rt, co
                            pairCtl->hist, (uint32_t)bits, o.costRead, numTiles, schedInBin ? o.tileOrder : (uint32_t*)nullptr, r->pairSort.histCopies);
     } else
     hipLaunchKernelGGL(binKernel, dim3(binGrid + (schedInBin ? 1u : 0u)), dim3(binThreads), 0, st, r->rects, wave_flags_of(r->visMask, r->n), order, count, rc.tilesX, shapeKey, r->pairKeys,
-                       r->pairVals, cap, binCtl, binStatus, binGroupAgg, binGroupBase, pairCtl->hist, r->pairSort.groupAgg, sort_group_words(r->pairSort, cap, passes), (uint32_t*)nextArena, (uint32_t)(r->frameArenaBytes / 4), (uint32_t)bits,
-                       o.costRead, numTiles, schedInBin ? o.tileOrder : (uint32_t*)nullptr, r->pairSort.histCopies);
+                       r->pairVals, cap, binCtl, binStatus, binGroupAgg, binGroupBase, pairCtl->hist, r->pairSort.groupAgg, sort_group_words(r->pairSort, cap, passes), (uint32_t*)nextArena, (uint32_t)(r->frameArenaBytes / 4),
+                       (uint32_t)bits | (gs_shared_gpu(ctx) ? 0u : 0x100u), o.costRead, numTiles, schedInBin ? o.tileOrder : (uint32_t*)nullptr, r->pairSort.histCopies);
     GS_TRY(mark_order_use(r));                                  // the next frame's depth sort may overwrite order[] from here on
     prof_record(r, 4);
     // the host only knows the capacity; the pair count of the last finished frame (pinned report) picks the sort's pass shape

@@ -283,13 +283,20 @@ __global__ __launch_bounds__(THREADS, KPT == KPT_B ? 4 : kMinWavesA) void oneswe
     // The GATHER pass of a frame's depth sort may instead deal whole blocks of consecutive partitions to the XCDs (gatherXcd != 0: 16 counters, two per XCD) so
     // that the 16 keys of a gathered 64-byte sector meet in one L2 -- 25 us faster per sort at C2, but only deadlock-free while no other kernel that spins
     // shares the GPU; gs_context_set_shared_gpu / GSPLAT_SHARED_GPU=1 selects the dependency-ordered form for it too.
-    const bool oneRound = !(GATHER && gatherXcd) && gridDim.x >= numParts;      // (the XCD deal is not the identity: its first tickets need not cover every partition)
+    //   gatherXcd bit 1 (the context shares the GPU with nobody: gs_shared_gpu() is false -- the condition the XCD deal has): the persistent grid's FIRST
+    //             partitions are static after all (workgroup b takes partition b, the counter hands out the rest): without a second spinning kernel the
+    //             not-yet-dispatched owners of first-round partitions get their slots as soon as anything exits, and the head of the kernel does not queue
+    //             on one address (bin_emit at C2: 78 us against 94; the pair passes of C3 / C4).  One such kernel beside any number of one-counter kernels is
+    //             still safe -- those finish with whatever workgroups they have and release their slots.
+    const bool xcdDeal = GATHER && (gatherXcd & 1u);
+    const bool staticFirst = (gatherXcd & 2u) != 0u;
+    const bool oneRound = !xcdDeal && gridDim.x >= numParts;      // (the XCD deal is not the identity: its first tickets need not cover every partition)
     for (uint32_t round = 0;; ++round) {
         if (oneRound && round) break;
         __syncthreads();                                    // previous partition's LDS reads are finished
         if (tid == 0) {
             uint32_t p;
-            if (GATHER && gatherXcd) {
+            if (xcdDeal) {
                 // Workgroup b runs on XCD b % 8 (MI355X_MICROARCH.md) = cls % 8: every XCD takes whole blocks of `xb` consecutive partitions (block j belongs
                 // to XCD j % 8; the two ticket classes of an XCD alternate inside its blocks): the other 15 requests for a sector then arrive at the L2 that
                 // already holds it.  Monotonic per class, a bijection.
@@ -299,7 +306,8 @@ __global__ __launch_bounds__(THREADS, KPT == KPT_B ? 4 : kMinWavesA) void oneswe
                 const uint32_t x = cls & 7u, u = t * 2u + (cls >> 3);       // u-th partition of XCD x
                 p = ((u / xb) * 8u + x) * xb + (u % xb);
             } else {
-                p = oneRound ? blockIdx.x : __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                p = (oneRound || (staticFirst && round == 0u)) ? blockIdx.x
+                                                               : (staticFirst ? gridDim.x : 0u) + __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             s_part = p;
         }
@@ -670,7 +678,7 @@ int32_t enqueue_sort_passes(gs_context* ctx, hipStream_t stream, SortState& st, 
         }
 #define GS_LAUNCH_ONESWEEP_K(B, G, KIN, K) \
         hipExtLaunchKernelGGL((onesweep_kernel<B, G, K>), dim3(grid), dim3(THREADS), 0, stream, evStart, evStop, 0, (const uint32_t*)(KIN), (const uint32_t*)vs, kdst, vd, \
-                              (const uint32_t*)hist, st.status, agg, st.groupIncl, (uint32_t*)control->tickets[p], &control->error, nUpper, nPtr, shift, epoch, mask, histCopies, (gatherKeys && !gs_shared_gpu(ctx)) ? 1u : 0u)
+                              (const uint32_t*)hist, st.status, agg, st.groupIncl, (uint32_t*)control->tickets[p], &control->error, nUpper, nPtr, shift, epoch, mask, histCopies, gs_shared_gpu(ctx) ? 0u : ((gatherKeys ? 1u : 0u) | 2u))
 #define GS_LAUNCH_ONESWEEP(B, G, KIN) do { if (shapeB) GS_LAUNCH_ONESWEEP_K(B, G, KIN, KPT_B); else GS_LAUNCH_ONESWEEP_K(B, G, KIN, KPT_A); } while (0)
         if (p == 0 && gatherKeys) GS_LAUNCH_ONESWEEP(8, true, gatherKeys);
         else if (shapeC) GS_LAUNCH_ONESWEEP_K(8, false, ks, KPT_C);
