@@ -106,21 +106,10 @@ int32_t gs_context_create(int32_t device, void* hip_stream, gs_context** out) {
     ctx->cuCount = ctx->props.multiProcessorCount > 0 ? ctx->props.multiProcessorCount : 256;
     if (hip_stream) { ctx->stream = (hipStream_t)hip_stream; ctx->ownStream = false; }
     else {
-        // (experiment, GSPLAT_PRIO="<main><aux>": 1 = the context's own queue at the highest priority, the second queue at the lowest; docs/experiments.md)
-        const char* pr = getenv("GSPLAT_PRIO");
-        int least = 0, greatest = 0;
-        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-        const hipError_t e = (pr && pr[0] == '1') ? hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, greatest) : hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
-        if (e != hipSuccess) { delete ctx; return fail(GS_ERR_HIP, "hipStreamCreate"); }
+        if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return fail(GS_ERR_HIP, "hipStreamCreate"); }
         ctx->ownStream = true;
     }
-    {
-        const char* pr = getenv("GSPLAT_PRIO");
-        int least = 0, greatest = 0;
-        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-        const hipError_t e = (pr && pr[0] && pr[1] == '1') ? hipStreamCreateWithPriority(&ctx->aux, hipStreamNonBlocking, least) : hipStreamCreateWithFlags(&ctx->aux, hipStreamNonBlocking);
-        if (e != hipSuccess) { gs_context_destroy(ctx); return fail(GS_ERR_HIP, "hipStreamCreate (aux)"); }
-    }
+    if (hipStreamCreateWithFlags(&ctx->aux, hipStreamNonBlocking) != hipSuccess) { gs_context_destroy(ctx); return fail(GS_ERR_HIP, "hipStreamCreate (aux)"); }
     // Measured on MI355X: running the depth sort on the second queue does not shorten the frame -- neither beside
     // calc_view only (round 1: 0.995 ms overlapped vs 0.962 serial at C2) nor in the pipelined form, beside the previous
     // frame's pair sort / blend / resolve and this frame's calc_view (round 2: 0.679 vs 0.663 ms at C2, 0.981 vs 0.956 at C3;
@@ -335,7 +324,6 @@ int32_t gs_renderer_set_frames_in_flight(gs_renderer* r, int32_t frames) {
             L->laneOf = r;
             hipError_t e = hipEventCreateWithFlags(&L->evTargetFree, hipEventDisableTiming);
             if (e == hipSuccess) e = hipEventCreateWithFlags(&L->evBlendDone, hipEventDisableTiming);
-            if (e == hipSuccess) e = hipEventCreateWithFlags(&L->evBlendFork, hipEventDisableTiming);
             if (e != hipSuccess) rc = fail_hip(e, "create lane events", __FILE__, __LINE__);
         }
         // the owner's settings as they are now; later changes are forwarded by the setters themselves
@@ -414,7 +402,6 @@ int32_t gs_renderer_destroy(gs_renderer* r) {
     (void)hipStreamSynchronize(r->ctx->stream);
     if (r->evTargetFree) (void)hipEventDestroy(r->evTargetFree);
     if (r->evBlendDone) (void)hipEventDestroy(r->evBlendDone);
-    if (r->evBlendFork) (void)hipEventDestroy(r->evBlendFork);
     if (r->evOrderFree) (void)hipEventDestroy(r->evOrderFree);
     if (r->evSortDone) (void)hipEventDestroy(r->evSortDone);
     if (r->view) (void)hipFree(r->view);

@@ -329,7 +329,6 @@ struct gs_renderer {
     gs_renderer* laneOf = nullptr;          // a lane's owner
     hipEvent_t evTargetFree = nullptr;      // a lane drawing into its owner's target: target's stream -> lane (before the blend) ...
     hipEvent_t evBlendDone = nullptr;       // ... and lane -> target's stream (after it)
-    hipEvent_t evBlendFork = nullptr;       // (experiment GSPLAT_BLEND_AUX: lane's stream -> its low-priority blend queue)
 };
 
 namespace gs {

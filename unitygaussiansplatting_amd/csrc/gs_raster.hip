@@ -1629,16 +1629,7 @@ int32_t enqueue_draw(gs_renderer* r, const gs_frame_params* p, gs_target* rt) {
         flatten_params(p, fc);
         hipLaunchKernelGGL(splat_depth_kernel, dim3(div_up(r->n, 256)), dim3(256), 0, st, r->asset->view, fc, (const uint32_t*)r->visMask, r->recW);
     }
-    // (experiment GSPLAT_BLEND_AUX=1: a lane's blend on its context's second queue -- created at the lowest priority with GSPLAT_PRIO=x1 -- so that the other
-    // frame's latency-bound kernels get the wave slots the blend's finished tiles free before the blend's own waiting tiles do)
-    static const bool blendAux = [] { const char* e = getenv("GSPLAT_BLEND_AUX"); return e && e[0] == '1'; }();
-    hipStream_t bst = st;
-    if (foreignTarget && blendAux && r->evBlendFork) {
-        GS_HIP(hipEventRecord(r->evBlendFork, st));
-        GS_HIP(hipStreamWaitEvent(r->ctx->aux, r->evBlendFork, 0));
-        bst = r->ctx->aux;
-    }
-#define GS_LAUNCH_BLEND_S(M, D, WL, HL) hipLaunchKernelGGL((blend_kernel<M, D, WL, HL>), dim3(numTiles), dim3(64u << (WL + HL - 6)), 0, bst, r->pairVals, tileStart, tileEnd, \
+#define GS_LAUNCH_BLEND_S(M, D, WL, HL) hipLaunchKernelGGL((blend_kernel<M, D, WL, HL>), dim3(numTiles), dim3(64u << (WL + HL - 6)), 0, st, r->pairVals, tileStart, tileEnd, \
                                              tileOrder, ds.costWrite, r->recs, rt->rgba16f, rc, dstIsZero, r->recW, rt->sceneDepth, \
                                              ds.binCtl, ds.pairSortError, r->hostReportDev)
 #define GS_LAUNCH_BLEND(M, D) do { if (twl == 4u) GS_LAUNCH_BLEND_S(M, D, 4, 4); else if (thl == 4u) GS_LAUNCH_BLEND_S(M, D, 5, 4); else GS_LAUNCH_BLEND_S(M, D, 5, 5); } while (0)
@@ -1649,9 +1640,8 @@ int32_t enqueue_draw(gs_renderer* r, const gs_frame_params* p, gs_target* rt) {
     prof_record(r, 6);
     GS_HIP(hipGetLastError());
     if (foreignTarget) {
-        GS_HIP(hipEventRecord(r->evBlendDone, bst));
+        GS_HIP(hipEventRecord(r->evBlendDone, st));
         GS_HIP(hipStreamWaitEvent(rt->ctx->stream, r->evBlendDone, 0));
-        if (bst != st) GS_HIP(hipStreamWaitEvent(st, r->evBlendDone, 0));       // (the lane's next frame reuses the blend's inputs)
     }
     GS_TRY(target_touched(rt, st));
     r->frameInFlight = true;
