@@ -4,7 +4,7 @@
 cd $GRAFT_REPO_ROOT; export PYTHONPATH=$PWD; O=$PWD/gpurun_out; mkdir -p $O
 T0=$(date +%s.%N)
 timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/r06_bench_driver_cmd.json 2> $O/r06_bench_driver_cmd.err
-T1=$(date +%s.%N); echo "driver command wall: $(echo "$T1 - $T0" | bc) s"
+T1=$(date +%s.%N); python -c "print(\"driver command wall: %.1f s\" % ($T1 - $T0))"
 timeout 600 python bench.py > $O/r06_bench_c2.json 2> $O/r06_bench_c2.err
 timeout 900 python bench.py --config C3 --steps 20 > $O/r06_bench_c3.json 2> $O/r06_bench_c3.err
 # (C5 / C2d / C4 on this build: gpurun_out/r06_all_*.json of call 21, every mode back to back, no oracle replay, no counters)
