@@ -177,14 +177,20 @@ int32_t gs_context_synchronize(gs_context* ctx);
  * blend / resolve and this frame's gs_renderer_calc_view.  Results are identical either way.  Default OFF: on MI355X every
  * kernel of the frame already fills the chip and the frame is not shorter.  Blocks until both queues are idle. */
 int32_t gs_context_set_overlap(gs_context* ctx, int32_t enabled);
-/* May OTHER kernels that wait on their own workgroups run on this GPU at the same time as this context's GS_SORT_FULL sorts -- another process using this
- * library, or another context of this process sorting concurrently?  Every kernel of the library takes its partitions in dependency order -- a running
- * workgroup only ever waits on workgroups that were started before it, so it makes progress whatever holds the other wave slots -- with ONE exception kept for
- * speed: the first pass of the full depth sort deals blocks of partitions to the XCDs (its random key gather then meets in one L2: 25 us per sort of 6 M
- * keys), which is only deadlock-free if the workgroups still waiting for a slot get one eventually.  shared > 0 makes that pass dependency-ordered too, 0 keeps
- * the XCD deal, < 0 (the default) decides per sort: shared while this process holds more than one context on the device.  Another PROCESS on the GPU is
+/* May OTHER kernels that wait on their own workgroups run on this GPU at the same time as this context's sorts and binning -- another process using this
+ * library, or another context of this process working concurrently?  By default every kernel of the library takes its partitions in dependency order -- a running
+ * workgroup only ever waits on workgroups that were started before it or on partitions a RUNNING workgroup holds, so it makes progress whatever holds the other
+ * wave slots.  TWO forms are kept for speed for a context that has the GPU to itself; both are only deadlock-free if the workgroups still waiting for a slot get
+ * one eventually (true beside any number of kernels of the default form, which finish with whatever workgroups they have -- not beside a second kernel of these forms):
+ *   - the first pass of the full depth sort (GS_SORT_FULL) deals blocks of partitions to the XCDs (its random key gather then meets in one L2: 25 us per sort
+ *     of 6 M keys);
+ *   - a persistent grid that walks more partitions than it has workgroups (bin_emit of GS_SORT_FULL; a pair sort of more than ~6.3 M pairs in either sort mode)
+ *     gives its FIRST partitions out statically, workgroup b taking partition b, instead of drawing every one from a single counter (whose ~1,000 simultaneous
+ *     requests at the head of the kernel are served 12 ns apart: 16 us per frame at 6 M splats, 0.1 ms at 50 M).
+ * shared > 0 selects the dependency-ordered forms everywhere, 0 keeps the two fast forms, < 0 (the default) decides per launch: shared while this process holds
+ * more than one context on the device (the lanes of gs_renderer_set_frames_in_flight always use the dependency-ordered forms).  Another PROCESS on the GPU is
  * something only the host knows: set 1 (or GSPLAT_SHARED_GPU=1 in the environment) there.  (A stall is never a hang: every spin is bounded and surfaces as
- * GS_ERR_SORT_TIMEOUT.)  GS_SORT_VISIBLE is unaffected: it has no such pass. */
+ * GS_ERR_SORT_TIMEOUT.) */
 int32_t gs_context_set_shared_gpu(gs_context* ctx, int32_t shared);
 int32_t gs_context_device_info(gs_context* ctx, char* name_out, size_t name_cap, int32_t* cu_count, uint64_t* hbm_bytes);
 

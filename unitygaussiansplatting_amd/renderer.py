@@ -74,8 +74,9 @@ class GpuContext:
         check(_lib.lib().gs_context_synchronize(self._h), "gs_context_synchronize")
 
     def SetSharedGpu(self, shared) -> None:
-        """Other kernels that wait on their own workgroups (another process / context sorting in GS_SORT_FULL) may share the GPU: gs_context_set_shared_gpu.
-        True / False pin it, None = automatic (shared while this process holds more than one context on the device)."""
+        """Other kernels that wait on their own workgroups (another process using the library, another context sorting or binning at the same time) may share
+        the GPU: gs_context_set_shared_gpu -- the full sort's XCD-dealt gather pass and a persistent grid's static first round give way to the dependency-ordered
+        forms.  True / False pin it, None = automatic (shared while this process holds more than one context on the device)."""
         check(_lib.lib().gs_context_set_shared_gpu(self._h, -1 if shared is None else int(bool(shared))), "gs_context_set_shared_gpu")
 
     def SetOverlap(self, enabled: bool) -> None:
