@@ -1,11 +1,11 @@
 """-m gpu: a seeded random walk over what the fixed-case parity tests pin one at a time -- asset preset and size, scene extent, camera (outside, inside
 the cloud, grazing, narrow / wide field of view), target size (odd, tiny, tall, wide), object transform (rotated, non-uniformly scaled, mirrored),
-_SplatScale / _SplatOpacityScale / _SHOrder / _SHOnly, sort mode, tile shape -- each case through the C-ABI and through the oracle:
+_SplatScale / _SplatOpacityScale / _SHOrder / _SHOnly, sort mode, tile shape, cutouts, deleted bits, blend mode -- each case through the C-ABI and through the oracle:
 
     order buffer              bit-exact (CSCalcDistances + the stable sort, SplatUtilities.compute:69-82, GpuSorting.cs:142-198)
     40-byte SplatViewData     bit-exact (CSCalcViewData, SplatUtilities.compute:189-252)
     (tile, splat) pairs, visible count   equal
-    RGBA16F target            <= 2^-9 relative to max(1, |c|), every pixel
+    RGBA16F target            <= 2^-9 relative to max(1, |c|), every pixel; the fast blend mode <= 4e-3
 
 Three seeds run in the suite; GSPLAT_PARITY_SEEDS=n adds a campaign of n more (scripts/r06_call27.sh ran 150 once)."""
 import os
@@ -15,7 +15,9 @@ import pytest
 
 import oracle_lib as O
 from common import RT_TOL, rt_err, views_equal
+from test_cutouts import CUTOUT_SETS
 from unitygaussiansplatting_amd import camera, creator, scenes
+from unitygaussiansplatting_amd.cutout import shader_data_array
 from unitygaussiansplatting_amd.renderer import GaussianSplatRenderer, RenderTarget, SortMode
 
 pytestmark = pytest.mark.gpu
@@ -48,13 +50,19 @@ def _case(seed):
                   m_SHOnly=bool(rng.random() < 0.15))
     mode = SortMode.Visible if rng.random() < 0.5 else SortMode.Full
     tile = [(0, 0), (16, 16), (32, 16), (32, 32)][int(rng.integers(4))]
-    return dict(n=n, quality=quality, extent=extent, cam=cam, tr=tr, fields=fields, mode=mode, tile=tile, kind=kind, asset_seed=int(rng.integers(1, 50)))
+    asset_seed = int(rng.integers(1, 50))
+    # (drawn last, so that the cases above are the ones of the first campaign) cutouts, deleted bits, the fast blend mode
+    cut = str(rng.choice(list(CUTOUT_SETS))) if rng.random() < 0.3 else None
+    bits_seed = int(rng.integers(1, 1000)) if rng.random() < 0.25 else None
+    blend = 1 if rng.random() < 0.2 else 0
+    return dict(n=n, quality=quality, extent=extent, cam=cam, tr=tr, fields=fields, mode=mode, tile=tile, kind=kind, asset_seed=asset_seed, cut=cut,
+                bits_seed=bits_seed, blend=blend)
 
 
 @pytest.mark.parametrize("seed", _SEEDS)
 def test_random_case_against_the_oracle(gpu_ctx, seed):
     c = _case(seed)
-    what = {k: c[k] for k in ("n", "quality", "extent", "kind", "fields", "mode", "tile")} | {"size": (c["cam"].pixelWidth, c["cam"].pixelHeight), "transform": c["tr"]}
+    what = {k: c[k] for k in ("n", "quality", "extent", "kind", "fields", "mode", "tile", "cut", "bits_seed", "blend")} | {"size": (c["cam"].pixelWidth, c["cam"].pixelHeight), "transform": c["tr"]}
     raw = scenes.make_splats(c["n"], c["asset_seed"], c["extent"])
     a = creator.CreateAssetFromSplatsNative(raw, c["quality"], name=f"rnd{seed}")
     r = GaussianSplatRenderer(gpu_ctx, a, c["tr"])
@@ -63,6 +71,13 @@ def test_random_case_against_the_oracle(gpu_ctx, seed):
     r.sortMode = c["mode"]
     r.OnEnable()
     r.SetTileShape(*c["tile"])
+    r.blendMode = c["blend"]
+    r.m_Cutouts = CUTOUT_SETS[c["cut"]] if c["cut"] else None
+    bits = None
+    if c["bits_seed"] is not None:
+        g = np.random.default_rng(c["bits_seed"])
+        bits = (g.integers(0, 2 ** 32, (a.splatCount + 31) // 32, dtype=np.uint64) & g.integers(0, 2 ** 32, (a.splatCount + 31) // 32, dtype=np.uint64)).astype(np.uint32)
+    r.SetDeletedBits(bits)
     cam = c["cam"]
     rt = RenderTarget(gpu_ctx, cam.pixelWidth, cam.pixelHeight)
     orc = O.Oracle(a)
@@ -73,14 +88,15 @@ def test_random_case_against_the_oracle(gpu_ctx, seed):
         r.CalcViewData(cm); rt.Clear(); r.Draw(cm, rt)
         st = r.FrameStats()
         P = r.FrameParams(cm)
-        want_view = orc.calc_view(P)
+        arr, ncut = shader_data_array(r.m_Cutouts, r.transform.localToWorldMatrix)
+        want_view = orc.calc_view(P, arr, ncut, bits)
         assert views_equal(r.DownloadView(), want_view), f"seed {seed} frame {k}: view records differ; {what}"
         pairs = orc.pairs(P, st)                                # (for the tile shape the draw reports; also sets orc.visible)
         assert st.visible_splats == orc.visible, f"seed {seed} frame {k}: visible {st.visible_splats} vs {orc.visible}; {what}"
         assert st.tile_pairs == pairs, f"seed {seed} frame {k}: pairs {st.tile_pairs} vs {pairs}; {what}"
-        ref = orc.draw(P, 0)
+        ref = orc.draw(P, c["blend"])
         e = rt_err(rt.Download(), ref)
-        assert e <= RT_TOL, f"seed {seed} frame {k}: target off by {e}; {what}"
+        assert e <= (RT_TOL if c["blend"] == 0 else 4e-3), f"seed {seed} frame {k}: target off by {e}; {what}"
         assert np.array_equal(r.DownloadOrder(), orc.order), f"seed {seed} frame {k}: order differs; {what}"
     r.OnDisable()
     rt.Dispose()
