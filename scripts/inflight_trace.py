@@ -1,7 +1,9 @@
 """Kernel durations with frames in flight, from a rocprofv3 --kernel-trace csv of `bench.py --sort-mode visible_in_flight --repeats 1`:
 per kernel the median duration one frame at a time (the `visible` mode's frames: one queue) and in flight (two queues), the share of the
 in-flight wall time during which 1 / 2 kernels run, and the busy time per queue.
-    python scripts/inflight_trace.py <kernel_trace.csv>"""
+    python scripts/inflight_trace.py <kernel_trace.csv> [fraction of the one-at-a-time part to drop, default 0.4]
+(lanes inside the library: trace `--sort-mode all` -- the owner's queue runs the full, reference-shaped and visible modes one after the other before the lanes start -- and
+pass 0.85: the tail of that part is the visible mode's frames)"""
 import collections, csv, re, statistics, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 def short(n):
@@ -22,7 +24,7 @@ t_split = by_q[qs[1]][0]
 seq = [r for r in rows if r["e"] < t_split and r["q"] == qs[0]]
 fl = [r for r in rows if r["s"] >= t_split]
 # drop warm-up: keep the last 60 % of each part
-seq = seq[int(len(seq) * 0.4):]; fl = fl[int(len(fl) * 0.4):]
+seq = seq[int(len(seq) * (float(sys.argv[2]) if len(sys.argv) > 2 else 0.4)):]; fl = fl[int(len(fl) * 0.4):]
 def med(part):
     d = collections.defaultdict(list)
     for r in part: d[r["k"]].append((r["e"] - r["s"]) / 1e3)
