@@ -401,7 +401,7 @@ int32_t gs_import_encode(const gs_import_input* in, const gs_import_formats* for
  * The arrays gs_ply_arrays points `out` at are owned by the handle and valid until gs_ply_close. */
 typedef struct gs_ply gs_ply;
 int32_t gs_ply_open(const char* path, gs_ply** out, uint32_t* splat_count);
-/* SPZ input (Niantic / Scaniverse .spz; SPZFileReader.cs:26-205): gzip stream, version 2, <= 10 M points.  Same handle type
+/* SPZ input (Niantic / Scaniverse .spz; SPZFileReader.cs:26-198): gzip stream, version 2, <= 10 M points.  Same handle type
  * and accessors as the PLY reader, but the arrays are ALREADY LINEAR (UnpackDataJob applies LinearScale, SH0ToColor and
  * PackSmallest3Rotation): pass them to gs_import_encode with formats.linearize = 0. */
 int32_t gs_spz_open(const char* path, gs_ply** out, uint32_t* splat_count);
