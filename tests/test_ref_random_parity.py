@@ -1,0 +1,63 @@
+"""CPU suite: the random walk of tests/test_gpu_random_parity.py (presets, scene extents, cameras outside / inside the cloud / grazing / far, narrow and wide
+fields of view, rotated / non-uniformly scaled / mirrored transforms, _SplatScale, _SplatOpacityScale, _SHOrder, _SHOnly, cutout sets, deleted bits) with the
+ORACLE on one side and the reference's own shader text compiled for the host (oracle/_ref `fused`, tests/ref_lib.py) on the other: the same cases the GPU is
+held to the oracle on, the oracle held to the reference on.  Per case, over two cameras (the second key pass goes through the first one's order):
+
+    LoadSplatData           every decoded field bit-equal                                  (GaussianSplatting.hlsl:428-608)
+    CSCalcDistances keys    bit-equal, through the stable order of the first pass          (SplatUtilities.compute:69-82)
+    CSCalcViewData          the 40-byte records as tests/ref_lib.py assert_view_is_the_fused_build states it    (SplatUtilities.compute:189-252)
+
+Six seeds run in the suite; GSPLAT_REF_PARITY_SEEDS=n adds a campaign of n more (150 were run once in this container: all passed).  Skipped where
+oracle/_ref was not built (no /root/reference)."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import ref_lib as R
+from test_cutouts import CUTOUT_SETS
+from test_gpu_random_parity import _case
+from unitygaussiansplatting_amd import camera, creator, scenes
+from unitygaussiansplatting_amd.cutout import shader_data_array
+
+_SEEDS = [1, 2, 3, 4, 5, 6] + [100 + k for k in range(int(os.environ.get("GSPLAT_REF_PARITY_SEEDS", "0")))]
+
+
+@pytest.fixture(autouse=True)
+def _canon0():
+    O.lib().gso_set_canon(0)
+    yield
+    O.lib().gso_set_canon(0)
+
+
+@pytest.mark.parametrize("seed", _SEEDS)
+def test_oracle_against_the_reference_text_on_a_random_case(seed):
+    c = _case(seed)
+    n = min(c["n"], 20_011)                                     # (the compat-layer build of the HLSL is 10-100x slower than the oracle)
+    what = {k: c[k] for k in ("quality", "extent", "kind", "fields", "cut", "bits_seed")} | {"n": n, "transform": c["tr"]}
+    raw = scenes.make_splats(n if c["quality"] not in ("Low", "VeryLow") else c["n"], c["asset_seed"], c["extent"])
+    a = creator.CreateAssetFromSplatsNative(raw, c["quality"], name=f"rnd{seed}")
+    ref = R.Ref(a, "fused")                                     # (skips where oracle/_ref was not built)
+    orc = O.Oracle(a)
+    assert np.array_equal(ref.decode_all().view(np.uint32), orc.decode_all().view(np.uint32)), f"seed {seed}: LoadSplatData differs; {what}"
+    tr = c["tr"] or camera.Transform()
+    cuts = CUTOUT_SETS[c["cut"]] if c["cut"] else None
+    arr, ncut = shader_data_array(cuts, tr.localToWorldMatrix)
+    bits = None
+    if c["bits_seed"] is not None:
+        g = np.random.default_rng(c["bits_seed"])
+        bits = (g.integers(0, 2 ** 32, (a.splatCount + 31) // 32, dtype=np.uint64) & g.integers(0, 2 ** 32, (a.splatCount + 31) // 32, dtype=np.uint64)).astype(np.uint32)
+    cam = c["cam"]
+    cams = [cam, camera.Camera(position=tuple(np.asarray(cam.position) * 1.03), pixelWidth=cam.pixelWidth, pixelHeight=cam.pixelHeight, fieldOfView=cam.fieldOfView)]
+    orc.reset_order(); ref.set_indices()
+    f = c["fields"]
+    for k, cm in enumerate(cams):
+        ms = camera.sort_matrix(cm, tr.localToWorldMatrix)
+        assert np.array_equal(ref.calc_distances(ms), orc.calc_distances(ms)), f"seed {seed} frame {k}: CSCalcDistances keys differ; {what}"
+        orc.sort(ms)                                            # the oracle's stable sort; the reference side reads its keys through the same order next time
+        ref.order[:] = orc.order
+        P = camera.frame_params(cm, tr, f["m_SplatScale"], f["m_OpacityScale"], f["m_SHOrder"], f["m_SHOnly"])
+        vo = orc.calc_view(P, arr, ncut, bits).copy()
+        vr = ref.calc_view(P, arr, ncut, bits)
+        R.assert_view_is_the_fused_build(vr, vo)
