@@ -6,6 +6,14 @@ held to the oracle on, the oracle held to the reference on.  Per case, over two 
     LoadSplatData           every decoded field bit-equal                                  (GaussianSplatting.hlsl:428-608)
     CSCalcDistances keys    bit-equal, through the stable order of the first pass          (SplatUtilities.compute:69-82)
     CSCalcViewData          the 40-byte records as tests/ref_lib.py assert_view_is_the_fused_build states it    (SplatUtilities.compute:189-252)
+    the frame               (targets of <= 120,000 pixels, first camera) the oracle's frame against the reference's vert + frag + blend state under the D3D rules
+                            of oracle/ref_build/ref_render.cpp with the render-texture y-flip (RenderGaussianSplats.shader:10-12,35-108): <= 2^-9 relative to
+                            max(1, |c|) at every pixel BUT AT MOST FOUR, those <= 2^-5, >= 95 % of the pixels bit-equal.  The exception is a tie no two
+                            rasterisers decide alike: a pixel centre within fp32 rounding of a quad's edge (traced for seed 130: the edge passes x = 508.49998 at
+                            the row of pixel centre 508.5; the model's float64 edge function leaves the fragment out, the oracle's fp32 footprint keeps it) where the
+                            fragment's alpha -- up to exp(-4) x opacity = 0.018 on an edge -- is still above the 1/255 discard.  34 random frames: 31 within the
+                            bar everywhere, three with 1-3 such pixels at 1.25-1.92 x 2^-9.  (The HIP kernels take the oracle's side of every such tie: their
+                            footprint arithmetic is the oracle's, bit for bit.)
 
 Six seeds run in the suite; GSPLAT_REF_PARITY_SEEDS=n adds a campaign of n more (150 were run once in this container: all passed).  Skipped where
 oracle/_ref was not built (no /root/reference)."""
@@ -16,6 +24,7 @@ import pytest
 
 import oracle_lib as O
 import ref_lib as R
+from common import RT_TOL, rt_diff
 from test_cutouts import CUTOUT_SETS
 from test_gpu_random_parity import _case
 from unitygaussiansplatting_amd import camera, creator, scenes
@@ -61,3 +70,12 @@ def test_oracle_against_the_reference_text_on_a_random_case(seed):
         vo = orc.calc_view(P, arr, ncut, bits).copy()
         vr = ref.calc_view(P, arr, ncut, bits)
         R.assert_view_is_the_fused_build(vr, vo)
+        W, H = cm.pixelWidth, cm.pixelHeight
+        if k == 0 and W * H <= 120_000:
+            want = orc.draw(P, 0)
+            ref.calc_view(R.flipped(P), arr, ncut, bits)
+            got = ref.draw(W, H, P.near_clip, P.far_clip)[::-1].copy()
+            e = rt_diff(got, want).max(axis=-1)
+            over = e > RT_TOL
+            assert over.sum() <= 4 and e.max() <= 2.0 ** -5 and (e == 0).mean() >= 0.95, \
+                f"seed {seed}: frame through the reference shaders: {int(over.sum())} pixels over the bar, max {e.max() / RT_TOL:.2f} x, {(e == 0).mean():.4f} bit-equal; {what}"
