@@ -1,0 +1,54 @@
+"""CPU suite: the native importer (csrc/gs_import.cpp: gs_import_encode) against the numpy importer (creator.py) on a seeded random walk -- splat counts around the
+chunk (256) and texture-tile boundaries, every position / scale / colour / SH format, Morton and LinearizeData on and off, and inputs made adversarial on
+purpose: coincident positions (empty chunk bounds), scales and opacity logits at the ends of the exp / sigmoid ranges, un-normalised and tied quaternion
+components, SH coefficients far outside the clamp, denormals and signed zeros.  The bar is test_import.py's: all five blobs, the bounds and the data hash
+identical byte for byte (GaussianSplatAssetCreator.cs:247-340, 576-1066; GaussianUtils.cs).  Eight seeds in the suite; GSPLAT_IMPORT_SEEDS=n adds n more
+(200 were run once: all passed)."""
+import os
+
+import numpy as np
+import pytest
+
+from test_import import _same
+from unitygaussiansplatting_amd import asset as A
+from unitygaussiansplatting_amd import creator, scenes
+
+_SEEDS = list(range(1, 9)) + [100 + k for k in range(int(os.environ.get("GSPLAT_IMPORT_SEEDS", "0")))]
+_VEC = [A.VectorFormat.Float32, A.VectorFormat.Norm16, A.VectorFormat.Norm11, A.VectorFormat.Norm6]
+_COL = [A.ColorFormat.Float32x4, A.ColorFormat.Float16x4, A.ColorFormat.Norm8x4]          # (BC7 / Cluster*: test_import.py's preset cases -- minutes of k-means in numpy)
+_SH = [A.SHFormat.Float32, A.SHFormat.Float16, A.SHFormat.Norm11, A.SHFormat.Norm6]
+
+
+def _adversarial(raw, rng):
+    n = len(raw)
+    pick = lambda frac: rng.random(n) < frac
+    f32 = np.float32
+    m = pick(0.1); raw.pos[m] = raw.pos[rng.integers(n)]                                   # coincident positions (a whole chunk may collapse)
+    m = pick(0.05); raw.scale[m] = rng.choice(np.array([-30.0, -20.0, 3.0, 10.0, 0.0], f32), (int(m.sum()), 3))
+    m = pick(0.05); raw.opacity[m] = rng.choice(np.array([-60.0, -40.0, 0.0, 40.0, 80.0], f32), int(m.sum()))
+    # ties for the largest component, zero components, tiny but normalisable norms.  (NOT the zero quaternion or a norm whose square underflows: normalize()
+    # gives NaN there and the reference's own (uint)(NaN * 1023.5f) is undefined -- GaussianUtils.cs / GaussianSplatAssetCreator.cs:604-640 -- so there is no byte to match)
+    m = pick(0.05)
+    r = rng.choice(np.array([0.5, -0.5, 0.0, 1.0, 1e-12], f32), (int(m.sum()), 4))
+    r[(r == 0).all(axis=1) | (np.abs(r).max(axis=1) < 1e-6)] = np.array([1e-12, 0.0, 0.5, -0.5], f32)
+    raw.rot[m] = r
+    m = pick(0.05); raw.sh[m] = rng.choice(np.array([-8.0, 8.0, 0.25, -0.0, 1e-40], f32), (int(m.sum()), 15, 3))   # far outside the Norm clamp, denormals, -0
+    m = pick(0.05); raw.dc0[m] = rng.choice(np.array([-6.0, 6.0, 0.0, -0.0, 1e-39], f32), (int(m.sum()), 3))
+    return raw
+
+
+@pytest.mark.parametrize("seed", _SEEDS)
+def test_native_importer_is_the_numpy_importer_on_a_random_case(seed):
+    rng = np.random.default_rng(31_000 + seed)
+    n = int(rng.choice([1, 2, 255, 256, 257, 511, 513, 2_047, 2_049, 4_099, 12_345]))
+    raw = scenes.make_splats(n, int(rng.integers(1, 1000)), float(rng.choice([0.01, 1.0, 50.0])))
+    if rng.random() < 0.7:
+        raw = _adversarial(raw, rng)
+    morton = bool(rng.random() < 0.6)
+    linearize = bool(rng.random() < 0.8)
+    if not linearize:
+        raw = creator.LinearizeData(raw)
+    fmt = dict(formatPos=_VEC[int(rng.integers(4))], formatScale=_VEC[int(rng.integers(4))], formatColor=_COL[int(rng.integers(3))], formatSH=_SH[int(rng.integers(4))])
+    a = creator.CreateAssetFromSplats(raw, "Medium", morton=morton, linearize=linearize, **fmt)
+    b = creator.CreateAssetFromSplatsNative(raw, "Medium", morton=morton, linearize=linearize, **fmt)
+    _same(a, b)
