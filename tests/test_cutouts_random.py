@@ -1,0 +1,55 @@
+"""CPU suite: IsSplatCut (SplatUtilities.compute:164-187; GaussianCutout.cs:24-40) on seeded random cutout lists -- one to five cutouts of either type, inverted
+or not, some disabled, some null entries, under random transforms (rotated, non-uniformly scaled, mirrored) of the cutouts and of the renderer -- the oracle's
+decision per splat against tests/test_cutouts.py's independent float64 restatement of the shader's decision table, for every splat in front of the camera
+that is not within 1e-4 of a cutout surface; a cut splat keeps its clip xyz, gets w = 0 and an all-zero remainder, an uncut one is untouched.
+Eight seeds in the suite; GSPLAT_CUTOUT_SEEDS=n adds n more (300 were run once: all passed)."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from common import default_camera, small_asset
+from test_cutouts import _decoded_positions, _expected_cut, _margin_ok
+from unitygaussiansplatting_amd import camera
+from unitygaussiansplatting_amd.cutout import GaussianCutout, Type, shader_data_array
+
+_SEEDS = list(range(1, 9)) + [100 + k for k in range(int(os.environ.get("GSPLAT_CUTOUT_SEEDS", "0")))]
+
+
+def _random_transform(rng, spread, mirrored_ok=True):
+    q = rng.normal(size=4); q /= np.linalg.norm(q)
+    sc = rng.uniform(0.3, 2.5, 3)
+    if mirrored_ok and rng.random() < 0.2:
+        sc[int(rng.integers(3))] *= -1.0
+    return camera.Transform(position=tuple(rng.uniform(-spread, spread, 3)), rotation=tuple(q), scale=tuple(sc))
+
+
+@pytest.mark.parametrize("seed", _SEEDS)
+def test_random_cutout_lists_against_the_decision_table(seed):
+    rng = np.random.default_rng(61_000 + seed)
+    a = small_asset(20000, 5, "VeryHigh")
+    tr = _random_transform(rng, 0.5) if rng.random() < 0.7 else camera.Transform()
+    cuts = []
+    for _ in range(int(rng.integers(1, 6))):
+        if rng.random() < 0.15:
+            cuts.append(None); continue
+        cuts.append(GaussianCutout(Type.Ellipsoid if rng.random() < 0.5 else Type.Box, bool(rng.random() < 0.5), _random_transform(rng, 1.5),
+                                   isActiveAndEnabled=bool(rng.random() < 0.85)))
+    cam = default_camera(az=float(rng.uniform(0, 360)), elev=float(rng.uniform(-30, 30)))
+    orc = O.Oracle(a)
+    P = camera.frame_params(cam, tr)
+    base = orc.calc_view(P).copy()
+    arr, n = shader_data_array(cuts, tr.localToWorldMatrix)
+    v = orc.calc_view(P, arr, n).copy()
+    pos = _decoded_positions(orc)
+    want_cut = _expected_cut(pos, cuts, tr.localToWorldMatrix)
+    ok = _margin_ok(pos, cuts, tr.localToWorldMatrix)
+    front = base["pos"][:, 3] > 0
+    got_cut = (v["pos"][:, 3] == 0.0) & (base["pos"][:, 3] != 0.0)
+    assert front.sum() > 1000
+    assert np.array_equal(got_cut[ok & front], want_cut[ok & front]), (seed, int((got_cut != want_cut)[ok & front].sum()))
+    cutm = v["pos"][:, 3] != base["pos"][:, 3]
+    assert np.array_equal(v["pos"][cutm, :3], base["pos"][cutm, :3])
+    assert (v["axis1"][cutm] == 0).all() and (v["axis2"][cutm] == 0).all() and (v["color"][cutm] == 0).all()
+    assert np.array_equal(v[~cutm].view(np.uint32), base[~cutm].view(np.uint32))
