@@ -7,7 +7,8 @@ _SplatScale / _SplatOpacityScale / _SHOrder / _SHOnly, sort mode, tile shape, cu
     (tile, splat) pairs, visible count   equal
     RGBA16F target            <= 2^-9 relative to max(1, |c|), every pixel; the fast blend mode <= 4e-3
 
-Three seeds run in the suite; GSPLAT_PARITY_SEEDS=n adds a campaign of n more (scripts/r06_call27.sh ran 150 once)."""
+Three seeds run in the suite; GSPLAT_PARITY_SEEDS=n (from GSPLAT_PARITY_SEED0, default 100) adds a campaign of n more (scripts/r06_call27.sh ran 150 once,
+scripts/r06_call31.sh 230 others)."""
 import os
 
 import numpy as np
@@ -17,12 +18,13 @@ import oracle_lib as O
 from common import RT_TOL, rt_err, views_equal
 from test_cutouts import CUTOUT_SETS
 from unitygaussiansplatting_amd import camera, creator, scenes
+from unitygaussiansplatting_amd._lib import GsError
 from unitygaussiansplatting_amd.cutout import shader_data_array
 from unitygaussiansplatting_amd.renderer import GaussianSplatRenderer, RenderTarget, SortMode
 
 pytestmark = pytest.mark.gpu
 
-_SEEDS = [1, 2, 3] + [100 + k for k in range(int(os.environ.get("GSPLAT_PARITY_SEEDS", "0")))]
+_SEEDS = [1, 2, 3] + [int(os.environ.get("GSPLAT_PARITY_SEED0", "100")) + k for k in range(int(os.environ.get("GSPLAT_PARITY_SEEDS", "0")))]
 _SIZES = [(320, 200), (333, 217), (17, 9), (8, 8), (640, 360), (1280, 720), (48, 1024), (1024, 48), (1, 1), (31, 33)]
 
 
@@ -86,7 +88,12 @@ def test_random_case_against_the_oracle(gpu_ctx, seed):
         r.SortPoints(cm)
         orc.sort(camera.sort_matrix(cm, r.transform.localToWorldMatrix))
         r.CalcViewData(cm); rt.Clear(); r.Draw(cm, rt)
-        st = r.FrameStats()
+        try:
+            st = r.FrameStats()
+        except GsError as ex:                                   # the documented protocol (gsplat_c.h: GS_ERR_PAIR_OVERFLOW): the frame outgrew the pair buffer,
+            assert ex.code == -6, ex                            # the library has grown it, the host draws the frame again (seed 1086: 60 k splats of a 0.5-unit scene at
+            rt.Clear(); r.Draw(cm, rt)                          # _SplatScale 2 from a grazing camera, 1280x720 in 16x16 tiles: more than the initial 4 M pairs)
+            st = r.FrameStats()
         P = r.FrameParams(cm)
         arr, ncut = shader_data_array(r.m_Cutouts, r.transform.localToWorldMatrix)
         want_view = orc.calc_view(P, arr, ncut, bits)
