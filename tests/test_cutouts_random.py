@@ -2,7 +2,7 @@
 or not, some disabled, some null entries, under random transforms (rotated, non-uniformly scaled, mirrored) of the cutouts and of the renderer -- the oracle's
 decision per splat against tests/test_cutouts.py's independent float64 restatement of the shader's decision table, for every splat in front of the camera
 that is not within 1e-4 of a cutout surface; a cut splat keeps its clip xyz, gets w = 0 and an all-zero remainder, an uncut one is untouched.
-Eight seeds in the suite; GSPLAT_CUTOUT_SEEDS=n adds n more (300 were run once: all passed)."""
+Eight seeds in the suite; GSPLAT_CUTOUT_SEEDS=n adds n more (2,000 were run once: all passed)."""
 import os
 
 import numpy as np

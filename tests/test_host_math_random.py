@@ -8,7 +8,7 @@
 
 The two culls are SAFETY properties of this implementation (the reference has no cull before its rasteriser): a cull that dropped a drawable splat would be a
 wrong frame nobody flags, so they are walked over many more cameras than a GPU budget allows.  Eight seeds in the suite; GSPLAT_HOSTMATH_SEEDS=n adds n more
-(400 were run once in this container: all passed)."""
+(3,000 were run once in this container = 9,024 cameras: all passed)."""
 import ctypes as C
 import os
 

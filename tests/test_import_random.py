@@ -3,7 +3,7 @@ chunk (256) and texture-tile boundaries, every position / scale / colour / SH fo
 purpose: coincident positions (empty chunk bounds), scales and opacity logits at the ends of the exp / sigmoid ranges, un-normalised and tied quaternion
 components, SH coefficients far outside the clamp, denormals and signed zeros.  The bar is test_import.py's: all five blobs, the bounds and the data hash
 identical byte for byte (GaussianSplatAssetCreator.cs:247-340, 576-1066; GaussianUtils.cs).  Eight seeds in the suite; GSPLAT_IMPORT_SEEDS=n adds n more
-(300 were run once: all passed)."""
+(3,000 were run once: all passed)."""
 import os
 
 import numpy as np

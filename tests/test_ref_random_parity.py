@@ -15,7 +15,7 @@ held to the oracle on, the oracle held to the reference on.  Per case, over two 
                             bar everywhere, three with 1-3 such pixels at 1.25-1.92 x 2^-9.  (The HIP kernels take the oracle's side of every such tie: their
                             footprint arithmetic is the oracle's, bit for bit.)
 
-Six seeds run in the suite; GSPLAT_REF_PARITY_SEEDS=n adds a campaign of n more (150 were run once in this container: all passed).  Skipped where
+Six seeds run in the suite; GSPLAT_REF_PARITY_SEEDS=n adds a campaign of n more (600 were run once in this container: all passed).  Skipped where
 oracle/_ref was not built (no /root/reference)."""
 import os
 

@@ -4,7 +4,7 @@ sequential stable sort of all N through the previous order on every SortPoints (
 GpuSorting.cs:142-198), on seeded random sequences: tie-heavy and plain scenes, 6 to 40 sorts drawn from a small pool of cameras (so matrices recur in
 any order: a recurring row moves to the front of the history), yaw-only / pitched / dolly cameras mixed, consolidations at random times, uploaded
 (random permutation) and reset base orders in between, arbitrary visibility sets.  Twelve seeds in the suite; GSPLAT_VISMODEL_SEEDS=n adds n more
-(300 were run once: all passed)."""
+(1,500 were run once: all passed)."""
 import os
 
 import numpy as np
