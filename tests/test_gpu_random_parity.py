@@ -8,7 +8,7 @@ _SplatScale / _SplatOpacityScale / _SHOrder / _SHOnly, sort mode, tile shape, cu
     RGBA16F target            <= 2^-9 relative to max(1, |c|), every pixel; the fast blend mode <= 4e-3
 
 Three seeds run in the suite; GSPLAT_PARITY_SEEDS=n (from GSPLAT_PARITY_SEED0, default 100) adds a campaign of n more (scripts/r06_call27.sh ran 150 once,
-scripts/r06_call31.sh 230 others)."""
+scripts/r06_call31.sh 230 others, scripts/r06_call33.sh 85 more)."""
 import os
 
 import numpy as np
