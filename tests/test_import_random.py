@@ -26,12 +26,10 @@ def _adversarial(raw, rng):
     m = pick(0.1); raw.pos[m] = raw.pos[rng.integers(n)]                                   # coincident positions (a whole chunk may collapse)
     m = pick(0.05); raw.scale[m] = rng.choice(np.array([-30.0, -20.0, 3.0, 10.0, 0.0], f32), (int(m.sum()), 3))
     m = pick(0.05); raw.opacity[m] = rng.choice(np.array([-60.0, -40.0, 0.0, 40.0, 80.0], f32), int(m.sum()))
-    # ties for the largest component, zero components, tiny but normalisable norms.  (NOT the zero quaternion or a norm whose square underflows: normalize()
-    # gives NaN there and the reference's own (uint)(NaN * 1023.5f) is undefined -- GaussianUtils.cs / GaussianSplatAssetCreator.cs:604-640 -- so there is no byte to match)
-    m = pick(0.05)
-    r = rng.choice(np.array([0.5, -0.5, 0.0, 1.0, 1e-12], f32), (int(m.sum()), 4))
-    r[(r == 0).all(axis=1) | (np.abs(r).max(axis=1) < 1e-6)] = np.array([1e-12, 0.0, 0.5, -0.5], f32)
-    raw.rot[m] = r
+    # ties for the largest component, zero components, near-zero norms and the zero quaternion itself.  (normalize() gives NaN there and the reference's own
+    # (uint)(NaN * 1023.5f) is unspecified -- GaussianUtils.cs:46-76 picks index 0, GaussianSplatAssetCreator.cs:604-640 casts; both importers define the cast as 0)
+    m = pick(0.05); raw.rot[m] = rng.choice(np.array([0.5, -0.5, 0.0, 1.0, 1e-20], f32), (int(m.sum()), 4))
+    m = pick(0.02); raw.rot[m] = f32(0.0)
     m = pick(0.05); raw.sh[m] = rng.choice(np.array([-8.0, 8.0, 0.25, -0.0, 1e-40], f32), (int(m.sum()), 15, 3))   # far outside the Norm clamp, denormals, -0
     m = pick(0.05); raw.dc0[m] = rng.choice(np.array([-6.0, 6.0, 0.0, -0.0, 1e-39], f32), (int(m.sum()), 3))
     return raw

@@ -248,7 +248,10 @@ def _sat(v):
 
 
 def _q(v, k):
-    return (v.astype(f32) * f32(k + 0.5)).astype(np.uint32)     # truncating cast
+    # truncating cast, through int64 like the native importer's (uint32_t)(int64_t)(v * k): a NaN (the zero quaternion's normalize()) becomes 0 in both --
+    # the reference's own (uint)(NaN * 1023.5f) is unspecified, so this is a definition, not a restatement
+    with np.errstate(invalid="ignore"):
+        return (v.astype(f32) * f32(k + 0.5)).astype(np.int64).astype(np.uint32)
 
 
 def EncodeFloat3ToNorm16(v):
